@@ -1,0 +1,555 @@
+// dart_amd/csrc/dg_api.hip -- libdartgpu.so: the C ABI of include/dartgpu.h over the HIP kernels.
+// gfx950 (MI355X) only; no CPU fallback anywhere: every entry point needs a live HIP device.
+#include "../../include/dartgpu.h"
+#include "dg_common.h"
+#include "dg_fm.h"
+#include "dg_chain.h"
+#include "dg_report.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static char g_init_error[512] = "";
+
+template <typename T> struct DBuf {
+    T *p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+#define N_TIMERS 12
+
+struct dg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = "";
+    DIndex ix{};
+    DParams pr{};
+    // index storage
+    void *d_bwt = nullptr, *d_sa = nullptr, *d_pac = nullptr, *d_lockey = nullptr, *d_locchr = nullptr, *d_chroff = nullptr;
+    // batch inputs
+    int n_reads = 0, max_rlen = 0;
+    size_t seq_bytes = 0;
+    DBuf<unsigned char> seq; DBuf<uint32_t> seq_off; DBuf<uint16_t> rlen;
+    // pipeline buffers
+    DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, nrep, rep_off, work_need, work_off, tile_sums, tmp_u32, tmp_off;
+    DBuf<DSeed> seeds, work; DBuf<DCand> cands;
+    DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
+    DBuf<dg_sj_out> sjpool, sjfinal;
+    DBuf<unsigned char> ws;
+    unsigned long long *d_ctr = nullptr; unsigned int *d_tops = nullptr; int *d_err = nullptr;
+    size_t used[3] = {0, 0, 0};
+    // timings
+    hipEvent_t ev[N_TIMERS + 1]; const char *tname[N_TIMERS]; int n_t = 0; float tms[N_TIMERS];
+    uint64_t counters[CTR_N];
+    int n_cu = 256;
+};
+
+static int fail(dg_ctx *c, int code, const char *what, hipError_t e)
+{
+    snprintf(c ? c->err : g_init_error, 512, "%s: %s", what, e == hipSuccess ? "error" : hipGetErrorString(e));
+    return code;
+}
+#define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(c, DG_ERR_HIP, #call, _e); } while (0)
+
+// ------------------------------------------------------------------------------------------
+// small utility kernels: exclusive scan (3 phases), field extraction, compaction
+// ------------------------------------------------------------------------------------------
+#define SCAN_TILE 2048
+__global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t *in, uint32_t *out, uint32_t *tile_sums, uint32_t n)
+{
+    __shared__ uint32_t sh[256];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    uint32_t v[8], sum = 0;
+    for (int i = 0; i < 8; i++) { v[i] = base + i < n ? in[base + i] : 0; sum += v[i]; }
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        uint32_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = sh[threadIdx.x] - sum;
+    for (int i = 0; i < 8; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = sh[255];
+}
+__global__ void __launch_bounds__(256) k_scan_top(uint32_t *tile_sums, uint32_t n_tiles, uint32_t *total_out)
+{
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < n_tiles; b += 256) {
+        const uint32_t i = b + threadIdx.x;
+        const uint32_t v = i < n_tiles ? tile_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            uint32_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_sums[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t *out, const uint32_t *tile_sums, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] += tile_sums[i / SCAN_TILE];
+}
+
+// out[0..n) = exclusive scan of in, out[n] = total
+static hipError_t scan_u32(dg_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    if (n == 0) return hipMemsetAsync(out, 0, 4, c->stream);
+    const uint32_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipError_t e = c->tile_sums.ensure(tiles + 1);
+    if (e != hipSuccess) return e;
+    k_scan_tiles<<<tiles, 256, 0, c->stream>>>(in, out, c->tile_sums.p, n);
+    k_scan_top<<<1, 256, 0, c->stream>>>(c->tile_sums.p, tiles, out + n);
+    k_scan_add<<<(n + 255) / 256, 256, 0, c->stream>>>(out, c->tile_sums.p, n);
+    return hipGetLastError();
+}
+
+__global__ void k_extract_ncigar(const dg_report_out *rep, uint32_t n, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rep[i].n_cigar;
+}
+__global__ void k_extract_nsj(const dg_read_out *rd, uint32_t n, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)rd[i].n_sj;
+}
+// CIGAR ops leave the report kernel in a bump pool (arrival order); lay them out in report order
+__global__ void k_compact_cigar(dg_report_out *rep, uint32_t n, const uint32_t *new_off, const uint32_t *pool, uint32_t *fin)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = rep[i].n_cigar, src = rep[i].cigar_off, dst = new_off[i];
+    for (uint32_t k = 0; k < m; k++) fin[dst + k] = pool[src + k];
+    rep[i].cigar_off = dst;
+}
+__global__ void k_compact_sj(dg_read_out *rd, uint32_t n, const uint32_t *new_off, const dg_sj_out *pool, dg_sj_out *fin)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = (uint32_t)rd[i].n_sj, src = (uint32_t)rd[i].sj_off, dst = new_off[i];
+    for (uint32_t k = 0; k < m; k++) fin[dst + k] = pool[src + k];
+    rd[i].sj_off = (int32_t)dst;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_report: persistent lanes, one read pair (or single read) at a time
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_report(const DIndex ix, const DParams pr, int n_units, int paired, const unsigned char *__restrict__ seq,
+         const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ seed_off,
+         const DSeed *__restrict__ seeds, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
+         const uint32_t *__restrict__ rep_off, const uint32_t *__restrict__ work_off, DSeed *__restrict__ work,
+         dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
+         dg_sj_out *sjpool, uint32_t sjcap, unsigned int *tops, unsigned char *ws, const WSLayout L,
+         unsigned long long *ctr, int *err)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_lanes = gridDim.x * blockDim.x;
+    LaneCtx cx;
+    cx.ix = &ix; cx.pr = &pr; cx.L = &L;
+    cx.ws = ws + (size_t)lane * L.stride;
+    cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
+    for (int u = lane; u < n_units; u += n_lanes) {
+        const int nm = paired ? 2 : 1;
+        DRead rd[2];
+        dg_report_out *rp[2];
+        DCand *cd[2];
+        int nc[2];
+        for (int m = 0; m < nm; m++) {
+            const int r = paired ? 2 * u + m : u;
+            cd[m] = cands + seed_off[r];
+            nc[m] = (int)ncand[r];
+            rp[m] = reports + rep_off[r];
+            uint32_t wo = work_off[r];
+            for (int i = 0; i < nc[m]; i++) if (cd[m][i].Score > 0) { cd[m][i].work_off = wo; wo += d_work_need(cd[m][i].count); }
+            rd[m].sub_score = 0; rd[m].mis_num = 0; rd[m].mapq = 0;      // defined start state
+            cx.seq = seq + seq_off[r]; cx.rlen = rlen[r];
+            d_gen_mapping_report(cx, m == 0, rd[m], cd[m], nc[m], seeds, work, rp[m], cigpool, tops + 0, cigcap, err);
+        }
+        if (paired) {
+            d_check_paired_final(pr, rd[0], rp[0], rd[1], rp[1]);
+            d_set_paired_flag(rd[0], rp[0], rd[1], rp[1]);
+        } else d_set_single_flag(rd[0], rp[0]);
+        for (int m = 0; m < nm; m++) {
+            const int r = paired ? 2 * u + m : u;
+            d_evaluate_mapq(rd[m], rp[m]);
+            dg_read_out o;
+            o.score = rd[m].score; o.sub_score = rd[m].sub_score; o.mis_num = rd[m].mis_num; o.mapq = rd[m].mapq;
+            o.n_rep = rd[m].CanNum; o.best = rd[m].iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
+            if (nc[m] > 0 && (rd[m].mapq == 50 || (pr.all_sj && rd[m].score > 0)))
+                d_collect_sj(ix, pr, cd[m][rd[m].iBest], work, r, sjpool, tops + 1, sjcap, o.sj_off, o.n_sj, err);
+            rout[r] = o;
+        }
+    }
+    d_wave_add(ctr + CTR_NW, cx.n_nw);
+    d_wave_add(ctr + CTR_NWCELLS, cx.nw_cells);
+    d_wave_add(ctr + CTR_RESEED, cx.n_reseed);
+    d_wave_add(ctr + CTR_RESEEDW, cx.reseed_w);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+extern "C" void dg_params_default(dg_params *p)
+{
+    p->max_gaps = 5; p->max_dup = 100; p->max_intron = 500000; p->min_intron = 5;
+    p->max_mismatch = 0; p->multi_hit = 0; p->all_sj = 0; p->paired = 0;
+}
+
+static void set_params(dg_ctx *c, const dg_params *p)
+{
+    c->pr.max_gaps = p->max_gaps; c->pr.max_dup = p->max_dup; c->pr.max_intron = p->max_intron; c->pr.min_intron = p->min_intron;
+    c->pr.max_mismatch = p->max_mismatch; c->pr.multi_hit = p->multi_hit; c->pr.all_sj = p->all_sj; c->pr.paired = p->paired;
+}
+
+extern "C" int dg_set_params(dg_ctx *c, const dg_params *p)
+{
+    if (!c || !p) return DG_ERR_ARG;
+    set_params(c, p);
+    return DG_OK;
+}
+
+extern "C" const char *dg_last_error(const dg_ctx *c) { return c ? c->err : g_init_error; }
+
+extern "C" void dg_destroy(dg_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void *ptrs[] = { c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff, c->d_ctr, c->d_tops, c->d_err };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    c->seq.release(); c->seq_off.release(); c->rlen.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
+    c->seed_off.release(); c->ncand.release(); c->nrep.release(); c->rep_off.release(); c->work_need.release(); c->work_off.release();
+    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release();
+    c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
+    c->ws.release();
+    for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int device, int *status)
+{
+    int st = DG_OK, ndev = 0;
+    dg_ctx *c = nullptr;
+    auto bail = [&](int code, const char *what, hipError_t e) -> dg_ctx * {
+        snprintf(g_init_error, sizeof g_init_error, "%s: %s", what, e == hipSuccess ? "invalid" : hipGetErrorString(e));
+        if (c) dg_destroy(c);
+        if (status) *status = code;
+        return nullptr;
+    };
+    if (!v || !p || !v->bwt || !v->sa || !v->pac || v->n_chr <= 0) return bail(DG_ERR_ARG, "dg_init arguments", hipSuccess);
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return bail(DG_ERR_NO_DEVICE, "no HIP device (libdartgpu has no CPU fallback)", e);
+    if (device < 0 || device >= ndev) return bail(DG_ERR_NO_DEVICE, "device ordinal out of range", hipSuccess);
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(DG_ERR_HIP, "hipSetDevice", e);
+    c = new dg_ctx();
+    c->device = device;
+    for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "hipStreamCreate", e);
+    for (int i = 0; i <= N_TIMERS; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail(DG_ERR_HIP, "hipEventCreate", e);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    set_params(c, p);
+
+    // ---- index upload: the .bwt blocks at a 64-byte aligned base (+ one block of padding so the
+    //      last, possibly partial, block can be fetched whole), sampled SA, pac, chromosome keys
+    const size_t bwt_bytes = (size_t)v->bwt_words * 4, sa_bytes = (size_t)v->n_sa * 8, pac_bytes = (size_t)(v->l_pac / 4 + 1);
+    if ((e = hipMalloc(&c->d_bwt, bwt_bytes + 128)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc bwt", e);
+    if ((e = hipMemset(c->d_bwt, 0, bwt_bytes + 128)) != hipSuccess) return bail(DG_ERR_HIP, "hipMemset", e);
+    if ((e = hipMemcpy(c->d_bwt, v->bwt, bwt_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload bwt", e);
+    if ((e = hipMalloc(&c->d_sa, sa_bytes)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc sa", e);
+    if ((e = hipMemcpy(c->d_sa, v->sa, sa_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload sa", e);
+    if ((e = hipMalloc(&c->d_pac, pac_bytes + 16)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc pac", e);
+    if ((e = hipMemcpy(c->d_pac, v->pac, pac_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload pac", e);
+    {
+        const int n = v->n_chr;
+        std::vector<int64_t> key(2 * n), off(n);
+        std::vector<int32_t> chr(2 * n);
+        for (int i = 0; i < n; i++) {       // ChrLocMap, bwt_index.cpp:246-250
+            off[i] = v->chr_off[i];
+            key[i] = v->chr_off[i] + v->chr_len[i] - 1; chr[i] = i;
+            key[2 * n - 1 - i] = 2 * v->l_pac - v->chr_off[i] - 1; chr[2 * n - 1 - i] = i;
+        }
+        if ((e = hipMalloc(&c->d_lockey, 16 * (size_t)n)) != hipSuccess || (e = hipMalloc(&c->d_locchr, 8 * (size_t)n)) != hipSuccess ||
+            (e = hipMalloc(&c->d_chroff, 8 * (size_t)n)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc chr tables", e);
+        if ((e = hipMemcpy(c->d_lockey, key.data(), 16 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(c->d_locchr, chr.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(c->d_chroff, off.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload chr tables", e);
+    }
+    if ((e = hipMalloc((void **)&c->d_ctr, CTR_N * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, 16)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc counters", e);
+    c->ix.bwt = (const uint4 *)c->d_bwt; c->ix.sa = (const uint64_t *)c->d_sa; c->ix.pac = (const uint8_t *)c->d_pac;
+    c->ix.loc_key = (const int64_t *)c->d_lockey; c->ix.loc_chr = (const int32_t *)c->d_locchr; c->ix.chr_off = (const int64_t *)c->d_chroff;
+    c->ix.primary = v->primary; for (int i = 0; i < 5; i++) c->ix.L2[i] = v->L2[i]; c->ix.seq_len = v->seq_len;
+    c->ix.l_pac = v->l_pac; c->ix.n_chr = v->n_chr; c->ix.sa_intv = v->sa_intv;
+    if (status) *status = st;
+    return c;
+}
+
+extern "C" int dg_batch_upload(dg_ctx *c, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && (!seq_off || !rlen || !seq))) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    size_t bytes = 0; int mx = 0;
+    for (int i = 0; i < n_reads; i++) {
+        if (rlen[i] > DG_MAX_RLEN) { snprintf(c->err, 512, "read %d longer than DG_MAX_RLEN", i); return DG_ERR_ARG; }
+        if ((size_t)seq_off[i] + rlen[i] > bytes) bytes = (size_t)seq_off[i] + rlen[i];
+        if (rlen[i] > mx) mx = rlen[i];
+    }
+    c->n_reads = n_reads; c->max_rlen = mx; c->seq_bytes = bytes;
+    HIPCHK(c->seq.ensure(bytes + 16)); HIPCHK(c->seq_off.ensure((size_t)n_reads + 1)); HIPCHK(c->rlen.ensure((size_t)n_reads + 1));
+    if (n_reads) {
+        HIPCHK(hipMemcpyAsync(c->seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->seq_off.p, seq_off, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->rlen.p, rlen, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DG_OK;
+}
+
+static WSLayout make_ws_layout(int R)
+{
+    WSLayout L;
+    auto al = [](uint32_t x) { return (x + 15u) & ~15u; };
+    uint32_t o = 0;
+    const uint32_t nmax = 2u * (uint32_t)R + 32u;                       // longest genome fragment of a segment pair
+    L.max_rlen = (uint32_t)R;
+    L.cig_off = o; L.cig_cap = 4u * (uint32_t)R + 64u; o = al(o + L.cig_cap * 4u);
+    L.nwbits_off = o; L.nwbits_words = ((uint32_t)R + 1u) * ((nmax + 15u) / 16u); o = al(o + L.nwbits_words * 4u);
+    L.rows_off = o; L.row_cap = nmax + 8u; o = al(o + 3u * L.row_cap * 4u);
+    L.str_off = o; L.str_cap = al(3u * (uint32_t)R + 64u); o = al(o + 6u * L.str_cap);
+    L.kmer_off = o; L.kmer_cap = (uint32_t)R + 8u; o = al(o + L.kmer_cap * 8u);
+    uint32_t rd = 64; while (rd < (uint32_t)R + 1u) rd <<= 1;
+    L.ring_diag = rd; L.ring_words = ((uint32_t)R + 64u) / 64u; L.ring_off = o; o = al(o + rd * L.ring_words * 8u);
+    L.stride = (o + 255u) & ~255u;
+    return L;
+}
+
+#define TICK(name) do { c->tname[c->n_t] = name; HIPCHK(hipEventRecord(c->ev[c->n_t + 1], c->stream)); c->n_t++; } while (0)
+
+extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
+{
+    if (!c) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const int n = c->n_reads;
+    const int paired = (c->pr.paired && (n % 2 == 0)) ? 1 : 0;      // Mapping.cpp:598
+    const int n_units = paired ? n / 2 : n;
+    c->used[0] = c->used[1] = c->used[2] = 0;
+    c->n_t = 0;
+    memset(c->counters, 0, sizeof c->counters);
+    if (used) used[0] = used[1] = used[2] = 0;
+    if (n == 0) return DG_OK;
+    const int H = c->max_rlen / 16 + 1;
+    const uint32_t nb = (uint32_t)((n + 255) / 256);
+    HIPCHK(c->hits.ensure((size_t)n * H)); HIPCHK(c->nhits.ensure(n)); HIPCHK(c->nseeds.ensure(n)); HIPCHK(c->seed_off.ensure((size_t)n + 1));
+    HIPCHK(c->ncand.ensure(n)); HIPCHK(c->nrep.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1));
+    HIPCHK(c->work_need.ensure(n)); HIPCHK(c->work_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n));
+    HIPCHK(c->tmp_u32.ensure(n)); HIPCHK(c->tmp_off.ensure((size_t)n + 1));
+    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_tops, 0, 16, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+
+    k_seed<<<nb, 256, 0, c->stream>>>(c->ix, c->pr, c->seq.p, c->seq_off.p, c->rlen.p, n, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
+    HIPCHK(hipGetLastError());
+    TICK("k_seed");
+    HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n));
+    uint32_t total_seeds = 0;
+    HIPCHK(hipMemcpyAsync(&total_seeds, c->seed_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    TICK("scan_seeds");
+    HIPCHK(c->seeds.ensure((size_t)total_seeds + 1)); HIPCHK(c->cands.ensure((size_t)total_seeds + 1));
+    if (total_seeds) {
+        k_locate<<<(total_seeds + 255) / 256, 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->seed_off.p, total_seeds, c->seeds.p, c->d_ctr);
+        HIPCHK(hipGetLastError());
+    }
+    TICK("k_locate");
+    k_chain<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p,
+                                                                  c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->d_ctr);
+    HIPCHK(hipGetLastError());
+    TICK("k_chain");
+    HIPCHK(scan_u32(c, c->nrep.p, c->rep_off.p, (uint32_t)n));
+    HIPCHK(scan_u32(c, c->work_need.p, c->work_off.p, (uint32_t)n));
+    uint32_t total_rep = 0, total_work = 0;
+    HIPCHK(hipMemcpyAsync(&total_rep, c->rep_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&total_work, c->work_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    TICK("scan_reports");
+    const size_t cigcap = (size_t)n * 48 + (size_t)total_rep * 16 + 4096, sjcap = (size_t)n * 4 + 1024;
+    HIPCHK(c->reports.ensure((size_t)total_rep + 1)); HIPCHK(c->work.ensure((size_t)total_work + 16));
+    HIPCHK(c->cigpool.ensure(cigcap)); HIPCHK(c->cigfinal.ensure(cigcap)); HIPCHK(c->sjpool.ensure(sjcap)); HIPCHK(c->sjfinal.ensure(sjcap));
+    const WSLayout L = make_ws_layout(c->max_rlen < 32 ? 32 : c->max_rlen);
+    int blocks = c->n_cu * 8;                                        // 8 one-wave workgroups per CU stay resident
+    if ((size_t)blocks * 64 > (size_t)n_units) blocks = (n_units + 63) / 64;
+    HIPCHK(c->ws.ensure((size_t)blocks * 64 * L.stride));
+    k_report<<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p,
+                                            c->ncand.p, c->rep_off.p, c->work_off.p, c->work.p, c->reads_out.p, c->reports.p, c->cigpool.p,
+                                            (uint32_t)cigcap, c->sjpool.p, (uint32_t)sjcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
+    HIPCHK(hipGetLastError());
+    TICK("k_report");
+    // deterministic layout of the variable-length outputs
+    HIPCHK(c->tmp_u32.ensure((size_t)total_rep + 1)); HIPCHK(c->tmp_off.ensure((size_t)total_rep + 2));
+    uint32_t total_cig = 0, total_sj = 0;
+    if (total_rep) {
+        k_extract_ncigar<<<(total_rep + 255) / 256, 256, 0, c->stream>>>(c->reports.p, total_rep, c->tmp_u32.p);
+        HIPCHK(scan_u32(c, c->tmp_u32.p, c->tmp_off.p, total_rep));
+        k_compact_cigar<<<(total_rep + 255) / 256, 256, 0, c->stream>>>(c->reports.p, total_rep, c->tmp_off.p, c->cigpool.p, c->cigfinal.p);
+        HIPCHK(hipMemcpyAsync(&total_cig, c->tmp_off.p + total_rep, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    HIPCHK(c->tmp_u32.ensure((size_t)n + 1)); HIPCHK(c->tmp_off.ensure((size_t)n + 2));
+    k_extract_nsj<<<nb, 256, 0, c->stream>>>(c->reads_out.p, (uint32_t)n, c->tmp_u32.p);
+    HIPCHK(scan_u32(c, c->tmp_u32.p, c->tmp_off.p, (uint32_t)n));
+    k_compact_sj<<<nb, 256, 0, c->stream>>>(c->reads_out.p, (uint32_t)n, c->tmp_off.p, c->sjpool.p, c->sjfinal.p);
+    HIPCHK(hipMemcpyAsync(&total_sj, c->tmp_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
+    int derr = 0;
+    HIPCHK(hipMemcpyAsync(&derr, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->counters, c->d_ctr, CTR_N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    TICK("compact");
+    HIPCHK(hipEventSynchronize(c->ev[c->n_t]));
+    for (int i = 0; i < c->n_t; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]); c->tms[i] = ms; }
+    c->counters[CTR_SEEDS] = total_seeds;
+    if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == 1 ? "cigar" : "splice junction"); return DG_ERR_INTERNAL; }
+    c->used[0] = total_rep; c->used[1] = total_cig; c->used[2] = total_sj;
+    if (used) { used[0] = total_rep; used[1] = total_cig; used[2] = total_sj; }
+    return DG_OK;
+}
+
+extern "C" int dg_batch_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3])
+{
+    if (!c || !caps) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (caps[0] < c->used[0] || caps[1] < c->used[1] || caps[2] < c->used[2]) { snprintf(c->err, 512, "output capacity too small"); return DG_ERR_CAPACITY; }
+    if (c->n_reads && ro) HIPCHK(hipMemcpyAsync(ro, c->reads_out.p, (size_t)c->n_reads * sizeof(dg_read_out), hipMemcpyDeviceToHost, c->stream));
+    if (c->used[0] && po) HIPCHK(hipMemcpyAsync(po, c->reports.p, c->used[0] * sizeof(dg_report_out), hipMemcpyDeviceToHost, c->stream));
+    if (c->used[1] && cig) HIPCHK(hipMemcpyAsync(cig, c->cigfinal.p, c->used[1] * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DG_OK;
+}
+
+extern "C" int dg_map_batch(dg_ctx *c, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
+                            dg_read_out *ro, dg_report_out *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3], size_t used[3])
+{
+    int rc = dg_batch_upload(c, n_reads, seq_off, rlen, seq);
+    if (rc) return rc;
+    if ((rc = dg_batch_run(c, used))) return rc;
+    return dg_batch_download(c, ro, po, cig, so, caps);
+}
+
+extern "C" int dg_last_timings(dg_ctx *c, const char **names, float *ms, int cap)
+{
+    if (!c) return 0;
+    int k = c->n_t < cap ? c->n_t : cap;
+    for (int i = 0; i < k; i++) { names[i] = c->tname[i]; ms[i] = c->tms[i]; }
+    return k;
+}
+
+extern "C" int dg_last_counters(dg_ctx *c, uint64_t *out, int cap)
+{
+    if (!c) return 0;
+    int k = CTR_N < cap ? CTR_N : cap;
+    for (int i = 0; i < k; i++) out[i] = c->counters[i];
+    return k;
+}
+
+// ---- stage probes ----
+extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
+                              uint32_t *seed_off, int32_t *rpos, int32_t *slen, int64_t *gpos, size_t cap, size_t *used)
+{
+    int rc = dg_batch_upload(c, n_reads, seq_off, rlen, seq);
+    if (rc) return rc;
+    const int n = n_reads;
+    if (used) *used = 0;
+    if (n == 0) return DG_OK;
+    const int H = c->max_rlen / 16 + 1;
+    HIPCHK(c->hits.ensure((size_t)n * H)); HIPCHK(c->nhits.ensure(n)); HIPCHK(c->nseeds.ensure(n)); HIPCHK(c->seed_off.ensure((size_t)n + 1));
+    HIPCHK(c->ncand.ensure(n)); HIPCHK(c->nrep.ensure(n)); HIPCHK(c->work_need.ensure(n));
+    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * 8, c->stream));
+    k_seed<<<(n + 255) / 256, 256, 0, c->stream>>>(c->ix, c->pr, c->seq.p, c->seq_off.p, c->rlen.p, n, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
+    HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n));
+    uint32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, c->seed_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (used) *used = total;
+    if (total > cap) return DG_ERR_CAPACITY;
+    HIPCHK(c->seeds.ensure((size_t)total + 1)); HIPCHK(c->cands.ensure((size_t)total + 1));
+    if (total) k_locate<<<(total + 255) / 256, 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->seed_off.p, total, c->seeds.p, c->d_ctr);
+    // the sort is the first half of k_chain; run it unpaired so every read is sorted on its own
+    k_chain<<<(n + 255) / 256, 256, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->d_ctr);
+    std::vector<DSeed> h(total);
+    HIPCHK(hipMemcpyAsync(seed_off, c->seed_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (total) HIPCHK(hipMemcpyAsync(h.data(), c->seeds.p, (size_t)total * sizeof(DSeed), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < total; i++) { rpos[i] = h[i].rPos; slen[i] = h[i].rLen; gpos[i] = h[i].gPos; }
+    return DG_OK;
+}
+
+__global__ void __launch_bounds__(64)
+k_probe_nw(int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b, const uint32_t *out_off,
+           uint32_t *out_len, char *out_a, char *out_b, unsigned char *ws, const WSLayout L, const DIndex ix, const DParams pr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    LaneCtx cx;
+    cx.ix = &ix; cx.pr = &pr; cx.L = &L; cx.ws = ws + (size_t)i * L.stride; cx.seq = nullptr; cx.rlen = 0;
+    cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
+    out_len[i] = (uint32_t)d_nw(cx, a + a_off[i], (int)(a_off[i + 1] - a_off[i]), b + b_off[i], (int)(b_off[i + 1] - b_off[i]), out_a + out_off[i], out_b + out_off[i]);
+}
+
+extern "C" int dg_probe_nw(dg_ctx *c, int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b,
+                           uint32_t *out_off, uint32_t *out_len, char *out_a, char *out_b, size_t cap)
+{
+    if (!c || n < 0) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) return DG_OK;
+    size_t tot = 0; int mx = 32;
+    for (int i = 0; i < n; i++) {
+        const int m = (int)(a_off[i + 1] - a_off[i]), nn = (int)(b_off[i + 1] - b_off[i]);
+        out_off[i] = (uint32_t)tot; tot += (size_t)m + nn;
+        if (m > mx) mx = m;
+        if ((nn + 1) / 2 > mx) mx = (nn + 1) / 2;      // workspace rows hold 2R+32 columns
+    }
+    if (tot > cap) return DG_ERR_CAPACITY;
+    const WSLayout L = make_ws_layout(mx);
+    unsigned char *d_ws = nullptr; char *d_a = nullptr, *d_b = nullptr, *d_oa = nullptr, *d_ob = nullptr; uint32_t *d_off = nullptr;
+    const size_t la = a_off[n], lb = b_off[n];
+    HIPCHK(hipMalloc((void **)&d_ws, (size_t)n * L.stride)); HIPCHK(hipMalloc((void **)&d_a, la + 16)); HIPCHK(hipMalloc((void **)&d_b, lb + 16));
+    HIPCHK(hipMalloc((void **)&d_oa, tot + 16)); HIPCHK(hipMalloc((void **)&d_ob, tot + 16)); HIPCHK(hipMalloc((void **)&d_off, (size_t)(4 * n + 4) * 4));
+    uint32_t *d_aoff = d_off, *d_boff = d_off + (n + 1), *d_ooff = d_off + 2 * (n + 1), *d_olen = d_off + 3 * (n + 1);
+    HIPCHK(hipMemcpy(d_a, a, la, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, b, lb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_aoff, a_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_boff, b_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_ooff, out_off, (size_t)n * 4, hipMemcpyHostToDevice));
+    k_probe_nw<<<(n + 63) / 64, 64, 0, c->stream>>>(n, d_aoff, d_boff, d_a, d_b, d_ooff, d_olen, d_oa, d_ob, d_ws, L, c->ix, c->pr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out_len, d_olen, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_a, d_oa, tot, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_b, d_ob, tot, hipMemcpyDeviceToHost));
+    (void)hipFree(d_ws); (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_oa); (void)hipFree(d_ob); (void)hipFree(d_off);
+    return DG_OK;
+}

@@ -1,0 +1,101 @@
+// dart_amd/csrc/dg_common.h -- device-side data layout shared by the kernels of libdartgpu.
+// gfx950 only (wave = 64). Names follow the reference's domain (seeds, candidates, reports).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DG_WAVE 64
+
+// One segment pair (SeedPair_t, structure.h:106-115).  PosDiff is not stored: every use in the
+// reference happens while PosDiff == gPos - rPos still holds, so it is derived.
+struct __attribute__((aligned(8))) DSeed {
+    int64_t  gPos;
+    int32_t  rPos;
+    int32_t  rLen;
+    int32_t  gLen;
+    uint32_t flags;       // bit0 bSimple, bit1 bAcceptorSite
+};
+#define SEED_SIMPLE   1u
+#define SEED_ACCEPTOR 2u
+
+// One maximal exact match before SA lookup: the SA interval of BWT_Search (bwt_search.cpp:139-182)
+struct __attribute__((aligned(16))) DHit {
+    uint64_t x0;          // first row of the forward interval
+    uint32_t freq;        // interval size (<= MaxDupNum)
+    uint16_t rPos, len;
+};
+
+// AlignmentCandidate_t (structure.h:125-132); SeedVec = seeds[first .. first+count)
+struct __attribute__((aligned(8))) DCand {
+    int64_t PosDiff;
+    int32_t first, count;
+    int32_t Score, PairedIdx;
+    int32_t SJtype;
+    uint32_t work_off;    // offset of this candidate's private working seed region
+    int32_t final_n;      // seeds left in the working region after the report stage
+    int32_t pad;
+};
+
+// The index on the device.  bwt keeps the reference's Occ-interleaved layout (one 64-byte block
+// per 128 rows = 4 x u64 cumulative counts + 8 x u32 of 2-bit symbols, bwtindex.c:53-75) at a
+// 64-byte aligned base, so one Occ query is exactly one aligned 64-byte line.
+struct DIndex {
+    const uint4    *bwt;          // 4 x uint4 per block
+    const uint64_t *sa;           // sampled SA, sa[0] = -1
+    const uint8_t  *pac;
+    const int64_t  *loc_key;      // ChrLocMap keys, ascending (2*n_chr)
+    const int32_t  *loc_chr;
+    const int64_t  *chr_off;
+    uint64_t primary, L2[5], seq_len;
+    int64_t  l_pac;
+    int32_t  n_chr, sa_intv;
+};
+
+struct DParams {
+    int32_t max_gaps, max_dup, max_intron, min_intron, max_mismatch, multi_hit, all_sj, paired;
+};
+
+// work counters (dg_last_counters)
+enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, CTR_NWCELLS, CTR_RESEED, CTR_RESEEDW, CTR_N };
+
+__device__ __forceinline__ uint8_t d_nt4(unsigned char c)   // nst_nt4_table, BWT_Index/bntseq.c:40
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    case '-': return 5;
+    default: return 4;
+    }
+}
+
+// RefSequence[g] (bwt_index.cpp:193-212,252) computed from the forward 2-bit pac; 0 outside [0,2L)
+__device__ __forceinline__ char d_refchar(const DIndex &ix, int64_t g)
+{
+    const int64_t L = ix.l_pac;
+    if (g < 0 || g >= 2 * L) return 0;
+    if (g < L) return "ACGT"[(ix.pac[g >> 2] >> ((~g & 3) << 1)) & 3];
+    g = 2 * L - 1 - g;
+    return "TGCA"[(ix.pac[g >> 2] >> ((~g & 3) << 1)) & 3];
+}
+
+// ChrLocMap.lower_bound(g): index of the smallest key >= g
+__device__ __forceinline__ int d_loc_lower_bound(const DIndex &ix, int64_t g)
+{
+    int lo = 0, hi = 2 * ix.n_chr;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (ix.loc_key[mid] < g) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__device__ __forceinline__ bool d_seed_less(const DSeed &a, const DSeed &b)   // CompByGenomePos, AlignmentCandidates.cpp:21-25
+{
+    return a.gPos == b.gPos ? a.rPos < b.rPos : a.gPos < b.gPos;
+}
+
+// wave-level sum of a per-lane counter, one atomic per wave
+__device__ __forceinline__ void d_wave_add(unsigned long long *dst, unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}

@@ -1,0 +1,782 @@
+// dart_amd/csrc/dg_report.h -- per-candidate gap filling, splice detection, CIGAR, coordinates,
+// then pair finalisation, FLAG, MAPQ and splice-junction tuples.
+//
+// Replaces GenMappingReport and everything it calls (AlignmentCandidates.cpp:37-61,83-116,136-163,
+// 299-306,385-467,547-624,685-1035,1052-1207), KmerAnalysis.cpp:25-166, tools.cpp:40-300,
+// nw_alignment.cpp:18-82, and from Mapping.cpp: CheckPairedFinalAlignments :479-530,
+// SetSingle/PairedAlignmentFlag :74-186, EvaluateMAPQ :188-206, UpdateLocalSJMap :532-565.
+//
+// One persistent lane = one read pair at a time (both mates, because pair finalisation and FLAGs
+// need both).  All per-lane scratch (CIGAR elements, NW traceback bits and rows, aligned strings,
+// re-seeding k-mer list and diagonal ring) lives in a lane-private slice of one HBM workspace;
+// each candidate edits its seeds in its own working region (sized by k_chain), so nothing is
+// allocated on the device.  Integer/byte work only -- no MFMA.
+#pragma once
+#include "dg_common.h"
+
+// per-lane workspace layout (bytes), derived on the host from the batch's longest read R
+struct WSLayout {
+    uint32_t cig_off, cig_cap;          // u32 elements  len<<4|op
+    uint32_t nwbits_off, nwbits_words;  // 2 bits per DP cell, rows padded to u32
+    uint32_t rows_off, row_cap;         // 3 int rows of row_cap entries
+    uint32_t str_off, str_cap;          // 6 char buffers of str_cap
+    uint32_t kmer_off, kmer_cap;        // u64 (wid<<32|pos)
+    uint32_t ring_off, ring_diag, ring_words;  // ring_diag diagonals x ring_words u64 bitmap words
+    uint32_t stride;                    // bytes per lane
+    uint32_t max_rlen;
+};
+
+struct LaneCtx {
+    const DIndex *ix;
+    const DParams *pr;
+    const unsigned char *seq;   // this read, ASCII
+    int rlen;
+    unsigned char *ws;          // lane workspace base
+    const WSLayout *L;
+    unsigned long long n_nw, nw_cells, n_reseed, reseed_w;
+};
+
+#define OP_M 0u
+#define OP_I 1u
+#define OP_D 2u
+#define OP_N 3u
+#define OP_S 4u
+#define CIG(len, op) ((((uint32_t)(len)) << 4) | (op))
+
+__device__ __forceinline__ uint32_t *ws_cig(LaneCtx &cx) { return (uint32_t *)(cx.ws + cx.L->cig_off); }
+__device__ __forceinline__ char *ws_str(LaneCtx &cx, int i) { return (char *)(cx.ws + cx.L->str_off + (uint32_t)i * cx.L->str_cap); }
+
+__device__ __forceinline__ int d_tr2(int v2) { return v2 >= 0 ? (v2 & ~1) : -((-v2) & ~1); }
+
+// ---------------------------------------------------------------------------------------------
+// nw_alignment (nw_alignment.cpp:18-82) restated on integers x2: s is built from
+// operands truncated toward zero to 16-bit integers; traceback needs only the predicates
+// s==r and s==t per cell (2 bits), kept in the lane's bit matrix; three rolling int rows.
+// a: m chars, b: n chars; oa/ob receive the gapped strings; returns their common length.
+// ---------------------------------------------------------------------------------------------
+__device__ inline int d_nw(LaneCtx &cx, const char *a, int m, const char *b, int n, char *oa, char *ob)
+{
+    uint32_t *bits = (uint32_t *)(cx.ws + cx.L->nwbits_off);
+    int *sprev = (int *)(cx.ws + cx.L->rows_off), *scur = sprev + cx.L->row_cap, *tprev = scur + cx.L->row_cap;
+    const int rw = (n + 15) >> 4;      // u32 words per bit-matrix row
+    cx.n_nw++; cx.nw_cells += (unsigned long long)m * (unsigned long long)n;
+    sprev[0] = 0;
+    for (int j = 1; j <= n; j++) { sprev[j] = -2 - j; tprev[j] = -131072; }
+    for (int i = 1; i <= m; i++) {
+        const uint8_t ca = d_nt4((unsigned char)a[i - 1]);
+        scur[0] = -2 - i;
+        int r = -131072;                 // r[i][0]
+        uint32_t acc = 0;
+        for (int j = 1; j <= n; j++) {
+            int x = r - 1, y = scur[j - 1] - 3;
+            r = x > y ? x : y;
+            x = tprev[j] - 1; y = sprev[j] - 3;
+            const int t = x > y ? x : y;
+            const int d = d_tr2(sprev[j - 1] + (ca == d_nt4((unsigned char)b[j - 1]) ? 3 : -3));
+            const int rr = d_tr2(r), tt = d_tr2(t);
+            const int s = d > rr ? (d > tt ? d : tt) : (rr > tt ? rr : tt);
+            scur[j] = s; tprev[j] = t;
+            acc |= ((s == r ? 1u : 0u) | (s == t ? 2u : 0u)) << (((j - 1) & 15) << 1);
+            if (((j - 1) & 15) == 15 || j == n) { bits[(size_t)(i - 1) * rw + ((j - 1) >> 4)] = acc; acc = 0; }
+        }
+        int *tmp = sprev; sprev = scur; scur = tmp;
+    }
+    // traceback :61-74, columns produced back to front
+    int i = m, j = n, k = 0;
+    while (i > 0 || j > 0) {
+        uint32_t f;
+        if (i == 0) f = 1;               // s[0][j] == r[0][j]
+        else if (j == 0) f = 2;          // s[i][0] == t[i][0], r[i][0] is the sentinel
+        else f = (bits[(size_t)(i - 1) * rw + ((j - 1) >> 4)] >> (((j - 1) & 15) << 1)) & 3u;
+        if (f & 1u) { oa[k] = '-'; ob[k] = b[j - 1]; j--; }
+        else if (f & 2u) { oa[k] = a[i - 1]; ob[k] = '-'; i--; }
+        else { oa[k] = a[i - 1]; ob[k] = b[j - 1]; i--; j--; }
+        k++;
+    }
+    for (int p = 0, q = k - 1; p < q; p++, q--) {
+        char c = oa[p]; oa[p] = oa[q]; oa[q] = c;
+        c = ob[p]; ob[p] = ob[q]; ob[q] = c;
+    }
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 8-mer re-seeding between two seeds (ReseedingWithSpecificRegion :596-624 +
+// GenerateLongestSimplePairsFromFragmentPair KmerAnalysis.cpp:134-166).
+// The reference sorts every 8-mer of the genome window by id, joins, then sorts the pairs by
+// (PosDiff,rPos).  Here the window is streamed once: window position g can only hit diagonals
+// g-rPos in (g-rl, g], so a ring of rl diagonals, each a bitmap over rPos, is complete -- and can
+// be folded into the running (s, max_len) state in increasing diagonal order -- as soon as g has
+// moved rl past it.  Same pairs, same order, O(window) time and O(rl^2/8) bytes.
+// ---------------------------------------------------------------------------------------------
+__device__ inline bool d_reseed(LaneCtx &cx, int rBegin, int rEnd, int64_t Lb, int64_t Rb, DSeed *out)
+{
+    const DIndex &ix = *cx.ix;
+    const int rl = rEnd - rBegin, gl = (int)(Rb - Lb);
+    int thr = (int)(rl * 0.85); if (thr < 8) thr = 8;
+    cx.n_reseed++; cx.reseed_w += (unsigned long long)(gl > 0 ? gl : 0);
+    uint64_t *km = (uint64_t *)(cx.ws + cx.L->kmer_off);
+    int nk = 0;
+    const unsigned char *rs = cx.seq + rBegin;
+    {   // read-gap k-mers in position order, with the reference's 'N' handling
+        int count = 0, head, tail = 0;
+        uint32_t wid = 0;
+        while (count < 8 && tail < rl) { if (rs[tail++] != 'N') count++; else count = 0; }
+        if (count == 8) {
+            head = tail - 8; wid = 0;
+            for (int i = head; i < head + 8; i++) wid = (wid << 2) + d_nt4(rs[i]);
+            km[nk++] = ((uint64_t)wid << 32) | (uint32_t)head;
+            for (head += 1; tail < rl; head++, tail++) {
+                if (rs[tail] != 'N') {
+                    wid = ((wid & 0x3FFF) << 2) + d_nt4(rs[tail]);
+                    km[nk++] = ((uint64_t)wid << 32) | (uint32_t)head;
+                } else {
+                    count = 0; tail++;
+                    while (count < 8 && tail < rl) { if (rs[tail++] != 'N') count++; else count = 0; }
+                    if (count == 8) {
+                        head = tail - 8; wid = 0;
+                        for (int i = head; i < head + 8; i++) wid = (wid << 2) + d_nt4(rs[i]);
+                        km[nk++] = ((uint64_t)wid << 32) | (uint32_t)head;
+                    } else break;
+                }
+            }
+        }
+    }
+    if (nk == 0 || gl < 8) return false;
+    for (int i = 1; i < nk; i++) {            // sort by (wid,pos)
+        uint64_t x = km[i]; int j = i;
+        while (j > 0 && km[j - 1] > x) { km[j] = km[j - 1]; j--; }
+        km[j] = x;
+    }
+    uint64_t *ring = (uint64_t *)(cx.ws + cx.L->ring_off);
+    const int RD = (int)cx.L->ring_diag, RW = (int)cx.L->ring_words;
+    for (int i = 0; i < RD * RW; i++) ring[i] = 0;
+    const int span = rl - 8;                  // rPos ranges over [0, span]
+    int s = 1, max_len = 0, best_r = 0;
+    int64_t best_g = 0;
+    int64_t next_fin = -(int64_t)span;        // smallest possible diagonal
+    auto finalize = [&](int64_t d) {
+        uint64_t *bm = ring + (size_t)((uint64_t)d & (uint64_t)(RD - 1)) * RW;
+        int cnt = 0, first = -1, last = -1;
+        for (int w = 0; w < RW; w++) {
+            const uint64_t v = bm[w];
+            if (v) {
+                cnt += __popcll(v);
+                if (first < 0) first = w * 64 + (__ffsll((unsigned long long)v) - 1);
+                last = w * 64 + 63 - __clzll((long long)v);
+                bm[w] = 0;
+            }
+        }
+        if (cnt == 0) return;
+        s += cnt - 1;
+        const int l = 8 + (last - first);
+        if (l > max_len && s > (l - 8) / 2) { best_r = first; best_g = d + first; max_len = l; s = 1; }
+    };
+    // the window holds no 'N' (RefSequence is ACGT, or '\0' past the end which is not 'N' either)
+    uint32_t wid = 0;
+    for (int i = 0; i < 8; i++) wid = (wid << 2) + d_nt4((unsigned char)d_refchar(ix, Lb + i));
+    for (int g = 0; g + 8 <= gl; g++) {
+        if (g > 0) wid = ((wid & 0x3FFF) << 2) + d_nt4((unsigned char)d_refchar(ix, Lb + g + 7));
+        while (next_fin < (int64_t)g - span) { finalize(next_fin); next_fin++; }
+        int lo = 0, hi = nk;                  // first read k-mer with this id
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(km[mid] >> 32) < wid) lo = mid + 1; else hi = mid; }
+        for (; lo < nk && (uint32_t)(km[lo] >> 32) == wid; lo++) {
+            const int rp = (int)(uint32_t)km[lo];
+            const int64_t d = (int64_t)g - rp;
+            ring[(size_t)((uint64_t)d & (uint64_t)(RD - 1)) * RW + (rp >> 6)] |= 1ull << (rp & 63);
+        }
+    }
+    for (const int64_t endd = (int64_t)(gl - 8); next_fin <= endd; next_fin++) finalize(next_fin);
+    if (max_len >= thr && max_len > 0) {
+        out->rLen = out->gLen = max_len;
+        out->rPos = best_r + rBegin;
+        out->gPos = best_g + Lb;
+        out->flags = SEED_SIMPLE;
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// clean-up of a candidate's seed list
+// ---------------------------------------------------------------------------------------------
+__device__ inline int d_remove_null(DSeed *s, int n)   // RemoveNullSeeds :299-306
+{
+    int k = 0;
+    for (int i = 0; i < n; i++) if (s[i].rLen != 0) { if (k != i) s[k] = s[i]; k++; }
+    return k;
+}
+
+// (rPos,index) pairs sorted by rPos; ties by index (ties are order-insensitive downstream)
+__device__ inline void d_sorted_rpos(const DSeed *s, int n, int2 *vec)
+{
+    for (int i = 0; i < n; i++) {
+        int2 x = make_int2(s[i].rPos, i);
+        int j = i;
+        while (j > 0 && (vec[j - 1].x > x.x)) { vec[j] = vec[j - 1]; j--; }
+        vec[j] = x;
+    }
+}
+
+__device__ inline int d_remove_tandem(DSeed *s, int n, int2 *vec)   // :817-842
+{
+    if (n < 2) return n;
+    d_sorted_rpos(s, n, vec);
+    bool any = false;
+    for (int i = 0; i < n;) {
+        int j = i + 1;
+        while (j < n && vec[j].x == vec[i].x) j++;
+        if (j - i > 1) { any = true; for (int k = i; k < j; k++) s[vec[k].y].rLen = s[vec[k].y].gLen = 0; }
+        i = j;
+    }
+    return any ? d_remove_null(s, n) : n;
+}
+
+__device__ inline int d_remove_transloc(DSeed *s, int n, int2 *vec)   // :844-902
+{
+    if (n < 2) return n;
+    d_sorted_rpos(s, n, vec);
+    bool any = false;
+    for (int i = 0; i < n; i++) {
+        if (vec[i].x != s[i].rPos) {
+            any = true;
+            int j = vec[i].y;
+            for (int q = i + 1; q <= j; q++) if (vec[q].y > j) j = vec[q].y;
+            int s1 = 0, s2 = 0;
+            for (int k = i; k <= j; k++) { if (k < vec[k].y) s1 += s[vec[k].y].rLen; else s2 += s[vec[k].y].rLen; }
+            if (s1 > s2) { for (int k = i; k <= j; k++) if (k > vec[k].y) s[vec[k].y].rLen = s[vec[k].y].gLen = 0; }
+            else { for (int k = i; k <= j; k++) if (k < vec[k].y) s[vec[k].y].rLen = s[vec[k].y].gLen = 0; }
+            i = j;
+        }
+    }
+    return any ? d_remove_null(s, n) : n;
+}
+
+__device__ inline void d_insertion_sort_seeds(DSeed *a, int n)
+{
+    for (int i = 1; i < n; i++) {
+        DSeed x = a[i];
+        int j = i;
+        while (j > 0 && d_seed_less(x, a[j - 1])) { a[j] = a[j - 1]; j--; }
+        a[j] = x;
+    }
+}
+
+__device__ inline int d_identify_missing(LaneCtx &cx, DSeed *s, int n)   // :685-700
+{
+    const int num = n;
+    for (int i = 1; i < num; i++) {
+        const int pd = (int)((s[i].gPos - s[i].rPos) - (s[i - 1].gPos - s[i - 1].rPos));
+        const int rGaps = s[i].rPos - s[i - 1].rPos - s[i - 1].rLen;
+        if (pd > cx.pr->max_gaps && rGaps > 20) {
+            DSeed ns;
+            if (d_reseed(cx, s[i - 1].rPos + s[i - 1].rLen, s[i].rPos, s[i - 1].gPos + s[i - 1].gLen, s[i].gPos, &ns)) s[n++] = ns;
+        }
+    }
+    if (n > num) d_insertion_sort_seeds(s, n);
+    return n;
+}
+
+// IdentifyBestGappedPartition :385-467 + FillGapsBetweenAdjacentSeeds :547-575; appends at s[n..]
+__device__ inline int d_fill_gaps(LaneCtx &cx, DSeed *s, int n, const DSeed L, const DSeed R)
+{
+    const DIndex &ix = *cx.ix;
+    int rGaps = R.rPos - (L.rPos + L.rLen);
+    char *g = ws_str(cx, 0), *f1 = ws_str(cx, 1), *f2 = ws_str(cx, 2), *f3 = ws_str(cx, 3), *f4 = ws_str(cx, 4);
+    int *Rv = (int *)ws_cig(cx), *Lv = Rv + rGaps + 1;      // the CIGAR scratch is idle at this stage
+    const char *rd = (const char *)cx.seq + L.rPos + L.rLen;
+    for (int i = 0; i <= rGaps; i++) Rv[i] = Lv[i] = 0;
+    for (int i = 0; i < rGaps; i++) g[i] = d_refchar(ix, L.gPos + L.gLen + i);
+    const int len = d_nw(cx, rd, rGaps, g, rGaps, f1, f2);
+    int i = len - 1;
+    while (i >= 0 && f2[i] == '-') i--;
+    int64_t gp = L.gPos + L.gLen + rGaps;
+    for (i += 1; i < len; i++, gp++) f2[i] = d_refchar(ix, gp);
+    int p = 0, sc = 0;
+    for (i = 0; i < len; i++) { if (f1[i] == f2[i]) sc++; if (f1[i] != '-') p++; Rv[p] = sc; }
+    for (i = 0; i < rGaps; i++) g[i] = d_refchar(ix, R.gPos - rGaps + i);
+    const int len3 = d_nw(cx, rd, rGaps, g, rGaps, f3, f4);
+    i = 0;
+    while (i < len3 && f4[i] == '-') i++;
+    gp = R.gPos - rGaps;
+    for (i -= 1; i >= 0; i--, gp--) f4[i] = d_refchar(ix, gp);
+    p = 0; sc = 0;
+    for (i = len3 - 1; i >= 0; i--) { if (f3[i] == f4[i]) sc++; if (f3[i] != '-') p++; Lv[rGaps - p] = sc; }
+    int max_score = 0, bp = 0;
+    for (i = 0; i <= rGaps; i++) { const int v = Rv[i] + Lv[i]; if (v > max_score) { max_score = v; bp = i; } }
+    int right_ext = 0, left_ext = 0;
+    if (!(max_score < (int)(rGaps * 0.8) || (rGaps - max_score) > cx.pr->max_mismatch)) {
+        for (p = bp, i = 0; p > 0; i++) { if (f1[i] != '-') p--; if (f2[i] != '-') right_ext++; }
+        for (p = rGaps - bp, i = len3 - 1; p > 0; i--) { if (f3[i] != '-') p--; if (f4[i] != '-') left_ext++; }
+    }
+    if (bp > 0) {
+        DSeed x; x.flags = 0; x.rPos = L.rPos + L.rLen; x.gPos = L.gPos + L.gLen; x.rLen = bp; x.gLen = right_ext;
+        s[n++] = x;
+    }
+    if ((rGaps -= bp) > 0) {
+        DSeed x; x.flags = 0; x.rLen = rGaps; x.gLen = left_ext; x.rPos = R.rPos - x.rLen; x.gPos = R.gPos - x.gLen;
+        s[n++] = x;
+    }
+    return n;
+}
+
+__device__ inline int d_seed_extension(LaneCtx &cx, DSeed *s, int n)   // :577-594
+{
+    const int num = n;
+    for (int i = 1; i < num; i++) {
+        const int pd = (int)((s[i].gPos - s[i].rPos) - (s[i - 1].gPos - s[i - 1].rPos));
+        if (pd > cx.pr->min_intron && s[i].rPos > s[i - 1].rPos + s[i - 1].rLen) n = d_fill_gaps(cx, s, n, s[i - 1], s[i]);
+    }
+    if (n > num) d_insertion_sort_seeds(s, n);
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// splice junctions (:6,702-815; main.cpp:18)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int d_shift_arr(int i) { return i == 0 ? 0 : ((i & 1) ? (i + 1) / 2 : -(i / 2)); }   // ShiftArr :6
+
+__device__ inline bool d_check_seq_fragment(const DIndex &ix, int64_t Lg, int64_t Rg, int shift)   // :702-730
+{
+    if (shift <= 0) { shift = -shift; Lg -= shift; Rg -= shift; }
+    for (int i = 0; i < shift; i++, Lg++, Rg++) if (d_refchar(ix, Lg) != d_refchar(ix, Rg)) return false;
+    return true;
+}
+
+__device__ inline int d_identify_sj(const DIndex &ix, int type, const DSeed &l, const DSeed &r)   // :732-756
+{
+    // SpliceJunctionArr = { "GT/AG", "CT/AC", "GC/AG", "CT/GC" }
+    const char d0 = type == 0 ? 'G' : (type == 2 ? 'G' : 'C');
+    const char d1 = type == 2 ? 'C' : 'T';
+    const char a0 = type == 3 ? 'G' : 'A';
+    const char a1 = (type == 0 || type == 2) ? 'G' : 'C';
+    int i = l.rLen < r.rLen ? l.rLen : r.rLen;
+    int j = l.gLen < r.gLen ? l.gLen : r.gLen;
+    if (i < j) j = i;
+    if (j > 9) j = 9;
+    j <<= 1;
+    const int64_t Lg = l.gPos + l.gLen, Rg = r.gPos;
+    int shift = 0;
+    for (i = 0; i <= j; i++) {
+        shift = d_shift_arr(i);
+        if (shift != 0 && !d_check_seq_fragment(ix, Lg, Rg, shift)) continue;
+        const int64_t g1 = Lg + shift, g2 = Rg - 2 + shift;
+        if (d_refchar(ix, g1) == d0 && d_refchar(ix, g1 + 1) == d1 && d_refchar(ix, g2) == a0 && d_refchar(ix, g2 + 1) == a1) break;
+    }
+    return i > j ? 10 : shift;
+}
+
+__device__ inline int d_check_splice(LaneCtx &cx, DSeed *s, int num, int2 *vec)   // :758-815
+{
+    const DIndex &ix = *cx.ix;
+    int2 *best = vec + num + 1;
+    int min_cost = 1000, best_type = -1, nbest = 0;
+    for (int type = 0; type < 4; type++) {
+        int nvec = 0, mis = 0, c = 0;
+        for (int i = 1; i < num; i++) {
+            if (((s[i].gPos - s[i].rPos) - (s[i - 1].gPos - s[i - 1].rPos)) > cx.pr->min_intron && (s[i - 1].flags & SEED_SIMPLE) && (s[i].flags & SEED_SIMPLE)) {
+                const int shift = d_identify_sj(ix, type, s[i - 1], s[i]);
+                if (shift != 10) vec[nvec++] = make_int2(i, shift);
+                else mis++;
+                c += shift < 0 ? -shift : shift;
+            }
+        }
+        if (nvec > 0 && c < min_cost) { min_cost = c; best_type = type; nbest = nvec; for (int q = 0; q < nvec; q++) best[q] = vec[q]; }
+        if (mis == 0) break;
+    }
+    if (best_type != -1) {
+        for (int q = 0; q < nbest; q++) {
+            const int j = best[q].x, shift = best[q].y;
+            s[j].flags |= SEED_ACCEPTOR;
+            if (shift != 0) {
+                s[j - 1].rLen += shift; s[j - 1].gLen += shift;
+                s[j].rLen -= shift; s[j].gLen -= shift;
+                s[j].rPos += shift; s[j].gPos += shift;
+            }
+        }
+    }
+    return best_type;
+}
+
+// ---------------------------------------------------------------------------------------------
+// overlaps and normal pairs (:904-1035)
+// ---------------------------------------------------------------------------------------------
+__device__ inline bool d_check_seed_overlapping(DSeed &p1, DSeed &p2)   // :904-954
+{
+    int ov;
+    bool master = true;
+    if ((ov = p1.rPos + p1.rLen - p2.rPos) > 0) {
+        if (p1.rLen < p2.rLen) {
+            master = false;
+            if (p1.rLen > ov) p1.gLen = (p1.rLen -= ov);
+            else p1.rLen = p1.gLen = 0;
+        } else {
+            if (p2.rLen > ov) { p2.rPos += ov; p2.gPos += ov; p2.gLen = (p2.rLen -= ov); }
+            else p2.rLen = p2.gLen = 0;
+        }
+    }
+    if ((p1.rLen > 0 && p2.rLen > 0) && (ov = (int)(p1.gPos + p1.gLen - p2.gPos)) > 0) {
+        if (p1.gLen < p2.gLen) {
+            master = false;
+            if (p1.rLen > ov) p1.gLen = (p1.rLen -= ov);
+            else p1.rLen = p1.gLen = 0;
+        } else {
+            if (p2.rLen > ov) { p2.rPos += ov; p2.gPos += ov; p2.gLen = (p2.rLen -= ov); }
+            else p2.rLen = p2.gLen = 0;
+        }
+    }
+    return master;
+}
+
+__device__ inline int d_check_overlapping_seeds(DSeed *s, int num)   // :956-999
+{
+    if (num < 2) return num;
+    bool any = false;
+    for (int i = 0; i < num;) {
+        if (s[i].rLen > 0) {
+            const int rEnd = s[i].rPos + s[i].rLen - 1;
+            const int64_t gEnd = s[i].gPos + s[i].gLen - 1;
+            for (int j = i + 1; j < num; j++) {
+                if (s[j].rLen == 0) continue;
+                if (rEnd < s[j].rPos && gEnd < s[j].gPos) break;
+                if (!d_check_seed_overlapping(s[i], s[j])) break;
+            }
+            if (s[i].rLen == 0) {
+                any = true;
+                i = i - 1;
+                while (i > 0 && s[i].rLen == 0) i--;
+                if (i < 0) i = 0;
+            } else i++;
+        } else { any = true; i++; }
+    }
+    return any ? d_remove_null(s, num) : num;
+}
+
+__device__ inline int d_identify_normal_pairs(DSeed *s, int n)   // :1001-1035
+{
+    if (n <= 1) return n;
+    n = d_check_overlapping_seeds(s, n);
+    const int num = n;
+    for (int i = 0, j = 1; j < num; i++, j++) {
+        if (s[j].rPos - s[i].rPos - s[i].rLen == 0) continue;
+        int rGaps = s[j].rPos - (s[i].rPos + s[i].rLen); if (rGaps < 0) rGaps = 0;
+        int gGaps = (int)(s[j].gPos - (s[i].gPos + s[i].gLen));
+        if (gGaps < 0) gGaps = 0; else if (gGaps > 30 && gGaps > (rGaps << 1)) gGaps = 0;
+        if (rGaps > 0 || gGaps > 0) {
+            DSeed x; x.flags = 0;
+            x.rPos = s[i].rPos + s[i].rLen; x.gPos = s[i].gPos + s[i].gLen; x.rLen = rGaps; x.gLen = gGaps;
+            s[n++] = x;
+        }
+    }
+    // inplace_merge(begin, begin+num, end) :1033 -- stable: an appended pair goes after every
+    // element of the first range that is not greater than it
+    for (int t = num; t < n; t++) {
+        DSeed x = s[t];
+        int j = t;
+        while (j > 0 && d_seed_less(x, s[j - 1])) { s[j] = s[j - 1]; j--; }
+        s[j] = x;
+    }
+    return n;
+}
+
+__device__ inline bool d_check_coordinate_validity(const DIndex &ix, const DSeed *s, int n)   // :136-163
+{
+    int64_t g1 = 0, g2 = 2 * ix.l_pac;
+    const int64_t L = ix.l_pac;
+    for (int i = 0; i < n; i++) if (s[i].gLen > 0) { g1 = s[i].gPos; break; }
+    for (int i = n - 1; i >= 0; i--) if (s[i].gLen > 0) { g2 = s[i].gPos + s[i].gLen - 1; break; }
+    return !((g1 < L && g2 >= L) || (g1 >= L && g2 < L));
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment pair -> CIGAR elements (tools.cpp:40-104,130-300)
+// ---------------------------------------------------------------------------------------------
+__device__ inline int d_add_cigar(const char *s1, const char *s2, int len, uint32_t *cig, int &nc)   // AddNewCigarElements :49-104
+{
+    uint32_t state = 99;
+    int c = 0, score = 0;
+    for (int i = 0; i < len; i++) {
+        uint32_t st;
+        if (s1[i] == '-') st = OP_D;
+        else if (s2[i] == '-') st = OP_I;
+        else { st = OP_M; if (s1[i] == s2[i]) score++; }
+        if (state == st) c++;
+        else { if (c > 0) cig[nc++] = CIG(c, state); c = 1; state = st; }
+    }
+    if (c > 0) cig[nc++] = CIG(c, state);
+    return score;
+}
+
+__device__ inline bool d_local_quality(const char *a1, const char *a2, int len)   // CheckLocalAlignmentQuality :166-201
+{
+    int n = 0, mis = 0, type = -1, st = 0;
+    for (int i = 0; i < len; i++) {
+        if (a1[i] == '-') { if (type != 0) { type = 0; st++; } }
+        else if (a2[i] == '-') { if (type != 1) { type = 1; st++; } }
+        else { n++; if (a1[i] != a2[i]) mis++; if (type != 2) { type = 2; st++; } }
+    }
+    return !(st >= 4 || (mis >= 3 && mis >= (int)(n * 0.3)));
+}
+
+// mode 0 = head (ProcessHeadSequencePair :203-249), 1 = tail (:251-300), 2 = normal (:130-164)
+__device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t *cig, int &nc)
+{
+    const DIndex &ix = *cx.ix;
+    if (mode == 2) {
+        if (sp.gPos - sp.rPos == -1) { cig[nc++] = CIG(sp.rLen, OP_S); return 0; }
+        if (sp.rLen == 0 || sp.gLen == 0) {
+            if (sp.rLen > 0) cig[nc++] = CIG(sp.rLen, OP_I);
+            else if (sp.gLen > 0) cig[nc++] = CIG(sp.gLen, OP_D);
+            return 0;
+        }
+    }
+    const char *rd = (const char *)cx.seq + sp.rPos;
+    char *g = ws_str(cx, 0);
+    for (int i = 0; i < sp.gLen; i++) g[i] = d_refchar(ix, sp.gPos + i);
+    if (sp.rLen == sp.gLen) {
+        int n = 0;
+        for (int i = 0; i < sp.rLen; i++) if (rd[i] != g[i]) n++;       // CalFragPairMismatchBases :40-47
+        if (n <= 2 && n <= (int)(sp.rLen * 0.2)) { cig[nc++] = CIG(sp.rLen, OP_M); return sp.rLen - n; }
+    }
+    char *o1 = ws_str(cx, 1), *o2 = ws_str(cx, 3);     // each spans two string slots (rLen+gLen chars)
+    int len = d_nw(cx, rd, sp.rLen, g, sp.gLen, o1, o2);
+    if (mode == 2) return d_add_cigar(o1, o2, len, cig, nc);
+    if (!d_local_quality(o1, o2, len)) { cig[nc++] = CIG(sp.rLen, OP_S); return 0; }
+    if (mode == 0) {
+        int p = 0;
+        while (p < len && o1[p] == '-') p++;
+        if (p > 0) { o1 += p; o2 += p; len -= p; sp.gPos += p; sp.gLen -= p; }
+        p = 0;
+        while (p < len && o2[p] == '-') p++;
+        if (p > 0) { o1 += p; o2 += p; len -= p; sp.rPos += p; sp.rLen -= p; cig[nc++] = CIG(p, OP_S); }
+        return d_add_cigar(o1, o2, len, cig, nc);
+    }
+    int p = len - 1, c = 0;
+    while (p >= 0 && o1[p] == '-') { c++; p--; }
+    if (c > 0) { len -= c; sp.gLen -= c; }
+    p = len - 1; c = 0;
+    while (p >= 0 && o2[p] == '-') { c++; p--; }
+    if (c > 0) { len -= c; sp.rLen -= c; }
+    const int score = d_add_cigar(o1, o2, len, cig, nc);
+    if (c > 0) cig[nc++] = CIG(c, OP_S);
+    return score;
+}
+
+// device-side per-read state (ReadItem_t)
+struct DRead {
+    int score, sub_score, mis_num, mapq, CanNum, iBest;
+};
+
+// GenMappingReport :1079-1207 for one read.  reports = this read's dg_report_out slots
+// (n_rep = max(ncand,1)); cands/seeds = this read's candidates and the global seed array;
+// work = global working-seed pool; cigpool/cigtop = bump pool for merged CIGAR ops.
+template <typename ReportT>
+__device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, DCand *cands, int ncand, const DSeed *seeds,
+                                            DSeed *work, ReportT *rep, uint32_t *cigpool, unsigned int *cigtop, uint32_t cigcap, int *err)
+{
+    const DIndex &ix = *cx.ix;
+    rd.score = rd.iBest = 0;
+    if (ncand == 0) {
+        rd.CanNum = 1;
+        rep[0].aln_score = 0; rep[0].sj_type = -1; rep[0].flag = 0; rep[0].paired_idx = -1; rep[0].chr = -1; rep[0].bdir = 0;
+        rep[0].pos = 0; rep[0].cigar_off = 0; rep[0].n_cigar = 0;
+        return;
+    }
+    rd.CanNum = ncand;
+    uint32_t *cig = ws_cig(cx);
+    for (int i = 0; i < ncand; i++) {
+        DCand &c = cands[i];
+        ReportT &rp = rep[i];
+        rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = c.PairedIdx; rp.chr = -1; rp.bdir = 0; rp.pos = 0;
+        rp.cigar_off = 0; rp.n_cigar = 0;
+        c.final_n = 0;
+        if (c.Score == 0) continue;
+        DSeed *s = work + c.work_off;
+        int n = c.count;
+        for (int q = 0; q < n; q++) s[q] = seeds[c.first + q];
+        int2 *vec = (int2 *)(s + 6 * c.count + 4);       // tail of the working region as int scratch
+        n = d_remove_tandem(s, n, vec);
+        n = d_remove_transloc(s, n, vec);
+        n = d_identify_missing(cx, s, n);
+        n = d_seed_extension(cx, s, n);
+        vec = (int2 *)(s + n + 1);
+        rp.sj_type = c.SJtype = d_check_splice(cx, s, n, vec);
+        n = d_identify_normal_pairs(s, n);
+        c.final_n = n;
+        const int num = n;
+        if (num > 1 && !d_check_coordinate_validity(ix, s, num)) continue;
+        int nc = 1, mis_num = 0, aln = 0;                 // cig[0] is kept free for a leading soft clip
+        for (int j = 0; j < num; j++) {
+            DSeed &sd = s[j];
+            if (sd.rLen == 0 && sd.gLen == 0) continue;
+            int g;
+            if (j > 0 && (g = (int)(sd.gPos - (s[j - 1].gPos + s[j - 1].gLen))) > 0) cig[nc++] = CIG(g, OP_N);
+            if (sd.flags & SEED_SIMPLE) { cig[nc++] = CIG(sd.rLen, OP_M); aln += sd.rLen; }
+            else {
+                const int score = d_process_pair(cx, sd, j == 0 ? 0 : (j == num - 1 ? 1 : 2), cig, nc);
+                aln += score;
+                mis_num += sd.rLen - score;
+            }
+        }
+        int c0 = 1;
+        if (num > 0) {
+            int j;
+            if ((j = s[0].rPos) > 0) { cig[0] = CIG(j, OP_S); c0 = 0; }
+            if ((j = cx.rlen - (s[num - 1].rPos + s[num - 1].rLen)) > 0) cig[nc++] = CIG(j, OP_S);
+        }
+        if (mis_num > cx.pr->max_mismatch || nc - c0 == 0) aln = 0;
+        for (int j = c0; j < nc; j++) if ((cig[j] & 15u) == OP_N && (int)(cig[j] >> 4) < cx.pr->min_intron) { aln = 0; break; }   // CheckMinIntronSize :1052
+        if (aln > 0) {
+            const int64_t gPos = s[0].gPos, end_gPos = s[num - 1].gPos + s[num - 1].gLen - 1;   // GenCoordinateInfo :83-116
+            const int lb = d_loc_lower_bound(ix, gPos);
+            rp.chr = ix.loc_chr[lb];
+            if (gPos < ix.l_pac) { rp.bdir = first ? 1 : 0; rp.pos = gPos + 1 - ix.chr_off[rp.chr]; }
+            else { rp.bdir = first ? 0 : 1; rp.pos = ix.loc_key[lb] - end_gPos + 1; }
+            if (rp.pos <= 0) aln = 0;
+            else {
+                if (gPos >= ix.l_pac) for (int a = c0, b = nc - 1; a < b; a++, b--) { const uint32_t t = cig[a]; cig[a] = cig[b]; cig[b] = t; }
+                // GenerateCIGAR :37-61: merge equal neighbours, drop zero-length runs, in place
+                int m = 0, cnt = 0;
+                uint32_t state = 99;
+                for (int j = c0; j < nc; j++) {
+                    const uint32_t op = cig[j] & 15u, ln = cig[j] >> 4;
+                    if (op != state) { if (cnt > 0) cig[m++] = CIG(cnt, state); cnt = (int)ln; state = op; }
+                    else cnt += (int)ln;
+                }
+                if (cnt > 0) cig[m++] = CIG(cnt, state);
+                const unsigned int off = atomicAdd(cigtop, (unsigned int)m);
+                if (off + (unsigned int)m > cigcap) { *err = 1; rp.n_cigar = 0; }
+                else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
+            }
+            rp.aln_score = aln;
+            if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis_num; rd.sub_score = rd.score; rd.score = aln; }
+            else if (aln == rd.score) rd.sub_score = rd.score;
+        }
+    }
+}
+
+// CheckPairedFinalAlignments, Mapping.cpp:479-530
+template <typename ReportT>
+__device__ inline void d_check_paired_final(const DParams &pr, DRead &r1, ReportT *p1, DRead &r2, ReportT *p2)
+{
+    bool mated = p1[r1.iBest].paired_idx == r2.iBest;
+    if (!pr.multi_hit && mated) return;
+    if (!mated && r1.score > 0 && r2.score > 0) {
+        int s = 0;
+        for (int i = 0; i < r1.CanNum; i++) {
+            int j;
+            if (p1[i].aln_score > 0 && (j = p1[i].paired_idx) != -1 && p2[j].aln_score > 0) {
+                mated = true;
+                if (s < p1[i].aln_score + p2[j].aln_score) {
+                    s = p1[i].aln_score + p2[j].aln_score;
+                    r1.iBest = i; r1.score = p1[i].aln_score;
+                    r2.iBest = j; r2.score = p2[j].aln_score;
+                }
+            }
+        }
+    }
+    if (mated) {
+        for (int i = 0; i < r1.CanNum; i++) {
+            int j;
+            if (p1[i].aln_score != r1.score || ((j = p1[i].paired_idx) != -1 && p2[j].aln_score != r2.score)) { p1[i].aln_score = 0; p1[i].paired_idx = -1; }
+        }
+    } else {
+        for (int i = 0; i < r1.CanNum; i++) {
+            if (p1[i].paired_idx != -1) p1[i].paired_idx = -1;
+            if (p1[i].aln_score > 0 && p1[i].aln_score != r1.score) p1[i].aln_score = 0;
+        }
+        for (int j = 0; j < r2.CanNum; j++) {
+            if (p2[j].paired_idx != -1) p2[j].paired_idx = -1;
+            if (p2[j].aln_score > 0 && p2[j].aln_score != r2.score) p2[j].aln_score = 0;
+        }
+    }
+}
+
+template <typename ReportT>
+__device__ inline void d_set_single_flag(DRead &r, ReportT *p)   // Mapping.cpp:74-99
+{
+    if (r.score > r.sub_score) p[r.iBest].flag = p[r.iBest].bdir ? 0 : 0x10;
+    else if (r.score > 0) { for (int i = 0; i < r.CanNum; i++) if (p[i].aln_score > 0) p[i].flag = p[i].bdir ? 0 : 0x10; }
+    else p[0].flag = 0x4;
+}
+
+template <typename ReportT>
+__device__ inline void d_set_mate_flags(DRead &a, ReportT *pa, DRead &b, ReportT *pb, int base)   // Mapping.cpp:124-153 / :155-184
+{
+    int j;
+    if (a.score > a.sub_score) {
+        const int i = a.iBest;
+        pa[i].flag = base | (pa[i].bdir ? 0x20 : 0x10);
+        if ((j = pa[i].paired_idx) != -1 && pb[j].aln_score > 0) pa[i].flag |= 0x2; else pa[i].flag |= 0x8;
+    } else if (a.score > 0) {
+        for (int i = 0; i < a.CanNum; i++) {
+            if (pa[i].aln_score > 0) {
+                pa[i].flag = base | (pa[i].bdir ? 0x20 : 0x10);
+                if ((j = pa[i].paired_idx) != -1 && pb[j].aln_score > 0) pa[i].flag |= 0x2; else pa[i].flag |= 0x8;
+            }
+        }
+    } else {
+        pa[0].flag = base | 0x4;
+        if (b.score == 0) pa[0].flag |= 0x8;
+        else pa[0].flag |= (pb[b.iBest].bdir ? 0x10 : 0x20);
+    }
+}
+
+template <typename ReportT>
+__device__ inline void d_set_paired_flag(DRead &r1, ReportT *p1, DRead &r2, ReportT *p2)   // Mapping.cpp:101-186
+{
+    if (r1.score > r1.sub_score && r2.score > r2.sub_score) {
+        const int i = r1.iBest, j = r2.iBest;
+        p1[i].flag = 0x41; p2[j].flag = 0x81;
+        if (j == p1[i].paired_idx) { p1[i].flag |= 0x2; p2[j].flag |= 0x2; }
+        p1[i].flag |= (p1[i].bdir ? 0x20 : 0x10);
+        p2[j].flag |= (p2[j].bdir ? 0x20 : 0x10);
+    } else {
+        d_set_mate_flags(r1, p1, r2, p2, 0x41);
+        d_set_mate_flags(r2, p2, r1, p1, 0x81);
+    }
+}
+
+template <typename ReportT>
+__device__ inline void d_evaluate_mapq(DRead &r, const ReportT *p)   // Mapping.cpp:188-206
+{
+    if (r.score == 0 || r.score == r.sub_score) r.mapq = 0;
+    else if (r.sub_score == 0 || r.score > r.sub_score) r.mapq = 50;
+    else {
+        int n = 0;
+        for (int i = 0; i < r.CanNum; i++) if (p[i].aln_score == r.score) n++;
+        r.mapq = n >= 10 ? 0 : (n >= 4 ? 1 : (n == 3 ? 2 : (n == 2 ? 3 : 50)));
+    }
+}
+
+// UpdateLocalSJMap, Mapping.cpp:532-565: tuples of the best candidate -> bump pool
+template <typename SjT>
+__device__ inline void d_collect_sj(const DIndex &ix, const DParams &pr, const DCand &c, const DSeed *work, int read_idx,
+                                    SjT *sjpool, unsigned int *sjtop, uint32_t sjcap, int32_t &sj_off, int32_t &n_sj, int *err)
+{
+    if (c.SJtype == -1) return;
+    const DSeed *s = work + c.work_off;
+    const int64_t L = ix.l_pac;
+    int cnt = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        unsigned int off = 0;
+        if (pass == 1) {
+            if (cnt == 0) return;
+            off = atomicAdd(sjtop, (unsigned int)cnt);
+            if (off + (unsigned int)cnt > sjcap) { *err = 2; return; }
+            sj_off = (int32_t)off; n_sj = cnt;
+        }
+        int k = 0;
+        for (int i = 1; i < c.final_n; i++) {
+            if (!(s[i].flags & SEED_ACCEPTOR)) continue;
+            int64_t g1, g2;
+            if (c.PosDiff < L) { g1 = s[i - 1].gPos + s[i - 1].gLen; g2 = s[i].gPos - 1; }
+            else { g1 = 2 * L - s[i].gPos; g2 = 2 * L - 1 - (s[i - 1].gPos + s[i - 1].gLen); }
+            int64_t d = g2 - g1; if (d < 0) d = -d;
+            if (d < pr.min_intron) continue;
+            if (pass == 1) { SjT t; t.g1 = g1; t.g2 = g2; t.type = c.SJtype; t.read_idx = read_idx; sjpool[off + k] = t; }
+            k++;
+        }
+        cnt = k;
+    }
+}

@@ -1,0 +1,245 @@
+"""ctypes binding of libdartgpu.so (include/dartgpu.h) plus the index loader.
+
+Python here is plumbing for tests and bench.py; the product's host program is the C++ `dart`
+command line (dart_amd/csrc/host/).  There is no CPU fallback: if libdartgpu.so is missing or no
+HIP device is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdartgpu.so")
+
+
+class IndexView(C.Structure):
+    _fields_ = [("bwt", C.c_void_p), ("bwt_words", C.c_uint64), ("primary", C.c_uint64), ("L2", C.c_uint64 * 5),
+                ("seq_len", C.c_uint64), ("sa", C.c_void_p), ("n_sa", C.c_uint64), ("sa_intv", C.c_int32),
+                ("pac", C.c_void_p), ("l_pac", C.c_int64), ("n_chr", C.c_int32), ("chr_off", C.c_void_p),
+                ("chr_len", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("max_gaps", "max_dup", "max_intron", "min_intron", "max_mismatch",
+                                          "multi_hit", "all_sj", "paired")]
+
+
+READ_OUT = np.dtype([("score", "<i4"), ("sub_score", "<i4"), ("mis_num", "<i4"), ("mapq", "<i4"), ("n_rep", "<i4"),
+                     ("best", "<i4"), ("rep_off", "<i4"), ("sj_off", "<i4"), ("n_sj", "<i4")])
+REPORT_OUT = np.dtype([("aln_score", "<i4"), ("sj_type", "<i4"), ("flag", "<i4"), ("paired_idx", "<i4"), ("chr", "<i4"),
+                       ("bdir", "<i4"), ("pos", "<i8"), ("cigar_off", "<u4"), ("n_cigar", "<u4")])
+SJ_OUT = np.dtype([("g1", "<i8"), ("g2", "<i8"), ("type", "<i4"), ("read_idx", "<i4")])
+assert READ_OUT.itemsize == 36 and REPORT_OUT.itemsize == 40 and SJ_OUT.itemsize == 24
+
+
+class Index:
+    """The BWA-format index files as the reference loads them (bwt_index.cpp:15-35,102-121,229-251)."""
+
+    def __init__(self, prefix: str):
+        self.prefix = prefix
+        raw = np.fromfile(prefix + ".bwt", dtype=np.uint8)
+        hdr = raw[:40].view(np.uint64)
+        self.primary = int(hdr[0])
+        self.L2 = [0] + [int(x) for x in hdr[1:5]]
+        self.seq_len = self.L2[4]
+        self.bwt = np.ascontiguousarray(raw[40:]).view(np.uint32)
+        sa_raw = np.fromfile(prefix + ".sa", dtype=np.uint64)
+        self.sa_intv = int(sa_raw[5])
+        self.n_sa = (self.seq_len + self.sa_intv) // self.sa_intv
+        sa = np.empty(self.n_sa, dtype=np.uint64)
+        sa[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        sa[1:] = sa_raw[7:7 + self.n_sa - 1]
+        self.sa = sa
+        self.pac = np.fromfile(prefix + ".pac", dtype=np.uint8)
+        with open(prefix + ".ann") as f:
+            first = f.readline().split()
+            self.l_pac, n = int(first[0]), int(first[1])
+            self.names, lens = [], []
+            for _ in range(n):
+                self.names.append(f.readline().split()[1])
+                lens.append(int(f.readline().split()[1]))
+        self.chr_len = np.asarray(lens, dtype=np.int64)
+        self.chr_off = np.concatenate([[0], np.cumsum(self.chr_len)[:-1]]).astype(np.int64)
+
+    def view(self) -> IndexView:
+        v = IndexView()
+        v.bwt = self.bwt.ctypes.data; v.bwt_words = self.bwt.size; v.primary = self.primary
+        for i in range(5):
+            v.L2[i] = self.L2[i]
+        v.seq_len = self.seq_len; v.sa = self.sa.ctypes.data; v.n_sa = self.n_sa; v.sa_intv = self.sa_intv
+        v.pac = self.pac.ctypes.data; v.l_pac = self.l_pac; v.n_chr = len(self.names)
+        v.chr_off = self.chr_off.ctypes.data; v.chr_len = self.chr_len.ctypes.data
+        return v
+
+
+def pack_reads(seqs):
+    """list of bytes / 2-D uint8 array -> (seq_off u32, rlen u16, flat uint8)."""
+    if isinstance(seqs, np.ndarray) and seqs.ndim == 2:
+        n, l = seqs.shape
+        return (np.arange(n, dtype=np.uint32) * np.uint32(l)), np.full(n, l, dtype=np.uint16), np.ascontiguousarray(seqs).reshape(-1)
+    lens = np.asarray([len(s) for s in seqs], dtype=np.uint16)
+    off = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]]).astype(np.uint32) if len(seqs) else np.zeros(0, np.uint32)
+    flat = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if len(seqs) else np.zeros(0, np.uint8)
+    return off, lens, flat
+
+
+def interleave_pairs(m1: np.ndarray, m2: np.ndarray) -> np.ndarray:
+    """mate 1 rows / mate 2 rows -> [2n, rlen] with mate 2 reverse-complemented the way the
+    reference's loader does (GetData.cpp:157-162: anything but ACGT/acgt becomes 'N')."""
+    comp = np.full(256, ord("N"), dtype=np.uint8)
+    for a, b in zip(b"ACGTacgt", b"TGCATGCA"):
+        comp[a] = b
+    out = np.empty((2 * m1.shape[0], m1.shape[1]), dtype=np.uint8)
+    out[0::2] = m1
+    out[1::2] = comp[m2[:, ::-1]]
+    return out
+
+
+def _load_lib():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libdartgpu.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.dg_init.restype = C.c_void_p
+    lib.dg_init.argtypes = [C.POINTER(IndexView), C.POINTER(Params), C.c_int, C.POINTER(C.c_int)]
+    lib.dg_last_error.restype = C.c_char_p
+    lib.dg_last_error.argtypes = [C.c_void_p]
+    lib.dg_destroy.argtypes = [C.c_void_p]
+    lib.dg_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+    lib.dg_params_default.argtypes = [C.POINTER(Params)]
+    vp = C.c_void_p
+    lib.dg_map_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.dg_batch_upload.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.dg_batch_run.argtypes = [vp, vp]
+    lib.dg_batch_download.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dg_last_timings.argtypes = [vp, vp, vp, C.c_int]
+    lib.dg_last_counters.argtypes = [vp, vp, C.c_int]
+    lib.dg_probe_seeds.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.dg_probe_nw.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t]
+    return lib
+
+
+def default_params(**kw) -> Params:
+    p = Params(5, 100, 500000, 5, 0, 0, 0, 0)
+    for k, v in kw.items():
+        setattr(p, k, int(v))
+    return p
+
+
+class BatchResult:
+    def __init__(self, reads, reports, cigar, sj):
+        self.reads, self.reports, self.cigar, self.sj = reads, reports, cigar, sj
+
+    def cigar_string(self, rep_index: int) -> str:
+        r = self.reports[rep_index]
+        ops = self.cigar[r["cigar_off"]: r["cigar_off"] + r["n_cigar"]]
+        return "".join("%d%s" % (o >> 4, "MIDNS"[o & 15]) for o in ops)
+
+
+class DartGPU:
+    """dg_ctx wrapper: DART's per-read mapping path on one MI355X."""
+
+    def __init__(self, index: Index, params: Params | None = None, device: int = 0):
+        self.lib = _load_lib()
+        self.index = index
+        self.params = params or default_params()
+        st = C.c_int(0)
+        v = index.view()
+        self.ctx = self.lib.dg_init(C.byref(v), C.byref(self.params), device, C.byref(st))
+        if not self.ctx:
+            raise RuntimeError("dg_init failed (%d): %s" % (st.value, (self.lib.dg_last_error(None) or b"").decode()))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.dg_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, (self.lib.dg_last_error(self.ctx) or b"").decode()))
+
+    def set_params(self, params: Params):
+        self.params = params
+        self._chk(self.lib.dg_set_params(self.ctx, C.byref(params)), "dg_set_params")
+
+    def upload(self, seq_off, rlen, flat):
+        self._n = len(rlen)
+        self._keep = (np.ascontiguousarray(seq_off, np.uint32), np.ascontiguousarray(rlen, np.uint16), np.ascontiguousarray(flat, np.uint8))
+        a, b, c = self._keep
+        self._chk(self.lib.dg_batch_upload(self.ctx, self._n, a.ctypes.data, b.ctypes.data, c.ctypes.data), "dg_batch_upload")
+
+    def run(self):
+        used = (C.c_size_t * 3)()
+        self._chk(self.lib.dg_batch_run(self.ctx, used), "dg_batch_run")
+        self._used = [int(x) for x in used]
+        return self._used
+
+    def download(self) -> BatchResult:
+        u = self._used
+        reads = np.zeros(self._n, dtype=READ_OUT)
+        reports = np.zeros(max(u[0], 1), dtype=REPORT_OUT)
+        cigar = np.zeros(max(u[1], 1), dtype=np.uint32)
+        sj = np.zeros(max(u[2], 1), dtype=SJ_OUT)
+        caps = (C.c_size_t * 3)(len(reports), len(cigar), len(sj))
+        self._chk(self.lib.dg_batch_download(self.ctx, reads.ctypes.data, reports.ctypes.data, cigar.ctypes.data, sj.ctypes.data, caps), "dg_batch_download")
+        return BatchResult(reads, reports[:u[0]], cigar[:u[1]], sj[:u[2]])
+
+    def map_batch(self, seq_off, rlen, flat) -> BatchResult:
+        self.upload(seq_off, rlen, flat)
+        self.run()
+        return self.download()
+
+    def timings(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = self.lib.dg_last_timings(self.ctx, names, ms, 16)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    def counters(self):
+        out = (C.c_uint64 * 16)()
+        n = self.lib.dg_last_counters(self.ctx, out, 16)
+        keys = ["steps", "occ_blocks", "lf_steps", "sa_lookups", "seeds", "candidates", "nw_calls", "nw_cells", "reseed_calls", "reseed_window"]
+        return {keys[i]: int(out[i]) for i in range(min(n, len(keys)))}
+
+    def probe_seeds(self, seq_off, rlen, flat):
+        n = len(rlen)
+        a, b, c = np.ascontiguousarray(seq_off, np.uint32), np.ascontiguousarray(rlen, np.uint16), np.ascontiguousarray(flat, np.uint8)
+        cap = max(1024, n * 64)
+        while True:
+            so = np.zeros(n + 1, np.uint32); rp = np.zeros(cap, np.int32); sl = np.zeros(cap, np.int32); gp = np.zeros(cap, np.int64)
+            used = C.c_size_t(0)
+            rc = self.lib.dg_probe_seeds(self.ctx, n, a.ctypes.data, b.ctypes.data, c.ctypes.data, so.ctypes.data, rp.ctypes.data,
+                                         sl.ctypes.data, gp.ctypes.data, cap, C.byref(used))
+            if rc == -4:
+                cap = int(used.value) + 16
+                continue
+            self._chk(rc, "dg_probe_seeds")
+            u = int(used.value)
+            return so, rp[:u], sl[:u], gp[:u]
+
+    def probe_nw(self, pairs):
+        n = len(pairs)
+        a_off = np.zeros(n + 1, np.uint32); b_off = np.zeros(n + 1, np.uint32)
+        for i, (x, y) in enumerate(pairs):
+            a_off[i + 1] = a_off[i] + len(x); b_off[i + 1] = b_off[i] + len(y)
+        a = np.frombuffer(b"".join(p[0] for p in pairs) + b"\0", dtype=np.uint8).copy()
+        b = np.frombuffer(b"".join(p[1] for p in pairs) + b"\0", dtype=np.uint8).copy()
+        cap = int(a_off[n]) + int(b_off[n]) + 16
+        out_off = np.zeros(n + 1, np.uint32); out_len = np.zeros(n + 1, np.uint32)
+        oa = np.zeros(cap, np.uint8); ob = np.zeros(cap, np.uint8)
+        self._chk(self.lib.dg_probe_nw(self.ctx, n, a_off.ctypes.data, b_off.ctypes.data, a.ctypes.data, b.ctypes.data, out_off.ctypes.data,
+                                       out_len.ctypes.data, oa.ctypes.data, ob.ctypes.data, cap), "dg_probe_nw")
+        res = []
+        for i in range(n):
+            o, l = int(out_off[i]), int(out_len[i])
+            res.append((oa[o:o + l].tobytes(), ob[o:o + l].tobytes()))
+        return res

@@ -1,0 +1,111 @@
+/* include/dartgpu.h -- C ABI of libdartgpu.so: DART's per-read mapping path on one MI355X.
+ *
+ * The drop-in seam is the chunk body of the reference's ReadMapping (Mapping.cpp:598-643):
+ * a batch of reads goes in, and for every read the fields that the reference leaves in
+ * ReadItem_t (structure.h:149-164: score, sub_score, mis_num, mapq, CanNum, iBestAlnCanIdx,
+ * AlnReportArr[]) plus the splice-junction tuples UpdateLocalSJMap (Mapping.cpp:532-565) would
+ * have added come out as flat records.  Plain pointers and sizes only; the library owns all
+ * device memory; the caller owns the host arrays.  Every entry point returns 0 on success or a
+ * negative dg_status; nothing here ever exits the process (the reference's only error
+ * behaviour on this path is exit(1) in main.cpp:199-227, which stays in the host program).
+ *
+ * There is no CPU fallback: without a HIP device dg_init fails with DG_ERR_NO_DEVICE.
+ */
+#ifndef DARTGPU_H
+#define DARTGPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dg_ctx dg_ctx;
+
+enum dg_status {
+    DG_OK = 0,
+    DG_ERR_NO_DEVICE = -1,   /* no HIP device / device index out of range                 */
+    DG_ERR_HIP = -2,         /* a HIP call failed; text in dg_last_error                  */
+    DG_ERR_ARG = -3,         /* bad argument (NULL, read longer than DG_MAX_RLEN, ...)    */
+    DG_ERR_CAPACITY = -4,    /* caller's output arrays too small; `used` holds the need   */
+    DG_ERR_INTERNAL = -5
+};
+
+#define DG_MAX_RLEN 1000     /* the reference's gz reader caps lines at 1024 bytes (GetData.cpp:186) */
+
+/* The index exactly as the reference loads it (bwt_index.cpp:15-35,102-121,147-159,229-251):
+ *   bwt   = contents of PREFIX.bwt after its 40-byte header (Occ-interleaved, 64 B per 128 rows)
+ *   sa    = sa[0..n_sa): sa[0] = (uint64)-1, sa[i] = contents of PREFIX.sa after its 56-byte header
+ *   pac   = PREFIX.pac, forward strand, 2 bits/base, MSB first
+ *   chr_* = per chromosome offset in the forward concatenation and length (PREFIX.ann)        */
+typedef struct {
+    const uint32_t *bwt; uint64_t bwt_words, primary, L2[5], seq_len;
+    const uint64_t *sa;  uint64_t n_sa; int32_t sa_intv;
+    const uint8_t  *pac; int64_t l_pac;
+    int32_t n_chr; const int64_t *chr_off; const int64_t *chr_len;
+} dg_index_view;
+
+/* Globals of the reference that steer the path (main.cpp:101-117,169-192) */
+typedef struct {
+    int32_t max_gaps;      /* MaxGaps       = 5       */
+    int32_t max_dup;       /* MaxDupNum     = 100     (-max_dup, 100..10000)  */
+    int32_t max_intron;    /* MaxIntronSize = 500000  (-max_intron)           */
+    int32_t min_intron;    /* MinIntronSize = 5       (-min_intron)           */
+    int32_t max_mismatch;  /* MaxMismatch   = 0       (-mis)                  */
+    int32_t multi_hit;     /* bMultiHit               (-m)                    */
+    int32_t all_sj;        /* bFindAllJunction        (-all_sj)               */
+    int32_t paired;        /* bPairEnd: reads 2i,2i+1 are mates; mate 2 already
+                              reverse-complemented as GetData.cpp:157-162 does */
+} dg_params;
+
+/* ReadItem_t after ReadMapping's per-read work (structure.h:149-164) */
+typedef struct { int32_t score, sub_score, mis_num, mapq, n_rep, best, rep_off, sj_off, n_sj; } dg_read_out;
+/* AlignmentReport_t + Coordinate_t (structure.h:117-141); CIGAR as BAM-style ops len<<4|op,
+ * op: M=0 I=1 D=2 N=3 S=4, already merged as GenerateCIGAR does (AlignmentCandidates.cpp:37-61) */
+typedef struct { int32_t aln_score, sj_type, flag, paired_idx, chr, bdir; int64_t pos; uint32_t cigar_off, n_cigar; } dg_report_out;
+/* one UpdateLocalSJMap key (Mapping.cpp:545-556): forward-strand g1,g2 and the SJ type */
+typedef struct { int64_t g1, g2; int32_t type, read_idx; } dg_sj_out;
+
+void        dg_params_default(dg_params *);
+/* uploads the index to device `device` (0-based HIP ordinal) and builds the device-side layout */
+dg_ctx     *dg_init(const dg_index_view *, const dg_params *, int device, int *status);
+void        dg_destroy(dg_ctx *);
+const char *dg_last_error(const dg_ctx *);   /* NULL ctx: error of the last failed dg_init */
+int         dg_set_params(dg_ctx *, const dg_params *);
+
+/* ---- the path: host buffers in, host records out (replaces Mapping.cpp:598-639) ----
+ * read i = seq[seq_off[i] .. +rlen[i]) ASCII as read from the file.
+ * caps/used index: 0 = reports, 1 = cigar ops, 2 = sj tuples.                               */
+int dg_map_batch(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
+                 dg_read_out *, dg_report_out *, uint32_t *cigar_ops, dg_sj_out *,
+                 const size_t caps[3], size_t used[3]);
+
+/* ---- the same path split so a caller can keep the batch resident in HBM (bench.py) ----
+ * dg_batch_upload copies reads to the device; dg_batch_run runs the whole path on the device
+ * leaving the result records in HBM (sizes in `used`); dg_batch_download copies them out.     */
+int dg_batch_upload(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq);
+int dg_batch_run(dg_ctx *, size_t used[3]);
+int dg_batch_download(dg_ctx *, dg_read_out *, dg_report_out *, uint32_t *cigar_ops, dg_sj_out *, const size_t caps[3]);
+
+/* per-kernel device time of the last dg_batch_run, measured with HIP events on the library's
+ * stream: names[i] -> ms[i]; returns the number of entries written (<= cap)                   */
+int dg_last_timings(dg_ctx *, const char **names, float *ms, int cap);
+/* work counters of the last run: [0] Occ-pair steps [1] Occ blocks touched [2] LF steps
+ * [3] SA lookups [4] seeds [5] candidates [6] NW calls [7] NW cells [8] reseed calls
+ * [9] reseed window bases                                                                    */
+int dg_last_counters(dg_ctx *, uint64_t *out, int cap);
+
+/* ---- stage probes (parity tests of single kernels; mirror oracle/dart_oracle.h) ----
+ * seeds of every read after the (gPos,rPos) sort (IdentifySeedPairs, AlignmentCandidates.cpp:181-215):
+ * read i owns [seed_off[i], seed_off[i+1]) of rpos/slen/gpos; seed_off has n_reads+1 entries. */
+int dg_probe_seeds(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
+                   uint32_t *seed_off, int32_t *rpos, int32_t *slen, int64_t *gpos, size_t cap, size_t *used);
+/* nw_alignment (nw_alignment.cpp:18-82) of n pairs: a[i]=s[a_off[i]..a_off[i+1]) etc.; outputs are
+ * NUL-free gapped strings of equal length out_len[i] at out_a/out_b + out_off[i] (cap each = sum of lengths) */
+int dg_probe_nw(dg_ctx *, int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b,
+                uint32_t *out_off, uint32_t *out_len, char *out_a, char *out_b, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
