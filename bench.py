@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- DART's per-read mapping hot path on N MI355X (one process per GPU).
+
+A "step" is one pass of the hot path (seed -> locate -> chain -> report) over one batch of
+synthetic 2x101 bp pairs that is already resident in HBM.  Workload at N=1: BASELINE.json
+configs[1], "GRCh38 chr20 index, 1 M paired-end 2x101 bp synthetic reads" -- a chr20-SIZED
+synthetic genome (real GRCh38 is unobtainable offline).  For N>1 every rank maps its
+own 1 M pairs (weak scaling: reads shard with no data-path collective) and the per-read records
+are gathered to rank 0 over RCCL inside the timed region (the SAM-order gather of north_star).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant
+kernel, live HIP-event time vs algorithmic bytes) and `cpu_baseline` (the oracle timed on a bounded
+sample of the same reads on the host cores; a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from dart_amd import synth, index_build, host
+
+CHR20_LEN = 64444167
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def prepare_index(cache_dir, genome_len, rank, barrier):
+    prefix = os.path.join(cache_dir, "g%d" % genome_len)
+    done = prefix + ".done"
+    if rank == 0 and not os.path.exists(done):
+        os.makedirs(cache_dir, exist_ok=True)
+        t = time.time()
+        g = synth.make_genome([genome_len], seed=20, repeat_scale=1.0, n_introns=0, names=["chr20"])
+        np.save(prefix + ".codes.npy", g.codes)
+        log("[bench] genome %d bp generated in %.1f s" % (genome_len, time.time() - t))
+        t = time.time()
+        index_build.build_index_from_genome(g, prefix)
+        torch.cuda.empty_cache()
+        log("[bench] index built in %.1f s" % (time.time() - t))
+        open(done, "w").write("ok")
+    barrier()
+    codes = np.load(prefix + ".codes.npy")
+    g = synth.Genome(["chr20"], [genome_len], codes, np.zeros((0, 3), np.int64))
+    return prefix, g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=1000000, help="pairs per GPU per step")
+    ap.add_argument("--genome", type=int, default=CHR20_LEN)
+    ap.add_argument("--mis", type=int, default=5, help="-mis N (MaxMismatch); the reference default is 0, see DESIGN.md")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=150000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache", default=os.environ.get("DART_BENCH_CACHE", "/tmp/dart_bench_cache"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    prefix, g = prepare_index(args.cache, args.genome, rank, barrier)
+    ix = host.Index(prefix)
+    params = host.default_params(paired=1, max_mismatch=args.mis)
+    gpu = host.DartGPU(ix, params, device=local)
+
+    t = time.time()
+    m1, m2 = synth.make_reads(g, args.pairs, rlen=101, seed=1000 + rank, sub_rate=0.01, indel_frac=0.02, n_frac=0.002)
+    arr = host.interleave_pairs(m1, m2)
+    so, rl, flat = host.pack_reads(arr)
+    gpu.upload(so, rl, flat)                       # inputs resident in HBM before the timed region
+    if rank == 0:
+        log("[bench] %d pairs generated + uploaded in %.1f s" % (args.pairs, time.time() - t))
+
+    gather_buf = None
+    def step():
+        gpu.run()
+        if dist is not None:                       # SAM-order gather of the per-read records to rank 0
+            nonlocal gather_buf
+            local_t = gpu.device_reads_tensor()
+            if rank == 0 and gather_buf is None:
+                gather_buf = [torch.empty_like(local_t) for _ in range(world)]
+            dist.gather(local_t, gather_buf if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    barrier(); torch.cuda.synchronize()
+    acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for name, ms in gpu.timings():
+            acc[name] = acc.get(name, 0.0) + ms
+    barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    counters = gpu.counters()
+    kern = {k: v / args.steps for k, v in acc.items()}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    reads_per_step = 2 * args.pairs * world
+    value = reads_per_step * args.steps / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel: algorithmic bytes (reference algorithm + layout,
+    #      SURVEY 8d) of one launch / its mean HIP-event duration ----
+    n_reads = 2 * args.pairs
+    alg = {
+        "k_seed": 64 * counters["occ_blocks"] + int(rl.sum()) + 16 * n_reads,
+        "k_locate": 64 * counters["lf_steps"] + 8 * counters["sa_lookups"] + 24 * counters["seeds"],
+    }
+    dom = max(("k_seed", "k_locate", "k_chain", "k_report"), key=lambda k: kern.get(k, 0.0))
+    per_read_B = (alg["k_seed"] + alg["k_locate"]) / n_reads
+    dom_bytes = alg.get(dom)
+    if dom_bytes is None:      # report/chain kernels: count the whole path's index bytes against them is wrong -> use their own I/O
+        dom_bytes = 24 * counters["seeds"] * 3 + 40 * n_reads
+    achieved = dom_bytes / (kern[dom] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(dom_bytes), "kernel_ms": round(kern[dom], 4),
+                "fm_bytes_per_read": round(per_read_B, 1)}
+
+    # ---- CPU baseline: the oracle ("port") on a bounded sample of the same reads, all host cores ----
+    cpu = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_py
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        ns = min(args.cpu_sample_pairs, args.pairs) * 2
+        orc = oracle_py.Oracle(prefix)
+        t = time.perf_counter()
+        o_reads, o_rep, o_cig, o_sj = orc.map_batch(orc.params(paired=1, max_mismatch=args.mis), so[:ns], rl[:ns], flat, threads=cores)
+        dt = time.perf_counter() - t
+        # parity on the sample (outside every timed region): GPU records of the first ns reads
+        res = gpu.download()
+        same = bool(np.array_equal(o_reads[["score", "sub_score", "mis_num", "mapq", "n_rep", "best", "n_sj"]],
+                                   res.reads[:ns][["score", "sub_score", "mis_num", "mapq", "n_rep", "best", "n_sj"]]))
+        nrep = int(o_reads["rep_off"][-1] + o_reads["n_rep"][-1])
+        same = same and bool(np.array_equal(o_rep[["aln_score", "sj_type", "flag", "paired_idx", "chr", "bdir", "pos", "n_cigar"]],
+                                            res.reports[:nrep][["aln_score", "sj_type", "flag", "paired_idx", "chr", "bdir", "pos", "n_cigar"]]))
+        same = same and bool(np.array_equal(o_cig, res.cigar[:len(o_cig)]))
+        cpu = {"value": round(ns / dt / 1e6, 5), "unit": "M reads/s", "cores": cores, "kind": "port",
+               "sample": "first %d pairs of the GPU batch, oracle/dart_oracle.c with %d threads, %.1f s wall" % (ns // 2, cores, dt),
+               "gpu_records_identical_on_sample": same}
+        log("[bench] oracle counters on sample:", orc.counters)
+
+    line = {
+        "metric": "M paired-end reads/sec (2x101 bp), hot path seed->locate->chain->report, records bit-identical to CPU dart",
+        "value": round(value, 4), "unit": "M reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64/u8 integer", "data": "synthetic",
+        "config": {"workload": "chr20-sized synthetic genome (%d bp, i.i.d. + planted repeats), %d pairs 2x101 bp per GPU, -mis %d"
+                               % (args.genome, args.pairs, args.mis),
+                   "pairs_per_gpu": args.pairs, "read_len": 101, "parallelism": "reads sharded x%d, RCCL gather of records" % world},
+        "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
+        "counters_per_launch": counters,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -462,6 +462,13 @@ extern "C" int dg_map_batch(dg_ctx *c, int n_reads, const uint32_t *seq_off, con
     return dg_batch_download(c, ro, po, cig, so, caps);
 }
 
+extern "C" int dg_batch_device_ptrs(dg_ctx *c, void *ptrs[4])
+{
+    if (!c || !ptrs) return DG_ERR_ARG;
+    ptrs[0] = c->reads_out.p; ptrs[1] = c->reports.p; ptrs[2] = c->cigfinal.p; ptrs[3] = c->sjfinal.p;
+    return DG_OK;
+}
+
 extern "C" int dg_last_timings(dg_ctx *c, const char **names, float *ms, int cap)
 {
     if (!c) return 0;

@@ -115,6 +115,7 @@ def _load_lib():
     lib.dg_batch_upload.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.dg_batch_run.argtypes = [vp, vp]
     lib.dg_batch_download.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dg_batch_device_ptrs.argtypes = [vp, vp]
     lib.dg_last_timings.argtypes = [vp, vp, vp, C.c_int]
     lib.dg_last_counters.argtypes = [vp, vp, C.c_int]
     lib.dg_probe_seeds.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
@@ -197,6 +198,18 @@ class DartGPU:
         self.upload(seq_off, rlen, flat)
         self.run()
         return self.download()
+
+    def device_reads_tensor(self):
+        """torch uint8 view [n_reads, 36] of the per-read records in HBM (for RCCL collectives)."""
+        import torch
+        ptrs = (C.c_void_p * 4)()
+        self._chk(self.lib.dg_batch_device_ptrs(self.ctx, ptrs), "dg_batch_device_ptrs")
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (self._n, READ_OUT.itemsize), "typestr": "|u1", "data": (int(ptrs[0]), False), "version": 2}
+        return torch.as_tensor(v, device="cuda")
 
     def timings(self):
         names = (C.c_char_p * 16)()

@@ -87,6 +87,11 @@ int dg_batch_upload(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16
 int dg_batch_run(dg_ctx *, size_t used[3]);
 int dg_batch_download(dg_ctx *, dg_read_out *, dg_report_out *, uint32_t *cigar_ops, dg_sj_out *, const size_t caps[3]);
 
+/* raw device pointers of the last run's records (valid until the next upload/run on this ctx):
+ * ptrs[0] dg_read_out[n_reads], [1] dg_report_out[used0], [2] cigar u32[used1], [3] dg_sj_out[used2].
+ * Lets a caller hand the records to RCCL (torch.distributed) without a host round trip.       */
+int dg_batch_device_ptrs(dg_ctx *, void *ptrs[4]);
+
 /* per-kernel device time of the last dg_batch_run, measured with HIP events on the library's
  * stream: names[i] -> ms[i]; returns the number of entries written (<= cap)                   */
 int dg_last_timings(dg_ctx *, const char **names, float *ms, int cap);

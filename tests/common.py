@@ -1,0 +1,89 @@
+"""Shared helpers of the test-suite: golden cases rebuilt from their seeds, flag parsing, SAM text."""
+from __future__ import annotations
+
+import gzip, hashlib, json, os, sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
+sys.path.insert(0, ROOT)
+from dart_amd import synth, index_build, host, sam  # noqa: E402
+
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+_cache = {}
+
+
+def sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def build_case(name: str, workdir: str):
+    """Regenerates a golden case's inputs from its seeds; builds its index with our own builder."""
+    if name in _cache:
+        return _cache[name]
+    spec = MANIFEST["cases"][name]
+    g = synth.make_genome(spec["lengths"], seed=spec["gseed"], repeat_scale=spec["rscale"], n_introns=spec["nintr"])
+    m1, m2 = synth.make_reads(g, spec["npairs"], rlen=spec["rlen"], seed=spec["rseed"], spliced_frac=spec["spliced"],
+                              paired=spec["paired"], sub_rate=spec["sub"], indel_frac=0.05, n_frac=0.01)
+    h = hashlib.sha256()
+    for a in (g.codes, m1, m2):
+        if a is not None:
+            h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == MANIFEST["manifest"][name]["inputs_sha256"], "synthetic generator drifted from the golden inputs"
+    prefix = os.path.join(workdir, name)
+    index_build.build_index_from_genome(g, prefix, device="cpu")
+    arr = host.interleave_pairs(m1, m2) if spec["paired"] else m1
+    n = arr.shape[0]
+    if spec["paired"]:
+        headers = ["r%d" % (i // 2) for i in range(n)]
+    else:
+        headers = ["r%d" % i for i in range(n)]
+    case = dict(name=name, spec=spec, genome=g, m1=m1, m2=m2, prefix=prefix, reads=arr, headers=headers,
+                seqs=[arr[i].tobytes().decode() for i in range(n)], quals=["I" * arr.shape[1]] * n,
+                runs=MANIFEST["manifest"][name]["runs"], index_sha=MANIFEST["manifest"][name]["index_sha256"])
+    _cache[name] = case
+    return case
+
+
+def parse_flags(flags):
+    """DART command-line flags -> (path params, host-only options)  (main.cpp:169-192)."""
+    p = dict(max_gaps=5, max_dup=100, max_intron=500000, min_intron=5, max_mismatch=0, multi_hit=0, all_sj=0)
+    h = dict(unique=False)
+    i = 0
+    while i < len(flags):
+        f = flags[i]
+        if f == "-mis": p["max_mismatch"] = int(flags[i + 1]); i += 1
+        elif f == "-max_dup": p["max_dup"] = min(max(int(flags[i + 1]), 100), 10000); i += 1
+        elif f == "-max_intron": p["max_intron"] = max(int(flags[i + 1]), 100000); i += 1
+        elif f == "-min_intron": p["min_intron"] = int(flags[i + 1]); i += 1
+        elif f == "-m": p["multi_hit"] = 1
+        elif f == "-all_sj": p["all_sj"] = 1
+        elif f == "-unique": h["unique"] = True
+        else: raise ValueError(f)
+        i += 1
+    return p, h
+
+
+def golden_sam(base):
+    return gzip.open(os.path.join(GOLDEN, base + ".sam.gz"), "rb").read().decode()
+
+
+def golden_junctions(base):
+    return open(os.path.join(GOLDEN, base + ".junctions.tab")).read()
+
+
+def records_to_text(case, params, hostopts, reads, reports, cigar, sj, ix: host.Index):
+    body = sam.format_records(case["headers"], case["seqs"], case["quals"], reads, reports, cigar, ix.names,
+                              paired=case["spec"]["paired"], multi_hit=bool(params["multi_hit"]), unique_only=hostopts["unique"])
+    text = sam.sam_header(ix.names, ix.chr_len) + body
+    junc = sam.junction_table(sj, ix.names, ix.chr_off, ix.chr_len, ix.l_pac)
+    return text, junc
+
+
+def first_diff(a: str, b: str):
+    la, lb = a.split("\n"), b.split("\n")
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return "line %d:\n  got      %s\n  expected %s" % (i, x[:240], y[:240])
+    return "length differs: %d vs %d lines" % (len(la), len(lb))

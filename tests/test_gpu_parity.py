@@ -1,0 +1,135 @@
+"""GPU suite (-m gpu): the HIP path through the C ABI against the oracle and the golden vectors."""
+import gzip, os
+import numpy as np
+import pytest
+import common, oracle_py
+from dart_amd import host, synth, index_build
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(common.MANIFEST["cases"])
+
+
+@pytest.fixture(scope="module")
+def ctxs(workdir):
+    out = {}
+    for name in CASES:
+        c = common.build_case(name, workdir)
+        ix = host.Index(c["prefix"])
+        out[name] = (c, ix, host.DartGPU(ix), oracle_py.Oracle(c["prefix"]))
+    yield out
+    for c, ix, gpu, orc in out.values():
+        gpu.close(); orc.close()
+
+
+def assert_same(res, ores):
+    reads, rep, cig, sj = ores
+    for f in reads.dtype.names:
+        assert np.array_equal(reads[f], res.reads[f]), "read field %s differs at %s" % (f, np.nonzero(reads[f] != res.reads[f])[0][:5])
+    assert len(rep) == len(res.reports)
+    for f in rep.dtype.names:
+        assert np.array_equal(rep[f], res.reports[f]), "report field %s differs at %s" % (f, np.nonzero(rep[f] != res.reports[f])[0][:5])
+    assert np.array_equal(cig, res.cigar)
+    assert np.array_equal(sj, res.sj)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_matches_golden_sam(name, ctxs):
+    c, ix, gpu, orc = ctxs[name]
+    so, rl, flat = host.pack_reads(c["reads"])
+    for run in c["runs"]:
+        p, h = common.parse_flags(run["flags"])
+        gpu.set_params(host.default_params(paired=int(c["spec"]["paired"]), **p))
+        res = gpu.map_batch(so, rl, flat)
+        text, junc = common.records_to_text(c, p, h, res.reads, res.reports, res.cigar, res.sj, ix)
+        want = common.golden_sam(run["base"])
+        assert text == want, common.first_diff(text, want)
+        assert junc == common.golden_junctions(run["base"])
+        assert_same(res, orc.map_batch(orc.params(paired=int(c["spec"]["paired"]), **p), so, rl, flat))
+
+
+def test_gpu_nw_known_answers(ctxs):
+    c, ix, gpu, orc = ctxs["se100"]
+    pairs, want = [], []
+    for line in gzip.open(os.path.join(common.GOLDEN, "nw_known_answers.tsv.gz"), "rt"):
+        a, b, o1, o2 = line.rstrip("\n").split("\t")
+        pairs.append((a.encode(), b.encode())); want.append((o1.encode(), o2.encode()))
+    assert gpu.probe_nw(pairs) == want
+
+
+def test_gpu_seeds_match_oracle(ctxs):
+    for name in CASES:
+        c, ix, gpu, orc = ctxs[name]
+        so, rl, flat = host.pack_reads(c["reads"])
+        gso, grp, gsl, ggp = gpu.probe_seeds(so, rl, flat)
+        for i in range(0, len(rl), 7):
+            rp, sl, gp = orc.seeds(orc.params(), c["reads"][i].tobytes())
+            a, b = gso[i], gso[i + 1]
+            assert np.array_equal(rp, grp[a:b]) and np.array_equal(sl, gsl[a:b]) and np.array_equal(gp, ggp[a:b]), (name, i)
+
+
+def test_gpu_edge_cases(ctxs):
+    """empty batch, ragged lengths, reads shorter than a seed, all-N reads, lower case, odd paired batch"""
+    c, ix, gpu, orc = ctxs["pe101_spliced"]
+    gpu.set_params(host.default_params(paired=1, max_mismatch=5))
+    res = gpu.map_batch(np.zeros(0, np.uint32), np.zeros(0, np.uint16), np.zeros(0, np.uint8))
+    assert len(res.reads) == 0 and len(res.reports) == 0
+    rng = np.random.default_rng(3)
+    asc = c["genome"].ascii()
+    seqs = []
+    for i in range(600):
+        L = int(rng.choice([1, 5, 13, 14, 16, 17, 30, 50, 75, 101, 130, 200, 250]))
+        p = int(rng.integers(0, c["genome"].total - 300))
+        s = bytearray(asc[p:p + L].tobytes())
+        k = i % 6
+        if k == 1: s = bytearray(b"N" * L)
+        elif k == 2: s = bytearray(bytes(s).lower())
+        elif k == 3 and L > 20: s[L // 2] = ord("N"); s[3] = ord("n")
+        elif k == 4 and L > 40: s = s[:20] + bytearray(b"ACGTTGCA") + s[20:]
+        seqs.append(bytes(s))
+    so, rl, flat = host.pack_reads(seqs)
+    for paired in (0, 1):
+        gpu.set_params(host.default_params(paired=paired, max_mismatch=3))
+        assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=paired, max_mismatch=3), so, rl, flat))
+    # odd count in paired mode is mapped read by read (Mapping.cpp:598)
+    gpu.set_params(host.default_params(paired=1, max_mismatch=3))
+    assert_same(gpu.map_batch(so[:-1], rl[:-1], flat), orc.map_batch(orc.params(paired=1, max_mismatch=3), so[:-1], rl[:-1], flat))
+
+
+def test_gpu_medium_batch_all_flag_sets(workdir):
+    """a fresh 3 Mbp genome, 20 k pairs, every flag set of SURVEY 8c"""
+    g = synth.make_genome([2000000, 1000000], seed=31, repeat_scale=50.0, n_introns=400)
+    prefix = os.path.join(workdir, "medium")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); gpu = host.DartGPU(ix); orc = oracle_py.Oracle(prefix)
+    m1, m2 = synth.make_reads(g, 20000, rlen=101, seed=32, spliced_frac=0.2, indel_frac=0.05, n_frac=0.01)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    for flags in ([], ["-mis", "5"], ["-mis", "5", "-m"], ["-mis", "2", "-all_sj", "-max_dup", "1000"], ["-mis", "5", "-min_intron", "10", "-max_intron", "200000"]):
+        p, _ = common.parse_flags(flags)
+        gpu.set_params(host.default_params(paired=1, **p))
+        assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=1, **p), so, rl, flat, threads=16))
+    gpu.close(); orc.close()
+
+
+def test_gpu_size_independent_properties(workdir):
+    """full-size style properties: batch-split invariance and pair-order invariance"""
+    g = synth.make_genome([1500000], seed=41, repeat_scale=30.0, n_introns=100)
+    prefix = os.path.join(workdir, "props")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
+    m1, m2 = synth.make_reads(g, 30000, rlen=101, seed=42, spliced_frac=0.1)
+    arr = host.interleave_pairs(m1, m2)
+    so, rl, flat = host.pack_reads(arr)
+    whole = gpu.map_batch(so, rl, flat)
+    # mapping two halves separately gives the same per-read records
+    h = 30000
+    a = gpu.map_batch(*host.pack_reads(arr[:h])); b = gpu.map_batch(*host.pack_reads(arr[h:]))
+    for f in ("score", "sub_score", "mis_num", "mapq", "n_rep", "best", "n_sj"):
+        assert np.array_equal(np.concatenate([a.reads[f], b.reads[f]]), whole.reads[f])
+    assert np.array_equal(np.concatenate([a.cigar, b.cigar]), whole.cigar)
+    # permuting the pairs permutes the records
+    perm = np.random.default_rng(1).permutation(30000)
+    idx = np.stack([2 * perm, 2 * perm + 1], 1).reshape(-1)
+    pres = gpu.map_batch(*host.pack_reads(arr[idx]))
+    for f in ("score", "sub_score", "mis_num", "mapq", "n_rep", "best"):
+        assert np.array_equal(pres.reads[f], whole.reads[f][idx])
+    gpu.close()
