@@ -5,6 +5,7 @@
 #include "dg_fm.h"
 #include "dg_chain.h"
 #include "dg_report.h"
+#include "dg_reseed.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,7 +44,7 @@ struct dg_ctx {
     DBuf<unsigned char> seq; DBuf<uint32_t> seq_off; DBuf<uint16_t> rlen;
     // pipeline buffers
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, nrep, rep_off, work_need, work_off, tile_sums, tmp_u32, tmp_off;
-    DBuf<DSeed> seeds, work; DBuf<DCand> cands;
+    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<unsigned char> ws;
@@ -161,8 +162,8 @@ __global__ void k_compact_sj(dg_read_out *rd, uint32_t n, const uint32_t *new_of
 __global__ void __launch_bounds__(64)
 k_report(const DIndex ix, const DParams pr, int n_units, int paired, const unsigned char *__restrict__ seq,
          const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ seed_off,
-         const DSeed *__restrict__ seeds, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
-         const uint32_t *__restrict__ rep_off, const uint32_t *__restrict__ work_off, DSeed *__restrict__ work,
+         const DJob *__restrict__ jobs, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
+         const uint32_t *__restrict__ rep_off, DSeed *__restrict__ work,
          dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
          dg_sj_out *sjpool, uint32_t sjcap, unsigned int *tops, unsigned char *ws, const WSLayout L,
          unsigned long long *ctr, int *err)
@@ -184,11 +185,9 @@ k_report(const DIndex ix, const DParams pr, int n_units, int paired, const unsig
             cd[m] = cands + seed_off[r];
             nc[m] = (int)ncand[r];
             rp[m] = reports + rep_off[r];
-            uint32_t wo = work_off[r];
-            for (int i = 0; i < nc[m]; i++) if (cd[m][i].Score > 0) { cd[m][i].work_off = wo; wo += d_work_need(cd[m][i].count); }
             rd[m].sub_score = 0; rd[m].mis_num = 0; rd[m].mapq = 0;      // defined start state
             cx.seq = seq + seq_off[r]; cx.rlen = rlen[r];
-            d_gen_mapping_report(cx, m == 0, rd[m], cd[m], nc[m], seeds, work, rp[m], cigpool, tops + 0, cigcap, err);
+            d_gen_mapping_report(cx, m == 0, rd[m], cd[m], nc[m], jobs, work, rp[m], cigpool, tops + 0, cigcap, err);
         }
         if (paired) {
             d_check_paired_final(pr, rd[0], rp[0], rd[1], rp[1]);
@@ -243,7 +242,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->nrep.release(); c->rep_off.release(); c->work_need.release(); c->work_off.release();
-    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release();
+    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -406,8 +405,16 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     int blocks = c->n_cu * 8;                                        // 8 one-wave workgroups per CU stay resident
     if ((size_t)blocks * 64 > (size_t)n_units) blocks = (n_units + 63) / 64;
     HIPCHK(c->ws.ensure((size_t)blocks * 64 * L.stride));
-    k_report<<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p,
-                                            c->ncand.p, c->rep_off.p, c->work_off.p, c->work.p, c->reads_out.p, c->reports.p, c->cigpool.p,
+    HIPCHK(c->jobs.ensure((size_t)total_seeds + 16));
+    k_prep<<<nb, 256, 0, c->stream>>>(c->pr, n, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work_off.p, c->work.p, c->jobs.p,
+                                        c->d_tops + 2, (uint32_t)c->jobs.cap, c->d_err);
+    HIPCHK(hipGetLastError());
+    TICK("k_prep");
+    k_reseed<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
+    HIPCHK(hipGetLastError());
+    TICK("k_reseed");
+    k_report<<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
+                                            c->ncand.p, c->rep_off.p, c->work.p, c->reads_out.p, c->reports.p, c->cigpool.p,
                                             (uint32_t)cigcap, c->sjpool.p, (uint32_t)sjcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_report");
@@ -434,7 +441,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(hipEventSynchronize(c->ev[c->n_t]));
     for (int i = 0; i < c->n_t; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]); c->tms[i] = ms; }
     c->counters[CTR_SEEDS] = total_seeds;
-    if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == 1 ? "cigar" : "splice junction"); return DG_ERR_INTERNAL; }
+    if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == 1 ? "cigar" : (derr == 2 ? "splice junction" : "reseed jobs")); return DG_ERR_INTERNAL; }
     c->used[0] = total_rep; c->used[1] = total_cig; c->used[2] = total_sj;
     if (used) { used[0] = total_rep; used[1] = total_cig; used[2] = total_sj; }
     return DG_OK;

@@ -78,7 +78,7 @@ __device__ inline int d_gen_candidates(const DIndex &ix, const DParams &pr, int 
             const int64_t pd0 = s[i].gPos - s[i].rPos;
             c.PosDiff = pd0 < 0 ? 0 : pd0;
             c.first = (int32_t)(base + i); c.count = k - i; c.Score = score; c.PairedIdx = -1; c.SJtype = -1;
-            c.work_off = 0; c.final_n = 0; c.pad = 0;
+            c.work_off = 0; c.final_n = 0; c.n_a = 0; c.job_first = 0; c.job_count = 0;
             out[nc++] = c;
         }
         i = k;

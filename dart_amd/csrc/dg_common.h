@@ -33,6 +33,21 @@ struct __attribute__((aligned(8))) DCand {
     int32_t SJtype;
     uint32_t work_off;    // offset of this candidate's private working seed region
     int32_t final_n;      // seeds left in the working region after the report stage
+    int32_t n_a;          // seeds left after the clean-up phase (k_prep)
+    uint32_t job_first;   // this candidate's re-seeding jobs = jobs[job_first .. job_first+job_count)
+    int32_t job_count;
+};
+
+// One ReseedingWithSpecificRegion call (AlignmentCandidates.cpp:596-624), queued by k_prep,
+// executed by one wave in k_reseed, consumed by k_report.
+struct __attribute__((aligned(8))) DJob {
+    int64_t Lb;           // genome window [Lb, Lb+glen)
+    int64_t gPos;         // result: seed genome position
+    int32_t glen;
+    int32_t rBegin, rl;   // read gap [rBegin, rBegin+rl)
+    uint32_t read;        // read index (for the sequence)
+    int32_t found;        // result: 1 = seed accepted
+    int32_t rPos, len;    // result
     int32_t pad;
 };
 

@@ -571,7 +571,7 @@ struct DRead {
 // (n_rep = max(ncand,1)); cands/seeds = this read's candidates and the global seed array;
 // work = global working-seed pool; cigpool/cigtop = bump pool for merged CIGAR ops.
 template <typename ReportT>
-__device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, DCand *cands, int ncand, const DSeed *seeds,
+__device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, DCand *cands, int ncand, const DJob *jobs,
                                             DSeed *work, ReportT *rep, uint32_t *cigpool, unsigned int *cigtop, uint32_t cigcap, int *err)
 {
     const DIndex &ix = *cx.ix;
@@ -591,14 +591,26 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, 
         rp.cigar_off = 0; rp.n_cigar = 0;
         c.final_n = 0;
         if (c.Score == 0) continue;
+        // the working region already went through k_prep (tandem / translocation clean-up);
+        // IdentifyMissingSeeds :685-700: append the seeds k_reseed found, then re-sort
         DSeed *s = work + c.work_off;
-        int n = c.count;
-        for (int q = 0; q < n; q++) s[q] = seeds[c.first + q];
-        int2 *vec = (int2 *)(s + 6 * c.count + 4);       // tail of the working region as int scratch
-        n = d_remove_tandem(s, n, vec);
-        n = d_remove_transloc(s, n, vec);
-        n = d_identify_missing(cx, s, n);
+        int n = c.n_a;
+        {
+            const int num = n;
+            for (int q = 0; q < c.job_count; q++) {
+                const DJob jb = jobs[c.job_first + q];
+                if (jb.found == 1) {
+                    DSeed ns; ns.gPos = jb.gPos; ns.rPos = jb.rPos; ns.rLen = ns.gLen = jb.len; ns.flags = SEED_SIMPLE;
+                    s[n++] = ns;
+                } else if (jb.found < 0) {               // read gap too long for the cooperative kernel
+                    DSeed ns;
+                    if (d_reseed(cx, jb.rBegin, jb.rBegin + jb.rl, jb.Lb, jb.Lb + jb.glen, &ns)) s[n++] = ns;
+                }
+            }
+            if (n > num) d_insertion_sort_seeds(s, n);
+        }
         n = d_seed_extension(cx, s, n);
+        int2 *vec;
         vec = (int2 *)(s + n + 1);
         rp.sj_type = c.SJtype = d_check_splice(cx, s, n, vec);
         n = d_identify_normal_pairs(s, n);

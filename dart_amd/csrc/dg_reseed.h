@@ -1,0 +1,227 @@
+// dart_amd/csrc/dg_reseed.h -- candidate clean-up (k_prep) and wave-cooperative 8-mer re-seeding
+// (k_reseed).
+//
+// k_prep replaces RemoveTandemRepeatSeeds / RemoveTranslocatedSeeds (AlignmentCandidates.cpp:
+// 817-902) and the *enumeration* half of IdentifyMissingSeeds (:685-700): every
+// ReseedingWithSpecificRegion call the reference would make becomes one DJob.
+// k_reseed replaces ReseedingWithSpecificRegion (:596-624) + KmerAnalysis.cpp:25-166.
+//
+// Why a separate kernel: a re-seeding window is up to MaxIntronSize (5e5) bases but only
+// 0.03-0.8 % of reads need one.  Inside the lane-per-read report kernel one such read
+// stalls its whole wave for tens of milliseconds; as a job queue the windows are spread over the
+// chip, one wave per window, 64 window positions per step.
+//
+// Algorithm (order-equivalent to the reference's sort/join/sort, see dg_report.h d_reseed for the
+// serial form): the read-gap 8-mers sit sorted in LDS behind a 64 Kbit presence filter; every lane
+// extracts the 8-mer of its window position straight from the 2-bit pac (one unaligned 24-bit
+// fetch; reverse-strand windows are read from the forward pac and reverse-complemented in
+// registers), and hits set bit rPos of diagonal (g - rPos) in an LDS ring of diagonals.  A diagonal
+// is complete once the window front has moved past it by the gap length; complete diagonals are
+// summarised 64 at a time (count, first, last rPos) and folded in increasing order into the
+// running (s, max_len) state of GenerateLongestSimplePairsFromFragmentPair -- bit-identical,
+// including the carry-over quirk of `s` (KmerAnalysis.cpp:147-161).
+// Bound: streaming pac reads (2 bit/base) + LDS; no MFMA.
+#pragma once
+#include "dg_common.h"
+#include "dg_report.h"
+
+#define RS_MAX_RL   263          // longest read gap handled cooperatively (span <= 255 -> 4 bitmap words)
+#define RS_RING     512          // diagonals in the ring (>= span + 64)
+#define RS_WORDS    4
+
+__global__ void __launch_bounds__(256)
+k_prep(const DParams pr, int n_reads, const uint32_t *__restrict__ seed_off, const DSeed *__restrict__ seeds,
+       DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ work_off,
+       DSeed *__restrict__ work, DJob *__restrict__ jobs, unsigned int *jobtop, uint32_t jobcap, int *err)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    DCand *cd = cands + seed_off[r];
+    const int nc = (int)ncand[r];
+    uint32_t wo = work_off[r];
+    for (int i = 0; i < nc; i++) {
+        DCand &c = cd[i];
+        c.final_n = 0; c.n_a = 0; c.job_count = 0; c.job_first = 0;
+        if (c.Score == 0) continue;
+        c.work_off = wo; wo += d_work_need(c.count);
+        DSeed *s = work + c.work_off;
+        int n = c.count;
+        for (int q = 0; q < n; q++) s[q] = seeds[c.first + q];
+        int2 *vec = (int2 *)(s + 6 * c.count + 4);       // tail of the working region as int scratch
+        n = d_remove_tandem(s, n, vec);
+        n = d_remove_transloc(s, n, vec);
+        c.n_a = n;
+        int cnt = 0;                                     // IdentifyMissingSeeds :691-697, enumeration only
+        for (int k = 1; k < n; k++) {
+            const int pd = (int)((s[k].gPos - s[k].rPos) - (s[k - 1].gPos - s[k - 1].rPos));
+            const int rGaps = s[k].rPos - s[k - 1].rPos - s[k - 1].rLen;
+            if (pd > pr.max_gaps && rGaps > 20) cnt++;
+        }
+        if (cnt == 0) continue;
+        const unsigned int first = atomicAdd(jobtop, (unsigned int)cnt);
+        if (first + (unsigned int)cnt > jobcap) { *err = 3; continue; }
+        c.job_first = first; c.job_count = cnt;
+        int w = 0;
+        for (int k = 1; k < n; k++) {
+            const int pd = (int)((s[k].gPos - s[k].rPos) - (s[k - 1].gPos - s[k - 1].rPos));
+            const int rGaps = s[k].rPos - s[k - 1].rPos - s[k - 1].rLen;
+            if (pd > pr.max_gaps && rGaps > 20) {
+                DJob j;
+                j.Lb = s[k - 1].gPos + s[k - 1].gLen;
+                j.glen = (int32_t)(s[k].gPos - j.Lb);
+                j.rBegin = s[k - 1].rPos + s[k - 1].rLen; j.rl = rGaps;
+                j.read = (uint32_t)r; j.found = rGaps > RS_MAX_RL ? -1 : 0;   // -1: left to the serial path in k_report
+                j.gPos = 0; j.rPos = 0; j.len = 0; j.pad = 0;
+                jobs[first + w++] = j;
+            }
+        }
+    }
+}
+
+// 8-mer id (CreateKmerID, KmerAnalysis.cpp:25-32) of text positions t..t+7, t in [0, 2L)
+__device__ __forceinline__ uint32_t d_window_kmer(const DIndex &ix, int64_t t)
+{
+    const int64_t L = ix.l_pac;
+    if (t >= 0 && t + 7 < L) {
+        const uint8_t *p = ix.pac + (t >> 2);
+        const uint32_t v = ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | (uint32_t)p[2];
+        return (v >> (8 - 2 * (int)(t & 3))) & 0xFFFFu;
+    }
+    if (t >= L && t + 7 < 2 * L) {                      // reverse half: complement of the mirrored forward 8-mer
+        const int64_t u = 2 * L - 1 - t - 7;
+        const uint8_t *p = ix.pac + (u >> 2);
+        const uint32_t v = ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | (uint32_t)p[2];
+        uint32_t x = (v >> (8 - 2 * (int)(u & 3))) & 0xFFFFu;
+        x = ((x & 0x3333u) << 2) | ((x >> 2) & 0x3333u);
+        x = ((x & 0x0F0Fu) << 4) | ((x >> 4) & 0x0F0Fu);
+        x = ((x << 8) | (x >> 8)) & 0xFFFFu;
+        return x ^ 0xFFFFu;
+    }
+    uint32_t wid = 0;                                    // straddles the strand boundary or the end
+    for (int i = 0; i < 8; i++) wid = (wid << 2) + d_nt4((unsigned char)d_refchar(ix, t + i));
+    return wid;
+}
+
+__global__ void __launch_bounds__(64)
+k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off,
+         DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, unsigned long long *ctr)
+{
+    __shared__ unsigned char rs[RS_MAX_RL + 9];
+    __shared__ uint64_t tmpk[RS_MAX_RL + 1], km[RS_MAX_RL + 1];
+    __shared__ uint32_t flt[2048];
+    __shared__ unsigned long long ring[RS_RING * RS_WORDS];
+    __shared__ int s_nk;
+    const int lane = threadIdx.x;
+    const unsigned int njobs = *jobtop;
+    unsigned long long n_done = 0, w_done = 0;
+    for (unsigned int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
+        const DJob job = jobs[jb];
+        if (job.found < 0) continue;                    // too long for the LDS ring: serial path in k_report
+        const int rl = job.rl, glen = job.glen;
+        int thr = (int)(rl * 0.85); if (thr < 8) thr = 8;
+        n_done += 1; w_done += (unsigned long long)(glen > 0 ? glen : 0);
+        const unsigned char *rd = seq + seq_off[job.read] + job.rBegin;
+        __syncthreads();
+        for (int i = lane; i < rl; i += 64) rs[i] = rd[i];
+        for (int i = lane; i < 2048; i += 64) flt[i] = 0;
+        for (int i = lane; i < RS_RING * RS_WORDS; i += 64) ring[i] = 0;
+        __syncthreads();
+        if (lane == 0) {   // CreateKmerVecFromReadSeq :34-80 on the read gap, position order
+            int nk = 0, count = 0, head, tail = 0;
+            uint32_t wid = 0;
+            while (count < 8 && tail < rl) { if (rs[tail++] != 'N') count++; else count = 0; }
+            if (count == 8) {
+                head = tail - 8; wid = 0;
+                for (int i = head; i < head + 8; i++) wid = (wid << 2) + d_nt4(rs[i]);
+                tmpk[nk++] = ((uint64_t)wid << 32) | (uint32_t)head;
+                for (head += 1; tail < rl; head++, tail++) {
+                    if (rs[tail] != 'N') {
+                        wid = ((wid & 0x3FFF) << 2) + d_nt4(rs[tail]);
+                        tmpk[nk++] = ((uint64_t)wid << 32) | (uint32_t)head;
+                    } else {
+                        count = 0; tail++;
+                        while (count < 8 && tail < rl) { if (rs[tail++] != 'N') count++; else count = 0; }
+                        if (count == 8) {
+                            head = tail - 8; wid = 0;
+                            for (int i = head; i < head + 8; i++) wid = (wid << 2) + d_nt4(rs[i]);
+                            tmpk[nk++] = ((uint64_t)wid << 32) | (uint32_t)head;
+                        } else break;
+                    }
+                }
+            }
+            s_nk = nk;
+        }
+        __syncthreads();
+        const int nk = s_nk;
+        int found = 0, best_r = 0, max_len = 0;
+        int64_t best_g = 0;
+        if (nk > 0 && glen >= 8) {
+            for (int e = lane; e < nk; e += 64) {       // rank sort by (wid,pos); keys are distinct
+                const uint64_t key = tmpk[e];
+                int rank = 0;
+                for (int j = 0; j < nk; j++) rank += tmpk[j] < key ? 1 : 0;
+                km[rank] = key;
+                const uint32_t w16 = (uint32_t)(key >> 32) & 0xFFFFu;
+                atomicOr(&flt[w16 >> 5], 1u << (w16 & 31));
+            }
+            __syncthreads();
+            const int span = rl - 8;
+            int s = 1;
+            int64_t next_fin = -(int64_t)span;
+            auto finalize_upto = [&](int64_t lim) {     // fold complete diagonals [next_fin, lim) in order
+                while (next_fin < lim) {
+                    const int64_t d = next_fin + lane;
+                    int cnt = 0, first = -1, last = -1;
+                    if (d < lim) {
+                        const int base = (int)((uint64_t)d & (RS_RING - 1)) * RS_WORDS;
+                        for (int w = 0; w < RS_WORDS; w++) {
+                            const unsigned long long v = ring[base + w];
+                            if (v) {
+                                cnt += __popcll(v);
+                                if (first < 0) first = w * 64 + (__ffsll((long long)v) - 1);
+                                last = w * 64 + 63 - __clzll((long long)v);
+                                ring[base + w] = 0;
+                            }
+                        }
+                    }
+                    unsigned long long mask = __ballot(cnt > 0);
+                    while (mask) {
+                        const int l = __ffsll((long long)mask) - 1;
+                        const int c = __shfl(cnt, l, 64), f = __shfl(first, l, 64), la = __shfl(last, l, 64);
+                        s += c - 1;
+                        const int len = 8 + (la - f);
+                        if (len > max_len && s > (len - 8) / 2) { best_r = f; best_g = next_fin + l + f; max_len = len; s = 1; }
+                        mask &= mask - 1;
+                    }
+                    next_fin = next_fin + 64 < lim ? next_fin + 64 : lim;
+                }
+            };
+            for (int g0 = 0; g0 + 8 <= glen; g0 += 64) {
+                finalize_upto((int64_t)g0 - span);
+                __syncthreads();
+                const int p = g0 + lane;
+                if (p + 8 <= glen) {
+                    const uint32_t wid = d_window_kmer(ix, job.Lb + p);
+                    const uint32_t w16 = wid & 0xFFFFu;
+                    if ((flt[w16 >> 5] >> (w16 & 31)) & 1u) {
+                        int lo = 0, hi = nk;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(km[mid] >> 32) < wid) lo = mid + 1; else hi = mid; }
+                        for (; lo < nk && (uint32_t)(km[lo] >> 32) == wid; lo++) {
+                            const int rp = (int)(uint32_t)km[lo];
+                            const int64_t d = (int64_t)p - rp;
+                            atomicOr(&ring[(int)((uint64_t)d & (RS_RING - 1)) * RS_WORDS + (rp >> 6)], 1ull << (rp & 63));
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            finalize_upto((int64_t)(glen - 8) + 1);
+            found = (max_len >= thr && max_len > 0) ? 1 : 0;
+        }
+        if (lane == 0) {
+            DJob &o = jobs[jb];
+            o.found = found; o.len = max_len; o.rPos = best_r + job.rBegin; o.gPos = best_g + job.Lb;
+        }
+    }
+    if (lane == 0) { if (n_done) atomicAdd(ctr + CTR_RESEED, n_done); if (w_done) atomicAdd(ctr + CTR_RESEEDW, w_done); }
+}

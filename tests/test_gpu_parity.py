@@ -60,6 +60,7 @@ def test_gpu_seeds_match_oracle(ctxs):
     for name in CASES:
         c, ix, gpu, orc = ctxs[name]
         so, rl, flat = host.pack_reads(c["reads"])
+        gpu.set_params(host.default_params())
         gso, grp, gsl, ggp = gpu.probe_seeds(so, rl, flat)
         for i in range(0, len(rl), 7):
             rp, sl, gp = orc.seeds(orc.params(), c["reads"][i].tobytes())
