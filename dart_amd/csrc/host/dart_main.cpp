@@ -1,0 +1,488 @@
+// dart_amd/csrc/host/dart_main.cpp -- `dart`: DART's command line over libdartgpu (C ABI only).
+//
+// Host-side mirror of the reference's driver for the north-star path:
+//   flags + defaults + messages + exit codes   main.cpp:96-239
+//   index files                                 bwt_index.cpp:15-159,229-251
+//   FASTA/FASTQ(.gz) readers, chunking, mate-2 reverse complement   GetData.cpp:44-247
+//   SAM header/records, statistics, junctions.tab   Mapping.cpp:208-369,567-577,683-716,741-751,806-822
+// Everything between "chunk read" and "records formatted" (Mapping.cpp:598-639) is dg_map_batch.
+// Out of scope and refused with a message: -bo (BAM via htslib), `index`, `update`.
+//
+// Batches are much larger than the reference's 4000-read chunks (a GPU launch needs >= 10^5 reads);
+// output order is input order, which equals the reference at -t 1.  -t keeps its
+// meaning for the host side: threads that format SAM text.  DART_GPUS=n spreads batches over n
+// devices (one dg_ctx each); DART_BATCH=reads sets the batch size.
+#include "dartgpu.h"
+#include <zlib.h>
+#include <sys/stat.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+static const char *VersionStr = "1.4.6";
+
+struct Options {
+    const char *index = nullptr, *out = "output.sam";
+    char sj[256] = "junctions.tab";
+    std::vector<std::string> f1, f2;
+    int threads = 4;
+    bool pair_end = false, multi = false, unique = false, silent = false, all_sj = false;
+    dg_params p;
+};
+
+static void usage(const char *prog, const Options &o)   // ShowProgramUsage, main.cpp:20-40
+{
+    fprintf(stdout, "\nDART v%s (Hsin-Nan Lin & Wen-Lian Hsu)\n\n", VersionStr);
+    fprintf(stdout, "Usage: %s -i Index_Prefix -f <ReadFile_A1 ReadFile_B1 ...> [-f2 <ReadFile_A2 ReadFile_B2 ...>] -o|-bo Alignment_Output\n\n", prog);
+    fprintf(stdout, "Options: -t INT        number of threads [4]\n");
+    fprintf(stdout, "         -f            files with #1 mates reads\n");
+    fprintf(stdout, "         -f2           files with #2 mates reads\n");
+    fprintf(stdout, "         -mis INT      maximal number of mismatches in an alignment\n");
+    fprintf(stdout, "         -max_dup INT  maximal number of repetitive fragments (between 100-10000) [%d]\n", o.p.max_dup);
+    fprintf(stdout, "         -o            alignment filename in SAM format\n");
+    fprintf(stdout, "         -bo           alignment filename in BAM format\n");
+    fprintf(stdout, "         -j            splice junction output filename [junctions.tab]\n");
+    fprintf(stdout, "         -m            output multiple alignments [false]\n");
+    fprintf(stdout, "         -all_sj       detect all splice junction regardless of mapq score [false]\n");
+    fprintf(stdout, "         -p            paired-end reads are interlaced in the same file\n");
+    fprintf(stdout, "         -unique       output unique alignments\n");
+    fprintf(stdout, "         -max_intron   the maximal intron size [500000]\n");
+    fprintf(stdout, "         -min_intron   the minimal intron size [10]\n");
+    fprintf(stdout, "         -v            version\n");
+    fprintf(stdout, "\n");
+}
+
+// ---------------------------------------------------------------------------------------------
+// index files
+// ---------------------------------------------------------------------------------------------
+struct HostIndex {
+    std::vector<uint32_t> bwt; std::vector<uint64_t> sa; std::vector<uint8_t> pac;
+    std::vector<std::string> names; std::vector<int64_t> off, len;
+    uint64_t primary = 0, L2[5] = {0, 0, 0, 0, 0}, seq_len = 0; int sa_intv = 32; int64_t l_pac = 0;
+    dg_index_view view() const {
+        dg_index_view v;
+        v.bwt = bwt.data(); v.bwt_words = bwt.size(); v.primary = primary; for (int i = 0; i < 5; i++) v.L2[i] = L2[i]; v.seq_len = seq_len;
+        v.sa = sa.data(); v.n_sa = sa.size(); v.sa_intv = sa_intv; v.pac = pac.data(); v.l_pac = l_pac;
+        v.n_chr = (int32_t)names.size(); v.chr_off = off.data(); v.chr_len = len.data();
+        return v;
+    }
+};
+
+static bool slurp(const std::string &fn, std::vector<uint8_t> &out)
+{
+    FILE *f = fopen(fn.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    out.resize((size_t)n);
+    bool ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+static bool file_exists(const std::string &fn) { FILE *f = fopen(fn.c_str(), "r"); if (!f) return false; fclose(f); return true; }
+
+static bool load_index(const std::string &prefix, HostIndex &ix)
+{
+    std::vector<uint8_t> raw;
+    if (!slurp(prefix + ".bwt", raw) || raw.size() < 40) return false;
+    memcpy(&ix.primary, raw.data(), 8); memcpy(&ix.L2[1], raw.data() + 8, 32); ix.seq_len = ix.L2[4];
+    ix.bwt.resize((raw.size() - 40) / 4); memcpy(ix.bwt.data(), raw.data() + 40, ix.bwt.size() * 4);
+    if (!slurp(prefix + ".sa", raw) || raw.size() < 56) return false;
+    uint64_t intv; memcpy(&intv, raw.data() + 40, 8); ix.sa_intv = (int)intv;
+    const uint64_t n_sa = (ix.seq_len + (uint64_t)ix.sa_intv) / (uint64_t)ix.sa_intv;
+    ix.sa.assign(n_sa, 0); ix.sa[0] = (uint64_t)-1;
+    memcpy(ix.sa.data() + 1, raw.data() + 56, std::min<size_t>((n_sa - 1) * 8, raw.size() - 56));
+    if (!slurp(prefix + ".pac", ix.pac)) return false;
+    ix.pac.resize(ix.pac.size() + 16, 0);
+    FILE *f = fopen((prefix + ".ann").c_str(), "r");
+    if (!f) return false;
+    long long xx; int n; unsigned seed;
+    if (fscanf(f, "%lld%d%u", &xx, &n, &seed) != 3) { fclose(f); return false; }
+    ix.l_pac = xx;
+    int64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        unsigned gi; char name[1024]; int c, l, na;
+        if (fscanf(f, "%u%1023s", &gi, name) != 2) { fclose(f); return false; }
+        while ((c = fgetc(f)) != '\n' && c != EOF) {}
+        if (fscanf(f, "%lld%d%d", &xx, &l, &na) != 3) { fclose(f); return false; }
+        ix.names.push_back(name); ix.off.push_back(total); ix.len.push_back(l); total += l;
+    }
+    fclose(f);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// readers
+// ---------------------------------------------------------------------------------------------
+struct Entry { std::string header, seq, qual; int rlen = 0; };
+
+static char comp_base(char c)   // tools.cpp:3-17
+{
+    switch (c) { case 'A': case 'a': return 'T'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; case 'T': case 't': return 'A'; default: return 'N'; }
+}
+static std::string revcomp(const std::string &s) { std::string r(s.size(), 'N'); for (size_t i = 0; i < s.size(); i++) r[i] = comp_base(s[s.size() - 1 - i]); return r; }
+
+static int hdr_beg(const char *s, int len) { for (int i = 1; i < len; i++) if (s[i] != '>' && s[i] != '@') return i; return len - 1; }
+static int hdr_end(const char *s, int len) { for (int i = 1; i < len; i++) if (s[i] == ' ' || s[i] == '/' || s[i] == '\t') return i; return len - 1; }
+
+struct Source {
+    FILE *fp = nullptr; gzFile gz = nullptr; bool fastq = true;
+    char *buf = nullptr; size_t cap = 0;
+    ~Source() { free(buf); }
+    // GetNextEntry, GetData.cpp:77-132
+    Entry next_plain() {
+        Entry e; ssize_t len;
+        if ((len = getline(&buf, &cap, fp)) != -1) {
+            int p1 = hdr_beg(buf, (int)len), p2 = hdr_end(buf, (int)len);
+            if (p2 > p1) e.header.assign(buf + p1, buf + p2);
+            if (fastq) {
+                ssize_t rl;
+                if ((rl = getline(&buf, &cap, fp)) != -1) {
+                    e.rlen = (int)rl - 1; e.seq.assign(buf, buf + e.rlen);
+                    if (getline(&buf, &cap, fp) == -1) {}
+                    ssize_t ql = getline(&buf, &cap, fp);
+                    if (ql < 0) ql = 0;
+                    size_t take = std::min<size_t>((size_t)e.rlen, strnlen(buf, (size_t)ql));
+                    e.qual.assign(buf, buf + take);
+                }
+            } else {
+                while ((len = getline(&buf, &cap, fp)) != -1) {
+                    if (buf[0] == '>') { fseek(fp, 0 - (long)len, SEEK_CUR); break; }
+                    buf[len - 1] = 0; e.seq += buf;
+                }
+                e.rlen = (int)e.seq.size();
+            }
+        }
+        return e;
+    }
+    // gzGetNextEntry, GetData.cpp:181-210
+    Entry next_gz() {
+        Entry e; char b[1024];
+        if (gzgets(gz, b, 1024) != NULL) {
+            int len = (int)strlen(b), p1 = hdr_beg(b, len), p2 = hdr_end(b, len);
+            len = p2 - p1;
+            if (len > 0 && (b[0] == '@' || b[0] == '>')) {
+                e.header.assign(b + p1, b + p2);
+                if (gzgets(gz, b, 1024) == NULL) { b[0] = '\n'; b[1] = 0; }
+                e.rlen = (int)strlen(b) - 1; e.seq.assign(b, b + e.rlen);
+                if (fastq) {
+                    if (gzgets(gz, b, 1024) == NULL || gzgets(gz, b, 1024) == NULL) b[0] = 0;
+                    e.qual.assign(b, b + std::min<size_t>((size_t)e.rlen, strlen(b)));
+                }
+            }
+        }
+        return e;
+    }
+    Entry next() { return gz ? next_gz() : next_plain(); }
+};
+
+// GetNextChunk, GetData.cpp:134-179: one reference-sized chunk appended to `out`
+static int next_chunk(Source &s1, Source *s2, bool pair_end, bool fastq, std::vector<Entry> &out)
+{
+    int count = 0, base = 0;
+    while (true) {
+        Entry e = s1.next();
+        if (e.rlen == 0) break;
+        base += e.rlen; count++; out.push_back(std::move(e));
+        Entry m = s2 ? s2->next() : s1.next();
+        if (m.rlen == 0) break;
+        if (pair_end) { m.seq = revcomp(m.seq); if (fastq) std::reverse(m.qual.begin(), m.qual.end()); }
+        base += m.rlen; count++; out.push_back(std::move(m));
+        if (count == 4000 || base > 1000000) break;
+    }
+    return count;
+}
+
+static bool check_read_format(const char *fn)   // CheckReadFormat, Mapping.cpp:718-726
+{
+    char b[1] = {0}; gzFile f = gzopen(fn, "rb");
+    if (!f) return false;
+    gzread(f, b, 1); gzclose(f);
+    return b[0] == '@';
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAM text
+// ---------------------------------------------------------------------------------------------
+struct Counters { long long total = 0, unique = 0, unmapped = 0, paired = 0; };
+static const char *XS_A[3] = { "", " XS:A:+", " XS:A:-" };
+
+static void cigar_text(const uint32_t *ops, uint32_t n, std::string &out)
+{
+    char b[16];
+    out.clear();
+    for (uint32_t i = 0; i < n; i++) { snprintf(b, sizeof b, "%u%c", ops[i] >> 4, "MIDNS"[ops[i] & 15 ? (ops[i] & 15) : 0]); out += b; }
+}
+
+// OutputPairedAlignments / OutputSingledAlignments (Mapping.cpp:208-369) for reads [lo,hi)
+static void format_range(const std::vector<Entry> &ev, int lo, int hi, int n_pair_mode, const dg_read_out *ro, const dg_report_out *po,
+                         const uint32_t *cig, const HostIndex &ix, const Options &o, bool fastq, std::string &out, Counters &ct)
+{
+    std::string cg, line;
+    for (int k = lo; k < hi; k++) {
+        const bool is_pair = k < n_pair_mode, mate2 = is_pair && (k & 1);
+        const Entry &e = ev[k];
+        const dg_read_out &r = ro[k];
+        const dg_report_out *rp = po + r.rep_off;
+        const char *q = fastq ? e.qual.c_str() : "*";
+        if (r.score == 0) {
+            ct.unmapped++;
+            out += e.header; out += '\t'; out += std::to_string(rp[0].flag); out += "\t*\t0\t0\t*\t*\t0\t0\t"; out += e.seq; out += '\t'; out += q; out += "\tAS:i:0\tXS:i:0\n";
+            continue;
+        }
+        if (!(!o.unique || r.mapq > 3)) continue;
+        if (r.mapq == 50) ct.unique++;
+        const dg_read_out *m = is_pair ? &ro[k ^ 1] : nullptr;
+        const dg_report_out *mp = m ? po + m->rep_off : nullptr;
+        std::string alt, altq;
+        bool have_alt = false;
+        for (int j = r.best; j < r.n_rep; j++) {
+            const dg_report_out &pr = rp[j];
+            const bool show = is_pair ? pr.aln_score > 0 : pr.aln_score == r.score;
+            if (show) {
+                int xs;
+                if (pr.sj_type == -1) xs = 0; else if (pr.sj_type == 0 || pr.sj_type == 2) xs = mate2 ? 2 : 1; else xs = mate2 ? 1 : 2;
+                const bool use_alt = mate2 ? pr.bdir == 1 : pr.bdir == 0;
+                if (use_alt && !have_alt) { alt = revcomp(e.seq); if (fastq) { altq = e.qual; std::reverse(altq.begin(), altq.end()); } have_alt = true; }
+                const std::string &s_out = use_alt ? alt : e.seq;
+                const char *q_out = fastq ? (use_alt ? altq.c_str() : e.qual.c_str()) : "*";
+                cigar_text(cig + pr.cigar_off, pr.n_cigar, cg);
+                char num[256];
+                int pj;
+                out += e.header;
+                if (is_pair && (pj = pr.paired_idx) != -1 && mp[pj].aln_score > 0) {
+                    const dg_report_out &a = mate2 ? mp[pj] : pr, &b = mate2 ? pr : mp[pj];
+                    const int l1 = mate2 ? ev[k ^ 1].rlen : e.rlen, l2 = mate2 ? e.rlen : ev[k ^ 1].rlen;
+                    int dist = (int)(b.pos - a.pos + (a.bdir ? l2 : 0 - l1));
+                    if (mate2) dist = 0 - dist; else if (j == r.best) ct.paired += 2;
+                    snprintf(num, sizeof num, "\t%d\t%s\t%lld\t%d\t", pr.flag, ix.names[pr.chr].c_str(), (long long)pr.pos, r.mapq);
+                    out += num; out += cg;
+                    snprintf(num, sizeof num, "\t=\t%lld\t%d\t", (long long)mp[pj].pos, dist);
+                    out += num;
+                } else {
+                    snprintf(num, sizeof num, "\t%d\t%s\t%lld\t%d\t", pr.flag, ix.names[pr.chr].c_str(), (long long)pr.pos, r.mapq);
+                    out += num; out += cg; out += "\t*\t0\t0\t";
+                }
+                out += s_out; out += '\t'; out += q_out;
+                snprintf(num, sizeof num, "\tNM:i:%d\tAS:i:%d\tXS:i:%d%s\n", r.mis_num, r.score, r.sub_score, XS_A[xs]);
+                out += num;
+                if (!is_pair && !o.multi) break;
+            }
+            if (is_pair && !o.multi) break;
+        }
+    }
+}
+
+int main(int argc, char *argv[])
+{
+    Options o;
+    dg_params_default(&o.p);
+    if (argc == 1 || strcmp(argv[1], "-h") == 0) { usage(argv[0], o); return 0; }
+    if (strcmp(argv[1], "update") == 0 || strcmp(argv[1], "index") == 0) {
+        fprintf(stderr, "dart (MI355X): the '%s' sub-command is outside this build's scope; build the index with bwt_index / bwa index\n", argv[1]);
+        return 0;
+    }
+    for (int i = 1; i < argc; i++) {   // main.cpp:136-205
+        std::string p = argv[i];
+        if (p == "-i") o.index = argv[++i];
+        else if (p == "-f") { while (++i < argc && argv[i][0] != '-') o.f1.push_back(argv[i]); i--; }
+        else if (p == "-f2") { while (++i < argc && argv[i][0] != '-') o.f2.push_back(argv[i]); i--; }
+        else if (p == "-t") { if ((o.threads = atoi(argv[++i])) <= 0) { fprintf(stdout, "Warning! Thread number should be a positive number!\n"); o.threads = 4; } }
+        else if (p == "-o") o.out = argv[++i];
+        else if (p == "-bo") { fprintf(stderr, "Error! BAM output (-bo) is outside this build's scope; use -o\n"); return 1; }
+        else if (p == "-mis" && i + 1 < argc) o.p.max_mismatch = atoi(argv[++i]);
+        else if (p == "-max_dup" && i + 1 < argc) { o.p.max_dup = atoi(argv[++i]); if (o.p.max_dup < 100) o.p.max_dup = 100; else if (o.p.max_dup >= 10000) o.p.max_dup = 10000; }
+        else if (p == "-silent") o.silent = true;
+        else if (p == "-j") { strncpy(o.sj, argv[++i], 255); o.sj[255] = 0; }
+        else if (p == "-p") o.pair_end = true;
+        else if (p == "-m") o.multi = true;
+        else if (p == "-unique") o.unique = true;
+        else if (p == "-all_sj") o.all_sj = true;
+        else if (p == "-max_intron") { if ((o.p.max_intron = atoi(argv[++i])) < 100000) o.p.max_intron = 100000; }
+        else if (p == "-min_intron") o.p.min_intron = atoi(argv[++i]);
+        else if (p == "-d" || p == "-debug") {}   // debug prints are not reproduced
+        else if (p == "-v" || p == "--version") { fprintf(stdout, "DART v%s\n\n", VersionStr); return 0; }
+        else { fprintf(stderr, "Error! Unknow parameter: %s\n", argv[i]); usage(argv[0], o); return 1; }
+    }
+    o.p.multi_hit = o.multi; o.p.all_sj = o.all_sj;
+    if (o.f1.empty()) { fprintf(stderr, "Error! Please specify a valid read input!\n"); usage(argv[0], o); return 1; }
+    if (!o.f2.empty() && o.f1.size() != o.f2.size()) {
+        fprintf(stderr, "Error! Paired-end reads input numbers do not match!\n");
+        fprintf(stderr, "Read1:\n"); for (auto &s : o.f1) fprintf(stderr, "\t%s\n", s.c_str());
+        fprintf(stderr, "Read2:\n"); for (auto &s : o.f2) fprintf(stderr, "\t%s\n", s.c_str());
+        return 1;
+    }
+    {   // CheckInputFiles / CheckOutputFileName, main.cpp:42-94,220
+        struct stat st; bool ok = true;
+        for (auto &s : o.f1) if (stat(s.c_str(), &st) == -1) { ok = false; fprintf(stderr, "Cannot access file:[%s]\n", s.c_str()); }
+        for (auto &s : o.f2) if (stat(s.c_str(), &st) == -1) { ok = false; fprintf(stderr, "Cannot access file:[%s]\n", s.c_str()); }
+        if (strcmp(o.out, "output.sam") != 0 && stat(o.out, &st) == 0) {
+            if (st.st_mode & S_IFDIR) { ok = false; fprintf(stdout, "Warning: %s is a directory!\n", o.out); }
+            else if (!(st.st_mode & S_IFREG)) { ok = false; fprintf(stdout, "Warning: %s is not a regular file!\n", o.out); }
+        }
+        if (!ok) return 0;
+    }
+    HostIndex ix;
+    if (!o.index || !file_exists(std::string(o.index) + ".ann") || !file_exists(std::string(o.index) + ".amb") || !file_exists(std::string(o.index) + ".pac")) {
+        fprintf(stderr, "Error! Please specify a valid reference index!\n"); usage(argv[0], o); return 1;
+    }
+    fprintf(stdout, "Load the genome index files...");
+    if (!load_index(o.index, ix)) { fprintf(stderr, "\n\nError! Index files are corrupt!\n"); return 0; }
+    fprintf(stdout, "\nLoad the reference sequences...\n");
+
+    int n_gpu = getenv("DART_GPUS") ? atoi(getenv("DART_GPUS")) : 1; if (n_gpu < 1) n_gpu = 1;
+    size_t batch_reads = getenv("DART_BATCH") ? (size_t)atoll(getenv("DART_BATCH")) : 1000000; batch_reads = std::max<size_t>(4000, batch_reads & ~(size_t)1);
+    std::vector<dg_ctx *> ctx;
+    dg_index_view view = ix.view();
+
+    FILE *sam = fopen(o.out, "w");
+    if (!sam) { fprintf(stderr, "Cannot write %s\n", o.out); return 1; }
+    fprintf(sam, "@PG\tID:Dart\tPN:Dart\tVN:%s\n", VersionStr);
+    for (size_t i = 0; i < ix.names.size(); i++) fprintf(sam, "@SQ\tSN:%s\tLN:%lld\n", ix.names[i].c_str(), (long long)ix.len[i]);
+
+    Counters total;
+    std::map<std::pair<int64_t, int64_t>, int> sjmap;
+    time_t t0 = time(NULL);
+    if (o.silent) fprintf(stdout, "Start read mapping...\n");
+    bool pair_end = o.pair_end;
+    for (size_t lib = 0; lib < o.f1.size(); lib++) {
+        Source s1, s2; bool sep = false;
+        const std::string &fn = o.f1[lib];
+        const bool gz = fn.substr(fn.find_last_of('.') + 1) == "gz";
+        const bool fastq = check_read_format(fn.c_str());
+        s1.fastq = s2.fastq = fastq;
+        if (gz) s1.gz = gzopen(fn.c_str(), "rb"); else s1.fp = fopen(fn.c_str(), "r");
+        if (o.f1.size() == o.f2.size()) {
+            sep = pair_end = true;
+            if (fastq != check_read_format(o.f2[lib].c_str())) { fprintf(stderr, "Error! %s and %s are with different format...\n", fn.c_str(), o.f2[lib].c_str()); return 1; }
+            if (gz) s2.gz = gzopen(o.f2[lib].c_str(), "rb"); else s2.fp = fopen(o.f2[lib].c_str(), "r");
+        }
+        if (!s1.fp && !s1.gz) continue;
+        if (sep && !s2.fp && !s2.gz) continue;
+        if (ctx.empty()) {   // contexts are created once the first library opens (so flag errors never touch the GPU)
+            o.p.paired = pair_end ? 1 : 0;
+            for (int d = 0; d < n_gpu; d++) {
+                int st = 0; dg_ctx *c = dg_init(&view, &o.p, d, &st);
+                if (!c) { fprintf(stderr, "Error! GPU %d: %s\n", d, dg_last_error(nullptr)); return 1; }
+                ctx.push_back(c);
+            }
+        }
+        bool eof = false;
+        while (!eof) {
+            // read up to n_gpu batches; an odd chunk (only the last can be) is mapped on its own, unpaired (Mapping.cpp:598)
+            struct Batch { std::vector<Entry> ev; int odd = 0; std::vector<dg_read_out> ro; std::vector<dg_report_out> po; std::vector<uint32_t> cig; std::vector<dg_sj_out> sj; size_t used[3] = {0, 0, 0}; int rc = 0; std::string err; };
+            std::vector<Batch> batches;
+            for (int d = 0; d < n_gpu && !eof; d++) {
+                Batch b;
+                while (b.ev.size() < batch_reads) {
+                    int c = next_chunk(s1, sep ? &s2 : nullptr, pair_end, fastq, b.ev);
+                    if (c == 0) { eof = true; break; }
+                    if (c & 1) { b.odd = c; eof = true; break; }
+                }
+                if (!b.ev.empty()) batches.push_back(std::move(b));
+            }
+            if (batches.empty()) break;
+            auto run = [&](Batch &b, dg_ctx *c) {
+                const int n = (int)b.ev.size(), n_even = n - b.odd;
+                std::vector<uint32_t> off(n); std::vector<uint16_t> rl(n); std::string flat;
+                size_t bases = 0; for (auto &e : b.ev) bases += (size_t)e.rlen;
+                flat.reserve(bases);
+                for (int k = 0; k < n; k++) {
+                    if (b.ev[k].rlen > DG_MAX_RLEN) { b.rc = DG_ERR_ARG; b.err = "read longer than DG_MAX_RLEN"; return; }
+                    off[k] = (uint32_t)flat.size(); rl[k] = (uint16_t)b.ev[k].rlen; flat += b.ev[k].seq;
+                }
+                b.ro.resize(n);
+                size_t caps[3] = { (size_t)n * 4 + 1024, (size_t)n * 16 + 4096, (size_t)n + 1024 };
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    b.po.resize(caps[0]); b.cig.resize(caps[1]); b.sj.resize(caps[2]);
+                    size_t used1[3] = {0, 0, 0}, used2[3] = {0, 0, 0};
+                    dg_params p = o.p; p.paired = pair_end ? 1 : 0;
+                    dg_set_params(c, &p);
+                    int rc = n_even ? dg_map_batch(c, n_even, off.data(), rl.data(), flat.data(), b.ro.data(), b.po.data(), b.cig.data(), b.sj.data(), caps, used1) : 0;
+                    if (rc == 0 && b.odd) {
+                        p.paired = 0; dg_set_params(c, &p);
+                        size_t caps2[3] = { caps[0] - used1[0], caps[1] - used1[1], caps[2] - used1[2] };
+                        rc = dg_map_batch(c, b.odd, off.data() + n_even, rl.data() + n_even, flat.data(), b.ro.data() + n_even, b.po.data() + used1[0],
+                                          b.cig.data() + used1[1], b.sj.data() + used1[2], caps2, used2);
+                        if (rc == DG_ERR_CAPACITY) for (int q = 0; q < 3; q++) used2[q] += used1[q];
+                        else {
+                            for (int k = n_even; k < n; k++) { b.ro[k].rep_off += (int32_t)used1[0]; b.ro[k].sj_off += (int32_t)used1[2]; }
+                            for (size_t k = 0; k < used2[0]; k++) b.po[used1[0] + k].cigar_off += (uint32_t)used1[1];
+                            for (size_t k = 0; k < used2[2]; k++) b.sj[used1[2] + k].read_idx += n_even;
+                        }
+                    }
+                    if (rc == DG_ERR_CAPACITY && attempt == 0) {       // `used` holds the need: grow once and repeat
+                        for (int q = 0; q < 3; q++) caps[q] = std::max(caps[q], used1[q] + used2[q]) * 2 + 1024;
+                        continue;
+                    }
+                    b.rc = rc; if (rc) b.err = dg_last_error(c);
+                    for (int q = 0; q < 3; q++) b.used[q] = used1[q] + used2[q];
+                    return;
+                }
+            };
+            std::vector<std::thread> th;
+            for (size_t d = 1; d < batches.size(); d++) th.emplace_back(run, std::ref(batches[d]), ctx[d]);
+            run(batches[0], ctx[0]);
+            for (auto &t : th) t.join();
+            for (auto &b : batches) {
+                if (b.rc) { fprintf(stderr, "\nError! GPU mapping failed (%d): %s\n", b.rc, b.err.c_str()); return 1; }
+                const int n = (int)b.ev.size(), n_pair_mode = pair_end ? n - b.odd : 0;
+                const int nt = std::max(1, std::min(o.threads, n / 2000 + 1));
+                std::vector<std::string> outs(nt); std::vector<Counters> cts(nt);
+                std::vector<std::thread> ft;
+                int per = ((n + nt - 1) / nt + 1) & ~1;
+                for (int t = 0; t < nt; t++) {
+                    const int lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
+                    ft.emplace_back([&, t, lo, hi]() { format_range(b.ev, lo, hi, n_pair_mode, b.ro.data(), b.po.data(), b.cig.data(), ix, o, fastq, outs[t], cts[t]); });
+                }
+                for (auto &t : ft) t.join();
+                for (int t = 0; t < nt; t++) {
+                    fwrite(outs[t].data(), 1, outs[t].size(), sam);
+                    total.unique += cts[t].unique; total.unmapped += cts[t].unmapped; total.paired += cts[t].paired;
+                }
+                total.total += n;
+                for (size_t k = 0; k < b.used[2]; k++) sjmap[std::make_pair(b.sj[k].g1, b.sj[k].g2)]++;   // UpdateLocal/GlobalSJMap, Mapping.cpp:532-577
+                if (!o.silent) { fprintf(stdout, "\r%lld %s tags have been processed in %lld seconds...", total.total, pair_end ? "paired-end" : "singled-end", (long long)(time(NULL) - t0)); fflush(stdout); }
+            }
+        }
+        if (s1.fp) fclose(s1.fp);
+        if (s2.fp) fclose(s2.fp);
+        if (s1.gz) gzclose(s1.gz);
+        if (s2.gz) gzclose(s2.gz);
+    }
+    if (!o.silent) fprintf(stdout, "\rAll the %lld %s reads have been processed in %lld seconds.\n", total.total, pair_end ? "paired-end" : "single-end", (long long)(time(NULL) - t0));
+    fclose(sam);
+    for (auto c : ctx) dg_destroy(c);
+
+    if (total.total > 0) {   // Mapping.cpp:812-822
+        const long long T = total.total, U = total.unmapped;
+        if (pair_end) fprintf(stdout, "\t# of total mapped reads = %lld (sensitivity = %.2f%%)\n\t# of paired sequences = %lld (%.2f%%)\n", T - U, (int)(10000 * (1.0 * (T - U) / T) + 0.5) / 100.0, total.paired, (int)(10000 * (1.0 * total.paired / T) + 0.5) / 100.0);
+        else fprintf(stdout, "\t# of total mapped reads = %lld (sensitivity = %.2f%%)\n", T - U, (int)(10000 * (1.0 * (T - U) / T) + 0.5) / 100.0);
+        fprintf(stdout, "\t# of unique mapped reads = %lld (%.2f%%)\n", total.unique, (int)(10000 * (1.0 * total.unique / T) + 0.5) / 100.0);
+        if (!o.unique) fprintf(stdout, "\t# of multiple mapped reads = %lld (%.2f%%)\n", T - U - total.unique, (int)(10000 * (1.0 * (T - U - total.unique) / T) + 0.5) / 100.0);
+        fprintf(stdout, "\t# of unmapped reads = %lld (%.2f%%)\n", U, (int)(10000 * (1.0 * U / T) + 0.5) / 100.0);
+        // OutputSpliceJunctions, Mapping.cpp:683-716
+        FILE *jf = fopen(o.sj, "w");
+        int nj = 0;
+        const int nc = (int)ix.names.size();
+        std::vector<int64_t> key(2 * nc); std::vector<int> who(2 * nc);
+        for (int i = 0; i < nc; i++) { key[i] = ix.off[i] + ix.len[i] - 1; who[i] = i; key[2 * nc - 1 - i] = 2 * ix.l_pac - ix.off[i] - 1; who[2 * nc - 1 - i] = i; }
+        for (auto &kv : sjmap) {
+            const int lo = (int)(std::lower_bound(key.begin(), key.end(), kv.first.first) - key.begin());
+            if (lo >= 2 * nc) continue;
+            const int c = who[lo];
+            if (jf) fprintf(jf, "%s\t%lld\t%lld\t%d\n", ix.names[c].c_str(), (long long)(kv.first.first + 1 - ix.off[c]), (long long)(kv.first.second + 1 - ix.off[c]), kv.second);
+            nj++;
+        }
+        if (jf) fclose(jf);
+        fprintf(stdout, "\t# of splice junctions = %d (file: %s)\n", nj, o.sj);
+        fprintf(stdout, "\tAlignment output: %s\n\n", o.out);
+    }
+    return 0;
+}

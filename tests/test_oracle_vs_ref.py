@@ -1,0 +1,36 @@
+"""CPU suite, only where oracle/_ref exists (this container): the oracle's command line against
+the reference's own object code, byte for byte, on input-format variants and a seeded fuzz."""
+import os, subprocess
+import pytest
+import common, oracle_py, cli_inputs
+from dart_amd import synth
+
+pytestmark = pytest.mark.skipif(not os.path.exists(oracle_py.REF_HARNESS), reason="oracle/_ref not built (no /root/reference)")
+
+
+def run_both(d, prefix, flags):
+    subprocess.run([oracle_py.REF_HARNESS, "map", "-i", prefix] + flags + ["-o", "ref.sam", "-j", "ref.j"], cwd=d, stdout=subprocess.DEVNULL, check=True)
+    subprocess.run([oracle_py.ORACLE_CLI, "-i", prefix] + flags + ["-o", "orc.sam", "-j", "orc.j", "-t", "3"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    a, b = open(os.path.join(d, "ref.sam")).read(), open(os.path.join(d, "orc.sam")).read()
+    assert a == b, common.first_diff(b, a)
+    assert open(os.path.join(d, "ref.j")).read() == open(os.path.join(d, "orc.j")).read()
+
+
+@pytest.mark.parametrize("flags,label", cli_inputs.VARIANTS, ids=[v[1] for v in cli_inputs.VARIANTS])
+def test_oracle_cli_matches_reference_on_input_variants(flags, label, workdir):
+    oracle_py.build()
+    c, d = cli_inputs.make(workdir)
+    run_both(d, c["prefix"], flags)
+
+
+def test_oracle_matches_reference_on_fresh_fuzz(workdir):
+    """a genome and reads that are in no fixture: repeats-heavy, short reads, 3 % errors"""
+    oracle_py.build()
+    d = os.path.join(workdir, "fuzz"); os.makedirs(d, exist_ok=True)
+    g = synth.make_genome([700000, 300000], seed=91, repeat_scale=80.0, n_introns=200)
+    g.write_fasta(os.path.join(d, "g.fa"))
+    subprocess.run([oracle_py.REF_INDEXER, "g.fa", "g"], cwd=d, stdout=subprocess.DEVNULL, check=True)
+    m1, m2 = synth.make_reads(g, 6000, rlen=76, seed=92, spliced_frac=0.25, sub_rate=0.03, indel_frac=0.05, n_frac=0.02)
+    synth.write_fastq(os.path.join(d, "a.fq"), m1, 1); synth.write_fastq(os.path.join(d, "b.fq"), m2, 2)
+    for flags in ([], ["-mis", "5"], ["-mis", "4", "-unique", "-max_dup", "500"]):
+        run_both(d, os.path.join(d, "g"), ["-f", "a.fq", "-f2", "b.fq"] + flags)
