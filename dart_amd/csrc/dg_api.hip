@@ -41,10 +41,10 @@ struct dg_ctx {
     // batch inputs
     int n_reads = 0, max_rlen = 0;
     size_t seq_bytes = 0;
-    DBuf<unsigned char> seq; DBuf<uint32_t> seq_off; DBuf<uint16_t> rlen;
+    DBuf<unsigned char> seq; DBuf<uint32_t> seq_off; DBuf<uint16_t> rlen; DBuf<uint32_t> enc;
     // pipeline buffers
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, nrep, rep_off, work_need, work_off, tile_sums, tmp_u32, tmp_off;
-    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs;
+    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> costkey; DBuf<uint32_t> perm, hist;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<unsigned char> ws;
@@ -157,50 +157,97 @@ __global__ void k_compact_sj(dg_read_out *rd, uint32_t n, const uint32_t *new_of
 }
 
 // ------------------------------------------------------------------------------------------
-// k_report: persistent lanes, one read pair (or single read) at a time
+// work ordering for k_report: reads are binned by a cost key (scored candidates, their seeds,
+// re-seed jobs) with a counting sort, heaviest first, and waves pull 64 reads at a time from that
+// list.  Lanes of one wave then walk similar paths (less divergence) and the heavy tail starts
+// first (longest-processing-time scheduling).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-k_report(const DIndex ix, const DParams pr, int n_units, int paired, const unsigned char *__restrict__ seq,
+#define COST_CLASSES 8
+__device__ __forceinline__ uint32_t d_cost_class(uint32_t cost)   // 0 = heaviest
+{
+    return cost > 255 ? 0u : cost > 128 ? 1u : cost > 64 ? 2u : cost > 40 ? 3u : cost > 24 ? 4u : cost > 16 ? 5u : cost > 0 ? 6u : 7u;
+}
+// pass 1: class of every read + per-(class, block) counts, laid out class-major for one scan
+__global__ void __launch_bounds__(256)
+k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
+       uint8_t *__restrict__ key, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t sh[COST_CLASSES];
+    if (threadIdx.x < COST_CLASSES) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = COST_CLASSES;
+    if (r < n_reads) {
+        const DCand *cd = cands + seed_off[r];
+        const int nc = (int)ncand[r];
+        uint32_t cost = 0;
+        for (int i = 0; i < nc; i++) if (cd[i].Score > 0) cost += 4u + 3u * (uint32_t)cd[i].n_a + 24u * (uint32_t)cd[i].job_count;
+        k = d_cost_class(cost);
+        key[r] = (uint8_t)k;
+    }
+    for (uint32_t c = 0; c < COST_CLASSES; c++) {
+        const unsigned long long m = __ballot(k == c);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&sh[c], (uint32_t)__popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x < COST_CLASSES) counts[(size_t)threadIdx.x * n_blocks + blockIdx.x] = sh[threadIdx.x];
+}
+// pass 2 (after an exclusive scan of counts): stable scatter -- inside a class reads keep index order
+__global__ void __launch_bounds__(256)
+k_cost_scatter(int n_reads, int n_blocks, const uint8_t *__restrict__ key, const uint32_t *__restrict__ offs, uint32_t *__restrict__ perm)
+{
+    __shared__ uint32_t wave_cnt[4][COST_CLASSES];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const uint32_t k = r < n_reads ? key[r] : COST_CLASSES;
+    uint32_t my_rank = 0;
+    for (uint32_t c = 0; c < COST_CLASSES; c++) {
+        const unsigned long long m = __ballot(k == c);
+        if (k == c) my_rank = (uint32_t)__popcll(m & ((1ull << ln) - 1ull));
+        if (ln == 0) wave_cnt[wv][c] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (r < n_reads) {
+        uint32_t before = 0;
+        for (int w = 0; w < wv; w++) before += wave_cnt[w][k];
+        perm[offs[(size_t)k * n_blocks + blockIdx.x] + before + my_rank] = (uint32_t)r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_report: persistent waves; one lane = one read at a time (GenMappingReport,
+// AlignmentCandidates.cpp:1079-1207); results go to the read's dg_read_out / dg_report_out slots
+// ------------------------------------------------------------------------------------------
+template <int MINW>
+__global__ void __launch_bounds__(64, MINW)
+k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsigned char *__restrict__ seq,
          const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ seed_off,
          const DJob *__restrict__ jobs, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
-         const uint32_t *__restrict__ rep_off, DSeed *__restrict__ work,
+         const uint32_t *__restrict__ rep_off, DSeed *__restrict__ work, const uint32_t *__restrict__ perm,
          dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
-         dg_sj_out *sjpool, uint32_t sjcap, unsigned int *tops, unsigned char *ws, const WSLayout L,
-         unsigned long long *ctr, int *err)
+         unsigned int *tops, unsigned char *ws, const WSLayout L, unsigned long long *ctr, int *err)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_lanes = gridDim.x * blockDim.x;
     LaneCtx cx;
     cx.ix = &ix; cx.pr = &pr; cx.L = &L;
     cx.ws = ws + (size_t)lane * L.stride;
     cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
-    for (int u = lane; u < n_units; u += n_lanes) {
-        const int nm = paired ? 2 : 1;
-        DRead rd[2];
-        dg_report_out *rp[2];
-        DCand *cd[2];
-        int nc[2];
-        for (int m = 0; m < nm; m++) {
-            const int r = paired ? 2 * u + m : u;
-            cd[m] = cands + seed_off[r];
-            nc[m] = (int)ncand[r];
-            rp[m] = reports + rep_off[r];
-            rd[m].sub_score = 0; rd[m].mis_num = 0; rd[m].mapq = 0;      // defined start state
+    while (true) {
+        unsigned int base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(tops + 3, 64u);
+        base = (unsigned int)__shfl((int)base, 0, 64);
+        if (base >= (unsigned int)n_reads) break;
+        const unsigned int idx = base + (threadIdx.x & 63);
+        if (idx < (unsigned int)n_reads) {
+            const int r = (int)perm[idx];
+            DRead rd;
+            rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0;           // defined start state
             cx.seq = seq + seq_off[r]; cx.rlen = rlen[r];
-            d_gen_mapping_report(cx, m == 0, rd[m], cd[m], nc[m], jobs, work, rp[m], cigpool, tops + 0, cigcap, err);
-        }
-        if (paired) {
-            d_check_paired_final(pr, rd[0], rp[0], rd[1], rp[1]);
-            d_set_paired_flag(rd[0], rp[0], rd[1], rp[1]);
-        } else d_set_single_flag(rd[0], rp[0]);
-        for (int m = 0; m < nm; m++) {
-            const int r = paired ? 2 * u + m : u;
-            d_evaluate_mapq(rd[m], rp[m]);
+            d_gen_mapping_report(cx, paired ? (r & 1) == 0 : true, rd, cands + seed_off[r], (int)ncand[r], jobs, work,
+                                 reports + rep_off[r], cigpool, tops + 0, cigcap, err);
             dg_read_out o;
-            o.score = rd[m].score; o.sub_score = rd[m].sub_score; o.mis_num = rd[m].mis_num; o.mapq = rd[m].mapq;
-            o.n_rep = rd[m].CanNum; o.best = rd[m].iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
-            if (nc[m] > 0 && (rd[m].mapq == 50 || (pr.all_sj && rd[m].score > 0)))
-                d_collect_sj(ix, pr, cd[m][rd[m].iBest], work, r, sjpool, tops + 1, sjcap, o.sj_off, o.n_sj, err);
+            o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
+            o.n_rep = rd.CanNum; o.best = rd.iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
             rout[r] = o;
         }
     }
@@ -208,6 +255,43 @@ k_report(const DIndex ix, const DParams pr, int n_units, int paired, const unsig
     d_wave_add(ctr + CTR_NWCELLS, cx.nw_cells);
     d_wave_add(ctr + CTR_RESEED, cx.n_reseed);
     d_wave_add(ctr + CTR_RESEEDW, cx.reseed_w);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finalize: one lane = one pair (or single read): CheckPairedFinalAlignments, FLAGs, MAPQ,
+// splice-junction tuples (Mapping.cpp:74-206,479-565,615-621)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_finalize(const DIndex ix, const DParams pr, int n_units, int paired, const uint32_t *__restrict__ seed_off,
+           const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const DSeed *__restrict__ work,
+           dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, dg_sj_out *sjpool, uint32_t sjcap,
+           unsigned int *tops, int *err)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_units) return;
+    const int nm = paired ? 2 : 1;
+    DRead rd[2];
+    dg_report_out *rp[2];
+    dg_read_out o[2];
+    for (int m = 0; m < nm; m++) {
+        const int r = paired ? 2 * u + m : u;
+        o[m] = rout[r];
+        rd[m].score = o[m].score; rd[m].sub_score = o[m].sub_score; rd[m].mis_num = o[m].mis_num; rd[m].mapq = 0;
+        rd[m].CanNum = o[m].n_rep; rd[m].iBest = o[m].best;
+        rp[m] = reports + o[m].rep_off;
+    }
+    if (paired) {
+        d_check_paired_final(pr, rd[0], rp[0], rd[1], rp[1]);
+        d_set_paired_flag(rd[0], rp[0], rd[1], rp[1]);
+    } else d_set_single_flag(rd[0], rp[0]);
+    for (int m = 0; m < nm; m++) {
+        const int r = paired ? 2 * u + m : u;
+        d_evaluate_mapq(rd[m], rp[m]);
+        o[m].score = rd[m].score; o[m].mapq = rd[m].mapq; o[m].best = rd[m].iBest;
+        if (ncand[r] > 0 && (rd[m].mapq == 50 || (pr.all_sj && rd[m].score > 0)))
+            d_collect_sj(ix, pr, cands[seed_off[r] + rd[m].iBest], work, r, sjpool, tops + 1, sjcap, o[m].sj_off, o[m].n_sj, err);
+        rout[r] = o[m];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -240,9 +324,9 @@ extern "C" void dg_destroy(dg_ctx *c)
     (void)hipSetDevice(c->device);
     void *ptrs[] = { c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff, c->d_ctr, c->d_tops, c->d_err };
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    c->seq.release(); c->seq_off.release(); c->rlen.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
+    c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->nrep.release(); c->rep_off.release(); c->work_need.release(); c->work_off.release();
-    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release();
+    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->costkey.release(); c->perm.release(); c->hist.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -277,9 +361,18 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     // ---- index upload: the .bwt blocks at a 64-byte aligned base (+ one block of padding so the
     //      last, possibly partial, block can be fetched whole), sampled SA, pac, chromosome keys
     const size_t bwt_bytes = (size_t)v->bwt_words * 4, sa_bytes = (size_t)v->n_sa * 8, pac_bytes = (size_t)(v->l_pac / 4 + 1);
-    if ((e = hipMalloc(&c->d_bwt, bwt_bytes + 128)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc bwt", e);
-    if ((e = hipMemset(c->d_bwt, 0, bwt_bytes + 128)) != hipSuccess) return bail(DG_ERR_HIP, "hipMemset", e);
-    if ((e = hipMemcpy(c->d_bwt, v->bwt, bwt_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload bwt", e);
+    {
+        const uint64_t n_blocks = (v->seq_len + 127) / 128;
+        void *raw = nullptr;
+        if ((e = hipMalloc(&raw, bwt_bytes + 128)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc bwt staging", e);
+        if ((e = hipMemcpy(raw, v->bwt, bwt_bytes, hipMemcpyHostToDevice)) != hipSuccess) { (void)hipFree(raw); return bail(DG_ERR_HIP, "upload bwt", e); }
+        if ((e = hipMalloc(&c->d_bwt, (n_blocks + 2) * 64)) != hipSuccess) { (void)hipFree(raw); return bail(DG_ERR_HIP, "hipMalloc bwt", e); }
+        if ((e = hipMemset(c->d_bwt, 0, (n_blocks + 2) * 64)) != hipSuccess) { (void)hipFree(raw); return bail(DG_ERR_HIP, "hipMemset", e); }
+        k_relayout_bwt<<<(unsigned)((n_blocks + 255) / 256), 256, 0, c->stream>>>((const uint32_t *)raw, v->bwt_words, (uint4 *)c->d_bwt, n_blocks);
+        e = hipStreamSynchronize(c->stream);
+        (void)hipFree(raw);
+        if (e != hipSuccess) return bail(DG_ERR_HIP, "k_relayout_bwt", e);
+    }
     if ((e = hipMalloc(&c->d_sa, sa_bytes)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc sa", e);
     if ((e = hipMemcpy(c->d_sa, v->sa, sa_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload sa", e);
     if ((e = hipMalloc(&c->d_pac, pac_bytes + 16)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc pac", e);
@@ -348,6 +441,19 @@ static WSLayout make_ws_layout(int R)
     return L;
 }
 
+// k_encode + k_seed (reads staged in LDS when 256 lanes x W words fit comfortably)
+static hipError_t launch_seed(dg_ctx *c, int n, int H)
+{
+    const int W = (c->max_rlen + 7) / 8 > 0 ? (c->max_rlen + 7) / 8 : 1;
+    hipError_t e = c->enc.ensure((size_t)W * n + 16);
+    if (e != hipSuccess) return e;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    k_encode<<<nb, 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, c->enc.p);
+    if (W <= 40) k_seed<true><<<nb, 256, (size_t)W * 256 * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
+    else k_seed<false><<<nb, 256, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
+    return hipGetLastError();
+}
+
 #define TICK(name) do { c->tname[c->n_t] = name; HIPCHK(hipEventRecord(c->ev[c->n_t + 1], c->stream)); c->n_t++; } while (0)
 
 extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
@@ -373,8 +479,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
 
-    k_seed<<<nb, 256, 0, c->stream>>>(c->ix, c->pr, c->seq.p, c->seq_off.p, c->rlen.p, n, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_seed(c, n, H));
     TICK("k_seed");
     HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n));
     uint32_t total_seeds = 0;
@@ -402,8 +507,8 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(c->reports.ensure((size_t)total_rep + 1)); HIPCHK(c->work.ensure((size_t)total_work + 16));
     HIPCHK(c->cigpool.ensure(cigcap)); HIPCHK(c->cigfinal.ensure(cigcap)); HIPCHK(c->sjpool.ensure(sjcap)); HIPCHK(c->sjfinal.ensure(sjcap));
     const WSLayout L = make_ws_layout(c->max_rlen < 32 ? 32 : c->max_rlen);
-    int blocks = c->n_cu * 8;                                        // 8 one-wave workgroups per CU stay resident
-    if ((size_t)blocks * 64 > (size_t)n_units) blocks = (n_units + 63) / 64;
+    int blocks = c->n_cu * (getenv("DG_REPORT_BPC") ? atoi(getenv("DG_REPORT_BPC")) : 16);   // 16 one-wave workgroups per CU (4 per SIMD)
+    if ((size_t)blocks * 64 > (size_t)n) blocks = (n + 63) / 64;
     HIPCHK(c->ws.ensure((size_t)blocks * 64 * L.stride));
     HIPCHK(c->jobs.ensure((size_t)total_seeds + 16));
     k_prep<<<nb, 256, 0, c->stream>>>(c->pr, n, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work_off.p, c->work.p, c->jobs.p,
@@ -413,11 +518,24 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     k_reseed<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
     HIPCHK(hipGetLastError());
     TICK("k_reseed");
-    k_report<<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
-                                            c->ncand.p, c->rep_off.p, c->work.p, c->reads_out.p, c->reports.p, c->cigpool.p,
-                                            (uint32_t)cigcap, c->sjpool.p, (uint32_t)sjcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
+    HIPCHK(c->costkey.ensure((size_t)n + 16)); HIPCHK(c->perm.ensure((size_t)n + 16)); HIPCHK(c->hist.ensure((size_t)COST_CLASSES * nb * 2 + 16));
+    k_cost<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->seed_off.p, c->cands.p, c->ncand.p, c->costkey.p, c->hist.p);
+    HIPCHK(scan_u32(c, c->hist.p, c->hist.p + (size_t)COST_CLASSES * nb + 8, COST_CLASSES * nb));
+    k_cost_scatter<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->costkey.p, c->hist.p + (size_t)COST_CLASSES * nb + 8, c->perm.p);
+    if (!getenv("DG_REPORT_W1"))
+        k_report<4><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
+                                            c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, c->reads_out.p, c->reports.p, c->cigpool.p,
+                                            (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
+    else
+        k_report<1><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
+                                            c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, c->reads_out.p, c->reports.p, c->cigpool.p,
+                                            (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_report");
+    k_finalize<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->seed_off.p, c->cands.p, c->ncand.p, c->work.p,
+                                                                     c->reads_out.p, c->reports.p, c->sjpool.p, (uint32_t)sjcap, c->d_tops, c->d_err);
+    HIPCHK(hipGetLastError());
+    TICK("k_finalize");
     // deterministic layout of the variable-length outputs
     HIPCHK(c->tmp_u32.ensure((size_t)total_rep + 1)); HIPCHK(c->tmp_off.ensure((size_t)total_rep + 2));
     uint32_t total_cig = 0, total_sj = 0;
@@ -505,7 +623,7 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
     HIPCHK(c->hits.ensure((size_t)n * H)); HIPCHK(c->nhits.ensure(n)); HIPCHK(c->nseeds.ensure(n)); HIPCHK(c->seed_off.ensure((size_t)n + 1));
     HIPCHK(c->ncand.ensure(n)); HIPCHK(c->nrep.ensure(n)); HIPCHK(c->work_need.ensure(n));
     HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * 8, c->stream));
-    k_seed<<<(n + 255) / 256, 256, 0, c->stream>>>(c->ix, c->pr, c->seq.p, c->seq_off.p, c->rlen.p, n, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
+    HIPCHK(launch_seed(c, n, H));
     HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n));
     uint32_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, c->seed_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));

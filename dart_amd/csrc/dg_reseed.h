@@ -196,17 +196,25 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
                     next_fin = next_fin + 64 < lim ? next_fin + 64 : lim;
                 }
             };
-            for (int g0 = 0; g0 + 8 <= glen; g0 += 64) {
+            // 4 window positions per lane per trip: the 4 pac fetches of a lane are issued together, so
+            // one L2/HBM latency is paid per 256 positions.  Live diagonals: span + 256 <= RS_RING.
+            for (int g0 = 0; g0 + 8 <= glen; g0 += 256) {
                 finalize_upto((int64_t)g0 - span);
                 __syncthreads();
-                const int p = g0 + lane;
-                if (p + 8 <= glen) {
-                    const uint32_t wid = d_window_kmer(ix, job.Lb + p);
-                    const uint32_t w16 = wid & 0xFFFFu;
-                    if ((flt[w16 >> 5] >> (w16 & 31)) & 1u) {
+                uint32_t wid[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int p = g0 + u * 64 + lane;
+                    wid[u] = p + 8 <= glen ? d_window_kmer(ix, job.Lb + p) : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int p = g0 + u * 64 + lane;
+                    const uint32_t w16 = wid[u] & 0xFFFFu;
+                    if (p + 8 <= glen && ((flt[w16 >> 5] >> (w16 & 31)) & 1u)) {
                         int lo = 0, hi = nk;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(km[mid] >> 32) < wid) lo = mid + 1; else hi = mid; }
-                        for (; lo < nk && (uint32_t)(km[lo] >> 32) == wid; lo++) {
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(km[mid] >> 32) < wid[u]) lo = mid + 1; else hi = mid; }
+                        for (; lo < nk && (uint32_t)(km[lo] >> 32) == wid[u]; lo++) {
                             const int rp = (int)(uint32_t)km[lo];
                             const int64_t d = (int64_t)p - rp;
                             atomicOr(&ring[(int)((uint64_t)d & (RS_RING - 1)) * RS_WORDS + (rp >> 6)], 1ull << (rp & 63));
