@@ -515,7 +515,8 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
                                         c->d_tops + 2, (uint32_t)c->jobs.cap, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_prep");
-    k_reseed<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
+    if (getenv("DG_RESEED_U1")) k_reseed<1><<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
+    else k_reseed<4><<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
     HIPCHK(hipGetLastError());
     TICK("k_reseed");
     HIPCHK(c->costkey.ensure((size_t)n + 16)); HIPCHK(c->perm.ensure((size_t)n + 16)); HIPCHK(c->hist.ensure((size_t)COST_CLASSES * nb * 2 + 16));
@@ -592,6 +593,16 @@ extern "C" int dg_batch_device_ptrs(dg_ctx *c, void *ptrs[4])
     if (!c || !ptrs) return DG_ERR_ARG;
     ptrs[0] = c->reads_out.p; ptrs[1] = c->reports.p; ptrs[2] = c->cigfinal.p; ptrs[3] = c->sjfinal.p;
     return DG_OK;
+}
+
+// debugging aid (not in the public header): the re-seed job queue of the last run
+extern "C" int dg_debug_jobs(dg_ctx *c, void *out, int cap)
+{
+    unsigned int n = 0;
+    if (hipMemcpy(&n, c->d_tops + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if ((int)n > cap) n = (unsigned)cap;
+    if (n && hipMemcpy(out, c->jobs.p, (size_t)n * sizeof(DJob), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)n;
 }
 
 extern "C" int dg_last_timings(dg_ctx *c, const char **names, float *ms, int cap)

@@ -102,6 +102,43 @@ __device__ __forceinline__ uint32_t d_window_kmer(const DIndex &ix, int64_t t)
     return wid;
 }
 
+// running state of GenerateLongestSimplePairsFromFragmentPair's scan (KmerAnalysis.cpp:146-163)
+struct RsFold { int s, max_len, best_r; int64_t best_g, next_fin; };
+
+// folds the complete diagonals [st.next_fin, lim) of the LDS ring into st, 64 diagonals per trip,
+// in increasing order; every lane of the wave calls it with the same arguments
+__device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, RsFold &st, const int64_t lim, const int lane)
+{
+    for (int64_t b0 = st.next_fin; b0 < lim; b0 += 64) {
+        const int64_t d = b0 + lane;
+        int cnt = 0, first = -1, last = -1;
+        if (d < lim) {
+            const int base = (int)((uint64_t)d & (RS_RING - 1)) * RS_WORDS;
+#pragma unroll
+            for (int w = 0; w < RS_WORDS; w++) {
+                const unsigned long long v = ring[base + w];
+                if (v) {
+                    cnt += __popcll(v);
+                    if (first < 0) first = w * 64 + (__ffsll((long long)v) - 1);
+                    last = w * 64 + 63 - __clzll((long long)v);
+                    ring[base + w] = 0;
+                }
+            }
+        }
+        unsigned long long mask = __ballot(cnt > 0);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            const int c = __shfl(cnt, l, 64), f = __shfl(first, l, 64), la = __shfl(last, l, 64);
+            st.s += c - 1;
+            const int len = 8 + (la - f);
+            if (len > st.max_len && st.s > (len - 8) / 2) { st.best_r = f; st.best_g = b0 + l + f; st.max_len = len; st.s = 1; }
+            mask &= mask - 1;
+        }
+    }
+    if (lim > st.next_fin) st.next_fin = lim;
+}
+
+template <int U>
 __global__ void __launch_bounds__(64)
 k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off,
          DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, unsigned long long *ctr)
@@ -166,49 +203,20 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
             }
             __syncthreads();
             const int span = rl - 8;
-            int s = 1;
-            int64_t next_fin = -(int64_t)span;
-            auto finalize_upto = [&](int64_t lim) {     // fold complete diagonals [next_fin, lim) in order
-                while (next_fin < lim) {
-                    const int64_t d = next_fin + lane;
-                    int cnt = 0, first = -1, last = -1;
-                    if (d < lim) {
-                        const int base = (int)((uint64_t)d & (RS_RING - 1)) * RS_WORDS;
-                        for (int w = 0; w < RS_WORDS; w++) {
-                            const unsigned long long v = ring[base + w];
-                            if (v) {
-                                cnt += __popcll(v);
-                                if (first < 0) first = w * 64 + (__ffsll((long long)v) - 1);
-                                last = w * 64 + 63 - __clzll((long long)v);
-                                ring[base + w] = 0;
-                            }
-                        }
-                    }
-                    unsigned long long mask = __ballot(cnt > 0);
-                    while (mask) {
-                        const int l = __ffsll((long long)mask) - 1;
-                        const int c = __shfl(cnt, l, 64), f = __shfl(first, l, 64), la = __shfl(last, l, 64);
-                        s += c - 1;
-                        const int len = 8 + (la - f);
-                        if (len > max_len && s > (len - 8) / 2) { best_r = f; best_g = next_fin + l + f; max_len = len; s = 1; }
-                        mask &= mask - 1;
-                    }
-                    next_fin = next_fin + 64 < lim ? next_fin + 64 : lim;
-                }
-            };
+            RsFold st; st.s = 1; st.max_len = 0; st.best_r = 0; st.best_g = 0; st.next_fin = -(int64_t)span;
             // 4 window positions per lane per trip: the 4 pac fetches of a lane are issued together, so
             // one L2/HBM latency is paid per 256 positions.  Live diagonals: span + 256 <= RS_RING.
-            for (int g0 = 0; g0 + 8 <= glen; g0 += 256) {
-                finalize_upto((int64_t)g0 - span);
+            for (int g0 = 0; g0 + 8 <= glen; g0 += 64 * U) {
+                d_rs_finalize(ring, st, (int64_t)g0 - span, lane);
                 __syncthreads();
-                uint32_t wid[4];
+                uint32_t wid[U];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < U; u++) {
                     const int p = g0 + u * 64 + lane;
                     wid[u] = p + 8 <= glen ? d_window_kmer(ix, job.Lb + p) : 0xFFFFFFFFu;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < U; u++) {
                     const int p = g0 + u * 64 + lane;
                     const uint32_t w16 = wid[u] & 0xFFFFu;
                     if (p + 8 <= glen && ((flt[w16 >> 5] >> (w16 & 31)) & 1u)) {
@@ -223,7 +231,8 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
                 }
                 __syncthreads();
             }
-            finalize_upto((int64_t)(glen - 8) + 1);
+            d_rs_finalize(ring, st, (int64_t)(glen - 8) + 1, lane);
+            max_len = st.max_len; best_r = st.best_r; best_g = st.best_g;
             found = (max_len >= thr && max_len > 0) ? 1 : 0;
         }
         if (lane == 0) {

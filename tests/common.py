@@ -85,5 +85,8 @@ def first_diff(a: str, b: str):
     la, lb = a.split("\n"), b.split("\n")
     for i, (x, y) in enumerate(zip(la, lb)):
         if x != y:
-            return "line %d:\n  got      %s\n  expected %s" % (i, x[:240], y[:240])
+            fx, fy = x.split("\t"), y.split("\t")
+            cols = [k for k in range(min(len(fx), len(fy))) if fx[k] != fy[k]]
+            return "line %d differs in columns %s:\n  got      %s | %s\n  expected %s | %s" % (
+                i, cols, " ".join(fx[:9]), " ".join(fx[11:]), " ".join(fy[:9]), " ".join(fy[11:]))
     return "length differs: %d vs %d lines" % (len(la), len(lb))
