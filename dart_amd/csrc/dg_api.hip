@@ -28,11 +28,13 @@ template <typename T> struct DBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-#define N_TIMERS 12
+#define N_TIMERS 16
 
 struct dg_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr;
+    float reseed_ms = 0;
     char err[512] = "";
     DIndex ix{};
     DParams pr{};
@@ -163,9 +165,9 @@ __global__ void k_compact_sj(dg_read_out *rd, uint32_t n, const uint32_t *new_of
 // first (longest-processing-time scheduling).
 // ------------------------------------------------------------------------------------------
 #define COST_CLASSES 8
-__device__ __forceinline__ uint32_t d_cost_class(uint32_t cost)   // 0 = heaviest
+__device__ __forceinline__ uint32_t d_cost_class(uint32_t cost, bool has_jobs)   // 0 = waits for k_reseed; then heaviest first
 {
-    return cost > 255 ? 0u : cost > 128 ? 1u : cost > 64 ? 2u : cost > 40 ? 3u : cost > 24 ? 4u : cost > 16 ? 5u : cost > 0 ? 6u : 7u;
+    return has_jobs ? 0u : cost > 128 ? 1u : cost > 64 ? 2u : cost > 40 ? 3u : cost > 24 ? 4u : cost > 16 ? 5u : cost > 0 ? 6u : 7u;
 }
 // pass 1: class of every read + per-(class, block) counts, laid out class-major for one scan
 __global__ void __launch_bounds__(256)
@@ -180,9 +182,9 @@ k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const D
     if (r < n_reads) {
         const DCand *cd = cands + seed_off[r];
         const int nc = (int)ncand[r];
-        uint32_t cost = 0;
-        for (int i = 0; i < nc; i++) if (cd[i].Score > 0) cost += 4u + 3u * (uint32_t)cd[i].n_a + 24u * (uint32_t)cd[i].job_count;
-        k = d_cost_class(cost);
+        uint32_t cost = 0; bool has_jobs = false;
+        for (int i = 0; i < nc; i++) if (cd[i].Score > 0) { cost += 4u + 3u * (uint32_t)cd[i].n_a; has_jobs = has_jobs || cd[i].job_count > 0; }
+        k = d_cost_class(cost, has_jobs);
         key[r] = (uint8_t)k;
     }
     for (uint32_t c = 0; c < COST_CLASSES; c++) {
@@ -224,7 +226,7 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
          const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ seed_off,
          const DJob *__restrict__ jobs, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
          const uint32_t *__restrict__ rep_off, DSeed *__restrict__ work, const uint32_t *__restrict__ perm,
-         dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
+         const uint32_t *__restrict__ n_jobreads_p, int job_part, dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
          unsigned int *tops, unsigned char *ws, const WSLayout L, unsigned long long *ctr, int *err)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,13 +234,17 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
     cx.ix = &ix; cx.pr = &pr; cx.L = &L;
     cx.ws = ws + (size_t)lane * L.stride;
     cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
+    // perm = [reads that wait for k_reseed | all other reads, heaviest class first]; this launch takes one part
+    const unsigned int n_jobreads = *n_jobreads_p;
+    const unsigned int lo = job_part ? 0u : n_jobreads, hi = job_part ? n_jobreads : (unsigned int)n_reads;
+    unsigned int *next = tops + (job_part ? 4 : 3);
     while (true) {
         unsigned int base = 0;
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(tops + 3, 64u);
-        base = (unsigned int)__shfl((int)base, 0, 64);
-        if (base >= (unsigned int)n_reads) break;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(next, 64u);
+        base = lo + (unsigned int)__shfl((int)base, 0, 64);
+        if (base >= hi) break;
         const unsigned int idx = base + (threadIdx.x & 63);
-        if (idx < (unsigned int)n_reads) {
+        if (idx < hi) {
             const int r = (int)perm[idx];
             DRead rd;
             rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0;           // defined start state
@@ -330,6 +336,10 @@ extern "C" void dg_destroy(dg_ctx *c)
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+    if (c->ev_reseed0) (void)hipEventDestroy(c->ev_reseed0);
+    if (c->ev_reseed1) (void)hipEventDestroy(c->ev_reseed1);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -352,7 +362,8 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     c = new dg_ctx();
     c->device = device;
     for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
-    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "hipStreamCreate", e);
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) return bail(DG_ERR_HIP, "hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess) return bail(DG_ERR_HIP, "hipEventCreate", e);
     for (int i = 0; i <= N_TIMERS; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail(DG_ERR_HIP, "hipEventCreate", e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -375,7 +386,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     }
     if ((e = hipMalloc(&c->d_sa, sa_bytes)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc sa", e);
     if ((e = hipMemcpy(c->d_sa, v->sa, sa_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload sa", e);
-    if ((e = hipMalloc(&c->d_pac, pac_bytes + 16)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc pac", e);
+    if ((e = hipMalloc(&c->d_pac, pac_bytes + 1024)) != hipSuccess || (e = hipMemset(c->d_pac, 0, pac_bytes + 1024)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc pac", e);
     if ((e = hipMemcpy(c->d_pac, v->pac, pac_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload pac", e);
     {
         const int n = v->n_chr;
@@ -392,7 +403,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
             (e = hipMemcpy(c->d_locchr, chr.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_chroff, off.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload chr tables", e);
     }
-    if ((e = hipMalloc((void **)&c->d_ctr, CTR_N * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, 16)) != hipSuccess ||
+    if ((e = hipMalloc((void **)&c->d_ctr, CTR_N * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, 32)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc counters", e);
     c->ix.bwt = (const uint4 *)c->d_bwt; c->ix.sa = (const uint64_t *)c->d_sa; c->ix.pac = (const uint8_t *)c->d_pac;
     c->ix.loc_key = (const int64_t *)c->d_lockey; c->ix.loc_chr = (const int32_t *)c->d_locchr; c->ix.chr_off = (const int64_t *)c->d_chroff;
@@ -431,8 +442,8 @@ static WSLayout make_ws_layout(int R)
     const uint32_t nmax = 2u * (uint32_t)R + 32u;                       // longest genome fragment of a segment pair
     L.max_rlen = (uint32_t)R;
     L.cig_off = o; L.cig_cap = 4u * (uint32_t)R + 64u; o = al(o + L.cig_cap * 4u);
-    L.nwbits_off = o; L.nwbits_words = ((uint32_t)R + 1u) * ((nmax + 15u) / 16u); o = al(o + L.nwbits_words * 4u);
-    L.rows_off = o; L.row_cap = nmax + 8u; o = al(o + 3u * L.row_cap * 4u);
+    L.nwbits_off = o; L.nwbits_words = ((uint32_t)R + 1u) * ((nmax + 7u) / 8u); o = al(o + L.nwbits_words * 4u);
+    L.rows_off = o; L.row_cap = (uint32_t)R + 8u; o = al(o + 2u * L.row_cap * 4u);          // strip boundary column: s and r per row
     L.str_off = o; L.str_cap = al(3u * (uint32_t)R + 64u); o = al(o + 6u * L.str_cap);
     L.kmer_off = o; L.kmer_cap = (uint32_t)R + 8u; o = al(o + L.kmer_cap * 8u);
     uint32_t rd = 64; while (rd < (uint32_t)R + 1u) rd <<= 1;
@@ -442,13 +453,14 @@ static WSLayout make_ws_layout(int R)
 }
 
 // k_encode + k_seed (reads staged in LDS when 256 lanes x W words fit comfortably)
-static hipError_t launch_seed(dg_ctx *c, int n, int H)
+static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode = nullptr)
 {
     const int W = (c->max_rlen + 7) / 8 > 0 ? (c->max_rlen + 7) / 8 : 1;
     hipError_t e = c->enc.ensure((size_t)W * n + 16);
     if (e != hipSuccess) return e;
     const unsigned nb = (unsigned)((n + 255) / 256);
-    k_encode<<<nb, 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, c->enc.p);
+    k_encode<<<(unsigned)(((size_t)n * W + 255) / 256), 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, c->enc.p);
+    if (after_encode) { e = hipEventRecord(after_encode, c->stream); if (e != hipSuccess) return e; }
     if (W <= 40) k_seed<true><<<nb, 256, (size_t)W * 256 * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
     else k_seed<false><<<nb, 256, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
     return hipGetLastError();
@@ -475,11 +487,13 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(c->work_need.ensure(n)); HIPCHK(c->work_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n));
     HIPCHK(c->tmp_u32.ensure(n)); HIPCHK(c->tmp_off.ensure((size_t)n + 1));
     HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_tops, 0, 16, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_tops, 0, 32, c->stream));
     HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
 
-    HIPCHK(launch_seed(c, n, H));
+    c->tname[c->n_t] = "k_encode";
+    HIPCHK(launch_seed(c, n, H, c->ev[c->n_t + 1]));
+    c->n_t++;
     TICK("k_seed");
     HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n));
     uint32_t total_seeds = 0;
@@ -515,24 +529,34 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
                                         c->d_tops + 2, (uint32_t)c->jobs.cap, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_prep");
-    if (getenv("DG_RESEED_U1")) k_reseed<1><<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
-    else k_reseed<4><<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
+    // k_reseed runs on a second stream, concurrently with the report of every read that has no
+    // re-seeding job (the 99 % case); only the job reads wait for it
+    HIPCHK(hipEventRecord(c->ev_prep, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_prep, 0));
+    HIPCHK(hipEventRecord(c->ev_reseed0, c->stream2));
+    k_reseed<<<c->n_cu * 4, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
     HIPCHK(hipGetLastError());
-    TICK("k_reseed");
+    HIPCHK(hipEventRecord(c->ev_reseed1, c->stream2));
     HIPCHK(c->costkey.ensure((size_t)n + 16)); HIPCHK(c->perm.ensure((size_t)n + 16)); HIPCHK(c->hist.ensure((size_t)COST_CLASSES * nb * 2 + 16));
     k_cost<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->seed_off.p, c->cands.p, c->ncand.p, c->costkey.p, c->hist.p);
-    HIPCHK(scan_u32(c, c->hist.p, c->hist.p + (size_t)COST_CLASSES * nb + 8, COST_CLASSES * nb));
-    k_cost_scatter<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->costkey.p, c->hist.p + (size_t)COST_CLASSES * nb + 8, c->perm.p);
-    if (!getenv("DG_REPORT_W1"))
-        k_report<4><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
-                                            c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, c->reads_out.p, c->reports.p, c->cigpool.p,
-                                            (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
-    else
-        k_report<1><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
-                                            c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, c->reads_out.p, c->reports.p, c->cigpool.p,
-                                            (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
+    uint32_t *class_offs = c->hist.p + (size_t)COST_CLASSES * nb + 8;
+    HIPCHK(scan_u32(c, c->hist.p, class_offs, COST_CLASSES * nb));
+    k_cost_scatter<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->costkey.p, class_offs, c->perm.p);
+    const uint32_t *n_jobreads_p = class_offs + (size_t)1 * nb;       // start of class 1 = number of class-0 (job) reads
+    TICK("order");
+    // one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves
+    const int blocks_main = blocks > c->n_cu * 4 ? blocks - c->n_cu : blocks;
+    k_report<4><<<blocks_main, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
+                                               c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, 0, c->reads_out.p, c->reports.p, c->cigpool.p,
+                                               (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_report");
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_reseed1, 0));
+    k_report<4><<<blocks_main < c->n_cu ? blocks_main : c->n_cu, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
+                                               c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, 1, c->reads_out.p, c->reports.p, c->cigpool.p,
+                                               (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
+    HIPCHK(hipGetLastError());
+    TICK("k_report_jobs");
     k_finalize<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->seed_off.p, c->cands.p, c->ncand.p, c->work.p,
                                                                      c->reads_out.p, c->reports.p, c->sjpool.p, (uint32_t)sjcap, c->d_tops, c->d_err);
     HIPCHK(hipGetLastError());
@@ -559,6 +583,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     TICK("compact");
     HIPCHK(hipEventSynchronize(c->ev[c->n_t]));
     for (int i = 0; i < c->n_t; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]); c->tms[i] = ms; }
+    if (c->n_t < N_TIMERS) { float ms = 0; (void)hipEventSynchronize(c->ev_reseed1); (void)hipEventElapsedTime(&ms, c->ev_reseed0, c->ev_reseed1); c->tname[c->n_t] = "k_reseed(overlapped)"; c->tms[c->n_t] = ms; c->n_t++; }
     c->counters[CTR_SEEDS] = total_seeds;
     if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == 1 ? "cigar" : (derr == 2 ? "splice junction" : "reseed jobs")); return DG_ERR_INTERNAL; }
     c->used[0] = total_rep; c->used[1] = total_cig; c->used[2] = total_sj;
@@ -676,7 +701,7 @@ extern "C" int dg_probe_nw(dg_ctx *c, int n, const uint32_t *a_off, const uint32
         const int m = (int)(a_off[i + 1] - a_off[i]), nn = (int)(b_off[i + 1] - b_off[i]);
         out_off[i] = (uint32_t)tot; tot += (size_t)m + nn;
         if (m > mx) mx = m;
-        if ((nn + 1) / 2 > mx) mx = (nn + 1) / 2;      // workspace rows hold 2R+32 columns
+        if ((nn + 1) / 2 > mx) mx = (nn + 1) / 2;      // workspace bit matrix holds 2R+32 columns
     }
     if (tot > cap) return DG_ERR_CAPACITY;
     const WSLayout L = make_ws_layout(mx);

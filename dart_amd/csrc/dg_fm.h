@@ -107,26 +107,27 @@ __global__ void k_relayout_bwt(const uint32_t *__restrict__ src, uint64_t src_wo
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_encode: ASCII reads -> 4 bit/base (nst_nt4_table codes 0..5), 8 bases per u32, word-major
-// (enc[w * n_reads + r]) so both this kernel's stores and k_seed's staging loads are coalesced.
+// k_encode: ASCII reads -> 4 bit/base (nst_nt4_table codes 0..5), 8 bases per u32, read-major
+// (enc[r * W + w]).  One thread per output word, so the 8-byte source groups of a read are
+// fetched by neighbouring lanes (coalesced) and the stores are contiguous.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_encode(const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen,
          int n_reads, int W, uint32_t *__restrict__ enc)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_reads * W) return;
+    const int r = (int)(t / W), w = (int)(t % W);
     const unsigned char *s = seq + seq_off[r];
     const int len = rlen[r];
-    for (int w = 0; w < W; w++) {
-        uint32_t v = 0;
-        for (int j = 0; j < 8; j++) {
-            const int p = w * 8 + j;
-            const uint32_t c = p < len ? d_nt4(s[p]) : 4u;
-            v |= c << (4 * j);
-        }
-        enc[(size_t)w * n_reads + r] = v;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int p = w * 8 + j;
+        const uint32_t c = p < len ? d_nt4(s[p]) : 4u;
+        v |= c << (4 * j);
     }
+    enc[t] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -145,13 +146,13 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long steps = 0, blocks = 0;
     if (USE_LDS) {
-        if (r < n_reads) for (int w = 0; w < W; w++) sh[w * 256 + threadIdx.x] = enc[(size_t)w * n_reads + r];
+        if (r < n_reads) for (int w = 0; w < W; w++) sh[w * 256 + threadIdx.x] = enc[(size_t)r * W + w];
         __syncthreads();
     }
     if (r < n_reads) {
         const int len = rlen[r], end_pos = len - 13;
         auto code = [&](int p) -> int {
-            const uint32_t w = USE_LDS ? sh[(p >> 3) * 256 + threadIdx.x] : enc[(size_t)(p >> 3) * n_reads + r];
+            const uint32_t w = USE_LDS ? sh[(p >> 3) * 256 + threadIdx.x] : enc[(size_t)r * W + (p >> 3)];
             return (int)((w >> ((p & 7) << 2)) & 15u);
         };
         int pos = 0, start = 0, p = 0, nh = 0;

@@ -46,40 +46,67 @@ struct LaneCtx {
 __device__ __forceinline__ uint32_t *ws_cig(LaneCtx &cx) { return (uint32_t *)(cx.ws + cx.L->cig_off); }
 __device__ __forceinline__ char *ws_str(LaneCtx &cx, int i) { return (char *)(cx.ws + cx.L->str_off + (uint32_t)i * cx.L->str_cap); }
 
-__device__ __forceinline__ int d_tr2(int v2) { return v2 >= 0 ? (v2 & ~1) : -((-v2) & ~1); }
+__device__ __forceinline__ int d_tr2(int v2) { return (int)(((unsigned)v2 + ((unsigned)v2 >> 31)) & ~1u); }   // 2*trunc(v2/2)
 
 // ---------------------------------------------------------------------------------------------
 // nw_alignment (nw_alignment.cpp:18-82) restated on integers x2: s is built from
 // operands truncated toward zero to 16-bit integers; traceback needs only the predicates
-// s==r and s==t per cell (2 bits), kept in the lane's bit matrix; three rolling int rows.
+// s==r and s==t per cell (2 bits).
+// Layout of the DP: columns are processed in strips of 8 that live in registers (s and t of the
+// previous row); only the strip's left boundary column (s, r per row) goes through the lane's
+// scratch, and it is prefetched one row ahead -- a cell costs ~30 VALU instead of ~10 dependent
+// memory round trips.  Matrices up to 8 columns (95 % of all calls) touch no row memory at all.
 // a: m chars, b: n chars; oa/ob receive the gapped strings; returns their common length.
 // ---------------------------------------------------------------------------------------------
+#define NW_STRIP 8
 __device__ inline int d_nw(LaneCtx &cx, const char *a, int m, const char *b, int n, char *oa, char *ob)
 {
-    uint32_t *bits = (uint32_t *)(cx.ws + cx.L->nwbits_off);
-    int *sprev = (int *)(cx.ws + cx.L->rows_off), *scur = sprev + cx.L->row_cap, *tprev = scur + cx.L->row_cap;
-    const int rw = (n + 15) >> 4;      // u32 words per bit-matrix row
+    uint32_t *bits = (uint32_t *)(cx.ws + cx.L->nwbits_off);         // bits[(i-1) * nstrips + strip]: 2 bits per cell
+    int *colS = (int *)(cx.ws + cx.L->rows_off), *colR = colS + cx.L->row_cap;
+    const int nstrips = (n + NW_STRIP - 1) / NW_STRIP;
     cx.n_nw++; cx.nw_cells += (unsigned long long)m * (unsigned long long)n;
-    sprev[0] = 0;
-    for (int j = 1; j <= n; j++) { sprev[j] = -2 - j; tprev[j] = -131072; }
-    for (int i = 1; i <= m; i++) {
-        const uint8_t ca = d_nt4((unsigned char)a[i - 1]);
-        scur[0] = -2 - i;
-        int r = -131072;                 // r[i][0]
-        uint32_t acc = 0;
-        for (int j = 1; j <= n; j++) {
-            int x = r - 1, y = scur[j - 1] - 3;
-            r = x > y ? x : y;
-            x = tprev[j] - 1; y = sprev[j] - 3;
-            const int t = x > y ? x : y;
-            const int d = d_tr2(sprev[j - 1] + (ca == d_nt4((unsigned char)b[j - 1]) ? 3 : -3));
-            const int rr = d_tr2(r), tt = d_tr2(t);
-            const int s = d > rr ? (d > tt ? d : tt) : (rr > tt ? rr : tt);
-            scur[j] = s; tprev[j] = t;
-            acc |= ((s == r ? 1u : 0u) | (s == t ? 2u : 0u)) << (((j - 1) & 15) << 1);
-            if (((j - 1) & 15) == 15 || j == n) { bits[(size_t)(i - 1) * rw + ((j - 1) >> 4)] = acc; acc = 0; }
+    for (int st = 0; st < nstrips; st++) {
+        const int j0 = st * NW_STRIP + 1;                             // first column of the strip (1-based)
+        const bool first = st == 0, last = st == nstrips - 1;
+        int sp[NW_STRIP], tp[NW_STRIP];
+        uint8_t cb[NW_STRIP];
+#pragma unroll
+        for (int q = 0; q < NW_STRIP; q++) {
+            const int j = j0 + q;
+            sp[q] = -2 - j; tp[q] = -131072;                          // s[0][j], t[0][j]
+            cb[q] = j <= n ? d_nt4((unsigned char)b[j - 1]) : 7;
         }
-        int *tmp = sprev; sprev = scur; scur = tmp;
+        int diag0 = first ? 0 : -2 - (j0 - 1);                        // s[0][j0-1]
+        int nxtS = 0, nxtR = 0;
+        if (!first && m > 0) { nxtS = colS[1]; nxtR = colR[1]; }
+        for (int i = 1; i <= m; i++) {
+            int left_s, left_r;
+            if (first) { left_s = -2 - i; left_r = -131072; }          // s[i][0], r[i][0]
+            else {
+                left_s = nxtS; left_r = nxtR;
+                if (i < m) { nxtS = colS[i + 1]; nxtR = colR[i + 1]; }  // prefetch the next row's boundary
+            }
+            const uint8_t ca = d_nt4((unsigned char)a[i - 1]);
+            int diag = diag0;
+            diag0 = left_s;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < NW_STRIP; q++) {
+                int x = left_r - 1, y = left_s - 3;
+                const int r = x > y ? x : y;
+                x = tp[q] - 1; y = sp[q] - 3;
+                const int t = x > y ? x : y;
+                const int d = d_tr2(diag + (ca == cb[q] ? 3 : -3));
+                const int rr = d_tr2(r), tt = d_tr2(t);
+                const int sv = d > rr ? (d > tt ? d : tt) : (rr > tt ? rr : tt);
+                acc |= ((sv == r ? 1u : 0u) | (sv == t ? 2u : 0u)) << (2 * q);
+                diag = sp[q];
+                sp[q] = sv; tp[q] = t;
+                left_s = sv; left_r = r;
+            }
+            bits[(size_t)(i - 1) * nstrips + st] = acc;
+            if (!last) { colS[i] = left_s; colR[i] = left_r; }
+        }
     }
     // traceback :61-74, columns produced back to front
     int i = m, j = n, k = 0;
@@ -87,7 +114,7 @@ __device__ inline int d_nw(LaneCtx &cx, const char *a, int m, const char *b, int
         uint32_t f;
         if (i == 0) f = 1;               // s[0][j] == r[0][j]
         else if (j == 0) f = 2;          // s[i][0] == t[i][0], r[i][0] is the sentinel
-        else f = (bits[(size_t)(i - 1) * rw + ((j - 1) >> 4)] >> (((j - 1) & 15) << 1)) & 3u;
+        else f = (bits[(size_t)(i - 1) * nstrips + ((j - 1) >> 3)] >> (((j - 1) & 7) << 1)) & 3u;
         if (f & 1u) { oa[k] = '-'; ob[k] = b[j - 1]; j--; }
         else if (f & 2u) { oa[k] = a[i - 1]; ob[k] = '-'; i--; }
         else { oa[k] = a[i - 1]; ob[k] = b[j - 1]; i--; j--; }

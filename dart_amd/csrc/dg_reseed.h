@@ -26,7 +26,7 @@
 #include "dg_report.h"
 
 #define RS_MAX_RL   263          // longest read gap handled cooperatively (span <= 255 -> 4 bitmap words)
-#define RS_RING     512          // diagonals in the ring (>= span + 64)
+#define RS_RING     2048         // diagonals in the ring (>= span + 63 + RS_CHUNK live at any time)
 #define RS_WORDS    4
 
 __global__ void __launch_bounds__(256)
@@ -105,40 +105,50 @@ __device__ __forceinline__ uint32_t d_window_kmer(const DIndex &ix, int64_t t)
 // running state of GenerateLongestSimplePairsFromFragmentPair's scan (KmerAnalysis.cpp:146-163)
 struct RsFold { int s, max_len, best_r; int64_t best_g, next_fin; };
 
-// folds the complete diagonals [st.next_fin, lim) of the LDS ring into st, 64 diagonals per trip,
-// in increasing order; every lane of the wave calls it with the same arguments
-__device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, RsFold &st, const int64_t lim, const int lane)
+// LDS ring of diagonals, word-major (ring[w * RS_RING + slot]) so that 64 consecutive diagonals are
+// read conflict-free; `dirty` has one bit per group of 64 diagonals that received a hit.
+// Folds the complete diagonal groups below `lim` (all remaining ones when `final`) into st, in
+// increasing diagonal order; every lane of the wave calls it with the same arguments.
+__device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, uint32_t *dirty, RsFold &st, const int64_t lim, const bool final, const int lane)
 {
-    for (int64_t b0 = st.next_fin; b0 < lim; b0 += 64) {
-        const int64_t d = b0 + lane;
-        int cnt = 0, first = -1, last = -1;
-        if (d < lim) {
-            const int base = (int)((uint64_t)d & (RS_RING - 1)) * RS_WORDS;
+    while (st.next_fin + 64 <= lim || (final && st.next_fin < lim)) {
+        const int64_t b0 = st.next_fin;
+        const uint32_t gbit = 1u << ((uint32_t)((uint64_t)b0 >> 6) & (RS_RING / 64 - 1));
+        if (*dirty & gbit) {
+            const int slot = (int)((uint64_t)(b0 + lane) & (RS_RING - 1));
+            int cnt = 0, first = -1, last = -1;
 #pragma unroll
             for (int w = 0; w < RS_WORDS; w++) {
-                const unsigned long long v = ring[base + w];
+                const unsigned long long v = ring[w * RS_RING + slot];
                 if (v) {
                     cnt += __popcll(v);
                     if (first < 0) first = w * 64 + (__ffsll((long long)v) - 1);
                     last = w * 64 + 63 - __clzll((long long)v);
-                    ring[base + w] = 0;
+                    ring[w * RS_RING + slot] = 0;
                 }
             }
+            if (lane == 0) *dirty &= ~gbit;
+            unsigned long long mask = __ballot(cnt > 0);
+            while (mask) {
+                const int l = __ffsll((long long)mask) - 1;
+                const int c = __shfl(cnt, l, 64), f = __shfl(first, l, 64), la = __shfl(last, l, 64);
+                st.s += c - 1;
+                const int len = 8 + (la - f);
+                if (len > st.max_len && st.s > (len - 8) / 2) { st.best_r = f; st.best_g = b0 + l + f; st.max_len = len; st.s = 1; }
+                mask &= mask - 1;
+            }
         }
-        unsigned long long mask = __ballot(cnt > 0);
-        while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            const int c = __shfl(cnt, l, 64), f = __shfl(first, l, 64), la = __shfl(last, l, 64);
-            st.s += c - 1;
-            const int len = 8 + (la - f);
-            if (len > st.max_len && st.s > (len - 8) / 2) { st.best_r = f; st.best_g = b0 + l + f; st.max_len = len; st.s = 1; }
-            mask &= mask - 1;
-        }
+        st.next_fin = b0 + 64;
     }
-    if (lim > st.next_fin) st.next_fin = lim;
 }
 
-template <int U>
+// the block is ONE wave: LDS operations of a wave complete in order, so ordering needs only a
+// compiler barrier + an LDS drain -- unlike __syncthreads() this leaves the prefetched global
+// load in flight (hipcc drains vmcnt at every __syncthreads fence)
+#define RS_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define RS_CHUNK 1024            // window positions per trip: one coalesced pac load (64 lanes x 4 bytes x 4 bases),
+                                 // 16 consecutive positions per lane; live diagonals: span + 63 + RS_CHUNK <= RS_RING
+
 __global__ void __launch_bounds__(64)
 k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off,
          DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, unsigned long long *ctr)
@@ -147,9 +157,12 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
     __shared__ uint64_t tmpk[RS_MAX_RL + 1], km[RS_MAX_RL + 1];
     __shared__ uint32_t flt[2048];
     __shared__ unsigned long long ring[RS_RING * RS_WORDS];
+    __shared__ uint32_t pacbuf[68];
+    __shared__ uint32_t s_dirty;
     __shared__ int s_nk;
     const int lane = threadIdx.x;
     const unsigned int njobs = *jobtop;
+    const int64_t L = ix.l_pac;
     unsigned long long n_done = 0, w_done = 0;
     for (unsigned int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
         const DJob job = jobs[jb];
@@ -162,6 +175,7 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
         for (int i = lane; i < rl; i += 64) rs[i] = rd[i];
         for (int i = lane; i < 2048; i += 64) flt[i] = 0;
         for (int i = lane; i < RS_RING * RS_WORDS; i += 64) ring[i] = 0;
+        if (lane == 0) s_dirty = 0;
         __syncthreads();
         if (lane == 0) {   // CreateKmerVecFromReadSeq :34-80 on the read gap, position order
             int nk = 0, count = 0, head, tail = 0;
@@ -203,35 +217,86 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
             }
             __syncthreads();
             const int span = rl - 8;
-            RsFold st; st.s = 1; st.max_len = 0; st.best_r = 0; st.best_g = 0; st.next_fin = -(int64_t)span;
-            // 4 window positions per lane per trip: the 4 pac fetches of a lane are issued together, so
-            // one L2/HBM latency is paid per 256 positions.  Live diagonals: span + 256 <= RS_RING.
-            for (int g0 = 0; g0 + 8 <= glen; g0 += 64 * U) {
-                d_rs_finalize(ring, st, (int64_t)g0 - span, lane);
-                __syncthreads();
-                uint32_t wid[U];
+            RsFold st; st.s = 1; st.max_len = 0; st.best_r = 0; st.best_g = 0;
+            st.next_fin = -(int64_t)(((span + 63) >> 6) << 6);          // aligned to the 64-diagonal groups
+            // window entirely inside one strand half -> k-mers come from coalesced pac dwords staged in LDS
+            const bool fwd = job.Lb >= 0 && job.Lb + glen <= L;
+            const bool rev = job.Lb >= L && job.Lb + glen <= 2 * L;
+            auto chunk_base = [&](int g0) -> int64_t {                  // first pac byte (4-aligned) of chunk g0
+                if (fwd) return (int64_t)(((job.Lb + g0) >> 2) & ~(int64_t)3);
+                int64_t ulo = 2 * L - 1 - (job.Lb + g0 + RS_CHUNK - 1) - 7;
+                if (ulo < 0) ulo = 0;
+                return (int64_t)((ulo >> 2) & ~(int64_t)3);
+            };
+            uint32_t pre0 = 0, pre1 = 0;
+            if (fwd || rev) {
+                const uint32_t *src = (const uint32_t *)(ix.pac + chunk_base(0));
+                pre0 = src[lane]; if (lane < 4) pre1 = src[64 + lane];
+            }
+            for (int g0 = 0; g0 + 8 <= glen; g0 += RS_CHUNK) {
+                d_rs_finalize(ring, &s_dirty, st, (int64_t)g0 - span, false, lane);
+                uint64_t x = 0;                 // the lane's 23 bases (46 bits), first base in the top bits
+                int o_rev = 0;
+                if (fwd || rev) {
+                    const int64_t B0 = chunk_base(g0);
+                    RS_WAVE_SYNC();
+                    pacbuf[lane] = pre0; if (lane < 4) pacbuf[64 + lane] = pre1;
+                    if (g0 + RS_CHUNK + 8 <= glen) {                    // prefetch the next chunk while this one is processed
+                        const uint32_t *src = (const uint32_t *)(ix.pac + chunk_base(g0 + RS_CHUNK));
+                        pre0 = src[lane]; if (lane < 4) pre1 = src[64 + lane];
+                    }
+                    RS_WAVE_SYNC();
+                    // first forward base this lane needs, relative to base 4*B0 of the staged bytes
+                    int64_t fb;
+                    if (fwd) fb = job.Lb + g0 + 16 * lane - 4 * B0;
+                    else { fb = 2 * L - 1 - (job.Lb + g0 + 16 * lane + 15) - 7 - 4 * B0; if (fb < 0) { o_rev = (int)-fb; fb = 0; } }
+                    const int m = (int)(fb >> 4), o = (int)(fb & 15);                 // dword index, base offset inside it
+                    const uint32_t w0 = __builtin_bswap32(pacbuf[m]), w1 = __builtin_bswap32(pacbuf[m + 1]), w2 = __builtin_bswap32(pacbuf[m + 2]);
+                    const uint64_t hi = ((uint64_t)w0 << 32) | w1;
+                    x = o ? ((hi << (2 * o)) | ((uint64_t)w2 >> (32 - 2 * o))) : hi;
+                    if (o_rev) x = o_rev > 23 ? 0 : x >> (2 * o_rev);     // window start of the reverse half clipped at forward base 0 (never a valid position)
+                }
+                uint32_t wid[16];
+                uint32_t pass = 0;
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int p = g0 + u * 64 + lane;
-                    wid[u] = p + 8 <= glen ? d_window_kmer(ix, job.Lb + p) : 0xFFFFFFFFu;
+                for (int j = 0; j < 16; j++) {
+                    const int p = g0 + 16 * lane + j;
+                    uint32_t w;
+                    if (fwd) w = (uint32_t)(x >> (48 - 2 * j)) & 0xFFFFu;
+                    else if (rev) {
+                        uint32_t f = (uint32_t)(x >> (48 - 2 * (15 - j))) & 0xFFFFu;      // forward 8-mer, mirrored position
+                        f = ((f & 0x3333u) << 2) | ((f >> 2) & 0x3333u);
+                        f = ((f & 0x0F0Fu) << 4) | ((f >> 4) & 0x0F0Fu);
+                        f = ((f << 8) | (f >> 8)) & 0xFFFFu;
+                        w = f ^ 0xFFFFu;
+                    } else w = p + 8 <= glen ? d_window_kmer(ix, job.Lb + p) : 0u;
+                    wid[j] = w;
                 }
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int p = g0 + u * 64 + lane;
-                    const uint32_t w16 = wid[u] & 0xFFFFu;
-                    if (p + 8 <= glen && ((flt[w16 >> 5] >> (w16 & 31)) & 1u)) {
-                        int lo = 0, hi = nk;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(km[mid] >> 32) < wid[u]) lo = mid + 1; else hi = mid; }
-                        for (; lo < nk && (uint32_t)(km[lo] >> 32) == wid[u]; lo++) {
-                            const int rp = (int)(uint32_t)km[lo];
-                            const int64_t d = (int64_t)p - rp;
-                            atomicOr(&ring[(int)((uint64_t)d & (RS_RING - 1)) * RS_WORDS + (rp >> 6)], 1ull << (rp & 63));
-                        }
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t w16 = wid[j] & 0xFFFFu;
+                    const bool ok = g0 + 16 * lane + j + 8 <= glen;
+                    pass |= (ok ? ((flt[w16 >> 5] >> (w16 & 31)) & 1u) : 0u) << j;
+                }
+                while (pass) {
+                    const int j = __ffs((int)pass) - 1;
+                    pass &= pass - 1;
+                    const int p = g0 + 16 * lane + j;
+                    uint32_t w = wid[0];
+#pragma unroll
+                    for (int q = 1; q < 16; q++) w = j == q ? wid[q] : w;
+                    int lo = 0, hi2 = nk;
+                    while (lo < hi2) { const int mid = (lo + hi2) >> 1; if ((uint32_t)(km[mid] >> 32) < w) lo = mid + 1; else hi2 = mid; }
+                    for (; lo < nk && (uint32_t)(km[lo] >> 32) == w; lo++) {
+                        const int rp = (int)(uint32_t)km[lo];
+                        const int64_t d = (int64_t)p - rp;
+                        atomicOr(&ring[(rp >> 6) * RS_RING + (int)((uint64_t)d & (RS_RING - 1))], 1ull << (rp & 63));
+                        atomicOr(&s_dirty, 1u << ((uint32_t)((uint64_t)d >> 6) & (RS_RING / 64 - 1)));
                     }
                 }
-                __syncthreads();
+                RS_WAVE_SYNC();
             }
-            d_rs_finalize(ring, st, (int64_t)(glen - 8) + 1, lane);
+            d_rs_finalize(ring, &s_dirty, st, (int64_t)(glen - 8) + 1, true, lane);
             max_len = st.max_len; best_r = st.best_r; best_g = st.best_g;
             found = (max_len >= thr && max_len > 0) ? 1 : 0;
         }
