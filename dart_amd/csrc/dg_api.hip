@@ -39,6 +39,7 @@ struct dg_ctx {
     DIndex ix{};
     DParams pr{};
     // index storage
+    void *d_ktab = nullptr, *d_sa_dense = nullptr;
     void *d_bwt = nullptr, *d_sa = nullptr, *d_pac = nullptr, *d_lockey = nullptr, *d_locchr = nullptr, *d_chroff = nullptr;
     // batch inputs
     int n_reads = 0, max_rlen = 0;
@@ -328,7 +329,7 @@ extern "C" void dg_destroy(dg_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = { c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff, c->d_ctr, c->d_tops, c->d_err };
+    void *ptrs[] = { c->d_ktab, c->d_sa_dense, c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff, c->d_ctr, c->d_tops, c->d_err };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->nrep.release(); c->rep_off.release(); c->work_need.release(); c->work_off.release();
@@ -409,6 +410,29 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     c->ix.loc_key = (const int64_t *)c->d_lockey; c->ix.loc_chr = (const int32_t *)c->d_locchr; c->ix.chr_off = (const int64_t *)c->d_chroff;
     c->ix.primary = v->primary; for (int i = 0; i < 5; i++) c->ix.L2[i] = v->L2[i]; c->ix.seq_len = v->seq_len;
     c->ix.l_pac = v->l_pac; c->ix.n_chr = v->n_chr; c->ix.sa_intv = v->sa_intv;
+    c->ix.ktab = nullptr; c->ix.ktab_k = 0; c->ix.sa_dense = nullptr; c->ix.sa_dense_intv = 0;
+    {   // denser SA: every 4th row (8 bytes per 4 text symbols); DG_SA_DENSE=0 turns it off, =2/8/16 changes the interval
+        int intv = getenv("DG_SA_DENSE") ? atoi(getenv("DG_SA_DENSE")) : 4;
+        if (intv >= 1 && intv < v->sa_intv && (intv & (intv - 1)) == 0 && v->seq_len < (1ull << 39)) {
+            const uint64_t n_entries = v->seq_len / (uint64_t)intv + 1;
+            if ((e = hipMalloc(&c->d_sa_dense, n_entries * 8)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc dense SA", e);
+            k_build_sa_dense<<<(unsigned)((n_entries + 255) / 256), 256, 0, c->stream>>>(c->ix, intv, n_entries, (uint64_t *)c->d_sa_dense);
+            if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_sa_dense", e);
+            c->ix.sa_dense = (const uint64_t *)c->d_sa_dense; c->ix.sa_dense_intv = intv;
+        }
+    }
+    {   // K-mer prefix table: K = 12 (402 MB) for genome-sized texts, smaller for small texts; DG_KTAB_K=0 turns it off
+        int K = v->seq_len >= (1ull << 26) ? 12 : (v->seq_len >= (1ull << 22) ? 10 : 8);
+        if (getenv("DG_KTAB_K")) K = atoi(getenv("DG_KTAB_K"));
+        if (K > 13) K = 13;
+        if (K >= 2) {
+            const size_t entries = (size_t)1 << (2 * K);
+            if ((e = hipMalloc(&c->d_ktab, entries * 24)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc k-mer table", e);
+            k_build_ktab<<<(unsigned)((entries + 255) / 256), 256, 0, c->stream>>>(c->ix, K, (uint64_t *)c->d_ktab);
+            if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_ktab", e);
+            c->ix.ktab = (const uint64_t *)c->d_ktab; c->ix.ktab_k = K;
+        }
+    }
     if (status) *status = st;
     return c;
 }
@@ -502,7 +526,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     TICK("scan_seeds");
     HIPCHK(c->seeds.ensure((size_t)total_seeds + 1)); HIPCHK(c->cands.ensure((size_t)total_seeds + 1));
     if (total_seeds) {
-        k_locate<<<(total_seeds + 255) / 256, 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->seed_off.p, total_seeds, c->seeds.p, c->d_ctr);
+        k_locate<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->nseeds.p, c->seed_off.p, c->seeds.p, c->d_ctr);
         HIPCHK(hipGetLastError());
     }
     TICK("k_locate");
@@ -667,7 +691,7 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
     if (used) *used = total;
     if (total > cap) return DG_ERR_CAPACITY;
     HIPCHK(c->seeds.ensure((size_t)total + 1)); HIPCHK(c->cands.ensure((size_t)total + 1));
-    if (total) k_locate<<<(total + 255) / 256, 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->seed_off.p, total, c->seeds.p, c->d_ctr);
+    if (total) k_locate<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->nseeds.p, c->seed_off.p, c->seeds.p, c->d_ctr);
     // the sort is the first half of k_chain; run it unpaired so every read is sorted on its own
     k_chain<<<(n + 255) / 256, 256, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->d_ctr);
     std::vector<DSeed> h(total);

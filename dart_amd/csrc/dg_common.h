@@ -57,6 +57,8 @@ struct __attribute__((aligned(8))) DJob {
 struct DIndex {
     const uint4    *bwt;          // 4 x uint4 per block
     const uint64_t *sa;           // sampled SA, sa[0] = -1
+    const uint64_t *sa_dense;     // SA of every sa_dense_intv-th row: (pos+1) in 40 bits | reference LF steps << 40; NULL = off
+    const uint64_t *ktab;         // K-mer prefix table (3 x u64 per entry), see dg_fm.h; NULL = off
     const uint8_t  *pac;
     const int64_t  *loc_key;      // ChrLocMap keys, ascending (2*n_chr)
     const int32_t  *loc_chr;
@@ -64,6 +66,7 @@ struct DIndex {
     uint64_t primary, L2[5], seq_len;
     int64_t  l_pac;
     int32_t  n_chr, sa_intv;
+    int32_t  ktab_k, sa_dense_intv;
 };
 
 struct DParams {
@@ -71,7 +74,8 @@ struct DParams {
 };
 
 // work counters (dg_last_counters)
-enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, CTR_NWCELLS, CTR_RESEED, CTR_RESEEDW, CTR_N };
+enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, CTR_NWCELLS, CTR_RESEED, CTR_RESEEDW,
+       CTR_STEPS_ACT, CTR_BLOCKS_ACT, CTR_KTAB, CTR_LF_ACT, CTR_N };   // *_ACT: steps/blocks this implementation really executed
 
 __device__ __forceinline__ uint8_t d_nt4(unsigned char c)   // nst_nt4_table, BWT_Index/bntseq.c:40
 {

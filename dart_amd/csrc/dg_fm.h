@@ -130,6 +130,67 @@ k_encode(const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq
     enc[t] = v;
 }
 
+// one step of BWT_Search (:152-170) with base c: returns false when the extension is empty
+__device__ __forceinline__ bool d_extend(const DIndex &ix, int c, uint64_t &x0, uint64_t &x1, uint64_t &x2, uint32_t &nblk)
+{
+    const int b = 3 - c;
+    const uint64_t k = x1 - 1, l = k + x2;
+    const uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
+    uint64_t tkb, tkp, tlb, tlp;
+    const OccBlock B = d_load_block(ix, kk >> 7);
+    d_occ_pair(B, b, (uint32_t)(kk & 127), tkb, tkp);
+    if ((ll >> 7) != (kk >> 7)) {
+        const OccBlock B2 = d_load_block(ix, ll >> 7);
+        d_occ_pair(B2, b, (uint32_t)(ll & 127), tlb, tlp);
+        nblk = 2;
+    } else {
+        d_occ_pair(B, b, (uint32_t)(ll & 127), tlb, tlp);
+        nblk = 1;
+    }
+    const uint64_t n2 = tlb - tkb;
+    if (n2 == 0) return false;
+    // sum over j > b of (tl[j] - tk[j]), using sum_j t[j] = row + 1
+    uint64_t above;
+    if (b == 0) above = (ll - kk) - n2;
+    else if (b == 1) above = (ll - kk) - n2 - (tlp - tkp);
+    else if (b == 2) above = tlp - tkp;
+    else above = 0;
+    x0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0) + above;
+    x1 = d_L2(ix, b) + 1 + tkb;
+    x2 = n2;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-mer prefix table (built once in dg_init by k_build_ktab): entry id = sum_i base[i] << 2i of
+// the first K bases of a search (first base in the lowest bits); it holds the bi-interval after
+// those K bases, i.e. after K-1 steps of BWT_Search, plus how many steps / Occ blocks the
+// reference's loop would have spent getting there (for the algorithmic-byte accounting).
+//   e[0] = x0, e[1] = x1, e[2] = x2 (40 bits) | ref_steps << 40 | ref_blocks << 48
+// x2 == 0: the K-mer does not occur; because K <= 16 such a search can never yield a seed
+// (bwt_search.cpp:173 needs len >= 16), so it is skipped with the reference's step count.
+// Results are unchanged by construction: the table is the reference's own loop, memoised.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (1u << (2 * K))) return;
+    int c = (int)(id & 3u);
+    uint64_t x0 = d_L2(ix, c) + 1, x1 = d_L2(ix, 3 - c) + 1, x2 = d_L2(ix, c + 1) - d_L2(ix, c);
+    uint32_t steps = 0, blocks = 0;
+    for (int i = 1; i < K; i++) {
+        c = (int)((id >> (2 * i)) & 3u);
+        uint32_t nb;
+        steps++;
+        const bool ok = d_extend(ix, c, x0, x1, x2, nb);
+        blocks += nb;
+        if (!ok) { x2 = 0; break; }
+    }
+    tab[(size_t)id * 3 + 0] = x0; tab[(size_t)id * 3 + 1] = x1;
+    tab[(size_t)id * 3 + 2] = (x2 & 0xFFFFFFFFFFull) | ((uint64_t)steps << 40) | ((uint64_t)blocks << 48);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_seed: one lane = one read.  Greedy left-to-right tiling with maximal exact matches
 // (IdentifySeedPairs + BWT_Search).  The two nested loops of the reference are flattened into one
@@ -144,17 +205,16 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
 {
     extern __shared__ uint32_t sh[];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long steps = 0, blocks = 0;
+    unsigned long long steps = 0, blocks = 0, steps_act = 0, blocks_act = 0, ktab_reads = 0;
     if (USE_LDS) {
         if (r < n_reads) for (int w = 0; w < W; w++) sh[w * 256 + threadIdx.x] = enc[(size_t)r * W + w];
         __syncthreads();
     }
     if (r < n_reads) {
         const int len = rlen[r], end_pos = len - 13;
-        auto code = [&](int p) -> int {
-            const uint32_t w = USE_LDS ? sh[(p >> 3) * 256 + threadIdx.x] : enc[(size_t)r * W + (p >> 3)];
-            return (int)((w >> ((p & 7) << 2)) & 15u);
-        };
+        const int K = ix.ktab ? ix.ktab_k : 0;
+        auto word = [&](int w) -> uint32_t { return w < W ? (USE_LDS ? sh[w * 256 + threadIdx.x] : enc[(size_t)r * W + w]) : 0x44444444u; };
+        auto code = [&](int p) -> int { return (int)((word(p >> 3) >> ((p & 7) << 2)) & 15u); };
         int pos = 0, start = 0, p = 0, nh = 0;
         uint32_t ns = 0;
         bool searching = false;
@@ -163,44 +223,44 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
             if (!searching) {
                 while (pos < end_pos && code(pos) > 3) pos++;
                 if (pos >= end_pos) break;
-                const int c = code(pos);
-                start = pos; p = pos + 1; searching = true;
-                x0 = d_L2(ix, c) + 1; x1 = d_L2(ix, 3 - c) + 1; x2 = d_L2(ix, c + 1) - d_L2(ix, c);
+                start = pos;
+                bool from_table = false;
+                if (K) {
+                    // the K 4-bit codes from `pos` on: 48 bits out of three staged words
+                    const int w0 = pos >> 3, sft = (pos & 7) << 2;
+                    const uint64_t lo = (uint64_t)word(w0) | ((uint64_t)word(w0 + 1) << 32);
+                    uint64_t v = sft ? ((lo >> sft) | ((uint64_t)word(w0 + 2) << (64 - sft))) : lo;
+                    v &= (1ull << (4 * K)) - 1ull;
+                    if ((v & 0x4444444444444444ull) == 0) {           // no N among them (codes 4,5 have bit 2 set)
+                        uint64_t x = v & 0x3333333333333333ull;       // nibbles -> 2-bit pairs, first base lowest
+                        x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+                        x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+                        x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+                        x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+                        const uint64_t *e = ix.ktab + (size_t)x * 3;
+                        const uint64_t e2 = e[2];
+                        ktab_reads++;
+                        steps += (e2 >> 40) & 0xFF; blocks += (e2 >> 48) & 0xFF;
+                        from_table = true;
+                        if ((e2 & 0xFFFFFFFFFFull) == 0) { pos = start + 1; continue; }   // cannot reach 16: no seed here
+                        x0 = e[0]; x1 = e[1]; x2 = e2 & 0xFFFFFFFFFFull;
+                        p = start + K; searching = true;
+                    }
+                }
+                if (!from_table) {
+                    const int c = code(pos);
+                    p = pos + 1; searching = true;
+                    x0 = d_L2(ix, c) + 1; x1 = d_L2(ix, 3 - c) + 1; x2 = d_L2(ix, c + 1) - d_L2(ix, c);
+                }
             }
             bool stop = p >= len;
             int c = 4;
             if (!stop) { c = code(p); stop = c > 3; }
             if (!stop) {
-                // one step of BWT_Search :152-170 for the single base b = 3 - c
-                const int b = 3 - c;
-                const uint64_t k = x1 - 1, l = k + x2;
-                const uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
-                uint64_t tkb, tkp, tlb, tlp;
-                const OccBlock B = d_load_block(ix, kk >> 7);
-                d_occ_pair(B, b, (uint32_t)(kk & 127), tkb, tkp);
-                if ((ll >> 7) != (kk >> 7)) {
-                    const OccBlock B2 = d_load_block(ix, ll >> 7);
-                    d_occ_pair(B2, b, (uint32_t)(ll & 127), tlb, tlp);
-                    blocks += 2;
-                } else {
-                    d_occ_pair(B, b, (uint32_t)(ll & 127), tlb, tlp);
-                    blocks += 1;
-                }
-                steps++;
-                const uint64_t n2 = tlb - tkb;
-                if (n2 == 0) stop = true;
-                else {
-                    // sum over j > b of (tl[j] - tk[j]), using sum_j t[j] = row + 1
-                    uint64_t above;
-                    if (b == 0) above = (ll - kk) - n2;
-                    else if (b == 1) above = (ll - kk) - n2 - (tlp - tkp);
-                    else if (b == 2) above = tlp - tkp;
-                    else above = 0;
-                    x0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0) + above;
-                    x1 = d_L2(ix, b) + 1 + tkb;
-                    x2 = n2;
-                    p++;
-                }
+                uint32_t nb;
+                const bool ok = d_extend(ix, c, x0, x1, x2, nb);
+                steps++; blocks += nb; steps_act++; blocks_act += nb;
+                if (ok) p++; else stop = true;
             }
             if (stop) {
                 const int l = p - start;
@@ -220,36 +280,86 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
     }
     d_wave_add(ctr + CTR_STEPS, steps);
     d_wave_add(ctr + CTR_BLOCKS, blocks);
+    d_wave_add(ctr + CTR_STEPS_ACT, steps_act);
+    d_wave_add(ctr + CTR_BLOCKS_ACT, blocks_act);
+    d_wave_add(ctr + CTR_KTAB, ktab_reads);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_locate: one lane = one seed occurrence (one row of a hit's SA interval): LF-walk to the
-// nearest sampled row (bwt_sa :127-137), then emit the seed.  Lane -> (read, hit, j) by binary
-// search of the per-read seed offsets (exclusive scan of nseeds).
+// k_build_sa_dense (once per dg_init): SA of every `intv`-th row, derived from the reference's
+// SA/32 by the reference's own walk (bwt_sa :127-137), so results cannot change.  Each entry
+// also remembers how many LF steps the reference needs from that row (algorithmic-byte accounting).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_locate(const DIndex ix, int n_reads, int H, const DHit *__restrict__ hits, const uint32_t *__restrict__ seed_off,
-         uint32_t total, DSeed *__restrict__ seeds, unsigned long long *ctr)
+k_build_sa_dense(const DIndex ix, int intv, uint64_t n_entries, uint64_t *__restrict__ dense)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long lf = 0;
-    if (t < total) {
-        int lo = 0, hi = n_reads;           // largest r with seed_off[r] <= t
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (seed_off[mid] <= t) lo = mid; else hi = mid; }
-        const int r = lo;
-        uint32_t u = t - seed_off[r];
-        const DHit *h = hits + (size_t)r * H;
-        while (u >= h->freq) { u -= h->freq; h++; }
-        uint64_t k = h->x0 + u;
-        const uint64_t mask = (uint64_t)ix.sa_intv - 1;
-        uint64_t steps = 0;
-        while (k & mask) { k = d_lf(ix, k); steps++; }
-        lf = steps;
-        DSeed s;
-        s.gPos = (int64_t)(steps + ix.sa[k / (uint64_t)ix.sa_intv]);
-        s.rPos = h->rPos; s.rLen = s.gLen = h->len; s.flags = SEED_SIMPLE;
-        seeds[t] = s;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    uint64_t k = i * (uint64_t)intv, steps = 0;
+    const uint64_t mask = (uint64_t)ix.sa_intv - 1;
+    while (k & mask) { k = d_lf(ix, k); steps++; }
+    const uint64_t pos = steps + ix.sa[k / (uint64_t)ix.sa_intv];      // sa[0] = -1 wraps as in the reference
+    dense[i] = ((pos + 1) & 0xFFFFFFFFFFull) | (steps << 40);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_locate: SA interval rows -> text positions (bwt_sa :127-137) -> seeds.
+// One wave owns 64 consecutive reads; their seed counts are prefix-summed with wave shuffles and
+// the wave then walks its seeds 64 at a time, one lane per seed occurrence (so a read with 100
+// repeat copies is spread over lanes, wavefront-compaction style): lane -> read by a 6-step binary
+// search over the in-register prefix (ds_bpermute), no global search; seeds come out coalesced.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_locate(const DIndex ix, int n_reads, int H, const DHit *__restrict__ hits, const uint32_t *__restrict__ nseeds,
+         const uint32_t *__restrict__ seed_off, DSeed *__restrict__ seeds, unsigned long long *ctr)
+{
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;      // first read of this wave
+    unsigned long long lf = 0, lf_act = 0, nsa = 0;
+    if (r0 < n_reads) {
+        const int r = r0 + lane;
+        const uint32_t mine = r < n_reads ? nseeds[r] : 0u;
+        uint32_t incl = mine;                                                        // inclusive prefix over the wave
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        const uint32_t total = __shfl(incl, 63, 64);
+        const uint32_t base = seed_off[r0];
+        for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+            const uint32_t u = c0 + lane;
+            int lo = 0;                                     // smallest lane j with incl[j] > u
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                const uint32_t v = __shfl(incl, lo + step - 1, 64);
+                if (v <= u) lo += step;
+            }
+            lo = lo > 63 ? 63 : lo;
+            const uint32_t excl = __shfl(incl, lo, 64) - __shfl(mine, lo, 64);      // all lanes take part in the shuffles
+            if (u < total) {
+                uint32_t w = u - excl;
+                const DHit *h = hits + (size_t)(r0 + lo) * H;
+                while (w >= h->freq) { w -= h->freq; h++; }
+                uint64_t k = h->x0 + w;
+                uint64_t steps = 0, pos;
+                if (ix.sa_dense) {
+                    const uint64_t mask = (uint64_t)ix.sa_dense_intv - 1;
+                    while (k & mask) { k = d_lf(ix, k); steps++; }
+                    const uint64_t e = ix.sa_dense[k / (uint64_t)ix.sa_dense_intv];
+                    pos = steps + (e & 0xFFFFFFFFFFull) - 1;
+                    lf += steps + (e >> 40); lf_act += steps;
+                } else {
+                    const uint64_t mask = (uint64_t)ix.sa_intv - 1;
+                    while (k & mask) { k = d_lf(ix, k); steps++; }
+                    pos = steps + ix.sa[k / (uint64_t)ix.sa_intv];
+                    lf += steps; lf_act += steps;
+                }
+                nsa++;
+                DSeed s;
+                s.gPos = (int64_t)pos;
+                s.rPos = h->rPos; s.rLen = s.gLen = h->len; s.flags = SEED_SIMPLE;
+                seeds[base + u] = s;
+            }
+        }
     }
     d_wave_add(ctr + CTR_LF, lf);
-    d_wave_add(ctr + CTR_SA, t < total ? 1 : 0);
+    d_wave_add(ctr + CTR_LF_ACT, lf_act);
+    d_wave_add(ctr + CTR_SA, nsa);
 }

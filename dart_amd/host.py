@@ -218,9 +218,10 @@ class DartGPU:
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
     def counters(self):
-        out = (C.c_uint64 * 16)()
-        n = self.lib.dg_last_counters(self.ctx, out, 16)
-        keys = ["steps", "occ_blocks", "lf_steps", "sa_lookups", "seeds", "candidates", "nw_calls", "nw_cells", "reseed_calls", "reseed_window"]
+        out = (C.c_uint64 * 32)()
+        n = self.lib.dg_last_counters(self.ctx, out, 32)
+        keys = ["steps", "occ_blocks", "lf_steps", "sa_lookups", "seeds", "candidates", "nw_calls", "nw_cells", "reseed_calls", "reseed_window",
+                "steps_executed", "occ_blocks_executed", "ktab_lookups", "lf_steps_executed"]
         return {keys[i]: int(out[i]) for i in range(min(n, len(keys)))}
 
     def probe_seeds(self, seq_off, rlen, flat):

@@ -97,7 +97,9 @@ int dg_batch_device_ptrs(dg_ctx *, void *ptrs[4]);
 int dg_last_timings(dg_ctx *, const char **names, float *ms, int cap);
 /* work counters of the last run: [0] Occ-pair steps [1] Occ blocks touched [2] LF steps
  * [3] SA lookups [4] seeds [5] candidates [6] NW calls [7] NW cells [8] reseed calls
- * [9] reseed window bases                                                                    */
+ * [9] reseed window bases -- [0..3] are counted as the REFERENCE's algorithm would execute them
+ * (the basis of the algorithmic-byte figure); [10] Occ-pair steps and [11] Occ blocks this
+ * implementation really executed, [12] k-mer prefix-table look-ups, [13] LF steps really executed */
 int dg_last_counters(dg_ctx *, uint64_t *out, int cap);
 
 /* ---- stage probes (parity tests of single kernels; mirror oracle/dart_oracle.h) ----
