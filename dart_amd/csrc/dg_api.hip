@@ -47,7 +47,7 @@ struct dg_ctx {
     DBuf<unsigned char> seq; DBuf<uint32_t> seq_off; DBuf<uint16_t> rlen; DBuf<uint32_t> enc;
     // pipeline buffers
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, nrep, rep_off, work_need, work_off, tile_sums, tmp_u32, tmp_off;
-    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> costkey; DBuf<uint32_t> perm, hist;
+    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> costkey; DBuf<uint32_t> perm, hist, heavy;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<unsigned char> ws;
@@ -333,7 +333,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->nrep.release(); c->rep_off.release(); c->work_need.release(); c->work_off.release();
-    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->costkey.release(); c->perm.release(); c->hist.release();
+    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->costkey.release(); c->perm.release(); c->hist.release(); c->heavy.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -404,7 +404,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
             (e = hipMemcpy(c->d_locchr, chr.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_chroff, off.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload chr tables", e);
     }
-    if ((e = hipMalloc((void **)&c->d_ctr, CTR_N * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, 32)) != hipSuccess ||
+    if ((e = hipMalloc((void **)&c->d_ctr, CTR_N * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, 64)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc counters", e);
     c->ix.bwt = (const uint4 *)c->d_bwt; c->ix.sa = (const uint64_t *)c->d_sa; c->ix.pac = (const uint8_t *)c->d_pac;
     c->ix.loc_key = (const int64_t *)c->d_lockey; c->ix.loc_chr = (const int32_t *)c->d_locchr; c->ix.chr_off = (const int64_t *)c->d_chroff;
@@ -511,7 +511,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(c->work_need.ensure(n)); HIPCHK(c->work_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n));
     HIPCHK(c->tmp_u32.ensure(n)); HIPCHK(c->tmp_off.ensure((size_t)n + 1));
     HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_tops, 0, 32, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_tops, 0, 64, c->stream));
     HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
 
@@ -530,8 +530,12 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
         HIPCHK(hipGetLastError());
     }
     TICK("k_locate");
+    HIPCHK(c->heavy.ensure((size_t)n_units + 16));
+    k_heavy_list<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(n_units, paired, c->seed_off.p, c->heavy.p, c->d_tops + 5);
     k_chain<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p,
                                                                   c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->d_ctr);
+    k_chain_heavy<<<c->n_cu * 8, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p,
+                                                     c->nrep.p, c->work_need.p, c->heavy.p, c->d_tops + 5, c->d_ctr);
     HIPCHK(hipGetLastError());
     TICK("k_chain");
     HIPCHK(scan_u32(c, c->nrep.p, c->rep_off.p, (uint32_t)n));
@@ -693,7 +697,11 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
     HIPCHK(c->seeds.ensure((size_t)total + 1)); HIPCHK(c->cands.ensure((size_t)total + 1));
     if (total) k_locate<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->nseeds.p, c->seed_off.p, c->seeds.p, c->d_ctr);
     // the sort is the first half of k_chain; run it unpaired so every read is sorted on its own
+    HIPCHK(c->heavy.ensure((size_t)n + 16));
+    HIPCHK(hipMemsetAsync(c->d_tops, 0, 64, c->stream));
+    k_heavy_list<<<(n + 255) / 256, 256, 0, c->stream>>>(n, 0, c->seed_off.p, c->heavy.p, c->d_tops + 5);
     k_chain<<<(n + 255) / 256, 256, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->d_ctr);
+    k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->heavy.p, c->d_tops + 5, c->d_ctr);
     std::vector<DSeed> h(total);
     HIPCHK(hipMemcpyAsync(seed_off, c->seed_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, c->stream));
     if (total) HIPCHK(hipMemcpyAsync(h.data(), c->seeds.p, (size_t)total * sizeof(DSeed), hipMemcpyDeviceToHost, c->stream));

@@ -1190,13 +1190,17 @@ static void read_free(read_t *r)
     free(r->rep); free(r->enc);
 }
 
-typedef struct {
+typedef struct job_s {
     ctx_t cx;
     int n_reads, paired, begin, end;    /* read index range [begin,end), pair aligned */
     const uint32_t *seq_off; const uint16_t *rlen; const char *seq;
-    read_t *reads;                      /* per-thread slice results kept until the gather */
+    read_t *reads;                      /* shared array; each thread touches its own range */
     sjvec sj;
-    char **seqz;
+    /* output phase */
+    size_t n_rep, n_cig, n_sj, base_rep, base_cig, base_sj;
+    orc_read_out *ro; orc_report_out *po; uint32_t *cigar_ops; orc_sj_out *so;
+    const size_t *caps; int overflow;
+    pthread_barrier_t *bar; struct job_s *all; int n_threads, tid;
 } job_t;
 
 static void map_range(job_t *jb)
@@ -1205,6 +1209,11 @@ static void map_range(job_t *jb)
     int i;
     seedvec s1 = {0, 0, 0}, s2 = {0, 0, 0};
     candvec c1 = {0, 0, 0}, c2 = {0, 0, 0};
+    for (i = jb->begin; i < jb->end; i++) {   /* NUL-terminated private copy like ReadItem_t::seq */
+        char *z = (char *)malloc((size_t)jb->rlen[i] + 1);
+        memcpy(z, jb->seq + jb->seq_off[i], jb->rlen[i]); z[jb->rlen[i]] = 0;
+        read_init(&jb->reads[i], z, jb->rlen[i]);
+    }
     for (i = jb->begin; i < jb->end;) {
         if (jb->paired && i + 1 < jb->end) {
             read_t *r1 = &jb->reads[i], *r2 = &jb->reads[i + 1];
@@ -1236,83 +1245,100 @@ static void map_range(job_t *jb)
         }
     }
     sv_free(&s1); sv_free(&s2);
+    for (i = jb->begin; i < jb->end; i++) {
+        int k;
+        jb->n_rep += (size_t)jb->reads[i].CanNum;
+        for (k = 0; k < jb->reads[i].CanNum; k++) jb->n_cig += (size_t)jb->reads[i].rep[k].ncig;
+    }
+    jb->n_sj = (size_t)jb->sj.n;
 }
 
-static void *map_thread(void *p) { map_range((job_t *)p); return 0; }
+/* every thread writes the flat records of its own read range at its prefix offsets */
+static void emit_range(job_t *jb)
+{
+    size_t nrep = jb->base_rep, ncig = jb->base_cig, nsj = jb->base_sj;
+    int i, k, sjpos = 0;
+    if (nrep + jb->n_rep > jb->caps[0] || ncig + jb->n_cig > jb->caps[1] || nsj + jb->n_sj > jb->caps[2]) jb->overflow = 1;
+    for (i = jb->begin; i < jb->end; i++) {
+        read_t *r = &jb->reads[i];
+        if (!jb->overflow) {
+            orc_read_out *o = &jb->ro[i];
+            o->score = r->score; o->sub_score = r->sub_score; o->mis_num = r->mis_num; o->mapq = r->mapq;
+            o->n_rep = r->CanNum; o->best = r->iBest; o->rep_off = (int32_t)nrep;
+            for (k = 0; k < r->CanNum; k++) {
+                orc_report_out *p = &jb->po[nrep++];
+                report_t *rp = &r->rep[k];
+                p->aln_score = rp->AlnScore; p->sj_type = rp->SJtype; p->flag = rp->iFrag; p->paired_idx = rp->PairedIdx;
+                p->chr = rp->chr; p->bdir = rp->bDir; p->pos = rp->gPos;
+                p->cigar_off = (uint32_t)ncig; p->n_cigar = (uint32_t)rp->ncig;
+                if (rp->ncig) memcpy(jb->cigar_ops + ncig, rp->cig, (size_t)rp->ncig * sizeof(uint32_t));
+                ncig += (size_t)rp->ncig;
+            }
+            o->sj_off = (int32_t)nsj; o->n_sj = 0;
+            while (sjpos < jb->sj.n && jb->sj.a[sjpos].read_idx == i) { jb->so[nsj++] = jb->sj.a[sjpos++]; o->n_sj++; }
+        }
+        free((char *)r->seq);
+        read_free(r);
+    }
+}
+
+static void *map_thread(void *p)
+{
+    job_t *jb = (job_t *)p;
+    map_range(jb);
+    if (jb->bar) pthread_barrier_wait(jb->bar);
+    if (jb->tid == 0) {
+        size_t a = 0, b = 0, c = 0; int t;
+        for (t = 0; t < jb->n_threads; t++) { jb->all[t].base_rep = a; jb->all[t].base_cig = b; jb->all[t].base_sj = c; a += jb->all[t].n_rep; b += jb->all[t].n_cig; c += jb->all[t].n_sj; }
+    }
+    if (jb->bar) pthread_barrier_wait(jb->bar);
+    emit_range(jb);
+    return 0;
+}
 
 int orc_map_batch(const orc_index *ix, const orc_params *pr, int n_reads, const uint32_t *seq_off,
                   const uint16_t *rlen, const char *seq, orc_read_out *ro, orc_report_out *po,
                   uint32_t *cigar_ops, orc_sj_out *so, const size_t caps[3], size_t used[3],
                   int n_threads, orc_counters *ctr)
 {
-    int t, i, k, rc = 0;
+    int t, k, rc = 0, per;
     read_t *reads = (read_t *)calloc((size_t)(n_reads > 0 ? n_reads : 1), sizeof(read_t));
-    char **seqz = (char **)calloc((size_t)(n_reads > 0 ? n_reads : 1), sizeof(char *));
     job_t *jobs;
     pthread_t *th;
-    size_t nrep = 0, ncig = 0, nsj = 0;
-    int per;
+    pthread_barrier_t bar;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n_reads / 2 + 1) n_threads = n_reads / 2 + 1;
     jobs = (job_t *)calloc((size_t)n_threads, sizeof(job_t));
     th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
-    for (i = 0; i < n_reads; i++) {   /* NUL-terminated private copy like ReadItem_t::seq */
-        seqz[i] = (char *)malloc((size_t)rlen[i] + 1);
-        memcpy(seqz[i], seq + seq_off[i], rlen[i]); seqz[i][rlen[i]] = 0;
-        read_init(&reads[i], seqz[i], rlen[i]);
-    }
     per = ((n_reads + n_threads - 1) / n_threads + 1) & ~1;
+    if (n_threads > 1) pthread_barrier_init(&bar, 0, (unsigned)n_threads);
     for (t = 0; t < n_threads; t++) {
-        jobs[t].cx.ix = ix; jobs[t].cx.pr = pr;
-        jobs[t].paired = pr->paired && (n_reads % 2 == 0);
-        jobs[t].begin = t * per < n_reads ? t * per : n_reads;
-        jobs[t].end = (t + 1) * per < n_reads ? (t + 1) * per : n_reads;
-        jobs[t].reads = reads;
-        if (n_threads > 1) pthread_create(&th[t], 0, map_thread, &jobs[t]);
-        else map_range(&jobs[t]);
+        job_t *jb = &jobs[t];
+        jb->cx.ix = ix; jb->cx.pr = pr;
+        jb->paired = pr->paired && (n_reads % 2 == 0);
+        jb->begin = t * per < n_reads ? t * per : n_reads;
+        jb->end = (t + 1) * per < n_reads ? (t + 1) * per : n_reads;
+        jb->reads = reads; jb->seq_off = seq_off; jb->rlen = rlen; jb->seq = seq;
+        jb->ro = ro; jb->po = po; jb->cigar_ops = cigar_ops; jb->so = so; jb->caps = caps;
+        jb->bar = n_threads > 1 ? &bar : 0; jb->all = jobs; jb->n_threads = n_threads; jb->tid = t;
     }
-    if (n_threads > 1) for (t = 0; t < n_threads; t++) pthread_join(th[t], 0);
+    if (n_threads > 1) {
+        for (t = 0; t < n_threads; t++) pthread_create(&th[t], 0, map_thread, &jobs[t]);
+        for (t = 0; t < n_threads; t++) pthread_join(th[t], 0);
+        pthread_barrier_destroy(&bar);
+    } else map_thread(&jobs[0]);
     if (ctr) memset(ctr, 0, sizeof *ctr);
+    used[0] = used[1] = used[2] = 0;
     for (t = 0; t < n_threads; t++) {
         if (ctr) {
             uint64_t *d = (uint64_t *)ctr; const uint64_t *s = (const uint64_t *)&jobs[t].cx.c;
             for (k = 0; k < (int)(sizeof(orc_counters) / sizeof(uint64_t)); k++) d[k] += s[k];
         }
+        if (jobs[t].overflow) rc = -1;
+        used[0] += jobs[t].n_rep; used[1] += jobs[t].n_cig; used[2] += jobs[t].n_sj;
+        free(jobs[t].sj.a);
     }
-    /* gather into the flat records, read order */
-    {
-        int *sjpos = (int *)calloc((size_t)n_threads, sizeof(int));
-        for (i = 0; i < n_reads; i++) {
-            read_t *r = &reads[i];
-            orc_read_out *o = &ro[i];
-            int tj = i / per;
-            o->score = r->score; o->sub_score = r->sub_score; o->mis_num = r->mis_num; o->mapq = r->mapq;
-            o->n_rep = r->CanNum; o->best = r->iBest; o->rep_off = (int32_t)nrep;
-            if (nrep + (size_t)r->CanNum > caps[0]) { rc = -1; break; }
-            for (k = 0; k < r->CanNum; k++) {
-                orc_report_out *p = &po[nrep++];
-                report_t *rp = &r->rep[k];
-                p->aln_score = rp->AlnScore; p->sj_type = rp->SJtype; p->flag = rp->iFrag; p->paired_idx = rp->PairedIdx;
-                p->chr = rp->chr; p->bdir = rp->bDir; p->pos = rp->gPos;
-                p->cigar_off = (uint32_t)ncig; p->n_cigar = (uint32_t)rp->ncig;
-                if (ncig + (size_t)rp->ncig > caps[1]) { rc = -1; break; }
-                if (rp->ncig) memcpy(cigar_ops + ncig, rp->cig, (size_t)rp->ncig * sizeof(uint32_t));
-                ncig += (size_t)rp->ncig;
-            }
-            if (rc) break;
-            o->sj_off = (int32_t)nsj; o->n_sj = 0;
-            while (sjpos[tj] < jobs[tj].sj.n && jobs[tj].sj.a[sjpos[tj]].read_idx == i) {
-                if (nsj >= caps[2]) { rc = -1; break; }
-                so[nsj++] = jobs[tj].sj.a[sjpos[tj]++]; o->n_sj++;
-            }
-            if (rc) break;
-        }
-        free(sjpos);
-    }
-    used[0] = nrep; used[1] = ncig; used[2] = nsj;
-    for (i = 0; i < n_reads; i++) { read_free(&reads[i]); free(seqz[i]); }
-    for (t = 0; t < n_threads; t++) free(jobs[t].sj.a);
-    free(reads); free(seqz); free(jobs); free(th);
+    free(reads); free(jobs); free(th);
     return rc;
 }
 

@@ -91,6 +91,21 @@ def test_gpu_edge_cases(ctxs):
     for paired in (0, 1):
         gpu.set_params(host.default_params(paired=paired, max_mismatch=3))
         assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=paired, max_mismatch=3), so, rl, flat))
+    # long reads whose seeds are > 263 read bases apart: re-seeding takes the serial in-kernel path
+    long_reads = []
+    for i in range(120):
+        p = int(rng.integers(1000, c["genome"].total - 120000))
+        D = int(rng.choice([700, 5000, 90000]))
+        gap = int(rng.integers(270, 420))
+        A = asc[p:p + 60].tobytes(); B = asc[p + 60 + gap + D:p + 120 + gap + D].tobytes()
+        if i % 3 == 0: X = bytes(rng.choice(list(b"ACGT"), gap).astype(np.uint8))                        # nothing to find
+        elif i % 3 == 1: X = asc[p + 60 + D:p + 60 + D + gap].tobytes()                                    # the gap continues after the jump
+        else: X = asc[p + 60:p + 60 + gap // 2].tobytes() + bytes(rng.choice(list(b"ACGT"), gap - gap // 2).astype(np.uint8))
+        long_reads.append(A + X + B)
+    so2, rl2, flat2 = host.pack_reads(long_reads)
+    gpu.set_params(host.default_params(paired=0, max_mismatch=8))
+    assert_same(gpu.map_batch(so2, rl2, flat2), orc.map_batch(orc.params(paired=0, max_mismatch=8), so2, rl2, flat2))
+    assert gpu.counters()["reseed_calls"] > 0
     # odd count in paired mode is mapped read by read (Mapping.cpp:598)
     gpu.set_params(host.default_params(paired=1, max_mismatch=3))
     assert_same(gpu.map_batch(so[:-1], rl[:-1], flat), orc.map_batch(orc.params(paired=1, max_mismatch=3), so[:-1], rl[:-1], flat))
