@@ -33,6 +33,31 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cores() -> int:
+    """cores this process may really use: the cgroup CPU quota when there is one (the GPU boxes
+    expose 256 hardware threads but grant a 16-core share per GPU), else the affinity mask"""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0]); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    if os.environ.get("DART_CPU_THREADS"):
+        n = int(os.environ["DART_CPU_THREADS"])
+    return n
+
+
 def prepare_index(cache_dir, genome_len, rank, barrier):
     prefix = os.path.join(cache_dir, "g%d" % genome_len)
     done = prefix + ".done"
@@ -169,12 +194,9 @@ def main():
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_py
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
-        ns = min(args.cpu_sample_pairs, args.pairs) * 2
+        cores = host_cores()
+        # enough work per thread that the sample is not dominated by thread start-up: >= 2000 pairs per core
+        ns = min(max(args.cpu_sample_pairs, 2000 * cores), args.pairs) * 2
         orc = oracle_py.Oracle(prefix)
         t = time.perf_counter()
         o_reads, o_rep, o_cig, o_sj = orc.map_batch(orc.params(paired=1, max_mismatch=args.mis), so[:ns], rl[:ns], flat, threads=cores)
