@@ -149,3 +149,16 @@ def test_gpu_size_independent_properties(workdir):
     for f in ("score", "sub_score", "mis_num", "mapq", "n_rep", "best"):
         assert np.array_equal(pres.reads[f], whole.reads[f][idx])
     gpu.close()
+
+
+def test_gpu_records_as_torch_tensor_for_rccl(ctxs):
+    """bench.py hands the per-read records to torch.distributed straight from HBM (dg_batch_device_ptrs)"""
+    import torch
+    c, ix, gpu, orc = ctxs["se100"]
+    so, rl, flat = host.pack_reads(c["reads"])
+    gpu.set_params(host.default_params(paired=0, max_mismatch=3))
+    res = gpu.map_batch(so, rl, flat)
+    t = gpu.device_reads_tensor()
+    assert t.is_cuda and tuple(t.shape) == (len(rl), host.READ_OUT.itemsize)
+    back = t.cpu().numpy().reshape(-1).view(host.READ_OUT)
+    assert np.array_equal(back, res.reads)
