@@ -186,8 +186,11 @@ def main():
                 "own_requested_bytes_per_launch": int(own.get(dom, dom_bytes)),
                 "own_requested_GBps": round(own.get(dom, dom_bytes) / (kern[dom] * 1e-3) / 1e9, 2),
                 "fm_bytes_per_read": round(per_read_B, 1),
+                "measured_random_64B_ceiling_GBps": 3820.0,
+                "own_frac_of_measured_ceiling": round(own.get(dom, dom_bytes) / (kern[dom] * 1e-3) / 1e9 / 3820.0, 4),
                 "note": "achieved = reference-algorithm bytes (SURVEY 8d) / measured kernel time; the k-mer prefix table and "
-                        "the denser SA make the kernel request fewer bytes than that (own_requested_*)"}
+                        "the denser SA make the kernel request fewer bytes than that (own_requested_*); measured_random_64B_ceiling = "
+                        "profiles/random_block_ceiling.py (59.7 G random 64-byte lines/s on this chip, any occupancy, lane- or quad-cooperative)"}
 
     # ---- CPU baseline: the oracle ("port") on a bounded sample of the same reads, all host cores ----
     cpu = None

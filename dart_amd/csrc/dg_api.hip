@@ -485,8 +485,13 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     const unsigned nb = (unsigned)((n + 255) / 256);
     k_encode<<<(unsigned)(((size_t)n * W + 255) / 256), 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, c->enc.p);
     if (after_encode) { e = hipEventRecord(after_encode, c->stream); if (e != hipSuccess) return e; }
-    if (W <= 40) k_seed<true><<<nb, 256, (size_t)W * 256 * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
-    else k_seed<false><<<nb, 256, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_ctr);
+    // persistent one-wave workgroups (6 per SIMD by registers) pulling reads from a queue (d_tops[6])
+    e = hipMemsetAsync(c->d_tops + 6, 0, 4, c->stream);
+    if (e != hipSuccess) return e;
+    unsigned blocks = (unsigned)c->n_cu * 24u;
+    if ((size_t)blocks * 64 > (size_t)n) blocks = (unsigned)((n + 63) / 64);
+    if (W <= 160) k_seed<true><<<blocks, 64, (size_t)W * 64 * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->d_ctr);
+    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->d_ctr);
     return hipGetLastError();
 }
 
@@ -551,6 +556,11 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     const WSLayout L = make_ws_layout(c->max_rlen < 32 ? 32 : c->max_rlen);
     int blocks = c->n_cu * (getenv("DG_REPORT_BPC") ? atoi(getenv("DG_REPORT_BPC")) : 16);   // 16 one-wave workgroups per CU (4 per SIMD)
     if ((size_t)blocks * 64 > (size_t)n) blocks = (n + 63) / 64;
+    {   // the lane workspace grows with the square of the longest read: keep it under ~12 GB by running fewer persistent waves
+        const size_t budget = (size_t)12 << 30, per_block = (size_t)64 * L.stride;
+        if ((size_t)blocks * per_block > budget) blocks = (int)(budget / per_block);
+        if (blocks < 1) blocks = 1;
+    }
     HIPCHK(c->ws.ensure((size_t)blocks * 64 * L.stride));
     HIPCHK(c->jobs.ensure((size_t)total_seeds + 16));
     k_prep<<<nb, 256, 0, c->stream>>>(c->pr, n, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work_off.p, c->work.p, c->jobs.p,
@@ -645,6 +655,66 @@ extern "C" int dg_batch_device_ptrs(dg_ctx *c, void *ptrs[4])
 {
     if (!c || !ptrs) return DG_ERR_ARG;
     ptrs[0] = c->reads_out.p; ptrs[1] = c->reports.p; ptrs[2] = c->cigfinal.p; ptrs[3] = c->sjfinal.p;
+    return DG_OK;
+}
+
+// ---- roofline calibration (not in the public header): random 64-byte block reads over the resident
+// Occ array, the access pattern of k_seed / k_locate without any of their arithmetic.
+// dependent = 1: the next block index depends on the loaded data (a chain per lane, like an FM walk);
+// dependent = 0: indices are a pure function of (lane, iteration).
+__global__ void __launch_bounds__(256)
+k_rand_blocks(const uint4 *__restrict__ bwt, uint64_t n_blocks, int iters, int dependent, uint32_t *__restrict__ sink)
+{
+    uint64_t x = (uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+        const uint4 *p = bwt + ((x % n_blocks) << 2);
+        const uint4 a = p[0], b = p[1], cc = p[2], d = p[3];
+        const uint32_t v = a.x ^ b.y ^ cc.z ^ d.w;
+        acc += v;
+        if (dependent) x += v;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+// quad-cooperative variant: the 4 lanes of a quad fetch the four 16-byte pieces of ONE block with one
+// instruction (one 64-byte line per quad per load instruction instead of four instructions per lane)
+__global__ void __launch_bounds__(256)
+k_rand_blocks_quad(const uint4 *__restrict__ bwt, uint64_t n_blocks, int iters, int dependent, uint32_t *__restrict__ sink)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t x = (uint64_t)(tid >> 2) * 0x9E3779B97F4A7C15ull + 12345;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+        const uint4 a = bwt[((x % n_blocks) << 2) + (tid & 3)];
+        uint32_t v = a.x ^ a.y ^ a.z ^ a.w;
+        v ^= __shfl_xor((int)v, 1, 64); v ^= __shfl_xor((int)v, 2, 64);      // every lane of the quad sees the whole block
+        acc += v;
+        if (dependent) x += v;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+extern "C" int dg_debug_random_blocks(dg_ctx *c, int iters, int dependent, int waves_per_cu, float *ms, unsigned long long *n_loads)
+{
+    if (!c) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t n_blocks = (c->ix.seq_len + 127) / 128;
+    const unsigned blocks = (unsigned)(c->n_cu * waves_per_cu / 4);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const int quad = dependent >> 1; dependent &= 1;
+    if (quad) k_rand_blocks_quad<<<blocks, 256, 0, c->stream>>>(c->ix.bwt, n_blocks, 4, dependent, (uint32_t *)c->d_err);
+    else k_rand_blocks<<<blocks, 256, 0, c->stream>>>(c->ix.bwt, n_blocks, 4, dependent, (uint32_t *)c->d_err);   // warm
+    HIPCHK(hipEventRecord(e0, c->stream));
+    if (quad) k_rand_blocks_quad<<<blocks, 256, 0, c->stream>>>(c->ix.bwt, n_blocks, iters, dependent, (uint32_t *)c->d_err);
+    else k_rand_blocks<<<blocks, 256, 0, c->stream>>>(c->ix.bwt, n_blocks, iters, dependent, (uint32_t *)c->d_err);
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    *n_loads = (unsigned long long)blocks * (quad ? 64ull : 256ull) * (unsigned long long)iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return DG_OK;
 }
 

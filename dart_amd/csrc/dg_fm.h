@@ -192,91 +192,113 @@ k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_seed: one lane = one read.  Greedy left-to-right tiling with maximal exact matches
+// k_seed: one lane = one read at a time.  Greedy left-to-right tiling with maximal exact matches
 // (IdentifySeedPairs + BWT_Search).  The two nested loops of the reference are flattened into one
-// loop whose every trip is exactly one bi-interval extension, so the lanes of a wave stay
+// loop whose every trip is at most one bi-interval extension, so the lanes of a wave stay
 // converged on the memory-bound step whatever their read positions are.
+// Reads differ a lot in work (every failed search restarts one base further, :209), so waves are
+// persistent and refill their idle lanes from a global read queue as soon as SEED_REFILL of them
+// are idle: one atomic per refill, each refilled lane stages its read's 4-bit words into its own
+// LDS column (the lane is the only reader of that column, so no barrier is needed).
 // Output: per read up to H intervals (a hit is >= 16 long, so H = max_rlen/16 + 1 always fits).
 // ---------------------------------------------------------------------------------------------
+#define SEED_REFILL 8
 template <bool USE_LDS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H,
-       DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned long long *ctr)
+       DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read, unsigned long long *ctr)
 {
     extern __shared__ uint32_t sh[];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x;
     unsigned long long steps = 0, blocks = 0, steps_act = 0, blocks_act = 0, ktab_reads = 0;
-    if (USE_LDS) {
-        if (r < n_reads) for (int w = 0; w < W; w++) sh[w * 256 + threadIdx.x] = enc[(size_t)r * W + w];
-        __syncthreads();
-    }
-    if (r < n_reads) {
-        const int len = rlen[r], end_pos = len - 13;
-        const int K = ix.ktab ? ix.ktab_k : 0;
-        auto word = [&](int w) -> uint32_t { return w < W ? (USE_LDS ? sh[w * 256 + threadIdx.x] : enc[(size_t)r * W + w]) : 0x44444444u; };
-        auto code = [&](int p) -> int { return (int)((word(p >> 3) >> ((p & 7) << 2)) & 15u); };
-        int pos = 0, start = 0, p = 0, nh = 0;
-        uint32_t ns = 0;
-        bool searching = false;
-        uint64_t x0 = 0, x1 = 0, x2 = 0;
-        while (true) {
+    const int K = ix.ktab ? ix.ktab_k : 0;
+    int r = -1, len = 0, end_pos = 0, pos = 0, start = 0, p = 0, nh = 0;
+    uint32_t ns = 0;
+    bool searching = false, exhausted = false;
+    uint64_t x0 = 0, x1 = 0, x2 = 0;
+    auto word = [&](int w) -> uint32_t { return w < W ? (USE_LDS ? sh[w * 64 + lane] : enc[(size_t)r * W + w]) : 0x44444444u; };
+    auto code = [&](int q) -> int { return (int)((word(q >> 3) >> ((q & 7) << 2)) & 15u); };
+    while (true) {
+        const unsigned long long idle = __ballot(r < 0);
+        if (idle) {
+            const int n_idle = __popcll(idle);
+            if (!exhausted && (n_idle >= SEED_REFILL || idle == ~0ull)) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(next_read, (unsigned int)n_idle);
+                base = (unsigned int)__shfl((int)base, 0, 64);
+                if (r < 0) {
+                    const unsigned int mine = base + (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
+                    if (mine < (unsigned int)n_reads) {
+                        r = (int)mine;
+                        if (USE_LDS) for (int w = 0; w < W; w++) sh[w * 64 + lane] = enc[(size_t)r * W + w];
+                        len = rlen[r]; end_pos = len - 13; pos = 0; nh = 0; ns = 0; searching = false;
+                    }
+                }
+                if (base + (unsigned int)n_idle >= (unsigned int)n_reads) exhausted = true;
+            }
+            if (__ballot(r >= 0) == 0) { if (exhausted) break; continue; }
+        }
+        if (r >= 0) {
+            bool finished = false;
             if (!searching) {
                 while (pos < end_pos && code(pos) > 3) pos++;
-                if (pos >= end_pos) break;
-                start = pos;
-                bool from_table = false;
-                if (K) {
-                    // the K 4-bit codes from `pos` on: 48 bits out of three staged words
-                    const int w0 = pos >> 3, sft = (pos & 7) << 2;
-                    const uint64_t lo = (uint64_t)word(w0) | ((uint64_t)word(w0 + 1) << 32);
-                    uint64_t v = sft ? ((lo >> sft) | ((uint64_t)word(w0 + 2) << (64 - sft))) : lo;
-                    v &= (1ull << (4 * K)) - 1ull;
-                    if ((v & 0x4444444444444444ull) == 0) {           // no N among them (codes 4,5 have bit 2 set)
-                        uint64_t x = v & 0x3333333333333333ull;       // nibbles -> 2-bit pairs, first base lowest
-                        x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-                        x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-                        x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-                        x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-                        const uint64_t *e = ix.ktab + (size_t)x * 3;
-                        const uint64_t e2 = e[2];
-                        ktab_reads++;
-                        steps += (e2 >> 40) & 0xFF; blocks += (e2 >> 48) & 0xFF;
-                        from_table = true;
-                        if ((e2 & 0xFFFFFFFFFFull) == 0) { pos = start + 1; continue; }   // cannot reach 16: no seed here
-                        x0 = e[0]; x1 = e[1]; x2 = e2 & 0xFFFFFFFFFFull;
-                        p = start + K; searching = true;
+                if (pos >= end_pos) finished = true;
+                else {
+                    start = pos;
+                    bool from_table = false;
+                    if (K) {
+                        // the K 4-bit codes from `pos` on: 48 bits out of three staged words
+                        const int w0 = pos >> 3, sft = (pos & 7) << 2;
+                        const uint64_t lo = (uint64_t)word(w0) | ((uint64_t)word(w0 + 1) << 32);
+                        uint64_t v = sft ? ((lo >> sft) | ((uint64_t)word(w0 + 2) << (64 - sft))) : lo;
+                        v &= (1ull << (4 * K)) - 1ull;
+                        if ((v & 0x4444444444444444ull) == 0) {           // no N among them (codes 4,5 have bit 2 set)
+                            uint64_t x = v & 0x3333333333333333ull;       // nibbles -> 2-bit pairs, first base lowest
+                            x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+                            x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+                            x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+                            x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+                            const uint64_t *e = ix.ktab + (size_t)x * 3;
+                            const uint64_t e2 = e[2];
+                            ktab_reads++;
+                            steps += (e2 >> 40) & 0xFF; blocks += (e2 >> 48) & 0xFF;
+                            from_table = true;
+                            if ((e2 & 0xFFFFFFFFFFull) == 0) pos = start + 1;   // cannot reach 16: no seed here, next start
+                            else { x0 = e[0]; x1 = e[1]; x2 = e2 & 0xFFFFFFFFFFull; p = start + K; searching = true; }
+                        }
+                    }
+                    if (!from_table) {
+                        const int c = code(pos);
+                        p = pos + 1; searching = true;
+                        x0 = d_L2(ix, c) + 1; x1 = d_L2(ix, 3 - c) + 1; x2 = d_L2(ix, c + 1) - d_L2(ix, c);
                     }
                 }
-                if (!from_table) {
-                    const int c = code(pos);
-                    p = pos + 1; searching = true;
-                    x0 = d_L2(ix, c) + 1; x1 = d_L2(ix, 3 - c) + 1; x2 = d_L2(ix, c + 1) - d_L2(ix, c);
+            }
+            if (searching) {
+                bool stop = p >= len;
+                int c = 4;
+                if (!stop) { c = code(p); stop = c > 3; }
+                if (!stop) {
+                    uint32_t nb;
+                    const bool ok = d_extend(ix, c, x0, x1, x2, nb);
+                    steps++; blocks += nb; steps_act++; blocks_act += nb;
+                    if (ok) p++; else stop = true;
+                }
+                if (stop) {
+                    const int l = p - start;
+                    if (x2 <= (uint64_t)pr.max_dup && l >= 16) {
+                        if (nh < H) {
+                            DHit h; h.x0 = x0; h.freq = (uint32_t)x2; h.rPos = (uint16_t)start; h.len = (uint16_t)l;
+                            hits[(size_t)r * H + nh] = h;
+                        }
+                        nh++; ns += (uint32_t)x2;
+                        pos = start + l;
+                    } else pos = start + 1;
+                    searching = false;
                 }
             }
-            bool stop = p >= len;
-            int c = 4;
-            if (!stop) { c = code(p); stop = c > 3; }
-            if (!stop) {
-                uint32_t nb;
-                const bool ok = d_extend(ix, c, x0, x1, x2, nb);
-                steps++; blocks += nb; steps_act++; blocks_act += nb;
-                if (ok) p++; else stop = true;
-            }
-            if (stop) {
-                const int l = p - start;
-                if (x2 <= (uint64_t)pr.max_dup && l >= 16) {
-                    if (nh < H) {
-                        DHit h; h.x0 = x0; h.freq = (uint32_t)x2; h.rPos = (uint16_t)start; h.len = (uint16_t)l;
-                        hits[(size_t)r * H + nh] = h;
-                    }
-                    nh++; ns += (uint32_t)x2;
-                    pos = start + l;
-                } else pos = start + 1;
-                searching = false;
-            }
+            if (finished) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; r = -1; }
         }
-        nhits[r] = (uint32_t)nh;
-        nseeds[r] = ns;
     }
     d_wave_add(ctr + CTR_STEPS, steps);
     d_wave_add(ctr + CTR_BLOCKS, blocks);

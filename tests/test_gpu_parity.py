@@ -106,6 +106,21 @@ def test_gpu_edge_cases(ctxs):
     gpu.set_params(host.default_params(paired=0, max_mismatch=8))
     assert_same(gpu.map_batch(so2, rl2, flat2), orc.map_batch(orc.params(paired=0, max_mismatch=8), so2, rl2, flat2))
     assert gpu.counters()["reseed_calls"] > 0
+    # reads up to DG_MAX_RLEN: k_seed without LDS staging, small persistent grid for the R^2 workspace
+    very_long = []
+    for i in range(40):
+        L = int(rng.choice([600, 800, 1000]))
+        p = int(rng.integers(1000, c["genome"].total - 3000))
+        s = bytearray(asc[p:p + L].tobytes())
+        for k in rng.integers(0, L, size=L // 40): s[int(k)] = int(rng.choice(list(b"ACGT")))
+        if i % 4 == 0: s = s[:L // 2] + bytearray(asc[p + L // 2 + 3000:p + L + 3000].tobytes())          # a 3 kb deletion in the middle
+        very_long.append(bytes(s))
+    so3, rl3, flat3 = host.pack_reads(very_long)
+    gpu.set_params(host.default_params(paired=0, max_mismatch=40))
+    assert_same(gpu.map_batch(so3, rl3, flat3), orc.map_batch(orc.params(paired=0, max_mismatch=40), so3, rl3, flat3))
+    too_long = [bytes(asc[100:1101].tobytes())]
+    with pytest.raises(RuntimeError):
+        gpu.map_batch(*host.pack_reads(too_long))
     # odd count in paired mode is mapped read by read (Mapping.cpp:598)
     gpu.set_params(host.default_params(paired=1, max_mismatch=3))
     assert_same(gpu.map_batch(so[:-1], rl[:-1], flat), orc.map_batch(orc.params(paired=1, max_mismatch=3), so[:-1], rl[:-1], flat))
