@@ -47,7 +47,7 @@ struct dg_ctx {
     DBuf<unsigned char> seq; DBuf<uint32_t> seq_off; DBuf<uint16_t> rlen; DBuf<uint32_t> enc;
     // pipeline buffers
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, nrep, rep_off, work_need, work_off, tile_sums, tmp_u32, tmp_off;
-    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> costkey; DBuf<uint32_t> perm, hist, heavy;
+    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> costkey; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<unsigned char> ws;
@@ -333,7 +333,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->nrep.release(); c->rep_off.release(); c->work_need.release(); c->work_off.release();
-    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->costkey.release(); c->perm.release(); c->hist.release(); c->heavy.release();
+    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->costkey.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -411,8 +411,11 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     c->ix.primary = v->primary; for (int i = 0; i < 5; i++) c->ix.L2[i] = v->L2[i]; c->ix.seq_len = v->seq_len;
     c->ix.l_pac = v->l_pac; c->ix.n_chr = v->n_chr; c->ix.sa_intv = v->sa_intv;
     c->ix.ktab = nullptr; c->ix.ktab_k = 0; c->ix.sa_dense = nullptr; c->ix.sa_dense_intv = 0;
-    {   // denser SA: every 4th row (8 bytes per 4 text symbols); DG_SA_DENSE=0 turns it off, =2/8/16 changes the interval
-        int intv = getenv("DG_SA_DENSE") ? atoi(getenv("DG_SA_DENSE")) : 4;
+    {   // full suffix array in HBM (8 bytes per text symbol: 1 GB for chr20, 50 GB for a human genome -- this is what
+        // 288 GB are for): locating a row is one load instead of a walk of up to 31 LF steps.  Texts too large for
+        // that fall back to every 2nd / 4th row; DG_SA_DENSE=0 turns it off, =2/4/8/16 forces an interval
+        int intv = v->seq_len <= (12ull << 30) ? 1 : (v->seq_len <= (24ull << 30) ? 2 : 4);
+        if (getenv("DG_SA_DENSE")) intv = atoi(getenv("DG_SA_DENSE"));
         if (intv >= 1 && intv < v->sa_intv && (intv & (intv - 1)) == 0 && v->seq_len < (1ull << 39)) {
             const uint64_t n_entries = v->seq_len / (uint64_t)intv + 1;
             if ((e = hipMalloc(&c->d_sa_dense, n_entries * 8)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc dense SA", e);
@@ -427,7 +430,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
         if (K > 13) K = 13;
         if (K >= 2) {
             const size_t entries = (size_t)1 << (2 * K);
-            if ((e = hipMalloc(&c->d_ktab, entries * 24)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc k-mer table", e);
+            if ((e = hipMalloc(&c->d_ktab, entries * 32)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc k-mer table", e);
             k_build_ktab<<<(unsigned)((entries + 255) / 256), 256, 0, c->stream>>>(c->ix, K, (uint64_t *)c->d_ktab);
             if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_ktab", e);
             c->ix.ktab = (const uint64_t *)c->d_ktab; c->ix.ktab_k = K;
@@ -485,13 +488,15 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     const unsigned nb = (unsigned)((n + 255) / 256);
     k_encode<<<(unsigned)(((size_t)n * W + 255) / 256), 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, c->enc.p);
     if (after_encode) { e = hipEventRecord(after_encode, c->stream); if (e != hipSuccess) return e; }
-    // persistent one-wave workgroups (6 per SIMD by registers) pulling reads from a queue (d_tops[6])
-    e = hipMemsetAsync(c->d_tops + 6, 0, 4, c->stream);
+    // persistent one-wave workgroups pulling reads from a queue (d_tops[6]); long walks go to d_tops[7]'s list
+    e = hipMemsetAsync(c->d_tops + 6, 0, 8, c->stream);
     if (e != hipSuccess) return e;
-    unsigned blocks = (unsigned)c->n_cu * 24u;
+    if ((e = c->seed_heavy.ensure((size_t)n + 16)) != hipSuccess) return e;
+    unsigned blocks = (unsigned)c->n_cu * (getenv("DG_SEED_WAVES") ? (unsigned)atoi(getenv("DG_SEED_WAVES")) : 8u);   // the kernel is VALU-issue bound from 2 waves per SIMD on
     if ((size_t)blocks * 64 > (size_t)n) blocks = (unsigned)((n + 63) / 64);
-    if (W <= 160) k_seed<true><<<blocks, 64, (size_t)W * 64 * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->d_ctr);
-    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->d_ctr);
+    if (W <= 160) k_seed<true><<<blocks, 64, ((size_t)W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr);
+    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr);
+    k_seed_heavy<<<(unsigned)c->n_cu * 8u, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, c->d_tops + 7, c->d_ctr);
     return hipGetLastError();
 }
 

@@ -58,12 +58,18 @@ __device__ __forceinline__ void d_plane_counts(const uint4 H, const uint4 Lo, ui
 }
 
 // Occ(b, row) and Occ(b^1, row) for the row at in-block offset o (bwt_occ4 :67-84, two of the four)
-__device__ __forceinline__ void d_occ_pair(const OccBlock &B, int b, uint32_t o, uint64_t &cb, uint64_t &cp)
+// (blocks are passed by value everywhere: a block chosen through a reference becomes a pointer select, which
+// keeps both blocks in scratch memory)
+__device__ __forceinline__ uint4 d_pick4(bool first, const uint4 a, const uint4 b)
+{
+    return make_uint4(first ? a.x : b.x, first ? a.y : b.y, first ? a.z : b.z, first ? a.w : b.w);
+}
+__device__ __forceinline__ void d_occ_pair(const OccBlock B, int b, uint32_t o, uint64_t &cb, uint64_t &cp)
 {
     const bool hi = (b & 2) != 0, lo = (b & 1) != 0;
     uint32_t P, Q;
     d_plane_counts(B.q2, B.q3, hi ? 0u : 0xFFFFFFFFu, o, P, Q);
-    const uint4 C = hi ? B.q1 : B.q0;                   // (C[2h] lo,hi, C[2h+1] lo,hi)
+    const uint4 C = d_pick4(hi, B.q1, B.q0);            // (C[2h] lo,hi, C[2h+1] lo,hi)
     const uint64_t c_even = d_u64(C.x, C.y) + (P - Q), c_odd = d_u64(C.z, C.w) + Q;
     cb = lo ? c_odd : c_even;
     cp = lo ? c_even : c_odd;
@@ -130,23 +136,18 @@ k_encode(const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq
     enc[t] = v;
 }
 
-// one step of BWT_Search (:152-170) with base c: returns false when the extension is empty
-__device__ __forceinline__ bool d_extend(const DIndex &ix, int c, uint64_t &x0, uint64_t &x1, uint64_t &x2, uint32_t &nblk)
+// one step of BWT_Search (:152-170) with base c, given the already loaded Occ blocks of rows kk and ll
+// (B2 is only read when they differ): returns false when the extension is empty
+__device__ __forceinline__ bool d_extend_finish(const DIndex &ix, int c, const OccBlock B, const OccBlock B2, uint64_t kk, uint64_t ll,
+                                                uint64_t &x0, uint64_t &x1, uint64_t &x2)
 {
     const int b = 3 - c;
-    const uint64_t k = x1 - 1, l = k + x2;
-    const uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
     uint64_t tkb, tkp, tlb, tlp;
-    const OccBlock B = d_load_block(ix, kk >> 7);
     d_occ_pair(B, b, (uint32_t)(kk & 127), tkb, tkp);
-    if ((ll >> 7) != (kk >> 7)) {
-        const OccBlock B2 = d_load_block(ix, ll >> 7);
-        d_occ_pair(B2, b, (uint32_t)(ll & 127), tlb, tlp);
-        nblk = 2;
-    } else {
-        d_occ_pair(B, b, (uint32_t)(ll & 127), tlb, tlp);
-        nblk = 1;
-    }
+    const bool same = (ll >> 7) == (kk >> 7);
+    OccBlock E;
+    E.q0 = d_pick4(same, B.q0, B2.q0); E.q1 = d_pick4(same, B.q1, B2.q1); E.q2 = d_pick4(same, B.q2, B2.q2); E.q3 = d_pick4(same, B.q3, B2.q3);
+    d_occ_pair(E, b, (uint32_t)(ll & 127), tlb, tlp);
     const uint64_t n2 = tlb - tkb;
     if (n2 == 0) return false;
     // sum over j > b of (tl[j] - tk[j]), using sum_j t[j] = row + 1
@@ -160,13 +161,41 @@ __device__ __forceinline__ bool d_extend(const DIndex &ix, int c, uint64_t &x0, 
     x2 = n2;
     return true;
 }
+__device__ __forceinline__ void d_extend_rows(const DIndex &ix, uint64_t x1, uint64_t x2, uint64_t &kk, uint64_t &ll)
+{
+    const uint64_t k = x1 - 1, l = k + x2;
+    kk = k - (k >= ix.primary); ll = l - (l >= ix.primary);
+}
+__device__ __forceinline__ bool d_extend(const DIndex &ix, int c, uint64_t &x0, uint64_t &x1, uint64_t &x2, uint32_t &nblk)
+{
+    uint64_t kk, ll;
+    d_extend_rows(ix, x1, x2, kk, ll);
+    const OccBlock B = d_load_block(ix, kk >> 7);
+    OccBlock B2;
+    B2.q0 = B2.q1 = B2.q2 = B2.q3 = make_uint4(0, 0, 0, 0);
+    nblk = 1;
+    if ((ll >> 7) != (kk >> 7)) { B2 = d_load_block(ix, ll >> 7); nblk = 2; }
+    return d_extend_finish(ix, c, B, B2, kk, ll, x0, x1, x2);
+}
+// LF mapping given the loaded block of row x = k - (k > primary), k != primary
+__device__ __forceinline__ uint64_t d_lf_finish(const DIndex &ix, const OccBlock B, uint64_t x)
+{
+    const uint32_t o = (uint32_t)(x & 127), wi = o >> 5, bit = o & 31;
+    const uint32_t hw = wi == 0 ? B.q2.x : wi == 1 ? B.q2.y : wi == 2 ? B.q2.z : B.q2.w;
+    const uint32_t lw = wi == 0 ? B.q3.x : wi == 1 ? B.q3.y : wi == 2 ? B.q3.z : B.q3.w;
+    const int c = (int)(((hw >> bit) & 1u) * 2u + ((lw >> bit) & 1u));
+    uint64_t cb, cp;
+    d_occ_pair(B, c, o, cb, cp);
+    return d_L2(ix, c) + cb;
+}
 
 // ---------------------------------------------------------------------------------------------
 // K-mer prefix table (built once in dg_init by k_build_ktab): entry id = sum_i base[i] << 2i of
 // the first K bases of a search (first base in the lowest bits); it holds the bi-interval after
 // those K bases, i.e. after K-1 steps of BWT_Search, plus how many steps / Occ blocks the
 // reference's loop would have spent getting there (for the algorithmic-byte accounting).
-//   e[0] = x0, e[1] = x1, e[2] = x2 (40 bits) | ref_steps << 40 | ref_blocks << 48
+//   32-byte entries (never straddle a 64-byte line):
+//   e[0] = x0, e[1] = x1, e[2] = x2 (40 bits) | ref_steps << 40 | ref_blocks << 48, e[3] spare
 // x2 == 0: the K-mer does not occur; because K <= 16 such a search can never yield a seed
 // (bwt_search.cpp:173 needs len >= 16), so it is skipped with the reference's step count.
 // Results are unchanged by construction: the table is the reference's own loop, memoised.
@@ -187,8 +216,9 @@ k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
         blocks += nb;
         if (!ok) { x2 = 0; break; }
     }
-    tab[(size_t)id * 3 + 0] = x0; tab[(size_t)id * 3 + 1] = x1;
-    tab[(size_t)id * 3 + 2] = (x2 & 0xFFFFFFFFFFull) | ((uint64_t)steps << 40) | ((uint64_t)blocks << 48);
+    tab[(size_t)id * 4 + 0] = x0; tab[(size_t)id * 4 + 1] = x1;
+    tab[(size_t)id * 4 + 2] = (x2 & 0xFFFFFFFFFFull) | ((uint64_t)steps << 40) | ((uint64_t)blocks << 48);
+    tab[(size_t)id * 4 + 3] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -203,108 +233,426 @@ k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
 // Output: per read up to H intervals (a hit is >= 16 long, so H = max_rlen/16 + 1 always fits).
 // ---------------------------------------------------------------------------------------------
 #define SEED_REFILL 8
+
+// 16 text symbols T[t..t+16) as 2-bit codes, first symbol in the lowest bits; *nv = how many of them
+// exist (the text ends at 2L).  T = forward strand + reverse complement, read from the forward pac.
+__device__ __forceinline__ uint32_t d_text16(const DIndex &ix, int64_t t, int &nv)
+{
+    const int64_t L = ix.l_pac;
+    const uint32_t *pw = (const uint32_t *)ix.pac;
+    nv = 16;
+    if (t >= 0 && t + 16 <= L) {
+        const uint64_t hi = ((uint64_t)__builtin_bswap32(pw[t >> 4]) << 32) | __builtin_bswap32(pw[(t >> 4) + 1]);
+        uint32_t y = (uint32_t)((hi << ((t & 15) << 1)) >> 32);           // 16 bases, first in the top bits
+        y = ((y & 0x33333333u) << 2) | ((y >> 2) & 0x33333333u);          // reverse the 2-bit groups
+        y = ((y & 0x0F0F0F0Fu) << 4) | ((y >> 4) & 0x0F0F0F0Fu);
+        return __builtin_bswap32(y);
+    }
+    if (t >= L && t + 16 <= 2 * L) {                                       // T[t+j] = 3 - fwd[2L-1-t-j]
+        const int64_t fs = 2 * L - 1 - t - 15;
+        const uint64_t hi = ((uint64_t)__builtin_bswap32(pw[fs >> 4]) << 32) | __builtin_bswap32(pw[(fs >> 4) + 1]);
+        const uint32_t y = (uint32_t)((hi << ((fs & 15) << 1)) >> 32);     // fwd[fs..fs+16), first in the top bits
+        return ~y;                                                          // group j from the bottom = fwd[2L-1-t-j]
+    }
+    uint32_t y = 0;                                                         // strand boundary or end of the text
+    nv = 0;
+    for (int j = 0; j < 16; j++) {
+        const char ch = d_refchar(ix, t + j);
+        if (ch == 0) break;
+        y |= (uint32_t)d_nt4((unsigned char)ch) << (2 * j);
+        nv = j + 1;
+    }
+    return y;
+}
+
+// One BWT_Search (bwt_search.cpp:139-182) in flight, advanced one memory access per trip:
+// mode 1 = FM steps, 3 = locating the unique row (LF steps), 2 = comparing with the text, 0 = done.
+struct Search {
+    uint64_t x0, x1, x2, lk;
+    int64_t tpos;
+    uint32_t lsteps;
+    int start, p, mode;
+    // what the reference's loop would have spent on this search (algorithmic-byte accounting)
+    uint32_t ref_steps, ref_blocks;
+    // result (valid when mode == 0): hit_len 0 = no seed; located = x0 already holds the text position
+    int hit_len; bool located;
+};
+struct SeedCtr { unsigned long long steps, blocks, steps_act, blocks_act, ktab, lf_ref, lf_act, n_direct; };
+
+__device__ __forceinline__ uint32_t d_pack2(uint64_t x)   // low 2 bits of 16 nibbles -> 32 bits, first base lowest
+{
+    x &= 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    return (uint32_t)(x | (x >> 16));
+}
+
+template <class WordFn>
+__device__ __forceinline__ uint64_t d_nibbles(WordFn &word, int q)   // the 16 4-bit codes from position q on
+{
+    const int w0 = q >> 3, sft = (q & 7) << 2;
+    const uint64_t lo = (uint64_t)word(w0) | ((uint64_t)word(w0 + 1) << 32);
+    return sft ? ((lo >> sft) | ((uint64_t)word(w0 + 2) << (64 - sft))) : lo;
+}
+
+__device__ __forceinline__ void d_search_end(const DParams &pr, Search &s)   // bwt_search.cpp:173-179
+{
+    const int l = s.p - s.start;
+    s.hit_len = (s.x2 <= (uint64_t)pr.max_dup && l >= 16) ? l : 0;
+    s.located = s.mode == 2;
+    s.mode = 0;
+}
+
+// Every trip of a search is split in three so that a wave whose lanes are in different modes pays ONE
+// memory latency per trip: d_begin_issue / d_trip_issue only compute the lane's addresses (TripAddr),
+// d_trip_load issues all loads from ONE place in the program, d_begin_finish / d_trip_finish consume them.
+// (With a load inside each divergent mode body the bodies load-and-wait one after the other; with
+// the loads in the bodies but the uses later, the compiler still waits in each body to copy the
+// value into the merged register.)
+struct TripAddr { const uint4 *pa, *pb, *p16; const uint32_t *p8; };     // nullptr = not needed
+struct TripData { OccBlock a, b; uint4 s16; uint2 s8; uint64_t kk, ll; uint32_t aux; };
+enum { T_NONE = 0, T_TABLE, T_SINGLE, T_STEP, T_STOP, T_LF, T_LF_PRIMARY, T_SA, T_CMP, T_CMP_SLOW };
+typedef uint2 __attribute__((aligned(4))) uint2_a4;
+
+__device__ __forceinline__ void d_trip_load(const TripAddr &ta, TripData &t)
+{
+    if (ta.pa) { t.a.q0 = ta.pa[0]; t.a.q1 = ta.pa[1]; t.a.q2 = ta.pa[2]; t.a.q3 = ta.pa[3]; }
+    if (ta.pb) { t.b.q0 = ta.pb[0]; t.b.q1 = ta.pb[1]; t.b.q2 = ta.pb[2]; t.b.q3 = ta.pb[3]; }
+    if (ta.p16) t.s16 = *ta.p16;
+    if (ta.p8) t.s8 = *(const uint2_a4 *)ta.p8;
+}
+
+// mode 0 -> begin a search at `start` (a position holding A/C/G/T): prefix table or the single-base interval
+template <class WordFn>
+__device__ __forceinline__ void d_begin_issue(const DIndex &ix, int K, WordFn &word, int start, Search &s, SeedCtr &c, TripAddr &ta, TripData &t)
+{
+    s.start = start; s.ref_steps = s.ref_blocks = 0; s.lsteps = 0; s.hit_len = 0; s.located = false;
+    t.aux = T_SINGLE;
+    if (K) {
+        const uint64_t v = d_nibbles(word, start) & ((1ull << (4 * K)) - 1ull);
+        if ((v & 0x4444444444444444ull) == 0) {           // no N among the K bases (codes 4,5 have bit 2 set)
+            const uint64_t *e = ix.ktab + (size_t)d_pack2(v) * 4;
+            ta.p16 = (const uint4 *)e; ta.p8 = (const uint32_t *)(e + 2);
+            c.ktab++;
+            t.aux = T_TABLE;
+        }
+    }
+}
+template <class WordFn>
+__device__ __forceinline__ void d_begin_finish(const DIndex &ix, int K, WordFn &word, Search &s, const TripData &t)
+{
+    if (t.aux == T_TABLE) {
+        const uint64_t e2 = d_u64(t.s8.x, t.s8.y);
+        s.ref_steps = (uint32_t)((e2 >> 40) & 0xFF); s.ref_blocks = (uint32_t)((e2 >> 48) & 0xFF);
+        if ((e2 & 0xFFFFFFFFFFull) == 0) { s.mode = 0; return; }   // cannot reach 16: no seed from this start
+        s.x0 = d_u64(t.s16.x, t.s16.y); s.x1 = d_u64(t.s16.z, t.s16.w); s.x2 = e2 & 0xFFFFFFFFFFull; s.p = s.start + K; s.mode = 1;
+        return;
+    }
+    const int cc = (int)((word(s.start >> 3) >> ((s.start & 7) << 2)) & 15u);
+    s.p = s.start + 1; s.mode = 1;
+    s.x0 = d_L2(ix, cc) + 1; s.x1 = d_L2(ix, 3 - cc) + 1; s.x2 = d_L2(ix, cc + 1) - d_L2(ix, cc);
+}
+
+// modes 1,3,2: the addresses of this trip
+template <class WordFn>
+__device__ __forceinline__ void d_trip_issue(const DIndex &ix, WordFn &word, int len, bool direct, Search &s, SeedCtr &c, TripAddr &ta, TripData &t)
+{
+    if (s.mode == 1 && direct && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
+    if (s.mode == 1) {
+        bool stop = s.p >= len;
+        if (!stop) stop = ((word(s.p >> 3) >> ((s.p & 7) << 2)) & 15u) > 3;
+        if (stop) { t.aux = T_STOP; return; }
+        d_extend_rows(ix, s.x1, s.x2, t.kk, t.ll);
+        ta.pa = ix.bwt + ((t.kk >> 7) << 2);
+        if ((t.ll >> 7) != (t.kk >> 7)) ta.pb = ix.bwt + ((t.ll >> 7) << 2);
+        t.aux = T_STEP;
+    } else if (s.mode == 3) {                      // bwt_sa on the unique row, one LF step per trip
+        if (s.lk & ((uint64_t)ix.sa_dense_intv - 1)) {
+            if (s.lk == ix.primary) { t.aux = T_LF_PRIMARY; return; }
+            t.kk = s.lk - (s.lk > ix.primary);
+            ta.pa = ix.bwt + ((t.kk >> 7) << 2);
+            t.aux = T_LF;
+        } else {
+            ta.p8 = (const uint32_t *)(ix.sa_dense + s.lk / (uint64_t)ix.sa_dense_intv);
+            t.aux = T_SA;
+        }
+    } else {                                       // mode 2: 16 text symbols
+        const int64_t tt = s.tpos + (s.p - s.start), L = ix.l_pac;
+        const uint32_t *pw = (const uint32_t *)ix.pac;
+        if (tt >= 0 && tt + 16 <= L) { ta.p8 = pw + (tt >> 4); t.kk = (uint64_t)(tt & 15); t.aux = T_CMP; t.ll = 0; }
+        else if (tt >= L && tt + 16 <= 2 * L) {
+            const int64_t fs = 2 * L - 1 - tt - 15;
+            ta.p8 = pw + (fs >> 4); t.kk = (uint64_t)(fs & 15); t.aux = T_CMP; t.ll = 1;
+        } else t.aux = T_CMP_SLOW;
+    }
+}
+
+// modes 1,3,2: consume the loads; when the search finishes, mode becomes 0 and hit_len/located hold the result
+template <class WordFn>
+__device__ __forceinline__ void d_trip_finish(const DIndex &ix, const DParams &pr, WordFn &word, int len, Search &s, SeedCtr &c, const TripData &t)
+{
+    if (t.aux == T_STOP) d_search_end(pr, s);
+    else if (t.aux == T_STEP) {
+        const int cc = (int)((word(s.p >> 3) >> ((s.p & 7) << 2)) & 15u);
+        const uint32_t nb = (t.ll >> 7) != (t.kk >> 7) ? 2u : 1u;
+        const bool ok = d_extend_finish(ix, cc, t.a, t.b, t.kk, t.ll, s.x0, s.x1, s.x2);
+        s.ref_steps++; s.ref_blocks += nb; c.steps_act++; c.blocks_act += nb;
+        if (ok) s.p++; else d_search_end(pr, s);
+    } else if (t.aux == T_LF) { s.lk = d_lf_finish(ix, t.a, t.kk); s.lsteps++; c.lf_act++; }
+    else if (t.aux == T_LF_PRIMARY) { s.lk = 0; s.lsteps++; c.lf_act++; }
+    else if (t.aux == T_SA) {
+        const uint64_t e = d_u64(t.s8.x, t.s8.y);
+        s.tpos = (int64_t)(s.lsteps + (e & 0xFFFFFFFFFFull) - 1);
+        s.lk = e;                                  // keeps the memoised reference LF count (bits 40..)
+        s.mode = 2; c.n_direct++;
+    } else {                                       // T_CMP / T_CMP_SLOW: the interval is one text position: compare 16 bases
+        int nv = 16;
+        uint32_t tx;
+        if (t.aux == T_CMP) {
+            const uint64_t hi = ((uint64_t)__builtin_bswap32(t.s8.x) << 32) | __builtin_bswap32(t.s8.y);
+            const uint32_t y = (uint32_t)((hi << (t.kk << 1)) >> 32);      // 16 bases, first in the top bits
+            if (t.ll) tx = ~y;                                             // reverse half: group j from the bottom = fwd[2L-1-t-j]
+            else {
+                uint32_t z = ((y & 0x33333333u) << 2) | ((y >> 2) & 0x33333333u);   // reverse the 2-bit groups
+                z = ((z & 0x0F0F0F0Fu) << 4) | ((z >> 4) & 0x0F0F0F0Fu);
+                tx = __builtin_bswap32(z);
+            }
+        } else tx = d_text16(ix, s.tpos + (s.p - s.start), nv);
+        const uint64_t v = d_nibbles(word, s.p);
+        const uint32_t rd2 = d_pack2(v);
+        const uint32_t nmask = d_pack2((v >> 2) & 0x1111111111111111ull);           // pair j = 1 where read base j is not ACGT
+        const int in_read = len - s.p < 16 ? len - s.p : 16;                       // bases left in the read
+        const uint32_t diff = rd2 ^ tx;
+        uint32_t stopm = ((diff | (diff >> 1)) & 0x55555555u) | nmask;
+        const int lim = in_read < nv ? in_read : nv;
+        if (lim < 16) stopm |= 0xFFFFFFFFu << (2 * lim);
+        const int j = stopm ? (__ffs((int)stopm) - 1) >> 1 : 16;                   // matched bases in this chunk
+        s.ref_steps += (uint32_t)j; s.ref_blocks += (uint32_t)j;                   // the reference: one step (one block, +<1 % crossings) per base
+        s.p += j;
+        if (j < 16) {
+            // a mismatch or the end of the text costs the reference one more (failing) step; N / end of read do not
+            if (j < in_read && !((nmask >> (2 * j)) & 1u)) { s.ref_steps++; s.ref_blocks++; }
+            d_search_end(pr, s);
+        }
+    }
+}
+
+// progress of a read handed from k_seed to k_seed_heavy
+struct __attribute__((aligned(8))) DHeavy { uint32_t read; int32_t pos, nh; uint32_t ns; };
+
+#define SEED_BAIL 20             // searches (starts tried) after which an unfinished read moves to the heavy queue:
+                                 // a clean read needs 3-8; only reads whose starts keep failing need more, and
+                                 // those are the ones 64-wide speculation helps (long single searches are not)
+
 template <bool USE_LDS>
 __global__ void __launch_bounds__(64)
 k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H,
-       DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read, unsigned long long *ctr)
+       DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
+       DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr)
 {
     extern __shared__ uint32_t sh[];
     const int lane = threadIdx.x;
-    unsigned long long steps = 0, blocks = 0, steps_act = 0, blocks_act = 0, ktab_reads = 0;
+    SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
     const int K = ix.ktab ? ix.ktab_k : 0;
-    int r = -1, len = 0, end_pos = 0, pos = 0, start = 0, p = 0, nh = 0;
-    uint32_t ns = 0;
-    bool searching = false, exhausted = false;
-    uint64_t x0 = 0, x1 = 0, x2 = 0;
+    const bool direct = ix.sa_dense != nullptr;      // unique intervals are finished by direct text comparison
+    int r = -1, len = 0, end_pos = 0, pos = 0, nh = 0;
+    uint32_t ns = 0, trips = 0, max_trips = 0, nsearch = 0;
+    bool exhausted = false;
+    unsigned int pool_next = 0, pool_end = 0;
+    Search s; s.mode = 0;
+    uint32_t wtrips = 0; const unsigned long long t_begin = wall_clock64();
     auto word = [&](int w) -> uint32_t { return w < W ? (USE_LDS ? sh[w * 64 + lane] : enc[(size_t)r * W + w]) : 0x44444444u; };
-    auto code = [&](int q) -> int { return (int)((word(q >> 3) >> ((q & 7) << 2)) & 15u); };
+    unsigned long long c_refill = 0, c_issue = 0, c_finish = 0; const unsigned long long c_begin = clock64();
     while (true) {
+        const unsigned long long c0 = clock64();
         const unsigned long long idle = __ballot(r < 0);
         if (idle) {
             const int n_idle = __popcll(idle);
             if (!exhausted && (n_idle >= SEED_REFILL || idle == ~0ull)) {
-                unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(next_read, (unsigned int)n_idle);
-                base = (unsigned int)__shfl((int)base, 0, 64);
-                if (r < 0) {
-                    const unsigned int mine = base + (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
-                    if (mine < (unsigned int)n_reads) {
-                        r = (int)mine;
-                        if (USE_LDS) for (int w = 0; w < W; w++) sh[w * 64 + lane] = enc[(size_t)r * W + w];
-                        len = rlen[r]; end_pos = len - 13; pos = 0; nh = 0; ns = 0; searching = false;
+                if (pool_next == pool_end) {
+                    // guided self-scheduling: one atomic buys this wave a run of reads (many at the start, few near the
+                    // end), so 2 M reads cost thousands of atomics on `next_read`, not one per refill
+                    unsigned int base = 0, chunk = 0;
+                    if (lane == 0) {
+                        const unsigned int seen = *(volatile unsigned int *)next_read;
+                        const unsigned int left = seen < (unsigned int)n_reads ? (unsigned int)n_reads - seen : 0u;
+                        chunk = left / (2u * gridDim.x);
+                        chunk = chunk < (unsigned int)SEED_REFILL ? (unsigned int)SEED_REFILL : (chunk > 512u ? 512u : chunk);
+                        base = atomicAdd(next_read, chunk);
                     }
+                    base = (unsigned int)__shfl((int)base, 0, 64); chunk = (unsigned int)__shfl((int)chunk, 0, 64);
+                    pool_next = base < (unsigned int)n_reads ? base : (unsigned int)n_reads;
+                    pool_end = base + chunk < (unsigned int)n_reads ? base + chunk : (unsigned int)n_reads;
+                    if (pool_next == pool_end) exhausted = true;
                 }
-                if (base + (unsigned int)n_idle >= (unsigned int)n_reads) exhausted = true;
+                const unsigned int avail = pool_end - pool_next;
+                const unsigned int rank = (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
+                const unsigned int take = (unsigned int)n_idle < avail ? (unsigned int)n_idle : avail;
+                if (r < 0 && rank < avail) {
+                    r = (int)(pool_next + rank);
+                    if (USE_LDS) sh[W * 64 + rank] = (uint32_t)lane;
+                    len = rlen[r]; end_pos = len - 13; pos = 0; nh = 0; ns = 0; s.mode = 0; trips = 0; nsearch = 0;
+                }
+                if (USE_LDS) {
+                    // the `take` new reads are consecutive, so their words are one contiguous run of enc: the whole
+                    // wave copies it with coalesced loads (two in flight per lane) and scatters into the lanes' LDS columns
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const uint32_t *src = enc + (size_t)pool_next * W;
+                    const unsigned int total = take * (unsigned int)W;
+                    for (unsigned int i0 = 0; i0 < total; i0 += 128) {
+                        const unsigned int i = i0 + lane, j = i + 64;
+                        uint32_t v0 = 0, v1 = 0;
+                        if (i < total) v0 = src[i];
+                        if (j < total) v1 = src[j];
+                        if (i < total) { const unsigned int rk = i / (unsigned int)W; sh[(i - rk * W) * 64 + sh[W * 64 + rk]] = v0; }
+                        if (j < total) { const unsigned int rk = j / (unsigned int)W; sh[(j - rk * W) * 64 + sh[W * 64 + rk]] = v1; }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                pool_next += take;
             }
             if (__ballot(r >= 0) == 0) { if (exhausted) break; continue; }
         }
+        wtrips++;
+        const unsigned long long c1 = clock64(); c_refill += c1 - c0;
+        unsigned long long c2 = c1;
         if (r >= 0) {
-            bool finished = false;
-            if (!searching) {
-                while (pos < end_pos && code(pos) > 3) pos++;
+            bool finished = false, beginning = false;
+            TripData t; t.aux = T_NONE;
+            TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
+            trips++;
+            // ---- issue phase: every lane computes its address and issues its load, nobody waits ----
+            if (s.mode == 0) {                       // IdentifySeedPairs :191-211: next start
+                while (pos < end_pos && ((word(pos >> 3) >> ((pos & 7) << 2)) & 15u) > 3) pos++;
                 if (pos >= end_pos) finished = true;
-                else {
-                    start = pos;
-                    bool from_table = false;
-                    if (K) {
-                        // the K 4-bit codes from `pos` on: 48 bits out of three staged words
-                        const int w0 = pos >> 3, sft = (pos & 7) << 2;
-                        const uint64_t lo = (uint64_t)word(w0) | ((uint64_t)word(w0 + 1) << 32);
-                        uint64_t v = sft ? ((lo >> sft) | ((uint64_t)word(w0 + 2) << (64 - sft))) : lo;
-                        v &= (1ull << (4 * K)) - 1ull;
-                        if ((v & 0x4444444444444444ull) == 0) {           // no N among them (codes 4,5 have bit 2 set)
-                            uint64_t x = v & 0x3333333333333333ull;       // nibbles -> 2-bit pairs, first base lowest
-                            x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-                            x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-                            x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-                            x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-                            const uint64_t *e = ix.ktab + (size_t)x * 3;
-                            const uint64_t e2 = e[2];
-                            ktab_reads++;
-                            steps += (e2 >> 40) & 0xFF; blocks += (e2 >> 48) & 0xFF;
-                            from_table = true;
-                            if ((e2 & 0xFFFFFFFFFFull) == 0) pos = start + 1;   // cannot reach 16: no seed here, next start
-                            else { x0 = e[0]; x1 = e[1]; x2 = e2 & 0xFFFFFFFFFFull; p = start + K; searching = true; }
-                        }
+                else if (nsearch >= SEED_BAIL) {     // long chain of failing starts: let a whole wave finish this read
+                    DHeavy hv; hv.read = (uint32_t)r; hv.pos = pos; hv.nh = nh; hv.ns = ns;
+                    heavy[atomicAdd(n_heavy, 1u)] = hv;
+                    max_trips = trips > max_trips ? trips : max_trips;
+                    r = -1;
+                } else { nsearch++; beginning = true; d_begin_issue(ix, K, word, pos, s, c, ta, t); }
+            } else d_trip_issue(ix, word, len, direct, s, c, ta, t);
+            d_trip_load(ta, t);
+            c2 = clock64();
+            // ---- finish phase ----
+            if (beginning) d_begin_finish(ix, K, word, s, t);
+            else if (t.aux != T_NONE) d_trip_finish(ix, pr, word, len, s, c, t);
+            if (r >= 0 && !finished && s.mode == 0) {            // a search just ended (or the table said "absent")
+                c.steps += s.ref_steps; c.blocks += s.ref_blocks;
+                if (s.hit_len) {
+                    if (nh < H) {
+                        DHit h; h.rPos = (uint16_t)s.start; h.len = (uint16_t)s.hit_len;
+                        if (s.located) { h.x0 = (uint64_t)s.tpos; h.freq = 1u | 0x80000000u; c.lf_ref += s.lsteps + (uint32_t)(s.lk >> 40); }
+                        else { h.x0 = s.x0; h.freq = (uint32_t)s.x2; }
+                        hits[(size_t)r * H + nh] = h;
                     }
-                    if (!from_table) {
-                        const int c = code(pos);
-                        p = pos + 1; searching = true;
-                        x0 = d_L2(ix, c) + 1; x1 = d_L2(ix, 3 - c) + 1; x2 = d_L2(ix, c + 1) - d_L2(ix, c);
-                    }
+                    nh++; ns += (uint32_t)s.x2;
+                    pos = s.start + s.hit_len;
+                } else pos = s.start + 1;
+            }
+            if (finished) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; r = -1; max_trips = trips > max_trips ? trips : max_trips; }
+        }
+        c_issue += c2 - c1; c_finish += clock64() - c2;
+    }
+    atomicMax(ctr + CTR_MAXTRIPS, (unsigned long long)max_trips);
+    if (lane == 0) {
+        const unsigned long long t_end = wall_clock64();
+        atomicMax(ctr + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(ctr + CTR_WTRIPS_SUM, (unsigned long long)wtrips);
+        atomicMax(ctr + CTR_T_END_MAX, t_end); atomicAdd(ctr + CTR_T_DUR_SUM, t_end - t_begin);
+        atomicMax(ctr + CTR_T_FIRST_END, ~t_end);
+        atomicAdd(ctr + CTR_C_REFILL, c_refill); atomicAdd(ctr + CTR_C_ISSUE, c_issue); atomicAdd(ctr + CTR_C_FINISH, c_finish); atomicAdd(ctr + CTR_C_TOTAL, (unsigned long long)clock64() - c_begin);
+    }
+    d_wave_add(ctr + CTR_STEPS, c.steps);
+    d_wave_add(ctr + CTR_BLOCKS, c.blocks);
+    d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
+    d_wave_add(ctr + CTR_BLOCKS_ACT, c.blocks_act);
+    d_wave_add(ctr + CTR_KTAB, c.ktab);
+    d_wave_add(ctr + CTR_LF, c.lf_ref);
+    d_wave_add(ctr + CTR_LF_ACT, c.lf_act);
+    d_wave_add(ctr + CTR_DIRECT, c.n_direct);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_seed_heavy: one wave = one read whose greedy walk is long (almost every start fails: an
+// unmappable or very noisy read).  BWT_Search(start) does not depend on earlier searches -- only
+// WHICH starts get searched does -- so the wave evaluates 64 consecutive starts at once, one per
+// lane, and then replays the reference's walk (hit: pos += len, else pos++; :198-209) over the 64
+// results with shuffles.  Results identical; only searches the walk really visits are charged to
+// the reference-equivalent counters (the speculative ones count as executed work only).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int W, int H,
+             DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds,
+             const DHeavy *__restrict__ heavy, const unsigned int *__restrict__ n_heavy_p, unsigned long long *ctr)
+{
+    extern __shared__ uint32_t sh[];                 // the read's 4-bit words, shared by the wave
+    const int lane = threadIdx.x;
+    const unsigned int n_heavy = *n_heavy_p;
+    SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int K = ix.ktab ? ix.ktab_k : 0;
+    const bool direct = ix.sa_dense != nullptr;
+    for (unsigned int hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
+        const DHeavy hv = heavy[hi];
+        const int r = (int)hv.read, len = rlen[r], end_pos = len - 13;
+        __syncthreads();
+        for (int w = lane; w < W; w += 64) sh[w] = enc[(size_t)r * W + w];
+        __syncthreads();
+        auto word = [&](int w) -> uint32_t { return w < W ? sh[w] : 0x44444444u; };
+        int pos = hv.pos, nh = hv.nh;
+        uint32_t ns = hv.ns;
+        while (pos < end_pos) {                      // uniform
+            Search s; s.mode = 0; s.hit_len = 0; s.located = false; s.ref_steps = s.ref_blocks = 0; s.start = pos + lane; s.x2 = 0; s.x0 = 0; s.tpos = 0; s.lsteps = 0; s.lk = 0;
+            const int st = pos + lane;
+            const bool acgt = st < end_pos && ((word(st >> 3) >> ((st & 7) << 2)) & 15u) <= 3;
+            {   // the 64 searches advance in lock step: one issue phase, one finish phase per trip
+                TripData t; t.aux = T_NONE;
+                TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
+                if (acgt) d_begin_issue(ix, K, word, st, s, c, ta, t);
+                d_trip_load(ta, t);
+                if (acgt) d_begin_finish(ix, K, word, s, t);
+                while (__ballot(acgt && s.mode != 0)) {
+                    t.aux = T_NONE; ta.pa = ta.pb = ta.p16 = nullptr; ta.p8 = nullptr;
+                    if (acgt && s.mode != 0) d_trip_issue(ix, word, len, direct, s, c, ta, t);
+                    d_trip_load(ta, t);
+                    if (t.aux != T_NONE) d_trip_finish(ix, pr, word, len, s, c, t);
                 }
             }
-            if (searching) {
-                bool stop = p >= len;
-                int c = 4;
-                if (!stop) { c = code(p); stop = c > 3; }
-                if (!stop) {
-                    uint32_t nb;
-                    const bool ok = d_extend(ix, c, x0, x1, x2, nb);
-                    steps++; blocks += nb; steps_act++; blocks_act += nb;
-                    if (ok) p++; else stop = true;
-                }
-                if (stop) {
-                    const int l = p - start;
-                    if (x2 <= (uint64_t)pr.max_dup && l >= 16) {
+            // replay the walk over the 64 results
+            int cur = pos;
+            const int lim = pos + 64 < end_pos ? pos + 64 : end_pos;
+            while (cur < lim) {                      // uniform
+                const int src = cur - pos;
+                const int is_acgt = __shfl((int)acgt, src, 64);
+                const int hl = __shfl(s.hit_len, src, 64);
+                if (lane == src && acgt) {           // this search is one the reference performs
+                    c.steps += s.ref_steps; c.blocks += s.ref_blocks;
+                    if (s.hit_len) {
                         if (nh < H) {
-                            DHit h; h.x0 = x0; h.freq = (uint32_t)x2; h.rPos = (uint16_t)start; h.len = (uint16_t)l;
+                            DHit h; h.rPos = (uint16_t)s.start; h.len = (uint16_t)s.hit_len;
+                            if (s.located) { h.x0 = (uint64_t)s.tpos; h.freq = 1u | 0x80000000u; c.lf_ref += s.lsteps + (uint32_t)(s.lk >> 40); }
+                            else { h.x0 = s.x0; h.freq = (uint32_t)s.x2; }
                             hits[(size_t)r * H + nh] = h;
                         }
-                        nh++; ns += (uint32_t)x2;
-                        pos = start + l;
-                    } else pos = start + 1;
-                    searching = false;
+                    }
                 }
+                if (is_acgt && hl) {
+                    const uint32_t fr = (uint32_t)__shfl((int)(uint32_t)s.x2, src, 64);
+                    nh++; ns += fr; cur += hl;
+                } else cur++;
             }
-            if (finished) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; r = -1; }
+            pos = cur;
         }
+        if (lane == 0) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; }
     }
-    d_wave_add(ctr + CTR_STEPS, steps);
-    d_wave_add(ctr + CTR_BLOCKS, blocks);
-    d_wave_add(ctr + CTR_STEPS_ACT, steps_act);
-    d_wave_add(ctr + CTR_BLOCKS_ACT, blocks_act);
-    d_wave_add(ctr + CTR_KTAB, ktab_reads);
+    d_wave_add(ctr + CTR_STEPS, c.steps);
+    d_wave_add(ctr + CTR_BLOCKS, c.blocks);
+    d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
+    d_wave_add(ctr + CTR_BLOCKS_ACT, c.blocks_act);
+    d_wave_add(ctr + CTR_KTAB, c.ktab);
+    d_wave_add(ctr + CTR_LF, c.lf_ref);
+    d_wave_add(ctr + CTR_LF_ACT, c.lf_act);
+    d_wave_add(ctr + CTR_DIRECT, c.n_direct);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,10 +706,11 @@ k_locate(const DIndex ix, int n_reads, int H, const DHit *__restrict__ hits, con
             if (u < total) {
                 uint32_t w = u - excl;
                 const DHit *h = hits + (size_t)(r0 + lo) * H;
-                while (w >= h->freq) { w -= h->freq; h++; }
+                while (w >= (h->freq & 0x7FFFFFFFu)) { w -= h->freq & 0x7FFFFFFFu; h++; }
                 uint64_t k = h->x0 + w;
                 uint64_t steps = 0, pos;
-                if (ix.sa_dense) {
+                if (h->freq & 0x80000000u) pos = h->x0;                          // k_seed already located this unique hit
+                else if (ix.sa_dense) {
                     const uint64_t mask = (uint64_t)ix.sa_dense_intv - 1;
                     while (k & mask) { k = d_lf(ix, k); steps++; }
                     const uint64_t e = ix.sa_dense[k / (uint64_t)ix.sa_dense_intv];
