@@ -424,13 +424,16 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
             c->ix.sa_dense = (const uint64_t *)c->d_sa_dense; c->ix.sa_dense_intv = intv;
         }
     }
-    {   // K-mer prefix table: K = 12 (402 MB) for genome-sized texts, smaller for small texts; DG_KTAB_K=0 turns it off
-        int K = v->seq_len >= (1ull << 26) ? 12 : (v->seq_len >= (1ull << 22) ? 10 : 8);
+    {   // K-mer prefix table: the smallest K with 4^K >= text length (so that most K-mers are unique or absent and a
+        // search needs the table plus a step or two), 8 <= K <= 15: 16 bytes per entry = 4.3 GB at K = 14 (chr20),
+        // 17 GB at K = 15 (human).  DG_KTAB_K=0 turns it off, =2..16 forces K (16 = 69 GB).
+        int K = 8;
+        while (K < 15 && (1ull << (2 * K)) < v->seq_len) K++;
         if (getenv("DG_KTAB_K")) K = atoi(getenv("DG_KTAB_K"));
-        if (K > 13) K = 13;
+        if (K > 16) K = 16;
         if (K >= 2) {
             const size_t entries = (size_t)1 << (2 * K);
-            if ((e = hipMalloc(&c->d_ktab, entries * 32)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc k-mer table", e);
+            if ((e = hipMalloc(&c->d_ktab, entries * 16)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc k-mer table", e);
             k_build_ktab<<<(unsigned)((entries + 255) / 256), 256, 0, c->stream>>>(c->ix, K, (uint64_t *)c->d_ktab);
             if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_ktab", e);
             c->ix.ktab = (const uint64_t *)c->d_ktab; c->ix.ktab_k = K;
@@ -482,11 +485,11 @@ static WSLayout make_ws_layout(int R)
 // k_encode + k_seed (reads staged in LDS when 256 lanes x W words fit comfortably)
 static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode = nullptr)
 {
-    const int W = (c->max_rlen + 7) / 8 > 0 ? (c->max_rlen + 7) / 8 : 1;
+    const int W = 2 * ((c->max_rlen + 15) / 16 > 0 ? (c->max_rlen + 15) / 16 : 1);   // 2-bit words + N-mask words per read
     hipError_t e = c->enc.ensure((size_t)W * n + 16);
     if (e != hipSuccess) return e;
     const unsigned nb = (unsigned)((n + 255) / 256);
-    k_encode<<<(unsigned)(((size_t)n * W + 255) / 256), 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, c->enc.p);
+    k_encode<<<(unsigned)(((size_t)n * (W / 2) + 255) / 256), 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, c->enc.p);
     if (after_encode) { e = hipEventRecord(after_encode, c->stream); if (e != hipSuccess) return e; }
     // persistent one-wave workgroups pulling reads from a queue (d_tops[6]); long walks go to d_tops[7]'s list
     e = hipMemsetAsync(c->d_tops + 6, 0, 8, c->stream);
@@ -494,8 +497,9 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     if ((e = c->seed_heavy.ensure((size_t)n + 16)) != hipSuccess) return e;
     unsigned blocks = (unsigned)c->n_cu * (getenv("DG_SEED_WAVES") ? (unsigned)atoi(getenv("DG_SEED_WAVES")) : 8u);   // the kernel is VALU-issue bound from 2 waves per SIMD on
     if ((size_t)blocks * 64 > (size_t)n) blocks = (unsigned)((n + 63) / 64);
-    if (W <= 160) k_seed<true><<<blocks, 64, ((size_t)W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr);
-    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr);
+    const int bail_trips = getenv("DG_SEED_BAIL_TRIPS") ? atoi(getenv("DG_SEED_BAIL_TRIPS")) : 128;
+    if (W <= 160) k_seed<true><<<blocks, 64, ((size_t)W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips);
+    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips);
     k_seed_heavy<<<(unsigned)c->n_cu * 8u, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, c->d_tops + 7, c->d_ctr);
     return hipGetLastError();
 }

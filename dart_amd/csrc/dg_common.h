@@ -75,7 +75,7 @@ struct DParams {
 
 // work counters (dg_last_counters)
 enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, CTR_NWCELLS, CTR_RESEED, CTR_RESEEDW,
-       CTR_STEPS_ACT, CTR_BLOCKS_ACT, CTR_KTAB, CTR_LF_ACT, CTR_DIRECT, CTR_MAXTRIPS, CTR_WTRIPS_MAX, CTR_WTRIPS_SUM, CTR_T_END_MAX, CTR_T_DUR_SUM, CTR_T_FIRST_END, CTR_C_REFILL, CTR_C_ISSUE, CTR_C_FINISH, CTR_C_TOTAL, CTR_N };   // *_ACT: steps/blocks this implementation really executed
+       CTR_STEPS_ACT, CTR_BLOCKS_ACT, CTR_KTAB, CTR_LF_ACT, CTR_DIRECT, CTR_MAXTRIPS, CTR_WTRIPS_MAX, CTR_WTRIPS_SUM, CTR_N };   // *_ACT: steps/blocks this implementation really executed
 
 __device__ __forceinline__ uint8_t d_nt4(unsigned char c)   // nst_nt4_table, BWT_Index/bntseq.c:40
 {

@@ -113,27 +113,35 @@ __global__ void k_relayout_bwt(const uint32_t *__restrict__ src, uint64_t src_wo
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_encode: ASCII reads -> 4 bit/base (nst_nt4_table codes 0..5), 8 bases per u32, read-major
-// (enc[r * W + w]).  One thread per output word, so the 8-byte source groups of a read are
-// fetched by neighbouring lanes (coalesced) and the stores are contiguous.
+// k_encode: ASCII reads -> the pac format of the text, read-major, W = 2*W2 words per read:
+//   words [0, W2): 2 bit/base (nst_nt4_table codes 0..3), 16 bases per u32, FIRST base in the TOP bits
+//   words [W2, W): the same positions, 0b11 where the read has no A/C/G/T there (N, or past the end)
+// so that 64 read bases and 64 text bases can be XORed word against word, and a K-mer is a shift.
+// One thread per output word: neighbouring lanes read neighbouring 16-byte groups and store contiguously.
 // ---------------------------------------------------------------------------------------------
+typedef uint4 __attribute__((aligned(1))) uint4_a1;
 __global__ void __launch_bounds__(256)
 k_encode(const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen,
          int n_reads, int W, uint32_t *__restrict__ enc)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n_reads * W) return;
-    const int r = (int)(t / W), w = (int)(t % W);
-    const unsigned char *s = seq + seq_off[r];
-    const int len = rlen[r];
-    uint32_t v = 0;
+    const int W2 = W >> 1;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread = 16 bases = one base word + one mask word
+    if (t >= (size_t)n_reads * W2) return;
+    const int r = (int)(t / W2), ww = (int)(t % W2);
+    const unsigned char *s = seq + seq_off[r] + ww * 16;
+    const int left = (int)rlen[r] - ww * 16;                            // bases of the read from this group on
+    uint32_t ch[4] = {0, 0, 0, 0};
+    if (left >= 16) { const uint4 q = *(const uint4_a1 *)s; ch[0] = q.x; ch[1] = q.y; ch[2] = q.z; ch[3] = q.w; }
+    else for (int j = 0; j < left; j++) ch[j >> 2] |= (uint32_t)s[j] << (8 * (j & 3));
+    uint32_t vb = 0, vm = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int p = w * 8 + j;
-        const uint32_t c = p < len ? d_nt4(s[p]) : 4u;
-        v |= c << (4 * j);
+    for (int j = 0; j < 16; j++) {
+        const uint32_t c = j < left ? d_nt4((unsigned char)(ch[j >> 2] >> (8 * (j & 3)))) : 4u;
+        vb |= (c > 3 ? 0u : c) << (30 - 2 * j);
+        vm |= (c > 3 ? 3u : 0u) << (30 - 2 * j);
     }
-    enc[t] = v;
+    enc[(size_t)r * W + ww] = vb;
+    enc[(size_t)r * W + W2 + ww] = vm;
 }
 
 // one step of BWT_Search (:152-170) with base c, given the already loaded Occ blocks of rows kk and ll
@@ -190,35 +198,37 @@ __device__ __forceinline__ uint64_t d_lf_finish(const DIndex &ix, const OccBlock
 }
 
 // ---------------------------------------------------------------------------------------------
-// K-mer prefix table (built once in dg_init by k_build_ktab): entry id = sum_i base[i] << 2i of
-// the first K bases of a search (first base in the lowest bits); it holds the bi-interval after
-// those K bases, i.e. after K-1 steps of BWT_Search, plus how many steps / Occ blocks the
-// reference's loop would have spent getting there (for the algorithmic-byte accounting).
-//   32-byte entries (never straddle a 64-byte line):
-//   e[0] = x0, e[1] = x1, e[2] = x2 (40 bits) | ref_steps << 40 | ref_blocks << 48, e[3] spare
+// K-mer prefix table (built once in dg_init by k_build_ktab): entry id = the first K bases of a
+// search as a 2K-bit number, first base in the top bits; it holds the bi-interval after those K
+// bases, i.e. after K-1 steps of BWT_Search, plus how many steps / Occ blocks the reference's
+// loop would have spent getting there (for the algorithmic-byte accounting).
+//   16-byte entries: w0 = x0 (40 bits) | x1[23:0] << 40
+//                    w1 = x1[39:24] | x2 (31 bits) << 16 | ref_steps (5) << 47 | ref_blocks (6) << 52 | overflow << 63
 // x2 == 0: the K-mer does not occur; because K <= 16 such a search can never yield a seed
 // (bwt_search.cpp:173 needs len >= 16), so it is skipped with the reference's step count.
+// overflow (x2 >= 2^31, a K-mer with billions of copies): the search starts from its first base instead.
 // Results are unchanged by construction: the table is the reference's own loop, memoised.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
 {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (1u << (2 * K))) return;
-    int c = (int)(id & 3u);
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (1ull << (2 * K))) return;
+    int c = (int)((id >> (2 * (K - 1))) & 3u);
     uint64_t x0 = d_L2(ix, c) + 1, x1 = d_L2(ix, 3 - c) + 1, x2 = d_L2(ix, c + 1) - d_L2(ix, c);
     uint32_t steps = 0, blocks = 0;
     for (int i = 1; i < K; i++) {
-        c = (int)((id >> (2 * i)) & 3u);
+        c = (int)((id >> (2 * (K - 1 - i))) & 3u);
         uint32_t nb;
         steps++;
         const bool ok = d_extend(ix, c, x0, x1, x2, nb);
         blocks += nb;
         if (!ok) { x2 = 0; break; }
     }
-    tab[(size_t)id * 4 + 0] = x0; tab[(size_t)id * 4 + 1] = x1;
-    tab[(size_t)id * 4 + 2] = (x2 & 0xFFFFFFFFFFull) | ((uint64_t)steps << 40) | ((uint64_t)blocks << 48);
-    tab[(size_t)id * 4 + 3] = 0;
+    uint64_t w0 = (x0 & 0xFFFFFFFFFFull) | ((x1 & 0xFFFFFFull) << 40);
+    uint64_t w1 = ((x1 >> 24) & 0xFFFFull) | ((x2 & 0x7FFFFFFFull) << 16) | ((uint64_t)steps << 47) | ((uint64_t)blocks << 52);
+    if (x2 >> 31) w1 |= 1ull << 63;
+    tab[id * 2 + 0] = w0; tab[id * 2 + 1] = w1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -228,38 +238,23 @@ k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
 // converged on the memory-bound step whatever their read positions are.
 // Reads differ a lot in work (every failed search restarts one base further, :209), so waves are
 // persistent and refill their idle lanes from a global read queue as soon as SEED_REFILL of them
-// are idle: one atomic per refill, each refilled lane stages its read's 4-bit words into its own
+// are idle: one atomic per refill, each refilled lane gets its read's words (k_encode format) staged into its own
 // LDS column (the lane is the only reader of that column, so no barrier is needed).
 // Output: per read up to H intervals (a hit is >= 16 long, so H = max_rlen/16 + 1 always fits).
 // ---------------------------------------------------------------------------------------------
 #define SEED_REFILL 8
 
-// 16 text symbols T[t..t+16) as 2-bit codes, first symbol in the lowest bits; *nv = how many of them
-// exist (the text ends at 2L).  T = forward strand + reverse complement, read from the forward pac.
-__device__ __forceinline__ uint32_t d_text16(const DIndex &ix, int64_t t, int &nv)
+// slow path of the text comparison (strand boundary, end of the text): up to 16 symbols T[t..t+16) in the
+// read's format (first symbol in the top bits); *nv = how many exist.  T = forward strand + reverse
+// complement, read from the forward pac.
+__device__ __forceinline__ uint32_t d_text16_slow(const DIndex &ix, int64_t t, int &nv)
 {
-    const int64_t L = ix.l_pac;
-    const uint32_t *pw = (const uint32_t *)ix.pac;
-    nv = 16;
-    if (t >= 0 && t + 16 <= L) {
-        const uint64_t hi = ((uint64_t)__builtin_bswap32(pw[t >> 4]) << 32) | __builtin_bswap32(pw[(t >> 4) + 1]);
-        uint32_t y = (uint32_t)((hi << ((t & 15) << 1)) >> 32);           // 16 bases, first in the top bits
-        y = ((y & 0x33333333u) << 2) | ((y >> 2) & 0x33333333u);          // reverse the 2-bit groups
-        y = ((y & 0x0F0F0F0Fu) << 4) | ((y >> 4) & 0x0F0F0F0Fu);
-        return __builtin_bswap32(y);
-    }
-    if (t >= L && t + 16 <= 2 * L) {                                       // T[t+j] = 3 - fwd[2L-1-t-j]
-        const int64_t fs = 2 * L - 1 - t - 15;
-        const uint64_t hi = ((uint64_t)__builtin_bswap32(pw[fs >> 4]) << 32) | __builtin_bswap32(pw[(fs >> 4) + 1]);
-        const uint32_t y = (uint32_t)((hi << ((fs & 15) << 1)) >> 32);     // fwd[fs..fs+16), first in the top bits
-        return ~y;                                                          // group j from the bottom = fwd[2L-1-t-j]
-    }
-    uint32_t y = 0;                                                         // strand boundary or end of the text
+    uint32_t y = 0;
     nv = 0;
     for (int j = 0; j < 16; j++) {
         const char ch = d_refchar(ix, t + j);
         if (ch == 0) break;
-        y |= (uint32_t)d_nt4((unsigned char)ch) << (2 * j);
+        y |= (uint32_t)d_nt4((unsigned char)ch) << (30 - 2 * j);
         nv = j + 1;
     }
     return y;
@@ -279,21 +274,20 @@ struct Search {
 };
 struct SeedCtr { unsigned long long steps, blocks, steps_act, blocks_act, ktab, lf_ref, lf_act, n_direct; };
 
-__device__ __forceinline__ uint32_t d_pack2(uint64_t x)   // low 2 bits of 16 nibbles -> 32 bits, first base lowest
+// the read as two word accessors: rb(w) = 16 bases (2 bit each, first base on top), rm(w) = 0b11 where not A/C/G/T
+// 16 positions starting at q, first on top
+template <class F>
+__device__ __forceinline__ uint32_t d_win16(F &f, int q)
 {
-    x &= 0x3333333333333333ull;
-    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-    return (uint32_t)(x | (x >> 16));
+    const int w = q >> 4;
+    return __funnelshift_l(f(w + 1), f(w), (uint32_t)((q & 15) << 1));
 }
-
-template <class WordFn>
-__device__ __forceinline__ uint64_t d_nibbles(WordFn &word, int q)   // the 16 4-bit codes from position q on
+template <class F>
+__device__ __forceinline__ uint32_t d_at(F &f, int q) { return (f(q >> 4) >> (30 - ((q & 15) << 1))) & 3u; }
+__device__ __forceinline__ uint32_t d_rev2(uint32_t x)      // reverse the order of the 16 2-bit groups
 {
-    const int w0 = q >> 3, sft = (q & 7) << 2;
-    const uint64_t lo = (uint64_t)word(w0) | ((uint64_t)word(w0 + 1) << 32);
-    return sft ? ((lo >> sft) | ((uint64_t)word(w0 + 2) << (64 - sft))) : lo;
+    const uint32_t y = __brev(x);
+    return ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
 }
 
 __device__ __forceinline__ void d_search_end(const DParams &pr, Search &s)   // bwt_search.cpp:173-179
@@ -310,59 +304,60 @@ __device__ __forceinline__ void d_search_end(const DParams &pr, Search &s)   // 
 // (With a load inside each divergent mode body the bodies load-and-wait one after the other; with
 // the loads in the bodies but the uses later, the compiler still waits in each body to copy the
 // value into the merged register.)
-struct TripAddr { const uint4 *pa, *pb, *p16; const uint32_t *p8; };     // nullptr = not needed
+typedef uint4 __attribute__((aligned(4))) uint4_a4;
+typedef uint2 __attribute__((aligned(4))) uint2_a4;
+struct TripAddr { const uint4 *pa, *pb; const uint4_a4 *p16; const uint2_a4 *p8; };     // nullptr = not needed
 struct TripData { OccBlock a, b; uint4 s16; uint2 s8; uint64_t kk, ll; uint32_t aux; };
 enum { T_NONE = 0, T_TABLE, T_SINGLE, T_STEP, T_STOP, T_LF, T_LF_PRIMARY, T_SA, T_CMP, T_CMP_SLOW };
-typedef uint2 __attribute__((aligned(4))) uint2_a4;
 
 __device__ __forceinline__ void d_trip_load(const TripAddr &ta, TripData &t)
 {
     if (ta.pa) { t.a.q0 = ta.pa[0]; t.a.q1 = ta.pa[1]; t.a.q2 = ta.pa[2]; t.a.q3 = ta.pa[3]; }
     if (ta.pb) { t.b.q0 = ta.pb[0]; t.b.q1 = ta.pb[1]; t.b.q2 = ta.pb[2]; t.b.q3 = ta.pb[3]; }
     if (ta.p16) t.s16 = *ta.p16;
-    if (ta.p8) t.s8 = *(const uint2_a4 *)ta.p8;
+    if (ta.p8) t.s8 = *ta.p8;
 }
 
 // mode 0 -> begin a search at `start` (a position holding A/C/G/T): prefix table or the single-base interval
-template <class WordFn>
-__device__ __forceinline__ void d_begin_issue(const DIndex &ix, int K, WordFn &word, int start, Search &s, SeedCtr &c, TripAddr &ta, TripData &t)
+template <class RB, class RM>
+__device__ __forceinline__ void d_begin_issue(const DIndex &ix, int K, RB &rb, RM &rm, int start, Search &s, SeedCtr &c, TripAddr &ta, TripData &t)
 {
     s.start = start; s.ref_steps = s.ref_blocks = 0; s.lsteps = 0; s.hit_len = 0; s.located = false;
     t.aux = T_SINGLE;
     if (K) {
-        const uint64_t v = d_nibbles(word, start) & ((1ull << (4 * K)) - 1ull);
-        if ((v & 0x4444444444444444ull) == 0) {           // no N among the K bases (codes 4,5 have bit 2 set)
-            const uint64_t *e = ix.ktab + (size_t)d_pack2(v) * 4;
-            ta.p16 = (const uint4 *)e; ta.p8 = (const uint32_t *)(e + 2);
+        const uint32_t sft = 32u - 2u * (uint32_t)K;
+        if ((d_win16(rm, start) >> sft) == 0) {            // K bases, none of them N or past the end
+            ta.p16 = (const uint4_a4 *)(ix.ktab + (size_t)(d_win16(rb, start) >> sft) * 2);
             c.ktab++;
             t.aux = T_TABLE;
         }
     }
 }
-template <class WordFn>
-__device__ __forceinline__ void d_begin_finish(const DIndex &ix, int K, WordFn &word, Search &s, const TripData &t)
+template <class RB>
+__device__ __forceinline__ void d_begin_finish(const DIndex &ix, int K, RB &rb, Search &s, const TripData &t)
 {
     if (t.aux == T_TABLE) {
-        const uint64_t e2 = d_u64(t.s8.x, t.s8.y);
-        s.ref_steps = (uint32_t)((e2 >> 40) & 0xFF); s.ref_blocks = (uint32_t)((e2 >> 48) & 0xFF);
-        if ((e2 & 0xFFFFFFFFFFull) == 0) { s.mode = 0; return; }   // cannot reach 16: no seed from this start
-        s.x0 = d_u64(t.s16.x, t.s16.y); s.x1 = d_u64(t.s16.z, t.s16.w); s.x2 = e2 & 0xFFFFFFFFFFull; s.p = s.start + K; s.mode = 1;
-        return;
+        const uint64_t w0 = d_u64(t.s16.x, t.s16.y), w1 = d_u64(t.s16.z, t.s16.w);
+        if (!(w1 >> 63)) {
+            const uint64_t x2 = (w1 >> 16) & 0x7FFFFFFFull;
+            s.ref_steps = (uint32_t)((w1 >> 47) & 31u); s.ref_blocks = (uint32_t)((w1 >> 52) & 63u);
+            if (x2 == 0) { s.mode = 0; return; }          // cannot reach 16: no seed from this start
+            s.x0 = w0 & 0xFFFFFFFFFFull; s.x1 = (w0 >> 40) | ((w1 & 0xFFFFull) << 24); s.x2 = x2; s.p = s.start + K; s.mode = 1;
+            return;
+        }
     }
-    const int cc = (int)((word(s.start >> 3) >> ((s.start & 7) << 2)) & 15u);
+    const int cc = (int)d_at(rb, s.start);
     s.p = s.start + 1; s.mode = 1;
     s.x0 = d_L2(ix, cc) + 1; s.x1 = d_L2(ix, 3 - cc) + 1; s.x2 = d_L2(ix, cc + 1) - d_L2(ix, cc);
 }
 
 // modes 1,3,2: the addresses of this trip
-template <class WordFn>
-__device__ __forceinline__ void d_trip_issue(const DIndex &ix, WordFn &word, int len, bool direct, Search &s, SeedCtr &c, TripAddr &ta, TripData &t)
+template <class RM>
+__device__ __forceinline__ void d_trip_issue(const DIndex &ix, RM &rm, int len, bool direct, Search &s, SeedCtr &c, TripAddr &ta, TripData &t)
 {
     if (s.mode == 1 && direct && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
     if (s.mode == 1) {
-        bool stop = s.p >= len;
-        if (!stop) stop = ((word(s.p >> 3) >> ((s.p & 7) << 2)) & 15u) > 3;
-        if (stop) { t.aux = T_STOP; return; }
+        if (s.p >= len || d_at(rm, s.p)) { t.aux = T_STOP; return; }
         d_extend_rows(ix, s.x1, s.x2, t.kk, t.ll);
         ta.pa = ix.bwt + ((t.kk >> 7) << 2);
         if ((t.ll >> 7) != (t.kk >> 7)) ta.pb = ix.bwt + ((t.ll >> 7) << 2);
@@ -374,27 +369,29 @@ __device__ __forceinline__ void d_trip_issue(const DIndex &ix, WordFn &word, int
             ta.pa = ix.bwt + ((t.kk >> 7) << 2);
             t.aux = T_LF;
         } else {
-            ta.p8 = (const uint32_t *)(ix.sa_dense + s.lk / (uint64_t)ix.sa_dense_intv);
+            ta.p8 = (const uint2_a4 *)(ix.sa_dense + s.lk / (uint64_t)ix.sa_dense_intv);
             t.aux = T_SA;
         }
-    } else {                                       // mode 2: 16 text symbols
+    } else {                                       // mode 2: 64 text symbols = five pac words
         const int64_t tt = s.tpos + (s.p - s.start), L = ix.l_pac;
         const uint32_t *pw = (const uint32_t *)ix.pac;
-        if (tt >= 0 && tt + 16 <= L) { ta.p8 = pw + (tt >> 4); t.kk = (uint64_t)(tt & 15); t.aux = T_CMP; t.ll = 0; }
-        else if (tt >= L && tt + 16 <= 2 * L) {
-            const int64_t fs = 2 * L - 1 - tt - 15;
-            ta.p8 = pw + (fs >> 4); t.kk = (uint64_t)(fs & 15); t.aux = T_CMP; t.ll = 1;
+        int64_t f0 = -1;                           // first forward-strand symbol of the window
+        if (tt >= 0 && tt + 64 <= L) { f0 = tt; t.ll = 0; }
+        else if (tt >= L && tt + 64 <= 2 * L) { f0 = 2 * L - 1 - tt - 63; t.ll = 1; }
+        if (f0 >= 0) {
+            ta.p16 = (const uint4_a4 *)(pw + (f0 >> 4)); ta.p8 = (const uint2_a4 *)(pw + (f0 >> 4) + 4);
+            t.kk = (uint64_t)((f0 & 15) << 1); t.aux = T_CMP;
         } else t.aux = T_CMP_SLOW;
     }
 }
 
 // modes 1,3,2: consume the loads; when the search finishes, mode becomes 0 and hit_len/located hold the result
-template <class WordFn>
-__device__ __forceinline__ void d_trip_finish(const DIndex &ix, const DParams &pr, WordFn &word, int len, Search &s, SeedCtr &c, const TripData &t)
+template <class RB, class RM>
+__device__ __forceinline__ void d_trip_finish(const DIndex &ix, const DParams &pr, RB &rb, RM &rm, int len, Search &s, SeedCtr &c, const TripData &t)
 {
     if (t.aux == T_STOP) d_search_end(pr, s);
     else if (t.aux == T_STEP) {
-        const int cc = (int)((word(s.p >> 3) >> ((s.p & 7) << 2)) & 15u);
+        const int cc = (int)d_at(rb, s.p);
         const uint32_t nb = (t.ll >> 7) != (t.kk >> 7) ? 2u : 1u;
         const bool ok = d_extend_finish(ix, cc, t.a, t.b, t.kk, t.ll, s.x0, s.x1, s.x2);
         s.ref_steps++; s.ref_blocks += nb; c.steps_act++; c.blocks_act += nb;
@@ -406,33 +403,33 @@ __device__ __forceinline__ void d_trip_finish(const DIndex &ix, const DParams &p
         s.tpos = (int64_t)(s.lsteps + (e & 0xFFFFFFFFFFull) - 1);
         s.lk = e;                                  // keeps the memoised reference LF count (bits 40..)
         s.mode = 2; c.n_direct++;
-    } else {                                       // T_CMP / T_CMP_SLOW: the interval is one text position: compare 16 bases
-        int nv = 16;
-        uint32_t tx;
+    } else {                                       // T_CMP / T_CMP_SLOW: the interval is one text position: compare up to 64 bases
+        int nv = 64, chunk = 64;
+        uint32_t T0, T1 = 0, T2 = 0, T3 = 0;
         if (t.aux == T_CMP) {
-            const uint64_t hi = ((uint64_t)__builtin_bswap32(t.s8.x) << 32) | __builtin_bswap32(t.s8.y);
-            const uint32_t y = (uint32_t)((hi << (t.kk << 1)) >> 32);      // 16 bases, first in the top bits
-            if (t.ll) tx = ~y;                                             // reverse half: group j from the bottom = fwd[2L-1-t-j]
-            else {
-                uint32_t z = ((y & 0x33333333u) << 2) | ((y >> 2) & 0x33333333u);   // reverse the 2-bit groups
-                z = ((z & 0x0F0F0F0Fu) << 4) | ((z >> 4) & 0x0F0F0F0Fu);
-                tx = __builtin_bswap32(z);
-            }
-        } else tx = d_text16(ix, s.tpos + (s.p - s.start), nv);
-        const uint64_t v = d_nibbles(word, s.p);
-        const uint32_t rd2 = d_pack2(v);
-        const uint32_t nmask = d_pack2((v >> 2) & 0x1111111111111111ull);           // pair j = 1 where read base j is not ACGT
-        const int in_read = len - s.p < 16 ? len - s.p : 16;                       // bases left in the read
-        const uint32_t diff = rd2 ^ tx;
-        uint32_t stopm = ((diff | (diff >> 1)) & 0x55555555u) | nmask;
+            const uint32_t d0 = __builtin_bswap32(t.s16.x), d1 = __builtin_bswap32(t.s16.y), d2 = __builtin_bswap32(t.s16.z),
+                           d3 = __builtin_bswap32(t.s16.w), d4 = __builtin_bswap32(t.s8.x), o = (uint32_t)t.kk;
+            const uint32_t s0 = __funnelshift_l(d1, d0, o), s1 = __funnelshift_l(d2, d1, o), s2 = __funnelshift_l(d3, d2, o), s3 = __funnelshift_l(d4, d3, o);
+            if (t.ll) { T0 = ~d_rev2(s3); T1 = ~d_rev2(s2); T2 = ~d_rev2(s1); T3 = ~d_rev2(s0); }   // T[t+j] = 3 - fwd[2L-1-t-j]
+            else { T0 = s0; T1 = s1; T2 = s2; T3 = s3; }
+        } else { T0 = d_text16_slow(ix, s.tpos + (s.p - s.start), nv); chunk = 16; }
+        const int w = s.p >> 4;
+        const uint32_t o = (uint32_t)((s.p & 15) << 1);
+        const uint32_t b0 = rb(w), b1 = rb(w + 1), b2 = rb(w + 2), b3 = rb(w + 3), b4 = rb(w + 4);
+        const uint32_t m0 = rm(w), m1 = rm(w + 1), m2 = rm(w + 2), m3 = rm(w + 3), m4 = rm(w + 4);
+        const uint32_t N0 = __funnelshift_l(m1, m0, o), N1 = __funnelshift_l(m2, m1, o), N2 = __funnelshift_l(m3, m2, o), N3 = __funnelshift_l(m4, m3, o);
+        const int in_read = len - s.p < chunk ? len - s.p : chunk;                 // bases left in the read
         const int lim = in_read < nv ? in_read : nv;
-        if (lim < 16) stopm |= 0xFFFFFFFFu << (2 * lim);
-        const int j = stopm ? (__ffs((int)stopm) - 1) >> 1 : 16;                   // matched bases in this chunk
+        auto tail = [&](int k) -> uint32_t { const int rem = lim - 16 * k; return rem >= 16 ? 0u : (rem <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu >> (2 * rem)); };
+        const uint32_t e0 = (__funnelshift_l(b1, b0, o) ^ T0) | N0 | tail(0), e1 = (__funnelshift_l(b2, b1, o) ^ T1) | N1 | tail(1),
+                       e2 = (__funnelshift_l(b3, b2, o) ^ T2) | N2 | tail(2), e3 = (__funnelshift_l(b4, b3, o) ^ T3) | N3 | tail(3);
+        const int j = e0 ? __clz((int)e0) >> 1 : e1 ? 16 + (__clz((int)e1) >> 1) : e2 ? 32 + (__clz((int)e2) >> 1) : e3 ? 48 + (__clz((int)e3) >> 1) : 64;
         s.ref_steps += (uint32_t)j; s.ref_blocks += (uint32_t)j;                   // the reference: one step (one block, +<1 % crossings) per base
         s.p += j;
-        if (j < 16) {
+        if (j < chunk) {
             // a mismatch or the end of the text costs the reference one more (failing) step; N / end of read do not
-            if (j < in_read && !((nmask >> (2 * j)) & 1u)) { s.ref_steps++; s.ref_blocks++; }
+            const uint32_t nsel = j < 16 ? N0 : j < 32 ? N1 : j < 48 ? N2 : N3;
+            if (j < in_read && !((nsel >> (30 - ((j & 15) << 1))) & 1u)) { s.ref_steps++; s.ref_blocks++; }
             d_search_end(pr, s);
         }
     }
@@ -449,7 +446,7 @@ template <bool USE_LDS>
 __global__ void __launch_bounds__(64)
 k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H,
        DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
-       DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr)
+       DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips)
 {
     extern __shared__ uint32_t sh[];
     const int lane = threadIdx.x;
@@ -461,11 +458,11 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
     bool exhausted = false;
     unsigned int pool_next = 0, pool_end = 0;
     Search s; s.mode = 0;
-    uint32_t wtrips = 0; const unsigned long long t_begin = wall_clock64();
-    auto word = [&](int w) -> uint32_t { return w < W ? (USE_LDS ? sh[w * 64 + lane] : enc[(size_t)r * W + w]) : 0x44444444u; };
-    unsigned long long c_refill = 0, c_issue = 0, c_finish = 0; const unsigned long long c_begin = clock64();
+    uint32_t wtrips = 0;
+    const int W2 = W >> 1;
+    auto rb = [&](int w) -> uint32_t { return w < W2 ? (USE_LDS ? sh[w * 64 + lane] : enc[(size_t)r * W + w]) : 0u; };
+    auto rm = [&](int w) -> uint32_t { return w < W2 ? (USE_LDS ? sh[(W2 + w) * 64 + lane] : enc[(size_t)r * W + W2 + w]) : 0xFFFFFFFFu; };
     while (true) {
-        const unsigned long long c0 = clock64();
         const unsigned long long idle = __ballot(r < 0);
         if (idle) {
             const int n_idle = __popcll(idle);
@@ -515,8 +512,6 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
             if (__ballot(r >= 0) == 0) { if (exhausted) break; continue; }
         }
         wtrips++;
-        const unsigned long long c1 = clock64(); c_refill += c1 - c0;
-        unsigned long long c2 = c1;
         if (r >= 0) {
             bool finished = false, beginning = false;
             TripData t; t.aux = T_NONE;
@@ -524,20 +519,19 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
             trips++;
             // ---- issue phase: every lane computes its address and issues its load, nobody waits ----
             if (s.mode == 0) {                       // IdentifySeedPairs :191-211: next start
-                while (pos < end_pos && ((word(pos >> 3) >> ((pos & 7) << 2)) & 15u) > 3) pos++;
+                while (pos < end_pos && d_at(rm, pos)) pos++;
                 if (pos >= end_pos) finished = true;
-                else if (nsearch >= SEED_BAIL) {     // long chain of failing starts: let a whole wave finish this read
+                else if (nsearch >= SEED_BAIL || trips >= (uint32_t)bail_trips) {     // long chain of failing starts: let a whole wave finish this read
                     DHeavy hv; hv.read = (uint32_t)r; hv.pos = pos; hv.nh = nh; hv.ns = ns;
                     heavy[atomicAdd(n_heavy, 1u)] = hv;
                     max_trips = trips > max_trips ? trips : max_trips;
                     r = -1;
-                } else { nsearch++; beginning = true; d_begin_issue(ix, K, word, pos, s, c, ta, t); }
-            } else d_trip_issue(ix, word, len, direct, s, c, ta, t);
+                } else { nsearch++; beginning = true; d_begin_issue(ix, K, rb, rm, pos, s, c, ta, t); }
+            } else d_trip_issue(ix, rm, len, direct, s, c, ta, t);
             d_trip_load(ta, t);
-            c2 = clock64();
             // ---- finish phase ----
-            if (beginning) d_begin_finish(ix, K, word, s, t);
-            else if (t.aux != T_NONE) d_trip_finish(ix, pr, word, len, s, c, t);
+            if (beginning) d_begin_finish(ix, K, rb, s, t);
+            else if (t.aux != T_NONE) d_trip_finish(ix, pr, rb, rm, len, s, c, t);
             if (r >= 0 && !finished && s.mode == 0) {            // a search just ended (or the table said "absent")
                 c.steps += s.ref_steps; c.blocks += s.ref_blocks;
                 if (s.hit_len) {
@@ -553,16 +547,9 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
             }
             if (finished) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; r = -1; max_trips = trips > max_trips ? trips : max_trips; }
         }
-        c_issue += c2 - c1; c_finish += clock64() - c2;
     }
     atomicMax(ctr + CTR_MAXTRIPS, (unsigned long long)max_trips);
-    if (lane == 0) {
-        const unsigned long long t_end = wall_clock64();
-        atomicMax(ctr + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(ctr + CTR_WTRIPS_SUM, (unsigned long long)wtrips);
-        atomicMax(ctr + CTR_T_END_MAX, t_end); atomicAdd(ctr + CTR_T_DUR_SUM, t_end - t_begin);
-        atomicMax(ctr + CTR_T_FIRST_END, ~t_end);
-        atomicAdd(ctr + CTR_C_REFILL, c_refill); atomicAdd(ctr + CTR_C_ISSUE, c_issue); atomicAdd(ctr + CTR_C_FINISH, c_finish); atomicAdd(ctr + CTR_C_TOTAL, (unsigned long long)clock64() - c_begin);
-    }
+    if (lane == 0) { atomicMax(ctr + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(ctr + CTR_WTRIPS_SUM, (unsigned long long)wtrips); }
     d_wave_add(ctr + CTR_STEPS, c.steps);
     d_wave_add(ctr + CTR_BLOCKS, c.blocks);
     d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
@@ -586,7 +573,8 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
              DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds,
              const DHeavy *__restrict__ heavy, const unsigned int *__restrict__ n_heavy_p, unsigned long long *ctr)
 {
-    extern __shared__ uint32_t sh[];                 // the read's 4-bit words, shared by the wave
+    extern __shared__ uint32_t sh[];                 // the read's words (k_encode format), shared by the wave
+    const int W2 = W >> 1;
     const int lane = threadIdx.x;
     const unsigned int n_heavy = *n_heavy_p;
     SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -598,24 +586,25 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
         __syncthreads();
         for (int w = lane; w < W; w += 64) sh[w] = enc[(size_t)r * W + w];
         __syncthreads();
-        auto word = [&](int w) -> uint32_t { return w < W ? sh[w] : 0x44444444u; };
+        auto rb = [&](int w) -> uint32_t { return w < W2 ? sh[w] : 0u; };
+        auto rm = [&](int w) -> uint32_t { return w < W2 ? sh[W2 + w] : 0xFFFFFFFFu; };
         int pos = hv.pos, nh = hv.nh;
         uint32_t ns = hv.ns;
         while (pos < end_pos) {                      // uniform
             Search s; s.mode = 0; s.hit_len = 0; s.located = false; s.ref_steps = s.ref_blocks = 0; s.start = pos + lane; s.x2 = 0; s.x0 = 0; s.tpos = 0; s.lsteps = 0; s.lk = 0;
             const int st = pos + lane;
-            const bool acgt = st < end_pos && ((word(st >> 3) >> ((st & 7) << 2)) & 15u) <= 3;
+            const bool acgt = st < end_pos && d_at(rm, st) == 0;
             {   // the 64 searches advance in lock step: one issue phase, one finish phase per trip
                 TripData t; t.aux = T_NONE;
                 TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
-                if (acgt) d_begin_issue(ix, K, word, st, s, c, ta, t);
+                if (acgt) d_begin_issue(ix, K, rb, rm, st, s, c, ta, t);
                 d_trip_load(ta, t);
-                if (acgt) d_begin_finish(ix, K, word, s, t);
+                if (acgt) d_begin_finish(ix, K, rb, s, t);
                 while (__ballot(acgt && s.mode != 0)) {
                     t.aux = T_NONE; ta.pa = ta.pb = ta.p16 = nullptr; ta.p8 = nullptr;
-                    if (acgt && s.mode != 0) d_trip_issue(ix, word, len, direct, s, c, ta, t);
+                    if (acgt && s.mode != 0) d_trip_issue(ix, rm, len, direct, s, c, ta, t);
                     d_trip_load(ta, t);
-                    if (t.aux != T_NONE) d_trip_finish(ix, pr, word, len, s, c, t);
+                    if (t.aux != T_NONE) d_trip_finish(ix, pr, rb, rm, len, s, c, t);
                 }
             }
             // replay the walk over the 64 results
