@@ -489,7 +489,9 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     hipError_t e = c->enc.ensure((size_t)W * n + 16);
     if (e != hipSuccess) return e;
     const unsigned nb = (unsigned)((n + 255) / 256);
-    k_encode<<<(unsigned)(((size_t)n * (W / 2) + 255) / 256), 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, c->enc.p);
+    int lg = 0;
+    while ((1 << lg) < W / 2) lg++;
+    k_encode<<<(unsigned)((((size_t)n << lg) + 255) / 256), 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, lg, c->enc.p);
     if (after_encode) { e = hipEventRecord(after_encode, c->stream); if (e != hipSuccess) return e; }
     // persistent one-wave workgroups pulling reads from a queue (d_tops[6]); long walks go to d_tops[7]'s list
     e = hipMemsetAsync(c->d_tops + 6, 0, 8, c->stream);
@@ -498,7 +500,7 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     unsigned blocks = (unsigned)c->n_cu * (getenv("DG_SEED_WAVES") ? (unsigned)atoi(getenv("DG_SEED_WAVES")) : 8u);   // the kernel is VALU-issue bound from 2 waves per SIMD on
     if ((size_t)blocks * 64 > (size_t)n) blocks = (unsigned)((n + 63) / 64);
     const int bail_trips = getenv("DG_SEED_BAIL_TRIPS") ? atoi(getenv("DG_SEED_BAIL_TRIPS")) : 128;
-    if (W <= 160) k_seed<true><<<blocks, 64, ((size_t)W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips);
+    if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips);
     else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips);
     k_seed_heavy<<<(unsigned)c->n_cu * 8u, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, c->d_tops + 7, c->d_ctr);
     return hipGetLastError();

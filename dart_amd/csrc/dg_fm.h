@@ -122,12 +122,14 @@ __global__ void k_relayout_bwt(const uint32_t *__restrict__ src, uint64_t src_wo
 typedef uint4 __attribute__((aligned(1))) uint4_a1;
 __global__ void __launch_bounds__(256)
 k_encode(const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen,
-         int n_reads, int W, uint32_t *__restrict__ enc)
+         int n_reads, int W, int lg, uint32_t *__restrict__ enc)
 {
     const int W2 = W >> 1;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread = 16 bases = one base word + one mask word
-    if (t >= (size_t)n_reads * W2) return;
-    const int r = (int)(t / W2), ww = (int)(t % W2);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread = 16 bases = one base word + one mask word;
+    const size_t rr = t >> lg;                                           // 2^lg >= W2 threads per read (no division)
+    const int ww = (int)(t & ((1u << lg) - 1u));
+    if (rr >= (size_t)n_reads || ww >= W2) return;
+    const int r = (int)rr;
     const unsigned char *s = seq + seq_off[r] + ww * 16;
     const int left = (int)rlen[r] - ww * 16;                            // bases of the read from this group on
     uint32_t ch[4] = {0, 0, 0, 0};
@@ -355,7 +357,6 @@ __device__ __forceinline__ void d_begin_finish(const DIndex &ix, int K, RB &rb, 
 template <class RM>
 __device__ __forceinline__ void d_trip_issue(const DIndex &ix, RM &rm, int len, bool direct, Search &s, SeedCtr &c, TripAddr &ta, TripData &t)
 {
-    if (s.mode == 1 && direct && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
     if (s.mode == 1) {
         if (s.p >= len || d_at(rm, s.p)) { t.aux = T_STOP; return; }
         d_extend_rows(ix, s.x1, s.x2, t.kk, t.ll);
@@ -460,79 +461,131 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
     Search s; s.mode = 0;
     uint32_t wtrips = 0;
     const int W2 = W >> 1;
-    auto rb = [&](int w) -> uint32_t { return w < W2 ? (USE_LDS ? sh[w * 64 + lane] : enc[(size_t)r * W + w]) : 0u; };
-    auto rm = [&](int w) -> uint32_t { return w < W2 ? (USE_LDS ? sh[(W2 + w) * 64 + lane] : enc[(size_t)r * W + W2 + w]) : 0xFFFFFFFFu; };
+    // USE_LDS: every lane owns two LDS columns of W words, the read it is working on (cur) and the next one,
+    // which is fetched while the lane is still busy (see the refill event below)
+    int cur = 0, r_nxt = -1, len_nxt = 0;
+    uint32_t pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;      // words of the reads being prefetched, in flight
+    unsigned int pend_total = 0;
+    uint32_t *const tab = sh + 2 * W * 64;             // rank in the batch -> lane | buffer << 8
+    auto rb = [&](int w) -> uint32_t { return w < W2 ? (USE_LDS ? sh[(cur * W + w) * 64 + lane] : enc[(size_t)r * W + w]) : 0u; };
+    auto rm = [&](int w) -> uint32_t { return w < W2 ? (USE_LDS ? sh[(cur * W + W2 + w) * 64 + lane] : enc[(size_t)r * W + W2 + w]) : 0xFFFFFFFFu; };
+    // guided self-scheduling: one atomic buys this wave a run of reads (many at the start, few near the end),
+    // so 2 M reads cost thousands of atomics on `next_read`, not one per refill
+    auto grab = [&]() {
+        unsigned int base = 0, chunk = 0;
+        if (lane == 0) {
+            const unsigned int seen = *(volatile unsigned int *)next_read;
+            const unsigned int left = seen < (unsigned int)n_reads ? (unsigned int)n_reads - seen : 0u;
+            chunk = left / (2u * gridDim.x);
+            chunk = chunk < (unsigned int)SEED_REFILL ? (unsigned int)SEED_REFILL : (chunk > 512u ? 512u : chunk);
+            base = atomicAdd(next_read, chunk);
+        }
+        base = (unsigned int)__shfl((int)base, 0, 64); chunk = (unsigned int)__shfl((int)chunk, 0, 64);
+        pool_next = base < (unsigned int)n_reads ? base : (unsigned int)n_reads;
+        pool_end = base + chunk < (unsigned int)n_reads ? base + chunk : (unsigned int)n_reads;
+        if (pool_next == pool_end) exhausted = true;
+    };
+    const unsigned int w_magic = (65536u + (unsigned int)W - 1u) / (unsigned int)W;      // i / W == (i * w_magic) >> 16 for i < 256
     while (true) {
         const unsigned long long idle = __ballot(r < 0);
+        bool event = false;
         if (idle) {
-            const int n_idle = __popcll(idle);
-            if (!exhausted && (n_idle >= SEED_REFILL || idle == ~0ull)) {
-                if (pool_next == pool_end) {
-                    // guided self-scheduling: one atomic buys this wave a run of reads (many at the start, few near the
-                    // end), so 2 M reads cost thousands of atomics on `next_read`, not one per refill
-                    unsigned int base = 0, chunk = 0;
-                    if (lane == 0) {
-                        const unsigned int seen = *(volatile unsigned int *)next_read;
-                        const unsigned int left = seen < (unsigned int)n_reads ? (unsigned int)n_reads - seen : 0u;
-                        chunk = left / (2u * gridDim.x);
-                        chunk = chunk < (unsigned int)SEED_REFILL ? (unsigned int)SEED_REFILL : (chunk > 512u ? 512u : chunk);
-                        base = atomicAdd(next_read, chunk);
-                    }
-                    base = (unsigned int)__shfl((int)base, 0, 64); chunk = (unsigned int)__shfl((int)chunk, 0, 64);
-                    pool_next = base < (unsigned int)n_reads ? base : (unsigned int)n_reads;
-                    pool_end = base + chunk < (unsigned int)n_reads ? base + chunk : (unsigned int)n_reads;
-                    if (pool_next == pool_end) exhausted = true;
-                }
-                const unsigned int avail = pool_end - pool_next;
-                const unsigned int rank = (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
-                const unsigned int take = (unsigned int)n_idle < avail ? (unsigned int)n_idle : avail;
-                if (r < 0 && rank < avail) {
-                    r = (int)(pool_next + rank);
-                    if (USE_LDS) sh[W * 64 + rank] = (uint32_t)lane;
-                    len = rlen[r]; end_pos = len - 13; pos = 0; nh = 0; ns = 0; s.mode = 0; trips = 0; nsearch = 0;
-                }
-                if (USE_LDS) {
-                    // the `take` new reads are consecutive, so their words are one contiguous run of enc: the whole
-                    // wave copies it with coalesced loads (two in flight per lane) and scatters into the lanes' LDS columns
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const uint32_t *src = enc + (size_t)pool_next * W;
-                    const unsigned int total = take * (unsigned int)W;
-                    for (unsigned int i0 = 0; i0 < total; i0 += 128) {
-                        const unsigned int i = i0 + lane, j = i + 64;
-                        uint32_t v0 = 0, v1 = 0;
-                        if (i < total) v0 = src[i];
-                        if (j < total) v1 = src[j];
-                        if (i < total) { const unsigned int rk = i / (unsigned int)W; sh[(i - rk * W) * 64 + sh[W * 64 + rk]] = v0; }
-                        if (j < total) { const unsigned int rk = j / (unsigned int)W; sh[(j - rk * W) * 64 + sh[W * 64 + rk]] = v1; }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                pool_next += take;
-            }
-            if (__ballot(r >= 0) == 0) { if (exhausted) break; continue; }
+            event = (__popcll(idle) >= SEED_REFILL || idle == ~0ull) && (!exhausted || __ballot(r < 0 && r_nxt >= 0) != 0);
+            if (!event && idle == ~0ull) break;          // nothing in work, nothing prefetched, nothing left to claim
         }
         wtrips++;
-        if (r >= 0) {
-            bool finished = false, beginning = false;
-            TripData t; t.aux = T_NONE;
-            TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
+        bool live = false, finished = false, beginning = false;
+        TripData t; t.aux = T_NONE;
+        TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
+        // The wave serves ONE search mode per trip, the one most of its lanes are in; the others wait a trip.  A trip
+        // then runs one mode's code instead of all four: the kernel is bound by instruction fetch (the I-cache of a CU
+        // pair is busy 85 % of the time when every trip walks every mode's code), not by memory or occupancy.
+        int sel;
+        {
+            const int n0 = __popcll(__ballot(r >= 0 && s.mode == 0)), n1 = __popcll(__ballot(r >= 0 && s.mode == 1)),
+                      n2 = __popcll(__ballot(r >= 0 && s.mode == 2)), n3 = __popcll(__ballot(r >= 0 && s.mode == 3));
+            const int m01 = n0 >= n1 ? 0 : 1, c01 = n0 >= n1 ? n0 : n1, m23 = n2 >= n3 ? 2 : 3, c23 = n2 >= n3 ? n2 : n3;
+            sel = c01 >= c23 ? m01 : m23;
+        }
+        // ---- issue phase: every chosen lane computes its address and issues its load, nobody waits ----
+        if (r >= 0 && s.mode == sel) {
             trips++;
-            // ---- issue phase: every lane computes its address and issues its load, nobody waits ----
+            live = true;
             if (s.mode == 0) {                       // IdentifySeedPairs :191-211: next start
                 while (pos < end_pos && d_at(rm, pos)) pos++;
                 if (pos >= end_pos) finished = true;
-                else if (nsearch >= SEED_BAIL || trips >= (uint32_t)bail_trips) {     // long chain of failing starts: let a whole wave finish this read
+                else if (nsearch >= SEED_BAIL || trips >= (uint32_t)bail_trips) {     // a long walk: let a whole wave finish this read
                     DHeavy hv; hv.read = (uint32_t)r; hv.pos = pos; hv.nh = nh; hv.ns = ns;
                     heavy[atomicAdd(n_heavy, 1u)] = hv;
                     max_trips = trips > max_trips ? trips : max_trips;
-                    r = -1;
+                    r = -1; live = false;
                 } else { nsearch++; beginning = true; d_begin_issue(ix, K, rb, rm, pos, s, c, ta, t); }
             } else d_trip_issue(ix, rm, len, direct, s, c, ta, t);
-            d_trip_load(ta, t);
-            // ---- finish phase ----
+        }
+        d_trip_load(ta, t);
+        // ---- refill event, placed where the wave has to wait for memory anyway ----
+        if (event) {
+            if (USE_LDS) {
+                // (a) the batch prefetched at the previous event has long arrived: scatter it into the owners' `next` columns
+                if (pend_total) {
+                    const uint32_t pv[4] = {pv0, pv1, pv2, pv3};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned int i = (unsigned int)(k * 64 + lane);
+                        if (i < pend_total) {
+                            const unsigned int rk = (i * w_magic) >> 16, e = tab[rk];
+                            sh[(((e >> 8) & 1u) * W + (i - rk * W)) * 64 + (e & 63u)] = pv[k];
+                        }
+                    }
+                    pend_total = 0;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                // (b) idle lanes switch to their prefetched read: no memory access, no wait
+                if (r < 0 && r_nxt >= 0) {
+                    r = r_nxt; r_nxt = -1; cur ^= 1;
+                    len = len_nxt; end_pos = len - 13; pos = 0; nh = 0; ns = 0; s.mode = 0; trips = 0; nsearch = 0;
+                }
+                // (c) lanes without a next read claim one; the wave issues coalesced loads for the whole batch (the
+                //     reads are consecutive, so their words are one contiguous run of enc) and goes back to work
+                const unsigned long long need = __ballot(r_nxt < 0);
+                if (need && !exhausted) {
+                    if (pool_next == pool_end) grab();
+                    const unsigned int avail = pool_end - pool_next, cap = 256u / (unsigned int)W ? 256u / (unsigned int)W : 1u;
+                    unsigned int take = (unsigned int)__popcll(need);
+                    take = take < avail ? take : avail; take = take < cap ? take : cap;
+                    const unsigned int rank = (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
+                    if (r_nxt < 0 && rank < take) {
+                        r_nxt = (int)(pool_next + rank);
+                        tab[rank] = (uint32_t)lane | ((uint32_t)(cur ^ 1) << 8);
+                        len_nxt = rlen[r_nxt];
+                    }
+                    const uint32_t *src = enc + (size_t)pool_next * W;
+                    pend_total = take * (unsigned int)W;
+                    if ((unsigned int)lane < pend_total) pv0 = src[lane];
+                    if ((unsigned int)lane + 64 < pend_total) pv1 = src[lane + 64];
+                    if ((unsigned int)lane + 128 < pend_total) pv2 = src[lane + 128];
+                    if ((unsigned int)lane + 192 < pend_total) pv3 = src[lane + 192];
+                    pool_next += take;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            } else if (!exhausted) {
+                if (pool_next == pool_end) grab();
+                const unsigned long long idl = __ballot(r < 0);
+                const unsigned int avail = pool_end - pool_next, n_idl = (unsigned int)__popcll(idl);
+                const unsigned int rank = (unsigned int)__popcll(idl & ((1ull << lane) - 1ull));
+                if (r < 0 && rank < avail) {
+                    r = (int)(pool_next + rank);
+                    len = rlen[r]; end_pos = len - 13; pos = 0; nh = 0; ns = 0; s.mode = 0; trips = 0; nsearch = 0;
+                }
+                pool_next += n_idl < avail ? n_idl : avail;
+            }
+        }
+        // ---- finish phase ----
+        if (live) {
             if (beginning) d_begin_finish(ix, K, rb, s, t);
             else if (t.aux != T_NONE) d_trip_finish(ix, pr, rb, rm, len, s, c, t);
-            if (r >= 0 && !finished && s.mode == 0) {            // a search just ended (or the table said "absent")
+            if (direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
+            if (!finished && s.mode == 0) {          // a search just ended (or the table said "absent")
                 c.steps += s.ref_steps; c.blocks += s.ref_blocks;
                 if (s.hit_len) {
                     if (nh < H) {
@@ -600,11 +653,13 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
                 if (acgt) d_begin_issue(ix, K, rb, rm, st, s, c, ta, t);
                 d_trip_load(ta, t);
                 if (acgt) d_begin_finish(ix, K, rb, s, t);
+                if (acgt && direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
                 while (__ballot(acgt && s.mode != 0)) {
                     t.aux = T_NONE; ta.pa = ta.pb = ta.p16 = nullptr; ta.p8 = nullptr;
                     if (acgt && s.mode != 0) d_trip_issue(ix, rm, len, direct, s, c, ta, t);
                     d_trip_load(ta, t);
                     if (t.aux != T_NONE) d_trip_finish(ix, pr, rb, rm, len, s, c, t);
+                    if (acgt && direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
                 }
             }
             // replay the walk over the 64 results
