@@ -165,11 +165,7 @@ __global__ void k_compact_sj(dg_read_out *rd, uint32_t n, const uint32_t *new_of
 // list.  Lanes of one wave then walk similar paths (less divergence) and the heavy tail starts
 // first (longest-processing-time scheduling).
 // ------------------------------------------------------------------------------------------
-#define COST_CLASSES 8
-__device__ __forceinline__ uint32_t d_cost_class(uint32_t cost, bool has_jobs)   // 0 = waits for k_reseed; then heaviest first
-{
-    return has_jobs ? 0u : cost > 128 ? 1u : cost > 64 ? 2u : cost > 40 ? 3u : cost > 24 ? 4u : cost > 16 ? 5u : cost > 0 ? 6u : 7u;
-}
+#define COST_CLASSES 16
 // pass 1: class of every read + per-(class, block) counts, laid out class-major for one scan
 __global__ void __launch_bounds__(256)
 k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
@@ -183,9 +179,17 @@ k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const D
     if (r < n_reads) {
         const DCand *cd = cands + seed_off[r];
         const int nc = (int)ncand[r];
-        uint32_t cost = 0; bool has_jobs = false;
-        for (int i = 0; i < nc; i++) if (cd[i].Score > 0) { cost += 4u + 3u * (uint32_t)cd[i].n_a; has_jobs = has_jobs || cd[i].job_count > 0; }
-        k = d_cost_class(cost, has_jobs);
+        // Reads of one class do the same things in the same order, so a wave's lanes stay converged in k_report:
+        // 0 = waits for k_reseed; 1-4 = some pair is too big for the register-only path (by seed count);
+        // 5-14 = small pairs only, by (live candidates, seeds); 15 = nothing to report
+        uint32_t tot = 0, live = 0; bool has_jobs = false, big = false;
+        for (int i = 0; i < nc; i++) if (cd[i].Score > 0) { live++; tot += (uint32_t)cd[i].n_a; has_jobs = has_jobs || cd[i].job_count > 0; big = big || cd[i].final_n != 0; }
+        if (has_jobs) k = 0;
+        else if (live == 0) k = 15;
+        else if (big) k = tot > 12 ? 1u : tot > 6 ? 2u : tot > 3 ? 3u : 4u;
+        else if (live >= 3) k = tot > 8 ? 5u : 6u;
+        else if (live == 2) k = tot > 4 ? 7u : tot > 2 ? 8u : 9u;
+        else k = tot >= 5 ? 10u : tot == 4 ? 11u : tot == 3 ? 12u : tot == 2 ? 13u : 14u;
         key[r] = (uint8_t)k;
     }
     for (uint32_t c = 0; c < COST_CLASSES; c++) {
@@ -565,7 +569,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(c->reports.ensure((size_t)total_rep + 1)); HIPCHK(c->work.ensure((size_t)total_work + 16));
     HIPCHK(c->cigpool.ensure(cigcap)); HIPCHK(c->cigfinal.ensure(cigcap)); HIPCHK(c->sjpool.ensure(sjcap)); HIPCHK(c->sjfinal.ensure(sjcap));
     const WSLayout L = make_ws_layout(c->max_rlen < 32 ? 32 : c->max_rlen);
-    int blocks = c->n_cu * (getenv("DG_REPORT_BPC") ? atoi(getenv("DG_REPORT_BPC")) : 16);   // 16 one-wave workgroups per CU (4 per SIMD)
+    int blocks = c->n_cu * (getenv("DG_REPORT_BPC") ? atoi(getenv("DG_REPORT_BPC")) : 8);   // 8 one-wave workgroups per CU (2 per SIMD: the kernel needs ~220 VGPRs to stay out of scratch)
     if ((size_t)blocks * 64 > (size_t)n) blocks = (n + 63) / 64;
     {   // the lane workspace grows with the square of the longest read: keep it under ~12 GB by running fewer persistent waves
         const size_t budget = (size_t)12 << 30, per_block = (size_t)64 * L.stride;
@@ -575,7 +579,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(c->ws.ensure((size_t)blocks * 64 * L.stride));
     HIPCHK(c->jobs.ensure((size_t)total_seeds + 16));
     k_prep<<<nb, 256, 0, c->stream>>>(c->pr, n, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work_off.p, c->work.p, c->jobs.p,
-                                        c->d_tops + 2, (uint32_t)c->jobs.cap, c->d_err);
+                                        c->d_tops + 2, (uint32_t)c->jobs.cap, c->d_err, c->rlen.p);
     HIPCHK(hipGetLastError());
     TICK("k_prep");
     // k_reseed runs on a second stream, concurrently with the report of every read that has no
@@ -595,13 +599,13 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     TICK("order");
     // one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves
     const int blocks_main = blocks > c->n_cu * 4 ? blocks - c->n_cu : blocks;
-    k_report<4><<<blocks_main, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
+    k_report<2><<<blocks_main, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
                                                c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, 0, c->reads_out.p, c->reports.p, c->cigpool.p,
                                                (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_report");
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_reseed1, 0));
-    k_report<4><<<blocks_main < c->n_cu ? blocks_main : c->n_cu, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
+    k_report<2><<<blocks_main < c->n_cu ? blocks_main : c->n_cu, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
                                                c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, 1, c->reads_out.p, c->reports.p, c->cigpool.p,
                                                (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());

@@ -91,9 +91,10 @@ __device__ __forceinline__ char d_refchar(const DIndex &ix, int64_t g)
 {
     const int64_t L = ix.l_pac;
     if (g < 0 || g >= 2 * L) return 0;
-    if (g < L) return "ACGT"[(ix.pac[g >> 2] >> ((~g & 3) << 1)) & 3];
-    g = 2 * L - 1 - g;
-    return "TGCA"[(ix.pac[g >> 2] >> ((~g & 3) << 1)) & 3];
+    const bool rev = g >= L;
+    const int64_t f = rev ? 2 * L - 1 - g : g;
+    const uint32_t c = (ix.pac[f >> 2] >> ((~f & 3) << 1)) & 3u;
+    return (char)((rev ? 0x41434754u : 0x54474341u) >> (8u * c));     // "TGCA"[c] : "ACGT"[c] without a table in memory
 }
 
 // ChrLocMap.lower_bound(g): index of the smallest key >= g

@@ -32,7 +32,7 @@
 __global__ void __launch_bounds__(256)
 k_prep(const DParams pr, int n_reads, const uint32_t *__restrict__ seed_off, const DSeed *__restrict__ seeds,
        DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ work_off,
-       DSeed *__restrict__ work, DJob *__restrict__ jobs, unsigned int *jobtop, uint32_t jobcap, int *err)
+       DSeed *__restrict__ work, DJob *__restrict__ jobs, unsigned int *jobtop, uint32_t jobcap, int *err, const uint16_t *__restrict__ rlen)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
@@ -52,11 +52,15 @@ k_prep(const DParams pr, int n_reads, const uint32_t *__restrict__ seed_off, con
         n = d_remove_transloc(s, n, vec);
         c.n_a = n;
         int cnt = 0;                                     // IdentifyMissingSeeds :691-697, enumeration only
+        int big = n > 0 && (s[0].rPos > 8 || (int)rlen[r] - (s[n - 1].rPos + s[n - 1].rLen) > 8) ? 1 : 0;
         for (int k = 1; k < n; k++) {
             const int pd = (int)((s[k].gPos - s[k].rPos) - (s[k - 1].gPos - s[k - 1].rPos));
             const int rGaps = s[k].rPos - s[k - 1].rPos - s[k - 1].rLen;
             if (pd > pr.max_gaps && rGaps > 20) cnt++;
+            if (rGaps > 8 || pd != 0) big = 1;
         }
+        c.final_n = big;                                 // scheduling hint for k_cost only (k_report sets the real value):
+                                                         // this candidate will need more than the register-only pair path
         if (cnt == 0) continue;
         const unsigned int first = atomicAdd(jobtop, (unsigned int)cnt);
         if (first + (unsigned int)cnt > jobcap) { *err = 3; continue; }
