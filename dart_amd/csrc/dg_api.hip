@@ -32,6 +32,7 @@ template <typename T> struct DBuf {
 
 struct dg_ctx {
     int device = 0;
+    bool owns_index = true;       // false for dg_clone()d contexts: the index arrays belong to the parent
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr;
     float reseed_ms = 0;
@@ -333,8 +334,10 @@ extern "C" void dg_destroy(dg_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = { c->d_ktab, c->d_sa_dense, c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff, c->d_ctr, c->d_tops, c->d_err };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    void *ptrs[] = { c->d_ktab, c->d_sa_dense, c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff };
+    if (c->owns_index) for (void *p : ptrs) if (p) (void)hipFree(p);
+    void *own[] = { c->d_ctr, c->d_tops, c->d_err };
+    for (void *p : own) if (p) (void)hipFree(p);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->nrep.release(); c->rep_off.release(); c->work_need.release(); c->work_off.release();
     c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->costkey.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
@@ -444,6 +447,28 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
         }
     }
     if (status) *status = st;
+    return c;
+}
+
+// A second context on the same device that shares the parent's index (no copy): its own streams, batch buffers
+// and counters, so that two batches can be in flight at once (one host thread per context).  The parent must
+// outlive its clones.
+extern "C" dg_ctx *dg_clone(dg_ctx *parent, int *status)
+{
+    if (status) *status = DG_ERR_ARG;
+    if (!parent) return nullptr;
+    hipError_t e;
+    if ((e = hipSetDevice(parent->device)) != hipSuccess) { if (status) *status = DG_ERR_HIP; return nullptr; }
+    dg_ctx *c = new dg_ctx();
+    c->device = parent->device; c->owns_index = false; c->n_cu = parent->n_cu;
+    c->ix = parent->ix; c->pr = parent->pr;
+    for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipStreamCreate(&c->stream2) == hipSuccess &&
+              hipEventCreate(&c->ev_prep) == hipSuccess && hipEventCreate(&c->ev_reseed0) == hipSuccess && hipEventCreate(&c->ev_reseed1) == hipSuccess;
+    for (int i = 0; ok && i <= N_TIMERS; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_ctr, CTR_N * 8) == hipSuccess && hipMalloc((void **)&c->d_tops, 64) == hipSuccess && hipMalloc((void **)&c->d_err, 4) == hipSuccess;
+    if (!ok) { snprintf(g_init_error, sizeof g_init_error, "dg_clone: stream/event/counter allocation failed"); dg_destroy(c); if (status) *status = DG_ERR_HIP; return nullptr; }
+    if (status) *status = DG_OK;
     return c;
 }
 

@@ -108,6 +108,8 @@ def _load_lib():
     lib.dg_last_error.restype = C.c_char_p
     lib.dg_last_error.argtypes = [C.c_void_p]
     lib.dg_destroy.argtypes = [C.c_void_p]
+    lib.dg_clone.restype = C.c_void_p
+    lib.dg_clone.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.dg_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
     lib.dg_params_default.argtypes = [C.POINTER(Params)]
     vp = C.c_void_p
@@ -153,7 +155,21 @@ class DartGPU:
         if not self.ctx:
             raise RuntimeError("dg_init failed (%d): %s" % (st.value, (self.lib.dg_last_error(None) or b"").decode()))
 
+    def clone(self):
+        """A second context sharing this one's index on the same device (dg_clone): for a second batch in flight."""
+        other = object.__new__(DartGPU)
+        other.lib, other.index, other.params, other._parent = self.lib, self.index, self.params, self
+        st = C.c_int(0)
+        other.ctx = self.lib.dg_clone(self.ctx, C.byref(st))
+        if not other.ctx:
+            raise RuntimeError("dg_clone failed (%d): %s" % (st.value, (self.lib.dg_last_error(None) or b"").decode()))
+        self._clones = getattr(self, "_clones", []) + [other]
+        return other
+
     def close(self):
+        for o in getattr(self, "_clones", []):
+            o.close()
+        self._clones = []
         if getattr(self, "ctx", None):
             self.lib.dg_destroy(self.ctx)
             self.ctx = None

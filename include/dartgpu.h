@@ -70,6 +70,10 @@ void        dg_params_default(dg_params *);
 /* uploads the index to device `device` (0-based HIP ordinal) and builds the device-side layout */
 dg_ctx     *dg_init(const dg_index_view *, const dg_params *, int device, int *status);
 void        dg_destroy(dg_ctx *);
+/* a second context on the same device sharing the parent's index (no copy): own streams and batch buffers, so two
+ * batches can be in flight at once, one host thread per context -- what the reference gets from running
+ * ReadMapping in `-t` threads over one shared index (Mapping.cpp:760-790).  Destroy clones before the parent. */
+dg_ctx     *dg_clone(dg_ctx *parent, int *status);
 const char *dg_last_error(const dg_ctx *);   /* NULL ctx: error of the last failed dg_init */
 int         dg_set_params(dg_ctx *, const dg_params *);
 

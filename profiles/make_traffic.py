@@ -1,0 +1,31 @@
+"""profiles/traffic.json from the PMC passes of run_profile.sh: HBM-side bytes per launch per kernel.
+bytes = (FETCH_SIZE + WRITE_SIZE) * 1024 (rocprofv3 reports KB), mean over the profiled dispatches; see _provenance."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+root, tag = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+def short(name):
+    n = name.split("(")[0].replace("void ", "")
+    return n.split("<")[0]
+out = defaultdict(float)
+for k, c in acc.items():
+    if "k_" not in k or "FETCH_SIZE" not in c:
+        continue
+    b = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) + (sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) if "WRITE_SIZE" in c else 0.0)
+    name = short(k)
+    if name == "k_seed_heavy":
+        name = "k_seed"                      # bench.py times the two seeding kernels as one stage
+    if name == "k_chain_heavy":
+        name = "k_chain"
+    out[name] += b * 1024.0
+doc = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes), profiles/run_profile.sh %s, "
+                      "default bench workload (2 M reads per launch), mean per launch; bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; k_seed = k_seed + "
+                      "k_seed_heavy, k_chain = k_chain + k_chain_heavy, k_report = mean of its two passes. For these 64-byte random reads "
+                      "FETCH_SIZE*1024/64 equals TCC_MISS_sum, i.e. one 64-B fabric request per line; the 2x correction of MI355X_MICROARCH.md "
+                      "applies to wide coalesced streams and is NOT applied here (uncalibrated for this access width)." % tag}
+doc.update({k: int(v) for k, v in sorted(out.items())})
+json.dump(doc, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json"), "w"), indent=1)
+print(json.dumps(doc, indent=1))
