@@ -767,19 +767,23 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, 
     rd.score = rd.iBest = 0;
     if (ncand == 0) {
         rd.CanNum = 1;
-        rep[0].aln_score = 0; rep[0].sj_type = -1; rep[0].flag = 0; rep[0].paired_idx = -1; rep[0].chr = -1; rep[0].bdir = 0;
-        rep[0].pos = 0; rep[0].cigar_off = 0; rep[0].n_cigar = 0;
+        ReportT rp;
+        rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = -1; rp.chr = -1; rp.bdir = 0;
+        rp.pos = 0; rp.cigar_off = 0; rp.n_cigar = 0;
+        rep[0] = rp;
         return;
     }
     rd.CanNum = ncand;
     uint32_t *cig = ws_cig(cx);
     for (int i = 0; i < ncand; i++) {
         DCand &c = cands[i];
-        ReportT &rp = rep[i];
+        // the record is assembled in registers and stored once (field-by-field stores were ~10 L2 requests per report)
+        ReportT rp;
         rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = c.PairedIdx; rp.chr = -1; rp.bdir = 0; rp.pos = 0;
         rp.cigar_off = 0; rp.n_cigar = 0;
-        c.final_n = 0;
-        if (c.Score == 0) continue;
+        int final_n = 0;
+        [&]() {
+        if (c.Score == 0) return;
         // the working region already went through k_prep (tandem / translocation clean-up);
         // IdentifyMissingSeeds :685-700: append the seeds k_reseed found, then re-sort
         DSeed *s = work + c.work_off;
@@ -803,9 +807,9 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, 
         vec = (int2 *)(s + n + 1);
         rp.sj_type = c.SJtype = d_check_splice(cx, s, n, vec);
         n = d_identify_normal_pairs(s, n);
-        c.final_n = n;
+        final_n = n;
         const int num = n;
-        if (num > 1 && !d_check_coordinate_validity(ix, s, num)) continue;
+        if (num > 1 && !d_check_coordinate_validity(ix, s, num)) return;
         int nc = 1, mis_num = 0, aln = 0;                 // cig[0] is kept free for a leading soft clip
         for (int j = 0; j < num; j++) {
             DSeed &sd = s[j];
@@ -853,6 +857,9 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, 
             if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis_num; rd.sub_score = rd.score; rd.score = aln; }
             else if (aln == rd.score) rd.sub_score = rd.score;
         }
+        }();
+        c.final_n = final_n;
+        rep[i] = rp;
     }
 }
 
