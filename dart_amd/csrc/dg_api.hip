@@ -57,6 +57,7 @@ struct dg_ctx {
     // timings
     hipEvent_t ev[N_TIMERS + 1]; const char *tname[N_TIMERS]; int n_t = 0; float tms[N_TIMERS];
     uint64_t counters[CTR_N];
+    uint64_t ctr_stripes[CTR_STRIPES * CTR_STRIDE];
     int n_cu = 256;
 };
 
@@ -256,7 +257,7 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
             rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0;           // defined start state
             cx.seq = seq + seq_off[r]; cx.rlen = rlen[r];
             d_gen_mapping_report(cx, paired ? (r & 1) == 0 : true, rd, cands + seed_off[r], (int)ncand[r], jobs, work,
-                                 reports + rep_off[r], cigpool, tops + 0, cigcap, err);
+                                 reports + rep_off[r], rep_off[r], cigpool, tops + 0, cigcap, err);
             dg_read_out o;
             o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
             o.n_rep = rd.CanNum; o.best = rd.iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
@@ -411,7 +412,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
             (e = hipMemcpy(c->d_locchr, chr.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_chroff, off.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload chr tables", e);
     }
-    if ((e = hipMalloc((void **)&c->d_ctr, CTR_N * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, 64)) != hipSuccess ||
+    if ((e = hipMalloc((void **)&c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, 64)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc counters", e);
     c->ix.bwt = (const uint4 *)c->d_bwt; c->ix.sa = (const uint64_t *)c->d_sa; c->ix.pac = (const uint8_t *)c->d_pac;
     c->ix.loc_key = (const int64_t *)c->d_lockey; c->ix.loc_chr = (const int32_t *)c->d_locchr; c->ix.chr_off = (const int64_t *)c->d_chroff;
@@ -466,7 +467,7 @@ extern "C" dg_ctx *dg_clone(dg_ctx *parent, int *status)
     bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipStreamCreate(&c->stream2) == hipSuccess &&
               hipEventCreate(&c->ev_prep) == hipSuccess && hipEventCreate(&c->ev_reseed0) == hipSuccess && hipEventCreate(&c->ev_reseed1) == hipSuccess;
     for (int i = 0; ok && i <= N_TIMERS; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_ctr, CTR_N * 8) == hipSuccess && hipMalloc((void **)&c->d_tops, 64) == hipSuccess && hipMalloc((void **)&c->d_err, 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8) == hipSuccess && hipMalloc((void **)&c->d_tops, 64) == hipSuccess && hipMalloc((void **)&c->d_err, 4) == hipSuccess;
     if (!ok) { snprintf(g_init_error, sizeof g_init_error, "dg_clone: stream/event/counter allocation failed"); dg_destroy(c); if (status) *status = DG_ERR_HIP; return nullptr; }
     if (status) *status = DG_OK;
     return c;
@@ -555,7 +556,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(c->ncand.ensure(n)); HIPCHK(c->nrep.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1));
     HIPCHK(c->work_need.ensure(n)); HIPCHK(c->work_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n));
     HIPCHK(c->tmp_u32.ensure(n)); HIPCHK(c->tmp_off.ensure((size_t)n + 1));
-    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_STRIPES * CTR_STRIDE * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_tops, 0, 64, c->stream));
     HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
@@ -571,7 +572,9 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     TICK("scan_seeds");
     HIPCHK(c->seeds.ensure((size_t)total_seeds + 1)); HIPCHK(c->cands.ensure((size_t)total_seeds + 1));
     if (total_seeds) {
-        k_locate<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->nseeds.p, c->seed_off.p, c->seeds.p, c->d_ctr);
+        HIPCHK(c->tmp_u32.ensure((size_t)total_seeds / 64 + 16));
+        k_tile_reads<<<nb, 256, 0, c->stream>>>(n, c->seed_off.p, c->tmp_u32.p);
+        k_locate<<<(unsigned)((total_seeds + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->tmp_u32.p, c->seed_off.p, c->seeds.p, c->d_ctr, total_seeds);
         HIPCHK(hipGetLastError());
     }
     TICK("k_locate");
@@ -590,8 +593,9 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(hipMemcpyAsync(&total_work, c->work_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     TICK("scan_reports");
-    const size_t cigcap = (size_t)n * 48 + (size_t)total_rep * 16 + 4096, sjcap = (size_t)n * 4 + 1024;
+    const size_t cigcap = (size_t)n * 48 + (size_t)total_rep * (16 + CIG_SLOT) + 4096, sjcap = (size_t)n * 4 + 1024;
     HIPCHK(c->reports.ensure((size_t)total_rep + 1)); HIPCHK(c->work.ensure((size_t)total_work + 16));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(c->d_tops + 0), (int)((size_t)total_rep * CIG_SLOT), 1, c->stream));   // overflow area starts behind the per-report slots
     HIPCHK(c->cigpool.ensure(cigcap)); HIPCHK(c->cigfinal.ensure(cigcap)); HIPCHK(c->sjpool.ensure(sjcap)); HIPCHK(c->sjfinal.ensure(sjcap));
     const WSLayout L = make_ws_layout(c->max_rlen < 32 ? 32 : c->max_rlen);
     int blocks = c->n_cu * (getenv("DG_REPORT_BPC") ? atoi(getenv("DG_REPORT_BPC")) : 8);   // 8 one-wave workgroups per CU (2 per SIMD: the kernel needs ~220 VGPRs to stay out of scratch)
@@ -656,12 +660,18 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(hipMemcpyAsync(&total_sj, c->tmp_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
     int derr = 0;
     HIPCHK(hipMemcpyAsync(&derr, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->counters, c->d_ctr, CTR_N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ctr_stripes, c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     TICK("compact");
     HIPCHK(hipEventSynchronize(c->ev[c->n_t]));
     for (int i = 0; i < c->n_t; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]); c->tms[i] = ms; }
     if (c->n_t < N_TIMERS) { float ms = 0; (void)hipEventSynchronize(c->ev_reseed1); (void)hipEventElapsedTime(&ms, c->ev_reseed0, c->ev_reseed1); c->tname[c->n_t] = "k_reseed(overlapped)"; c->tms[c->n_t] = ms; c->n_t++; }
+    for (int k = 0; k < CTR_N; k++) {
+        uint64_t v = 0;
+        const bool is_max = k == CTR_MAXTRIPS || k == CTR_WTRIPS_MAX;
+        for (int s = 0; s < CTR_STRIPES; s++) { const uint64_t x = c->ctr_stripes[s * CTR_STRIDE + k]; v = is_max ? (x > v ? x : v) : v + x; }
+        c->counters[k] = v;
+    }
     c->counters[CTR_SEEDS] = total_seeds;
     if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == 1 ? "cigar" : (derr == 2 ? "splice junction" : "reseed jobs")); return DG_ERR_INTERNAL; }
     c->used[0] = total_rep; c->used[1] = total_cig; c->used[2] = total_sj;
@@ -796,7 +806,7 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
     const int H = c->max_rlen / 16 + 1;
     HIPCHK(c->hits.ensure((size_t)n * H)); HIPCHK(c->nhits.ensure(n)); HIPCHK(c->nseeds.ensure(n)); HIPCHK(c->seed_off.ensure((size_t)n + 1));
     HIPCHK(c->ncand.ensure(n)); HIPCHK(c->nrep.ensure(n)); HIPCHK(c->work_need.ensure(n));
-    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_STRIPES * CTR_STRIDE * 8, c->stream));
     HIPCHK(launch_seed(c, n, H));
     HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n));
     uint32_t total = 0;
@@ -805,7 +815,11 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
     if (used) *used = total;
     if (total > cap) return DG_ERR_CAPACITY;
     HIPCHK(c->seeds.ensure((size_t)total + 1)); HIPCHK(c->cands.ensure((size_t)total + 1));
-    if (total) k_locate<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->nseeds.p, c->seed_off.p, c->seeds.p, c->d_ctr);
+    if (total) {
+        HIPCHK(c->tmp_u32.ensure((size_t)total / 64 + 16));
+        k_tile_reads<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(n, c->seed_off.p, c->tmp_u32.p);
+        k_locate<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->tmp_u32.p, c->seed_off.p, c->seeds.p, c->d_ctr, total);
+    }
     // the sort is the first half of k_chain; run it unpaired so every read is sorted on its own
     HIPCHK(c->heavy.ensure((size_t)n + 16));
     HIPCHK(hipMemsetAsync(c->d_tops, 0, 64, c->stream));

@@ -329,7 +329,7 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
             }
         }
     }
-    if (lane == 0 && nc_total) atomicAdd(ctr + CTR_CANDS, nc_total);
+    if (lane == 0 && nc_total) atomicAdd(d_ctr_stripe(ctr) + CTR_CANDS, nc_total);
 }
 
 // list of heavy units (order irrelevant: every unit writes only its own slots)

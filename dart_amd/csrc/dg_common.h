@@ -110,9 +110,15 @@ __device__ __forceinline__ bool d_seed_less(const DSeed &a, const DSeed &b)   //
     return a.gPos == b.gPos ? a.rPos < b.rPos : a.gPos < b.gPos;
 }
 
+// The work counters live in CTR_STRIPES copies, 256 bytes apart, chosen by workgroup: atomics on ONE address
+// serialise at ~6 ns each on this chip (three counters updated by each of k_locate's 56 k waves cost 1 ms,
+// more than the kernel's work).  dg_batch_run sums (or, for the two maxima, maximises) the stripes.
+#define CTR_STRIPES 64
+#define CTR_STRIDE  32
+__device__ __forceinline__ unsigned long long *d_ctr_stripe(unsigned long long *ctr) { return ctr + (blockIdx.x & (CTR_STRIPES - 1)) * CTR_STRIDE; }
 // wave-level sum of a per-lane counter, one atomic per wave
 __device__ __forceinline__ void d_wave_add(unsigned long long *dst, unsigned long long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(d_ctr_stripe(dst), v);
 }

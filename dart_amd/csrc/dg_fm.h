@@ -601,8 +601,8 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
             if (finished) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; r = -1; max_trips = trips > max_trips ? trips : max_trips; }
         }
     }
-    atomicMax(ctr + CTR_MAXTRIPS, (unsigned long long)max_trips);
-    if (lane == 0) { atomicMax(ctr + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(ctr + CTR_WTRIPS_SUM, (unsigned long long)wtrips); }
+    atomicMax(d_ctr_stripe(ctr) + CTR_MAXTRIPS, (unsigned long long)max_trips);
+    if (lane == 0) { atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips); }
     d_wave_add(ctr + CTR_STEPS, c.steps);
     d_wave_add(ctr + CTR_BLOCKS, c.blocks);
     d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
@@ -718,60 +718,78 @@ k_build_sa_dense(const DIndex ix, int intv, uint64_t n_entries, uint64_t *__rest
 
 // ---------------------------------------------------------------------------------------------
 // k_locate: SA interval rows -> text positions (bwt_sa :127-137) -> seeds.
-// One wave owns 64 consecutive reads; their seed counts are prefix-summed with wave shuffles and
-// the wave then walks its seeds 64 at a time, one lane per seed occurrence (so a read with 100
-// repeat copies is spread over lanes, wavefront-compaction style): lane -> read by a 6-step binary
-// search over the in-register prefix (ds_bpermute), no global search; seeds come out coalesced.
+// One wave = 64 consecutive seed OCCURRENCES (a repeat-family read has hundreds, a clean read one
+// or two: per-read work units leave the kernel waiting for its heaviest wave).  k_tile_reads
+// records, for every tile of 64 seeds, the read that holds the tile's first seed; the wave loads
+// the scan values of the next 64 reads with one coalesced load and each lane finds its read with a
+// 6-step shuffle search (windows of 64 reads are walked when a tile spans more, i.e. across reads
+// without seeds), then its hit among the read's <= H hits.  Seeds come out coalesced, in
+// (read, hit, SA-interval row) order as in the reference.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_locate(const DIndex ix, int n_reads, int H, const DHit *__restrict__ hits, const uint32_t *__restrict__ nseeds,
-         const uint32_t *__restrict__ seed_off, DSeed *__restrict__ seeds, unsigned long long *ctr)
+k_tile_reads(int n_reads, const uint32_t *__restrict__ seed_off, uint32_t *__restrict__ tile_read)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t first = seed_off[r], end = seed_off[r + 1];
+    if (end == first) return;
+    for (uint32_t t = (first + 63) >> 6; (t << 6) < end; t++) tile_read[t] = (uint32_t)r;
+}
+
+__global__ void __launch_bounds__(256)
+k_locate(const DIndex ix, int n_reads, int H, const DHit *__restrict__ hits, const uint32_t *__restrict__ tile_read,
+         const uint32_t *__restrict__ seed_off, DSeed *__restrict__ seeds, unsigned long long *ctr, uint32_t total)
 {
     const int lane = threadIdx.x & 63;
-    const int r0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;      // first read of this wave
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t u = (tile << 6) + (uint32_t)lane;
     unsigned long long lf = 0, lf_act = 0, nsa = 0;
-    if (r0 < n_reads) {
-        const int r = r0 + lane;
-        const uint32_t mine = r < n_reads ? nseeds[r] : 0u;
-        uint32_t incl = mine;                                                        // inclusive prefix over the wave
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-        const uint32_t total = __shfl(incl, 63, 64);
-        const uint32_t base = seed_off[r0];
-        for (uint32_t c0 = 0; c0 < total; c0 += 64) {
-            const uint32_t u = c0 + lane;
-            int lo = 0;                                     // smallest lane j with incl[j] > u
+    if ((tile << 6) < total) {                               // wave-uniform
+        int r0 = (int)tile_read[tile];
+        const uint32_t u_last = (tile << 6) + 63 < total ? (tile << 6) + 63 : total - 1;
+        int r = -1;
+        uint32_t first = 0;
+        while (true) {                                       // uniform: windows of 64 reads
+            const int rr = r0 + lane;
+            const uint32_t nxt = rr + 1 <= n_reads ? seed_off[rr + 1] : 0xFFFFFFFFu;   // seeds before read rr+1
+            // number of reads in the window that end at or before u = offset of u's read in the window
+            int lo = 0;
 #pragma unroll
             for (int step = 32; step > 0; step >>= 1) {
-                const uint32_t v = __shfl(incl, lo + step - 1, 64);
+                const uint32_t v = __shfl(nxt, lo + step - 1, 64);
                 if (v <= u) lo += step;
             }
-            lo = lo > 63 ? 63 : lo;
-            const uint32_t excl = __shfl(incl, lo, 64) - __shfl(mine, lo, 64);      // all lanes take part in the shuffles
-            if (u < total) {
-                uint32_t w = u - excl;
-                const DHit *h = hits + (size_t)(r0 + lo) * H;
-                while (w >= (h->freq & 0x7FFFFFFFu)) { w -= h->freq & 0x7FFFFFFFu; h++; }
-                uint64_t k = h->x0 + w;
-                uint64_t steps = 0, pos;
-                if (h->freq & 0x80000000u) pos = h->x0;                          // k_seed already located this unique hit
-                else if (ix.sa_dense) {
-                    const uint64_t mask = (uint64_t)ix.sa_dense_intv - 1;
-                    while (k & mask) { k = d_lf(ix, k); steps++; }
-                    const uint64_t e = ix.sa_dense[k / (uint64_t)ix.sa_dense_intv];
-                    pos = steps + (e & 0xFFFFFFFFFFull) - 1;
-                    lf += steps + (e >> 40); lf_act += steps;
-                } else {
-                    const uint64_t mask = (uint64_t)ix.sa_intv - 1;
-                    while (k & mask) { k = d_lf(ix, k); steps++; }
-                    pos = steps + ix.sa[k / (uint64_t)ix.sa_intv];
-                    lf += steps; lf_act += steps;
-                }
-                nsa++;
-                DSeed s;
-                s.gPos = (int64_t)pos;
-                s.rPos = h->rPos; s.rLen = s.gLen = h->len; s.flags = SEED_SIMPLE;
-                seeds[base + u] = s;
+            if (__shfl(nxt, lo, 64) <= u) lo++;              // lo = 64: u's read lies beyond this window
+            const uint32_t win_end = __shfl(nxt, 63, 64);    // seeds before read r0+64
+            if (r < 0 && u < total && lo < 64) { r = r0 + lo; first = seed_off[r]; }
+            if (win_end > u_last) break;
+            r0 += 64;
+        }
+        if (u < total) {
+            uint32_t w = u - first;
+            const DHit *h = hits + (size_t)r * H;
+            uint32_t fr = h->freq;
+            while (w >= (fr & 0x7FFFFFFFu)) { w -= fr & 0x7FFFFFFFu; h++; fr = h->freq; }
+            uint64_t k = h->x0 + w;
+            uint64_t steps = 0, pos;
+            if (fr & 0x80000000u) pos = h->x0;               // k_seed already located this unique hit
+            else if (ix.sa_dense) {
+                const uint64_t mask = (uint64_t)ix.sa_dense_intv - 1;
+                while (k & mask) { k = d_lf(ix, k); steps++; }
+                const uint64_t e = ix.sa_dense[k / (uint64_t)ix.sa_dense_intv];
+                pos = steps + (e & 0xFFFFFFFFFFull) - 1;
+                lf += steps + (e >> 40); lf_act += steps;
+            } else {
+                const uint64_t mask = (uint64_t)ix.sa_intv - 1;
+                while (k & mask) { k = d_lf(ix, k); steps++; }
+                pos = steps + ix.sa[k / (uint64_t)ix.sa_intv];
+                lf += steps; lf_act += steps;
             }
+            nsa++;
+            DSeed s;
+            s.gPos = (int64_t)pos;
+            s.rPos = h->rPos; s.rLen = s.gLen = h->len; s.flags = SEED_SIMPLE;
+            seeds[u] = s;
         }
     }
     d_wave_add(ctr + CTR_LF, lf);

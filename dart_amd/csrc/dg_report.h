@@ -752,6 +752,7 @@ __device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t 
 }
 
 // device-side per-read state (ReadItem_t)
+#define CIG_SLOT 8
 struct DRead {
     int score, sub_score, mis_num, mapq, CanNum, iBest;
 };
@@ -761,7 +762,7 @@ struct DRead {
 // work = global working-seed pool; cigpool/cigtop = bump pool for merged CIGAR ops.
 template <typename ReportT>
 __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, DCand *cands, int ncand, const DJob *jobs,
-                                            DSeed *work, ReportT *rep, uint32_t *cigpool, unsigned int *cigtop, uint32_t cigcap, int *err)
+                                            DSeed *work, ReportT *rep, uint32_t rep_index0, uint32_t *cigpool, unsigned int *cigtop, uint32_t cigcap, int *err)
 {
     const DIndex &ix = *cx.ix;
     rd.score = rd.iBest = 0;
@@ -849,7 +850,9 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, 
                     else cnt += (int)ln;
                 }
                 if (cnt > 0) cig[m++] = CIG(cnt, state);
-                const unsigned int off = atomicAdd(cigtop, (unsigned int)m);
+                // every report owns CIG_SLOT ops of the pool (no atomic: one hot bump counter serialises at ~6 ns per wave
+                // update); the rare longer CIGAR goes to the bump-allocated overflow area behind the slots
+                const unsigned int off = m <= CIG_SLOT ? (rep_index0 + (unsigned int)i) * CIG_SLOT : atomicAdd(cigtop, (unsigned int)m);
                 if (off + (unsigned int)m > cigcap) { *err = 1; rp.n_cigar = 0; }
                 else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
             }

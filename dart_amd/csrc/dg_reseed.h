@@ -309,5 +309,5 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
             o.found = found; o.len = max_len; o.rPos = best_r + job.rBegin; o.gPos = best_g + job.Lb;
         }
     }
-    if (lane == 0) { if (n_done) atomicAdd(ctr + CTR_RESEED, n_done); if (w_done) atomicAdd(ctr + CTR_RESEEDW, w_done); }
+    if (lane == 0) { if (n_done) atomicAdd(d_ctr_stripe(ctr) + CTR_RESEED, n_done); if (w_done) atomicAdd(d_ctr_stripe(ctr) + CTR_RESEEDW, w_done); }
 }
