@@ -101,9 +101,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # DART_BENCH_REHEARSE=1: several ranks on ONE GPU with gloo (the 1-GPU box cannot run RCCL across ranks);
+        # exercises the threading/ordering/barrier logic of the N>1 path, not its performance
+        rehearse = os.environ.get("DART_BENCH_REHEARSE") == "1"
+        if rehearse:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
 
+    rehearse = world > 1 and os.environ.get("DART_BENCH_REHEARSE") == "1"
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -131,6 +137,8 @@ def main():
     def gather(cx):
         nonlocal gather_buf
         local_t = cx.device_reads_tensor()
+        if rehearse:
+            local_t = local_t.cpu()
         if rank == 0 and gather_buf is None:
             gather_buf = [torch.empty_like(local_t) for _ in range(world)]
         dist.gather(local_t, gather_buf if rank == 0 else None, dst=0)
@@ -178,7 +186,7 @@ def main():
     barrier(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     counters = gpu.counters()
