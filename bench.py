@@ -58,14 +58,15 @@ def host_cores() -> int:
     return n
 
 
-def prepare_index(cache_dir, genome_len, rank, barrier):
-    prefix = os.path.join(cache_dir, "g%d" % genome_len)
+def prepare_index(cache_dir, genome_len, rank, barrier, n_introns=0):
+    prefix = os.path.join(cache_dir, "g%d" % genome_len + ("_i%d" % n_introns if n_introns else ""))
     done = prefix + ".done"
     if rank == 0 and not os.path.exists(done):
         os.makedirs(cache_dir, exist_ok=True)
         t = time.time()
-        g = synth.make_genome([genome_len], seed=20, repeat_scale=1.0, n_introns=0, names=["chr20"])
+        g = synth.make_genome([genome_len], seed=20, repeat_scale=1.0, n_introns=n_introns, names=["chr20"])
         np.save(prefix + ".codes.npy", g.codes)
+        np.save(prefix + ".introns.npy", g.introns)
         log("[bench] genome %d bp generated in %.1f s" % (genome_len, time.time() - t))
         t = time.time()
         index_build.build_index_from_genome(g, prefix)
@@ -74,7 +75,8 @@ def prepare_index(cache_dir, genome_len, rank, barrier):
         open(done, "w").write("ok")
     barrier()
     codes = np.load(prefix + ".codes.npy")
-    g = synth.Genome(["chr20"], [genome_len], codes, np.zeros((0, 3), np.int64))
+    ipath = prefix + ".introns.npy"
+    g = synth.Genome(["chr20"], [genome_len], codes, np.load(ipath) if os.path.exists(ipath) else np.zeros((0, 3), np.int64))
     return prefix, g
 
 
@@ -87,6 +89,9 @@ def main():
     ap.add_argument("--genome", type=int, default=CHR20_LEN)
     ap.add_argument("--mis", type=int, default=5, help="-mis N (MaxMismatch); the reference default is 0, see DESIGN.md")
     ap.add_argument("--cpu-sample-pairs", type=int, default=150000)
+    ap.add_argument("--rlen", type=int, default=101)
+    ap.add_argument("--spliced", type=float, default=0.0, help="fraction of reads spanning a planted intron (BASELINE config 5 shape: --rlen 151 --spliced 0.3 --introns 20000)")
+    ap.add_argument("--introns", type=int, default=0, help="introns planted in the synthetic genome")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "4")),
                     help="batches in flight per GPU: contexts sharing one index, one host thread each (dg_clone)")
@@ -114,13 +119,13 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    prefix, g = prepare_index(args.cache, args.genome, rank, barrier)
+    prefix, g = prepare_index(args.cache, args.genome, rank, barrier, args.introns)
     ix = host.Index(prefix)
     params = host.default_params(paired=1, max_mismatch=args.mis)
     gpu = host.DartGPU(ix, params, device=local)
 
     t = time.time()
-    m1, m2 = synth.make_reads(g, args.pairs, rlen=101, seed=1000 + rank, sub_rate=0.01, indel_frac=0.02, n_frac=0.002)
+    m1, m2 = synth.make_reads(g, args.pairs, rlen=args.rlen, seed=1000 + rank, sub_rate=0.01, indel_frac=0.02, n_frac=0.002, spliced_frac=args.spliced)
     arr = host.interleave_pairs(m1, m2)
     so, rl, flat = host.pack_reads(arr)
     gpu.upload(so, rl, flat)                       # inputs resident in HBM before the timed region
@@ -282,8 +287,9 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64/u8 integer", "data": "synthetic",
         "config": {"workload": "chr20-sized synthetic genome (%d bp, i.i.d. + planted repeats), %d pairs 2x101 bp per GPU, -mis %d"
-                               % (args.genome, args.pairs, args.mis),
-                   "pairs_per_gpu": args.pairs, "read_len": 101, "batches_in_flight_per_gpu": len(ctxs), "parallelism": "reads sharded x%d, RCCL gather of records" % world},
+                               % (args.genome, args.pairs, args.mis) if args.rlen == 101 else
+                               "chr20-sized synthetic genome (%d bp, %d planted introns), %d pairs 2x%d bp per GPU, %.0f %% spliced, -mis %d" % (args.genome, args.introns, args.pairs, args.rlen, 100 * args.spliced, args.mis),
+                   "pairs_per_gpu": args.pairs, "read_len": args.rlen, "spliced_fraction": args.spliced, "batches_in_flight_per_gpu": len(ctxs), "parallelism": "reads sharded x%d, RCCL gather of records" % world},
         "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
         "kernels_ms_one_batch_in_flight": {k: round(v, 4) for k, v in iso.items()},
         "counters_per_launch": counters,

@@ -616,7 +616,9 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(hipEventRecord(c->ev_prep, c->stream));
     HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_prep, 0));
     HIPCHK(hipEventRecord(c->ev_reseed0, c->stream2));
-    k_reseed<<<c->n_cu * 4, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
+    k_reseed<1><<<c->n_cu * 8, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
+    k_reseed<2><<<c->n_cu * 5, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
+    k_reseed<4><<<c->n_cu * 3, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_reseed1, c->stream2));
     HIPCHK(c->costkey.ensure((size_t)n + 16)); HIPCHK(c->perm.ensure((size_t)n + 16)); HIPCHK(c->hist.ensure((size_t)COST_CLASSES * nb * 2 + 16));

@@ -26,7 +26,7 @@
 #include "dg_report.h"
 
 #define RS_MAX_RL   263          // longest read gap handled cooperatively (span <= 255 -> 4 bitmap words)
-#define RS_RING     2048         // diagonals in the ring (>= span + 63 + RS_CHUNK live at any time)
+#define RS_RING     1024         // diagonals in the ring (>= span + 63 + RS_CHUNK live at any time): 32 KB of LDS, 4 waves per CU
 #define RS_WORDS    4
 
 __global__ void __launch_bounds__(256)
@@ -113,6 +113,7 @@ struct RsFold { int s, max_len, best_r; int64_t best_g, next_fin; };
 // read conflict-free; `dirty` has one bit per group of 64 diagonals that received a hit.
 // Folds the complete diagonal groups below `lim` (all remaining ones when `final`) into st, in
 // increasing diagonal order; every lane of the wave calls it with the same arguments.
+template <int WORDS>
 __device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, uint32_t *dirty, RsFold &st, const int64_t lim, const bool final, const int lane)
 {
     while (st.next_fin + 64 <= lim || (final && st.next_fin < lim)) {
@@ -122,7 +123,7 @@ __device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, uint32_t
             const int slot = (int)((uint64_t)(b0 + lane) & (RS_RING - 1));
             int cnt = 0, first = -1, last = -1;
 #pragma unroll
-            for (int w = 0; w < RS_WORDS; w++) {
+            for (int w = 0; w < WORDS; w++) {
                 const unsigned long long v = ring[w * RS_RING + slot];
                 if (v) {
                     cnt += __popcll(v);
@@ -150,9 +151,13 @@ __device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, uint32_t
 // compiler barrier + an LDS drain -- unlike __syncthreads() this leaves the prefetched global
 // load in flight (hipcc drains vmcnt at every __syncthreads fence)
 #define RS_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define RS_CHUNK 1024            // window positions per trip: one coalesced pac load (64 lanes x 4 bytes x 4 bases),
-                                 // 16 consecutive positions per lane; live diagonals: span + 63 + RS_CHUNK <= RS_RING
+#define RS_CHUNK 512             // window positions per trip: one coalesced pac load, RS_PPL consecutive positions per lane;
+                                 // live diagonals: span + 63 + RS_CHUNK <= RS_RING
+#define RS_PPL (RS_CHUNK / 64)
 
+// WORDS = 64-bit bitmap words per diagonal: a job with read gap rl needs (rl - 8) / 64 + 1 of them; the kernel is
+// instantiated for 1, 2 and 4 (8 / 16 / 32 KB of ring, so 8 / 5 / 3 waves per CU) and each instance takes the jobs of its size
+template <int WORDS>
 __global__ void __launch_bounds__(64)
 k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off,
          DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, unsigned long long *ctr)
@@ -160,7 +165,7 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
     __shared__ unsigned char rs[RS_MAX_RL + 9];
     __shared__ uint64_t tmpk[RS_MAX_RL + 1], km[RS_MAX_RL + 1];
     __shared__ uint32_t flt[2048];
-    __shared__ unsigned long long ring[RS_RING * RS_WORDS];
+    __shared__ unsigned long long ring[RS_RING * WORDS];
     __shared__ uint32_t pacbuf[68];
     __shared__ uint32_t s_dirty;
     __shared__ int s_nk;
@@ -172,13 +177,17 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
         const DJob job = jobs[jb];
         if (job.found < 0) continue;                    // too long for the LDS ring: serial path in k_report
         const int rl = job.rl, glen = job.glen;
+        {
+            const int need = rl >= 8 ? (rl - 8) / 64 + 1 : 1;
+            if ((need <= 1 ? 1 : (need <= 2 ? 2 : 4)) != WORDS) continue;
+        }
         int thr = (int)(rl * 0.85); if (thr < 8) thr = 8;
         n_done += 1; w_done += (unsigned long long)(glen > 0 ? glen : 0);
         const unsigned char *rd = seq + seq_off[job.read] + job.rBegin;
         __syncthreads();
         for (int i = lane; i < rl; i += 64) rs[i] = rd[i];
         for (int i = lane; i < 2048; i += 64) flt[i] = 0;
-        for (int i = lane; i < RS_RING * RS_WORDS; i += 64) ring[i] = 0;
+        for (int i = lane; i < RS_RING * WORDS; i += 64) ring[i] = 0;
         if (lane == 0) s_dirty = 0;
         __syncthreads();
         if (lane == 0) {   // CreateKmerVecFromReadSeq :34-80 on the read gap, position order
@@ -238,8 +247,8 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
                 pre0 = src[lane]; if (lane < 4) pre1 = src[64 + lane];
             }
             for (int g0 = 0; g0 + 8 <= glen; g0 += RS_CHUNK) {
-                d_rs_finalize(ring, &s_dirty, st, (int64_t)g0 - span, false, lane);
-                uint64_t x = 0;                 // the lane's 23 bases (46 bits), first base in the top bits
+                d_rs_finalize<WORDS>(ring, &s_dirty, st, (int64_t)g0 - span, false, lane);
+                uint64_t x = 0;                 // the lane's RS_PPL + 7 bases, first base in the top bits
                 int o_rev = 0;
                 if (fwd || rev) {
                     const int64_t B0 = chunk_base(g0);
@@ -252,23 +261,23 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
                     RS_WAVE_SYNC();
                     // first forward base this lane needs, relative to base 4*B0 of the staged bytes
                     int64_t fb;
-                    if (fwd) fb = job.Lb + g0 + 16 * lane - 4 * B0;
-                    else { fb = 2 * L - 1 - (job.Lb + g0 + 16 * lane + 15) - 7 - 4 * B0; if (fb < 0) { o_rev = (int)-fb; fb = 0; } }
+                    if (fwd) fb = job.Lb + g0 + RS_PPL * lane - 4 * B0;
+                    else { fb = 2 * L - 1 - (job.Lb + g0 + RS_PPL * lane + RS_PPL - 1) - 7 - 4 * B0; if (fb < 0) { o_rev = (int)-fb; fb = 0; } }
                     const int m = (int)(fb >> 4), o = (int)(fb & 15);                 // dword index, base offset inside it
                     const uint32_t w0 = __builtin_bswap32(pacbuf[m]), w1 = __builtin_bswap32(pacbuf[m + 1]), w2 = __builtin_bswap32(pacbuf[m + 2]);
                     const uint64_t hi = ((uint64_t)w0 << 32) | w1;
                     x = o ? ((hi << (2 * o)) | ((uint64_t)w2 >> (32 - 2 * o))) : hi;
                     if (o_rev) x = o_rev > 23 ? 0 : x >> (2 * o_rev);     // window start of the reverse half clipped at forward base 0 (never a valid position)
                 }
-                uint32_t wid[16];
+                uint32_t wid[RS_PPL];
                 uint32_t pass = 0;
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int p = g0 + 16 * lane + j;
+                for (int j = 0; j < RS_PPL; j++) {
+                    const int p = g0 + RS_PPL * lane + j;
                     uint32_t w;
                     if (fwd) w = (uint32_t)(x >> (48 - 2 * j)) & 0xFFFFu;
                     else if (rev) {
-                        uint32_t f = (uint32_t)(x >> (48 - 2 * (15 - j))) & 0xFFFFu;      // forward 8-mer, mirrored position
+                        uint32_t f = (uint32_t)(x >> (48 - 2 * (RS_PPL - 1 - j))) & 0xFFFFu;      // forward 8-mer, mirrored position
                         f = ((f & 0x3333u) << 2) | ((f >> 2) & 0x3333u);
                         f = ((f & 0x0F0Fu) << 4) | ((f >> 4) & 0x0F0Fu);
                         f = ((f << 8) | (f >> 8)) & 0xFFFFu;
@@ -277,18 +286,18 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
                     wid[j] = w;
                 }
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
+                for (int j = 0; j < RS_PPL; j++) {
                     const uint32_t w16 = wid[j] & 0xFFFFu;
-                    const bool ok = g0 + 16 * lane + j + 8 <= glen;
+                    const bool ok = g0 + RS_PPL * lane + j + 8 <= glen;
                     pass |= (ok ? ((flt[w16 >> 5] >> (w16 & 31)) & 1u) : 0u) << j;
                 }
                 while (pass) {
                     const int j = __ffs((int)pass) - 1;
                     pass &= pass - 1;
-                    const int p = g0 + 16 * lane + j;
+                    const int p = g0 + RS_PPL * lane + j;
                     uint32_t w = wid[0];
 #pragma unroll
-                    for (int q = 1; q < 16; q++) w = j == q ? wid[q] : w;
+                    for (int q = 1; q < RS_PPL; q++) w = j == q ? wid[q] : w;
                     int lo = 0, hi2 = nk;
                     while (lo < hi2) { const int mid = (lo + hi2) >> 1; if ((uint32_t)(km[mid] >> 32) < w) lo = mid + 1; else hi2 = mid; }
                     for (; lo < nk && (uint32_t)(km[lo] >> 32) == w; lo++) {
@@ -300,7 +309,7 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
                 }
                 RS_WAVE_SYNC();
             }
-            d_rs_finalize(ring, &s_dirty, st, (int64_t)(glen - 8) + 1, true, lane);
+            d_rs_finalize<WORDS>(ring, &s_dirty, st, (int64_t)(glen - 8) + 1, true, lane);
             max_len = st.max_len; best_r = st.best_r; best_g = st.best_g;
             found = (max_len >= thr && max_len > 0) ? 1 : 0;
         }
