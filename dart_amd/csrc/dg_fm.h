@@ -205,7 +205,9 @@ __device__ __forceinline__ uint64_t d_lf_finish(const DIndex &ix, const OccBlock
 // bases, i.e. after K-1 steps of BWT_Search, plus how many steps / Occ blocks the reference's
 // loop would have spent getting there (for the algorithmic-byte accounting).
 //   16-byte entries: w0 = x0 (40 bits) | x1[23:0] << 40
-//                    w1 = x1[39:24] | x2 (31 bits) << 16 | ref_steps (5) << 47 | ref_blocks (6) << 52 | overflow << 63
+//                    w1 = x1[39:24] | x2 (31 bits) << 16 | ref_steps (5) << 47 | ref_blocks (6) << 52 | located << 62 | overflow << 63
+//   located: a unique K-mer (x2 == 1, full/dense SA present) holds its text position + 1 in the x1 field and the
+//   reference's LF count of bwt_sa in the x2 field: the search skips the locate trip
 // x2 == 0: the K-mer does not occur; because K <= 16 such a search can never yield a seed
 // (bwt_search.cpp:173 needs len >= 16), so it is skipped with the reference's step count.
 // overflow (x2 >= 2^31, a K-mer with billions of copies): the search starts from its first base instead.
@@ -227,8 +229,21 @@ k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
         blocks += nb;
         if (!ok) { x2 = 0; break; }
     }
+    uint64_t lfc = 0;
+    if (x2 == 1 && ix.sa_dense) {
+        // a unique K-mer: the search goes straight to the text comparison, so the entry carries the text position
+        // (bwt_sa of row x0, same encoding as an SA entry: pos+1 and the reference's LF count) in place of x1
+        uint64_t k = x0, st = 0;
+        const uint64_t mask = (uint64_t)ix.sa_dense_intv - 1;
+        while (k & mask) { k = d_lf(ix, k); st++; }
+        const uint64_t e = ix.sa_dense[k / (uint64_t)ix.sa_dense_intv];
+        x1 = (st + (e & 0xFFFFFFFFFFull)) & 0xFFFFFFFFFFull;          // (pos + 1), pos = st + SA - 1
+        lfc = st + (e >> 40);                                          // the walk to a sampled row has no fixed bound
+    }
     uint64_t w0 = (x0 & 0xFFFFFFFFFFull) | ((x1 & 0xFFFFFFull) << 40);
-    uint64_t w1 = ((x1 >> 24) & 0xFFFFull) | ((x2 & 0x7FFFFFFFull) << 16) | ((uint64_t)steps << 47) | ((uint64_t)blocks << 52);
+    const bool located = x2 == 1 && ix.sa_dense;
+    uint64_t w1 = ((x1 >> 24) & 0xFFFFull) | (((located ? lfc : x2) & 0x7FFFFFFFull) << 16) | ((uint64_t)steps << 47) | ((uint64_t)blocks << 52);
+    if (located) w1 |= 1ull << 62;
     if (x2 >> 31) w1 |= 1ull << 63;
     tab[id * 2 + 0] = w0; tab[id * 2 + 1] = w1;
 }
@@ -336,15 +351,20 @@ __device__ __forceinline__ void d_begin_issue(const DIndex &ix, int K, RB &rb, R
     }
 }
 template <class RB>
-__device__ __forceinline__ void d_begin_finish(const DIndex &ix, int K, RB &rb, Search &s, const TripData &t)
+__device__ __forceinline__ void d_begin_finish(const DIndex &ix, int K, RB &rb, Search &s, SeedCtr &c, const TripData &t)
 {
     if (t.aux == T_TABLE) {
         const uint64_t w0 = d_u64(t.s16.x, t.s16.y), w1 = d_u64(t.s16.z, t.s16.w);
         if (!(w1 >> 63)) {
-            const uint64_t x2 = (w1 >> 16) & 0x7FFFFFFFull;
+            const bool located = (w1 >> 62) & 1ull;       // unique K-mer: the entry already is the located position (see k_build_ktab)
+            const uint64_t f2 = (w1 >> 16) & 0x7FFFFFFFull, x2 = located ? 1ull : f2;
             s.ref_steps = (uint32_t)((w1 >> 47) & 31u); s.ref_blocks = (uint32_t)((w1 >> 52) & 63u);
             if (x2 == 0) { s.mode = 0; return; }          // cannot reach 16: no seed from this start
             s.x0 = w0 & 0xFFFFFFFFFFull; s.x1 = (w0 >> 40) | ((w1 & 0xFFFFull) << 24); s.x2 = x2; s.p = s.start + K; s.mode = 1;
+            if (located) {
+                s.lk = s.x1 | (f2 << 40);
+                s.tpos = (int64_t)s.x1 - 1; s.lsteps = 0; s.mode = 2; c.n_direct++;
+            }
             return;
         }
     }
@@ -582,7 +602,7 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
         }
         // ---- finish phase ----
         if (live) {
-            if (beginning) d_begin_finish(ix, K, rb, s, t);
+            if (beginning) d_begin_finish(ix, K, rb, s, c, t);
             else if (t.aux != T_NONE) d_trip_finish(ix, pr, rb, rm, len, s, c, t);
             if (direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
             if (!finished && s.mode == 0) {          // a search just ended (or the table said "absent")
@@ -652,7 +672,7 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
                 TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
                 if (acgt) d_begin_issue(ix, K, rb, rm, st, s, c, ta, t);
                 d_trip_load(ta, t);
-                if (acgt) d_begin_finish(ix, K, rb, s, t);
+                if (acgt) d_begin_finish(ix, K, rb, s, c, t);
                 if (acgt && direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
                 while (__ballot(acgt && s.mode != 0)) {
                     t.aux = T_NONE; ta.pa = ta.pb = ta.p16 = nullptr; ta.p8 = nullptr;

@@ -207,3 +207,29 @@ def test_gpu_cloned_contexts_run_concurrently(workdir):
     for j in range(3):
         assert_same(out[j], orc.map_batch(orc.params(paired=1, max_mismatch=5), *batches[j], threads=16))
     gpu.close(); orc.close()
+
+
+def test_gpu_reference_equivalent_counters(workdir):
+    """The algorithmic-byte accounting: the kernels skip most of the reference's memory accesses (prefix
+    table, full SA, direct text comparison) but memoise what the reference would have done -- those counters must equal
+    the oracle's, which counts while really executing the reference algorithm."""
+    g = synth.make_genome([3000000], seed=5, repeat_scale=20.0)
+    prefix = os.path.join(workdir, "ctr")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    m1, m2 = synth.make_reads(g, 20000, rlen=101, seed=6)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=8)
+    oc = orc.counters
+    gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
+    gpu.map_batch(so, rl, flat)
+    c = gpu.counters()
+    assert c["steps"] == oc["n_2occ4"]
+    assert c["lf_steps"] == oc["n_lf"]
+    assert c["sa_lookups"] == oc["n_sa"]
+    assert c["nw_calls"] == oc["n_nw"] and c["nw_cells"] == oc["nw_cells"]
+    assert c["reseed_calls"] == oc["n_reseed"] and c["reseed_window"] == oc["reseed_window"]
+    # Occ blocks: inside a direct text comparison every base is charged one block; the reference fetches two when the
+    # interval's two rows straddle a 128-row block (1 in 128 steps), so the figure is a lower bound, < 1 % under
+    assert 0 <= oc["n_occ_blocks"] - (c["occ_blocks"] + c["lf_steps"]) <= 1e-2 * oc["n_occ_blocks"]
+    gpu.close(); orc.close()
