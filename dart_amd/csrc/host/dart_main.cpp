@@ -11,7 +11,8 @@
 // Batches are much larger than the reference's 4000-read chunks (a GPU launch needs >= 10^5 reads);
 // output order is input order, which equals the reference at -t 1.  -t keeps its
 // meaning for the host side: threads that format SAM text.  DART_GPUS=n spreads batches over n
-// devices (one dg_ctx each); DART_BATCH=reads sets the batch size.
+// devices, DART_INFLIGHT=k (default 1) contexts per device (dg_clone); parsing (one thread per mate file),
+// mapping + formatting (one worker per context) and the ordered writer run as a pipeline; DART_BATCH=reads sets the batch size; DART_TIMING=1 prints the stage times.
 #include "dartgpu.h"
 #include <zlib.h>
 #include <sys/stat.h>
@@ -20,7 +21,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -134,7 +140,26 @@ static int hdr_end(const char *s, int len) { for (int i = 1; i < len; i++) if (s
 struct Source {
     FILE *fp = nullptr; gzFile gz = nullptr; bool fastq = true;
     char *buf = nullptr; size_t cap = 0;
-    ~Source() { free(buf); }
+    // block reader for plain FASTQ: lines are handed out as (pointer into the block, length incl. newline), like getline
+    // without the copy and the per-call locking; a line stays valid until the next call
+    char *blk = nullptr; size_t blk_cap = 0, blk_beg = 0, blk_end = 0; bool blk_eof = false;
+    ssize_t block_line(char **line) {
+        while (true) {
+            char *nl = blk_end > blk_beg ? (char *)memchr(blk + blk_beg, '\n', blk_end - blk_beg) : nullptr;
+            if (nl) { *line = blk + blk_beg; const ssize_t len = nl - (blk + blk_beg) + 1; blk_beg += (size_t)len; return len; }
+            if (blk_eof) {
+                if (blk_end == blk_beg) return -1;
+                *line = blk + blk_beg; const ssize_t len = (ssize_t)(blk_end - blk_beg); blk_beg = blk_end; return len;   // last line without newline
+            }
+            if (!blk) { blk_cap = (size_t)8 << 20; blk = (char *)malloc(blk_cap + 1); }
+            if (blk_beg > 0) { memmove(blk, blk + blk_beg, blk_end - blk_beg); blk_end -= blk_beg; blk_beg = 0; }
+            if (blk_end == blk_cap) { blk_cap *= 2; blk = (char *)realloc(blk, blk_cap + 1); }
+            const size_t got = fread(blk + blk_end, 1, blk_cap - blk_end, fp);
+            if (got == 0) blk_eof = true;
+            blk_end += got;
+        }
+    }
+    ~Source() { free(buf); free(blk); }
     // GetNextEntry, GetData.cpp:77-132
     Entry next_plain() {
         Entry e; ssize_t len;
@@ -182,18 +207,117 @@ struct Source {
     Entry next() { return gz ? next_gz() : next_plain(); }
 };
 
+// A run of reads in flat buffers (no per-read allocation: with one std::string per field the allocator, not the
+// parsing, was the cost): read k = header [hoff[k],hoff[k+1]), bases [soff[k],soff[k+1]), qualities [qoff[k],qoff[k+1]).
+struct Reads {
+    std::string hdr, seq, qual;
+    std::vector<uint32_t> hoff{0}, soff{0}, qoff{0};
+    size_t size() const { return soff.size() - 1; }
+    int rlen(size_t k) const { return (int)(soff[k + 1] - soff[k]); }
+    void add(const char *h, size_t hl, const char *s, size_t sl, const char *q, size_t ql, bool rc, bool fastq) {
+        hdr.append(h, hl); hoff.push_back((uint32_t)hdr.size());
+        if (rc) { const size_t o = seq.size(); seq.resize(o + sl); for (size_t i = 0; i < sl; i++) seq[o + i] = comp_base(s[sl - 1 - i]); }
+        else seq.append(s, sl);
+        soff.push_back((uint32_t)seq.size());
+        if (rc && fastq) { const size_t o = qual.size(); qual.resize(o + ql); for (size_t i = 0; i < ql; i++) qual[o + i] = q[ql - 1 - i]; }
+        else qual.append(q, ql);
+        qoff.push_back((uint32_t)qual.size());
+    }
+    void add_from(const Reads &r, size_t k) {             // copy read k of r
+        hdr.append(r.hdr, r.hoff[k], r.hoff[k + 1] - r.hoff[k]); hoff.push_back((uint32_t)hdr.size());
+        seq.append(r.seq, r.soff[k], r.soff[k + 1] - r.soff[k]); soff.push_back((uint32_t)seq.size());
+        qual.append(r.qual, r.qoff[k], r.qoff[k + 1] - r.qoff[k]); qoff.push_back((uint32_t)qual.size());
+    }
+};
+
+// one read from a Source appended to R (mate 2 of a pair: reverse-complemented, qualities reversed, GetData.cpp:160-166);
+// false = end of the stream (an entry of length 0, as in the reference).  Plain FASTQ is parsed straight into the flat
+// buffers; FASTA and gz go through the Entry readers above.
+static bool read_into(Source &s, Reads &R, bool rc)
+{
+    if (s.gz || !s.fastq) {
+        Entry e = s.next();
+        if (e.rlen == 0) return false;
+        R.add(e.header.data(), e.header.size(), e.seq.data(), e.seq.size(), e.qual.data(), e.qual.size(), rc, s.fastq);
+        return true;
+    }
+    char *ln;                                             // GetNextEntry, GetData.cpp:77-132 (FASTQ branch)
+    ssize_t len = s.block_line(&ln);
+    if (len == -1) return false;
+    const int p1 = hdr_beg(ln, (int)len), p2 = hdr_end(ln, (int)len);
+    const size_t h0 = R.hdr.size(), s0 = R.seq.size();
+    if (p2 > p1) R.hdr.append(ln + p1, (size_t)(p2 - p1));
+    ssize_t rl = s.block_line(&ln);
+    const int rlen = rl == -1 ? 0 : (int)rl - 1;
+    if (rlen > 0) {
+        if (rc) { R.seq.resize(s0 + (size_t)rlen); for (int i = 0; i < rlen; i++) R.seq[s0 + i] = comp_base(ln[rlen - 1 - i]); }
+        else R.seq.append(ln, (size_t)rlen);
+    }
+    if (rl != -1) {
+        if (s.block_line(&ln) == -1) {}
+        ssize_t ql = s.block_line(&ln);
+        if (ql < 0) ql = 0;
+        if (rlen > 0) {
+            const size_t take = std::min<size_t>((size_t)rlen, ql > 0 ? strnlen(ln, (size_t)ql) : 0), q0 = R.qual.size();
+            if (rc) { R.qual.resize(q0 + take); for (size_t i = 0; i < take; i++) R.qual[q0 + i] = ln[take - 1 - i]; }
+            else R.qual.append(ln, take);
+        }
+    }
+    if (rlen <= 0) { R.hdr.resize(h0); R.seq.resize(s0); return false; }     // an entry of length 0 ends the stream
+    R.hoff.push_back((uint32_t)R.hdr.size()); R.soff.push_back((uint32_t)R.seq.size()); R.qoff.push_back((uint32_t)R.qual.size());
+    return true;
+}
+
+// A Source parsed by its own thread, BLOCK reads at a time (the two mate files are parsed concurrently; mate 2 is
+// reverse-complemented there too).  The consumer walks the blocks in file order.
+struct Prefetch {
+    static const size_t BLOCK = 16384;
+    Source *src = nullptr; bool rc = false;
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    std::deque<std::unique_ptr<Reads>> q; bool eof = false, stop = false;
+    std::unique_ptr<Reads> cur; size_t pos = 0;
+    void start(Source *s, bool revcomp_mate) {
+        src = s; rc = revcomp_mate;
+        th = std::thread([this]() {
+            while (true) {
+                std::unique_ptr<Reads> blk(new Reads());
+                blk->seq.reserve(BLOCK * 160); blk->qual.reserve(BLOCK * 160); blk->hdr.reserve(BLOCK * 24);
+                bool end = false;
+                while (blk->size() < BLOCK) if (!read_into(*src, *blk, rc)) { end = true; break; }
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this]() { return q.size() < 64 || stop; });
+                if (stop) return;
+                if (blk->size()) q.push_back(std::move(blk));
+                if (end) { eof = true; cv.notify_all(); return; }
+                cv.notify_all();
+            }
+        });
+    }
+    // appends the next read to R; false at the end of the stream
+    bool next_into(Reads &R) {
+        if (!cur || pos == cur->size()) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [this]() { return !q.empty() || eof; });
+            if (q.empty()) return false;
+            cur = std::move(q.front()); q.pop_front(); pos = 0;
+            cv.notify_all();
+        }
+        R.add_from(*cur, pos++);
+        return true;
+    }
+    void finish() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+    ~Prefetch() { finish(); }
+};
+
 // GetNextChunk, GetData.cpp:134-179: one reference-sized chunk appended to `out`
-static int next_chunk(Source &s1, Source *s2, bool pair_end, bool fastq, std::vector<Entry> &out)
+static int next_chunk(Source &s1, Source *s2, bool pair_end, Reads &out, Prefetch *p1 = nullptr, Prefetch *p2 = nullptr)
 {
     int count = 0, base = 0;
     while (true) {
-        Entry e = s1.next();
-        if (e.rlen == 0) break;
-        base += e.rlen; count++; out.push_back(std::move(e));
-        Entry m = s2 ? s2->next() : s1.next();
-        if (m.rlen == 0) break;
-        if (pair_end) { m.seq = revcomp(m.seq); if (fastq) std::reverse(m.qual.begin(), m.qual.end()); }
-        base += m.rlen; count++; out.push_back(std::move(m));
+        if (!(p1 ? p1->next_into(out) : read_into(s1, out, false))) break;
+        base += out.rlen(out.size() - 1); count++;
+        if (!(p2 ? p2->next_into(out) : read_into(s2 ? *s2 : s1, out, pair_end))) break;
+        base += out.rlen(out.size() - 1); count++;
         if (count == 4000 || base > 1000000) break;
     }
     return count;
@@ -213,35 +337,45 @@ static bool check_read_format(const char *fn)   // CheckReadFormat, Mapping.cpp:
 struct Counters { long long total = 0, unique = 0, unmapped = 0, paired = 0; };
 static const char *XS_A[3] = { "", " XS:A:+", " XS:A:-" };
 
-static void cigar_text(const uint32_t *ops, uint32_t n, std::string &out)
+// decimal text without snprintf (the formatter was spending most of its time there)
+static inline void put_int(std::string &out, long long v)
 {
-    char b[16];
-    out.clear();
-    for (uint32_t i = 0; i < n; i++) { snprintf(b, sizeof b, "%u%c", ops[i] >> 4, "MIDNS"[ops[i] & 15 ? (ops[i] & 15) : 0]); out += b; }
+    char b[24]; int n = 0;
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) out += '-';
+    while (n) out += b[--n];
+}
+static inline void put_cigar(std::string &out, const uint32_t *ops, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) { put_int(out, ops[i] >> 4); out += "MIDNS"[ops[i] & 15 ? (ops[i] & 15) : 0]; }
 }
 
 // OutputPairedAlignments / OutputSingledAlignments (Mapping.cpp:208-369) for reads [lo,hi)
-static void format_range(const std::vector<Entry> &ev, int lo, int hi, int n_pair_mode, const dg_read_out *ro, const dg_report_out *po,
+static void format_range(const Reads &R, int lo, int hi, int n_pair_mode, const dg_read_out *ro, const dg_report_out *po,
                          const uint32_t *cig, const HostIndex &ix, const Options &o, bool fastq, std::string &out, Counters &ct)
 {
-    std::string cg, line;
+    out.reserve((size_t)(hi - lo) * 300);
+    struct View { const char *header; size_t hl; const char *seq; size_t sl; const char *qual; size_t ql; int rlen; };
     for (int k = lo; k < hi; k++) {
         const bool is_pair = k < n_pair_mode, mate2 = is_pair && (k & 1);
-        const Entry &e = ev[k];
+        View e;
+        e.header = R.hdr.data() + R.hoff[k]; e.hl = R.hoff[k + 1] - R.hoff[k];
+        e.seq = R.seq.data() + R.soff[k]; e.sl = R.soff[k + 1] - R.soff[k]; e.rlen = (int)e.sl;
+        e.qual = R.qual.data() + R.qoff[k]; e.ql = strnlen(e.qual, R.qoff[k + 1] - R.qoff[k]);   // the reference prints a C string
         const dg_read_out &r = ro[k];
         const dg_report_out *rp = po + r.rep_off;
-        const char *q = fastq ? e.qual.c_str() : "*";
         if (r.score == 0) {
             ct.unmapped++;
-            out += e.header; out += '\t'; out += std::to_string(rp[0].flag); out += "\t*\t0\t0\t*\t*\t0\t0\t"; out += e.seq; out += '\t'; out += q; out += "\tAS:i:0\tXS:i:0\n";
+            out.append(e.header, e.hl); out += '\t'; put_int(out, rp[0].flag); out += "\t*\t0\t0\t*\t*\t0\t0\t"; out.append(e.seq, e.sl); out += '\t';
+            if (fastq) out.append(e.qual, e.ql); else out += '*';
+            out += "\tAS:i:0\tXS:i:0\n";
             continue;
         }
         if (!(!o.unique || r.mapq > 3)) continue;
         if (r.mapq == 50) ct.unique++;
         const dg_read_out *m = is_pair ? &ro[k ^ 1] : nullptr;
         const dg_report_out *mp = m ? po + m->rep_off : nullptr;
-        std::string alt, altq;
-        bool have_alt = false;
         for (int j = r.best; j < r.n_rep; j++) {
             const dg_report_out &pr = rp[j];
             const bool show = is_pair ? pr.aln_score > 0 : pr.aln_score == r.score;
@@ -249,29 +383,23 @@ static void format_range(const std::vector<Entry> &ev, int lo, int hi, int n_pai
                 int xs;
                 if (pr.sj_type == -1) xs = 0; else if (pr.sj_type == 0 || pr.sj_type == 2) xs = mate2 ? 2 : 1; else xs = mate2 ? 1 : 2;
                 const bool use_alt = mate2 ? pr.bdir == 1 : pr.bdir == 0;
-                if (use_alt && !have_alt) { alt = revcomp(e.seq); if (fastq) { altq = e.qual; std::reverse(altq.begin(), altq.end()); } have_alt = true; }
-                const std::string &s_out = use_alt ? alt : e.seq;
-                const char *q_out = fastq ? (use_alt ? altq.c_str() : e.qual.c_str()) : "*";
-                cigar_text(cig + pr.cigar_off, pr.n_cigar, cg);
-                char num[256];
                 int pj;
-                out += e.header;
+                out.append(e.header, e.hl);
+                out += '\t'; put_int(out, pr.flag); out += '\t'; out += ix.names[pr.chr]; out += '\t'; put_int(out, (long long)pr.pos); out += '\t'; put_int(out, r.mapq); out += '\t';
+                put_cigar(out, cig + pr.cigar_off, pr.n_cigar);
                 if (is_pair && (pj = pr.paired_idx) != -1 && mp[pj].aln_score > 0) {
                     const dg_report_out &a = mate2 ? mp[pj] : pr, &b = mate2 ? pr : mp[pj];
-                    const int l1 = mate2 ? ev[k ^ 1].rlen : e.rlen, l2 = mate2 ? e.rlen : ev[k ^ 1].rlen;
+                    const int l1 = mate2 ? R.rlen(k ^ 1) : e.rlen, l2 = mate2 ? e.rlen : R.rlen(k ^ 1);
                     int dist = (int)(b.pos - a.pos + (a.bdir ? l2 : 0 - l1));
                     if (mate2) dist = 0 - dist; else if (j == r.best) ct.paired += 2;
-                    snprintf(num, sizeof num, "\t%d\t%s\t%lld\t%d\t", pr.flag, ix.names[pr.chr].c_str(), (long long)pr.pos, r.mapq);
-                    out += num; out += cg;
-                    snprintf(num, sizeof num, "\t=\t%lld\t%d\t", (long long)mp[pj].pos, dist);
-                    out += num;
-                } else {
-                    snprintf(num, sizeof num, "\t%d\t%s\t%lld\t%d\t", pr.flag, ix.names[pr.chr].c_str(), (long long)pr.pos, r.mapq);
-                    out += num; out += cg; out += "\t*\t0\t0\t";
-                }
-                out += s_out; out += '\t'; out += q_out;
-                snprintf(num, sizeof num, "\tNM:i:%d\tAS:i:%d\tXS:i:%d%s\n", r.mis_num, r.score, r.sub_score, XS_A[xs]);
-                out += num;
+                    out += "\t=\t"; put_int(out, (long long)mp[pj].pos); out += '\t'; put_int(out, dist); out += '\t';
+                } else out += "\t*\t0\t0\t";
+                if (use_alt) { for (size_t i = e.sl; i-- > 0;) out += comp_base(e.seq[i]); } else out.append(e.seq, e.sl);
+                out += '\t';
+                if (!fastq) out += '*';
+                else if (use_alt) { for (size_t i = e.ql; i-- > 0;) out += e.qual[i]; }
+                else out.append(e.qual, e.ql);
+                out += "\tNM:i:"; put_int(out, r.mis_num); out += "\tAS:i:"; put_int(out, r.score); out += "\tXS:i:"; put_int(out, r.sub_score); out += XS_A[xs]; out += '\n';
                 if (!is_pair && !o.multi) break;
             }
             if (is_pair && !o.multi) break;
@@ -338,7 +466,7 @@ int main(int argc, char *argv[])
 
     int n_gpu = getenv("DART_GPUS") ? atoi(getenv("DART_GPUS")) : 1; if (n_gpu < 1) n_gpu = 1;
     size_t batch_reads = getenv("DART_BATCH") ? (size_t)atoll(getenv("DART_BATCH")) : 1000000; batch_reads = std::max<size_t>(4000, batch_reads & ~(size_t)1);
-    std::vector<dg_ctx *> ctx;
+    std::vector<dg_ctx *> ctx, roots, clones;
     dg_index_view view = ix.view();
 
     FILE *sam = fopen(o.out, "w");
@@ -365,92 +493,164 @@ int main(int argc, char *argv[])
         }
         if (!s1.fp && !s1.gz) continue;
         if (sep && !s2.fp && !s2.gz) continue;
+        // the mate files start being parsed now, i.e. also while dg_init uploads the index and builds its tables
+        Prefetch pf1, pf2;
+        if (sep) { pf1.start(&s1, false); pf2.start(&s2, pair_end); }
         if (ctx.empty()) {   // contexts are created once the first library opens (so flag errors never touch the GPU)
             o.p.paired = pair_end ? 1 : 0;
+            const int inflight = std::max(1, getenv("DART_INFLIGHT") ? atoi(getenv("DART_INFLIGHT")) : 1);
             for (int d = 0; d < n_gpu; d++) {
                 int st = 0; dg_ctx *c = dg_init(&view, &o.p, d, &st);
                 if (!c) { fprintf(stderr, "Error! GPU %d: %s\n", d, dg_last_error(nullptr)); return 1; }
-                ctx.push_back(c);
+                ctx.push_back(c); roots.push_back(c);
+                for (int k = 1; k < inflight; k++) {
+                    dg_ctx *cl = dg_clone(c, &st);
+                    if (!cl) { fprintf(stderr, "Error! GPU %d: %s\n", d, dg_last_error(nullptr)); return 1; }
+                    ctx.push_back(cl); clones.push_back(cl);
+                }
             }
         }
-        bool eof = false;
-        while (!eof) {
-            // read up to n_gpu batches; an odd chunk (only the last can be) is mapped on its own, unpaired (Mapping.cpp:598)
-            struct Batch { std::vector<Entry> ev; int odd = 0; std::vector<dg_read_out> ro; std::vector<dg_report_out> po; std::vector<uint32_t> cig; std::vector<dg_sj_out> sj; size_t used[3] = {0, 0, 0}; int rc = 0; std::string err; };
-            std::vector<Batch> batches;
-            for (int d = 0; d < n_gpu && !eof; d++) {
-                Batch b;
-                while (b.ev.size() < batch_reads) {
-                    int c = next_chunk(s1, sep ? &s2 : nullptr, pair_end, fastq, b.ev);
+        // ---- three-stage pipeline: reader thread -> mapping workers (one per context) -> ordered writer ----
+        // Contexts = devices x DART_INFLIGHT (dg_clone: contexts of a device share its index), so the next batch is
+        // parsed, and the previous one formatted and written, while the GPUs map.  Output order = input order.
+        struct Batch { Reads rd; int odd = 0; std::unique_ptr<dg_read_out[]> ro; std::unique_ptr<dg_report_out[]> po; std::unique_ptr<uint32_t[]> cig; std::unique_ptr<dg_sj_out[]> sj;   // new T[n]: no zero fill
+                       size_t n_reads = 0; size_t used[3] = {0, 0, 0}; int rc = 0; std::string err; size_t seq = 0; std::vector<std::string> outs; std::vector<Counters> cts; };
+        std::mutex mu; std::condition_variable cv_in, cv_out, cv_space;
+        std::deque<std::unique_ptr<Batch>> inq; std::map<size_t, std::unique_ptr<Batch>> done;
+        bool reader_done = false, failed = false; size_t in_flight = 0;
+        const size_t max_in_flight = ctx.size() + 2;
+        double t_read = 0, t_map = 0, t_fmt = 0, t_write = 0;
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+
+        std::thread reader([&]() {
+            bool eof = false; size_t seqno = 0;
+            while (!eof) {
+                // an odd chunk (only the last can be) is mapped on its own, unpaired (Mapping.cpp:598)
+                const double t = now();
+                std::unique_ptr<Batch> b(new Batch());
+                b->rd.seq.reserve(batch_reads * 110); b->rd.qual.reserve(batch_reads * 110); b->rd.hdr.reserve(batch_reads * 16);
+                while (b->rd.size() < batch_reads) {
+                    int c = next_chunk(s1, sep ? &s2 : nullptr, pair_end, b->rd, sep ? &pf1 : nullptr, sep ? &pf2 : nullptr);
                     if (c == 0) { eof = true; break; }
-                    if (c & 1) { b.odd = c; eof = true; break; }
+                    if (c & 1) { b->odd = c; eof = true; break; }
                 }
-                if (!b.ev.empty()) batches.push_back(std::move(b));
+                t_read += now() - t;
+                if (b->rd.size() == 0) break;
+                b->seq = seqno++;
+                std::unique_lock<std::mutex> lk(mu);
+                cv_space.wait(lk, [&]() { return in_flight < max_in_flight || failed; });
+                if (failed) break;
+                in_flight++; inq.push_back(std::move(b));
+                cv_in.notify_one();
             }
-            if (batches.empty()) break;
-            auto run = [&](Batch &b, dg_ctx *c) {
-                const int n = (int)b.ev.size(), n_even = n - b.odd;
-                std::vector<uint32_t> off(n); std::vector<uint16_t> rl(n); std::string flat;
-                size_t bases = 0; for (auto &e : b.ev) bases += (size_t)e.rlen;
-                flat.reserve(bases);
-                for (int k = 0; k < n; k++) {
-                    if (b.ev[k].rlen > DG_MAX_RLEN) { b.rc = DG_ERR_ARG; b.err = "read longer than DG_MAX_RLEN"; return; }
-                    off[k] = (uint32_t)flat.size(); rl[k] = (uint16_t)b.ev[k].rlen; flat += b.ev[k].seq;
-                }
-                b.ro.resize(n);
-                size_t caps[3] = { (size_t)n * 4 + 1024, (size_t)n * 16 + 4096, (size_t)n + 1024 };
-                for (int attempt = 0; attempt < 2; attempt++) {
-                    b.po.resize(caps[0]); b.cig.resize(caps[1]); b.sj.resize(caps[2]);
-                    size_t used1[3] = {0, 0, 0}, used2[3] = {0, 0, 0};
-                    dg_params p = o.p; p.paired = pair_end ? 1 : 0;
-                    dg_set_params(c, &p);
-                    int rc = n_even ? dg_map_batch(c, n_even, off.data(), rl.data(), flat.data(), b.ro.data(), b.po.data(), b.cig.data(), b.sj.data(), caps, used1) : 0;
-                    if (rc == 0 && b.odd) {
-                        p.paired = 0; dg_set_params(c, &p);
-                        size_t caps2[3] = { caps[0] - used1[0], caps[1] - used1[1], caps[2] - used1[2] };
-                        rc = dg_map_batch(c, b.odd, off.data() + n_even, rl.data() + n_even, flat.data(), b.ro.data() + n_even, b.po.data() + used1[0],
-                                          b.cig.data() + used1[1], b.sj.data() + used1[2], caps2, used2);
-                        if (rc == DG_ERR_CAPACITY) for (int q = 0; q < 3; q++) used2[q] += used1[q];
-                        else {
-                            for (int k = n_even; k < n; k++) { b.ro[k].rep_off += (int32_t)used1[0]; b.ro[k].sj_off += (int32_t)used1[2]; }
-                            for (size_t k = 0; k < used2[0]; k++) b.po[used1[0] + k].cigar_off += (uint32_t)used1[1];
-                            for (size_t k = 0; k < used2[2]; k++) b.sj[used1[2] + k].read_idx += n_even;
-                        }
-                    }
-                    if (rc == DG_ERR_CAPACITY && attempt == 0) {       // `used` holds the need: grow once and repeat
-                        for (int q = 0; q < 3; q++) caps[q] = std::max(caps[q], used1[q] + used2[q]) * 2 + 1024;
-                        continue;
-                    }
-                    b.rc = rc; if (rc) b.err = dg_last_error(c);
-                    for (int q = 0; q < 3; q++) b.used[q] = used1[q] + used2[q];
-                    return;
-                }
-            };
-            std::vector<std::thread> th;
-            for (size_t d = 1; d < batches.size(); d++) th.emplace_back(run, std::ref(batches[d]), ctx[d]);
-            run(batches[0], ctx[0]);
-            for (auto &t : th) t.join();
-            for (auto &b : batches) {
-                if (b.rc) { fprintf(stderr, "\nError! GPU mapping failed (%d): %s\n", b.rc, b.err.c_str()); return 1; }
-                const int n = (int)b.ev.size(), n_pair_mode = pair_end ? n - b.odd : 0;
-                const int nt = std::max(1, std::min(o.threads, n / 2000 + 1));
-                std::vector<std::string> outs(nt); std::vector<Counters> cts(nt);
-                std::vector<std::thread> ft;
-                int per = ((n + nt - 1) / nt + 1) & ~1;
-                for (int t = 0; t < nt; t++) {
-                    const int lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
-                    ft.emplace_back([&, t, lo, hi]() { format_range(b.ev, lo, hi, n_pair_mode, b.ro.data(), b.po.data(), b.cig.data(), ix, o, fastq, outs[t], cts[t]); });
-                }
-                for (auto &t : ft) t.join();
-                for (int t = 0; t < nt; t++) {
-                    fwrite(outs[t].data(), 1, outs[t].size(), sam);
-                    total.unique += cts[t].unique; total.unmapped += cts[t].unmapped; total.paired += cts[t].paired;
-                }
-                total.total += n;
-                for (size_t k = 0; k < b.used[2]; k++) sjmap[std::make_pair(b.sj[k].g1, b.sj[k].g2)]++;   // UpdateLocal/GlobalSJMap, Mapping.cpp:532-577
-                if (!o.silent) { fprintf(stdout, "\r%lld %s tags have been processed in %lld seconds...", total.total, pair_end ? "paired-end" : "singled-end", (long long)(time(NULL) - t0)); fflush(stdout); }
+            std::lock_guard<std::mutex> lk(mu);
+            reader_done = true; cv_in.notify_all(); cv_out.notify_all();
+        });
+
+        auto map_one = [&](Batch &b, dg_ctx *c) {
+            const int n = (int)b.rd.size(), n_even = n - b.odd;
+            const std::vector<uint32_t> &off = b.rd.soff; std::vector<uint16_t> rl(n); const std::string &flat = b.rd.seq;   // the parsed bases are the device input
+            for (int k = 0; k < n; k++) {
+                if (b.rd.rlen(k) > DG_MAX_RLEN) { b.rc = DG_ERR_ARG; b.err = "read longer than DG_MAX_RLEN"; return; }
+                rl[k] = (uint16_t)b.rd.rlen(k);
             }
+            b.ro.reset(new dg_read_out[n]); b.n_reads = (size_t)n;
+            size_t caps[3] = { (size_t)n * 4 + 1024, (size_t)n * 16 + 4096, (size_t)n + 1024 };
+            for (int attempt = 0; attempt < 2; attempt++) {
+                b.po.reset(new dg_report_out[caps[0]]); b.cig.reset(new uint32_t[caps[1]]); b.sj.reset(new dg_sj_out[caps[2]]);
+                size_t used1[3] = {0, 0, 0}, used2[3] = {0, 0, 0};
+                dg_params p = o.p; p.paired = pair_end ? 1 : 0;
+                dg_set_params(c, &p);
+                int rc = n_even ? dg_map_batch(c, n_even, off.data(), rl.data(), flat.data(), b.ro.get(), b.po.get(), b.cig.get(), b.sj.get(), caps, used1) : 0;
+                if (rc == 0 && b.odd) {
+                    p.paired = 0; dg_set_params(c, &p);
+                    size_t caps2[3] = { caps[0] - used1[0], caps[1] - used1[1], caps[2] - used1[2] };
+                    rc = dg_map_batch(c, b.odd, off.data() + n_even, rl.data() + n_even, flat.data(), b.ro.get() + n_even, b.po.get() + used1[0],
+                                      b.cig.get() + used1[1], b.sj.get() + used1[2], caps2, used2);
+                    if (rc == DG_ERR_CAPACITY) for (int q = 0; q < 3; q++) used2[q] += used1[q];
+                    else {
+                        for (int k = n_even; k < n; k++) { b.ro[k].rep_off += (int32_t)used1[0]; b.ro[k].sj_off += (int32_t)used1[2]; }
+                        for (size_t k = 0; k < used2[0]; k++) b.po[used1[0] + k].cigar_off += (uint32_t)used1[1];
+                        for (size_t k = 0; k < used2[2]; k++) b.sj[used1[2] + k].read_idx += n_even;
+                    }
+                }
+                if (rc == DG_ERR_CAPACITY && attempt == 0) {       // `used` holds the need: grow once and repeat
+                    for (int q = 0; q < 3; q++) caps[q] = std::max(caps[q], used1[q] + used2[q]) * 2 + 1024;
+                    continue;
+                }
+                b.rc = rc; if (rc) b.err = dg_last_error(c);
+                for (int q = 0; q < 3; q++) b.used[q] = used1[q] + used2[q];
+                return;
+            }
+        };
+        auto format_one = [&](Batch &b) {
+            const int n = (int)b.rd.size(), n_pair_mode = pair_end ? n - b.odd : 0;
+            const int nt = std::max(1, std::min(o.threads, n / 2000 + 1));
+            b.outs.assign(nt, std::string()); b.cts.assign(nt, Counters());
+            std::vector<std::thread> ft;
+            int per = ((n + nt - 1) / nt + 1) & ~1;
+            for (int t = 0; t < nt; t++) {
+                const int lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
+                ft.emplace_back([&, t, lo, hi]() { format_range(b.rd, lo, hi, n_pair_mode, b.ro.get(), b.po.get(), b.cig.get(), ix, o, fastq, b.outs[t], b.cts[t]); });
+            }
+            for (auto &t : ft) t.join();
+            b.rd = Reads();                                      // the text is all the writer needs
+        };
+        std::vector<std::thread> workers;
+        for (size_t w = 0; w < ctx.size(); w++) workers.emplace_back([&, w]() {
+            while (true) {
+                std::unique_ptr<Batch> b;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_in.wait(lk, [&]() { return !inq.empty() || reader_done || failed; });
+                    if (failed || inq.empty()) return;
+                    b = std::move(inq.front()); inq.pop_front();
+                }
+                double t = now();
+                map_one(*b, ctx[w]);
+                const double tm = now() - t; t = now();
+                if (!b->rc) format_one(*b);
+                const double tf = now() - t;
+                std::lock_guard<std::mutex> lk(mu);
+                t_map += tm; t_fmt += tf;
+                if (b->rc) failed = true;
+                const size_t k = b->seq;
+                done[k] = std::move(b);
+                cv_out.notify_all(); if (failed) { cv_in.notify_all(); cv_space.notify_all(); }
+            }
+        });
+        // ordered writer (this thread)
+        size_t next_out = 0; bool bad = false; std::string bad_msg; int bad_rc = 0;
+        while (true) {
+            std::unique_ptr<Batch> b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_out.wait(lk, [&]() { return done.count(next_out) || failed || (reader_done && in_flight == 0); });
+                if (done.count(next_out)) { b = std::move(done[next_out]); done.erase(next_out); }
+                else if (failed) { for (auto &kv : done) if (kv.second->rc) { bad_rc = kv.second->rc; bad_msg = kv.second->err; } bad = true; }
+                else break;
+            }
+            if (bad) break;
+            if (b->rc) { bad = true; bad_rc = b->rc; bad_msg = b->err; std::lock_guard<std::mutex> lk(mu); failed = true; cv_in.notify_all(); cv_space.notify_all(); break; }
+            const double t = now();
+            const size_t n = b->n_reads;
+            for (size_t t2 = 0; t2 < b->outs.size(); t2++) {
+                fwrite(b->outs[t2].data(), 1, b->outs[t2].size(), sam);
+                total.unique += b->cts[t2].unique; total.unmapped += b->cts[t2].unmapped; total.paired += b->cts[t2].paired;
+            }
+            total.total += (long long)n;
+            for (size_t k = 0; k < b->used[2]; k++) sjmap[std::make_pair(b->sj[k].g1, b->sj[k].g2)]++;   // UpdateLocal/GlobalSJMap, Mapping.cpp:532-577
+            if (!o.silent) { fprintf(stdout, "\r%lld %s tags have been processed in %lld seconds...", total.total, pair_end ? "paired-end" : "singled-end", (long long)(time(NULL) - t0)); fflush(stdout); }
+            t_write += now() - t;
+            next_out++;
+            std::lock_guard<std::mutex> lk(mu);
+            in_flight--; cv_space.notify_all();
         }
+        reader.join();
+        pf1.finish(); pf2.finish();
+        for (auto &w : workers) w.join();
+        if (bad) { fprintf(stderr, "\nError! GPU mapping failed (%d): %s\n", bad_rc, bad_msg.c_str()); return 1; }
+        if (getenv("DART_TIMING")) fprintf(stderr, "[dart timing] read+parse %.3f s, map (sum over workers) %.3f s, format %.3f s, write %.3f s\n", t_read, t_map, t_fmt, t_write);
         if (s1.fp) fclose(s1.fp);
         if (s2.fp) fclose(s2.fp);
         if (s1.gz) gzclose(s1.gz);
@@ -458,7 +658,8 @@ int main(int argc, char *argv[])
     }
     if (!o.silent) fprintf(stdout, "\rAll the %lld %s reads have been processed in %lld seconds.\n", total.total, pair_end ? "paired-end" : "single-end", (long long)(time(NULL) - t0));
     fclose(sam);
-    for (auto c : ctx) dg_destroy(c);
+    for (auto c : clones) dg_destroy(c);
+    for (auto c : roots) dg_destroy(c);
 
     if (total.total > 0) {   // Mapping.cpp:812-822
         const long long T = total.total, U = total.unmapped;

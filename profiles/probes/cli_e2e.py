@@ -1,0 +1,27 @@
+"""End-to-end timing of the product's `dart` command line (FASTQ on /tmp -> SAM on /tmp) on the bench workload, and a
+byte comparison of its SAM / junctions with the oracle's command line.  Usage: python profiles/probes/cli_e2e.py [pairs]"""
+import os, sys, time, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench
+from dart_amd import synth
+import oracle_py
+pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+prefix, g = bench.prepare_index("/tmp/dart_bench_cache", bench.CHR20_LEN, 0, lambda: None)
+m1, m2 = synth.make_reads(g, pairs, rlen=101, seed=1000, sub_rate=0.01, indel_frac=0.02, n_frac=0.002)
+d = "/tmp/cli_e2e"; os.makedirs(d, exist_ok=True)
+synth.write_fastq(os.path.join(d, "1.fq"), m1, 1); synth.write_fastq(os.path.join(d, "2.fq"), m2, 2)
+dart = os.path.join(ROOT, "dart_amd", "dart")
+for env_extra in ({"DART_INFLIGHT": "1"}, {"DART_INFLIGHT": "2"}, {"DART_INFLIGHT": "3"}):
+    env = dict(os.environ, DART_TIMING="1", **env_extra)
+    t = time.time()
+    r = subprocess.run([dart, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-o", "gpu.sam", "-j", "gpu.j", "-t", "16", "-mis", "5"], cwd=d, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    dt = time.time() - t
+    print(env_extra, "dart wall %.2f s = %.2f M reads/s (incl. index load + dg_init)" % (dt, 2 * pairs / dt / 1e6), r.stderr.decode().strip().splitlines()[-1:])
+if os.environ.get("CLI_E2E_COMPARE", "1") == "1":
+    oracle_py.build()
+    t = time.time()
+    subprocess.run([oracle_py.ORACLE_CLI, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-o", "orc.sam", "-j", "orc.j", "-t", "16", "-mis", "5"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    print("oracle CLI wall %.2f s" % (time.time() - t))
+    same = subprocess.run(["cmp", "gpu.sam", "orc.sam"], cwd=d).returncode == 0 and subprocess.run(["cmp", "gpu.j", "orc.j"], cwd=d).returncode == 0
+    print("SAM + junctions byte-identical to the oracle CLI:", same, os.path.getsize(os.path.join(d, "gpu.sam")), "bytes")
