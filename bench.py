@@ -218,7 +218,8 @@ def main():
         "k_seed": 64 * counters["occ_blocks"] + int(rl.sum()) + 16 * n_reads,
         "k_locate": 64 * counters["lf_steps"] + 8 * counters["sa_lookups"] + 24 * counters["seeds"],
     }
-    dom = max(("k_seed", "k_locate", "k_chain", "k_report"), key=lambda k: kern.get(k, 0.0))
+    # the dominant kernel = the longest when a step runs alone (the shared, in-flight durations move with scheduling)
+    dom = max(("k_seed", "k_locate", "k_chain", "k_report"), key=lambda k: iso.get(k, kern.get(k, 0.0)))
     per_read_B = (alg["k_seed"] + alg["k_locate"]) / n_reads
     dom_bytes = alg.get(dom)
     if dom_bytes is None:      # report/chain kernels: count the whole path's index bytes against them is wrong -> use their own I/O
