@@ -147,6 +147,8 @@ def main():
         if rank == 0 and gather_buf is None:
             gather_buf = [torch.empty_like(local_t) for _ in range(world)]
         dist.gather(local_t, gather_buf if rank == 0 else None, dst=0)
+        if not rehearse:
+            torch.cuda.synchronize()           # the context's next run overwrites these records: the copy must have left HBM
 
     import threading
     def run_steps(n_steps, acc, ctxs=ctxs):
