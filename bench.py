@@ -148,7 +148,9 @@ def main():
             gather_buf = [torch.empty_like(local_t) for _ in range(world)]
         dist.gather(local_t, gather_buf if rank == 0 else None, dst=0)
         if not rehearse:
-            torch.cuda.synchronize()           # the context's next run overwrites these records: the copy must have left HBM
+            # the context's next run overwrites these records: wait for the copy on torch's stream only (a device-wide
+            # synchronize would also wait for the other batches in flight)
+            torch.cuda.current_stream().synchronize()
 
     import threading
     def run_steps(n_steps, acc, ctxs=ctxs):
