@@ -418,7 +418,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     c->ix.loc_key = (const int64_t *)c->d_lockey; c->ix.loc_chr = (const int32_t *)c->d_locchr; c->ix.chr_off = (const int64_t *)c->d_chroff;
     c->ix.primary = v->primary; for (int i = 0; i < 5; i++) c->ix.L2[i] = v->L2[i]; c->ix.seq_len = v->seq_len;
     c->ix.l_pac = v->l_pac; c->ix.n_chr = v->n_chr; c->ix.sa_intv = v->sa_intv;
-    c->ix.ktab = nullptr; c->ix.ktab_k = 0; c->ix.sa_dense = nullptr; c->ix.sa_dense_intv = 0;
+    c->ix.ktab = nullptr; c->ix.ktab_k = 0; c->ix.sa_dense = nullptr; c->ix.sa_dense_intv = 0; c->ix.sa_dense_shift = 0;
     {   // full suffix array in HBM (8 bytes per text symbol: 1 GB for chr20, 50 GB for a human genome -- this is what
         // 288 GB are for): locating a row is one load instead of a walk of up to 31 LF steps.  Texts too large for
         // that fall back to every 2nd / 4th row; DG_SA_DENSE=0 turns it off, =2/4/8/16 forces an interval
@@ -430,6 +430,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
             k_build_sa_dense<<<(unsigned)((n_entries + 255) / 256), 256, 0, c->stream>>>(c->ix, intv, n_entries, (uint64_t *)c->d_sa_dense);
             if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_sa_dense", e);
             c->ix.sa_dense = (const uint64_t *)c->d_sa_dense; c->ix.sa_dense_intv = intv;
+            for (int sh = 0; (1 << sh) < intv; sh++) c->ix.sa_dense_shift = sh + 1;
         }
     }
     {   // K-mer prefix table: the smallest K with 4^K >= text length (so that most K-mers are unique or absent and a

@@ -67,6 +67,7 @@ struct DIndex {
     int64_t  l_pac;
     int32_t  n_chr, sa_intv;
     int32_t  ktab_k, sa_dense_intv;
+    int32_t  sa_dense_shift;      // log2(sa_dense_intv): a 64-bit division by a run-time value is ~150 instructions per lane
 };
 
 struct DParams {

@@ -236,7 +236,7 @@ k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
         uint64_t k = x0, st = 0;
         const uint64_t mask = (uint64_t)ix.sa_dense_intv - 1;
         while (k & mask) { k = d_lf(ix, k); st++; }
-        const uint64_t e = ix.sa_dense[k / (uint64_t)ix.sa_dense_intv];
+        const uint64_t e = ix.sa_dense[k >> ix.sa_dense_shift];
         x1 = (st + (e & 0xFFFFFFFFFFull)) & 0xFFFFFFFFFFull;          // (pos + 1), pos = st + SA - 1
         lfc = st + (e >> 40);                                          // the walk to a sampled row has no fixed bound
     }
@@ -390,7 +390,7 @@ __device__ __forceinline__ void d_trip_issue(const DIndex &ix, RM &rm, int len, 
             ta.pa = ix.bwt + ((t.kk >> 7) << 2);
             t.aux = T_LF;
         } else {
-            ta.p8 = (const uint2_a4 *)(ix.sa_dense + s.lk / (uint64_t)ix.sa_dense_intv);
+            ta.p8 = (const uint2_a4 *)(ix.sa_dense + (s.lk >> ix.sa_dense_shift));
             t.aux = T_SA;
         }
     } else {                                       // mode 2: 64 text symbols = five pac words
@@ -796,7 +796,7 @@ k_locate(const DIndex ix, int n_reads, int H, const DHit *__restrict__ hits, con
             else if (ix.sa_dense) {
                 const uint64_t mask = (uint64_t)ix.sa_dense_intv - 1;
                 while (k & mask) { k = d_lf(ix, k); steps++; }
-                const uint64_t e = ix.sa_dense[k / (uint64_t)ix.sa_dense_intv];
+                const uint64_t e = ix.sa_dense[k >> ix.sa_dense_shift];
                 pos = steps + (e & 0xFFFFFFFFFFull) - 1;
                 lf += steps + (e >> 40); lf_act += steps;
             } else {
