@@ -83,8 +83,8 @@ def prepare_index(cache_dir, genome_len, rank, barrier, n_introns=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=1000000, help="pairs per GPU per step")
     ap.add_argument("--genome", type=int, default=CHR20_LEN)
     ap.add_argument("--mis", type=int, default=5, help="-mis N (MaxMismatch); the reference default is 0, see DESIGN.md")
@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--spliced", type=float, default=0.0, help="fraction of reads spanning a planted intron (BASELINE config 5 shape: --rlen 151 --spliced 0.3 --introns 20000)")
     ap.add_argument("--introns", type=int, default=0, help="introns planted in the synthetic genome")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("DART_BENCH_STAGGER_MS", "0")))
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "4")),
                     help="batches in flight per GPU: contexts sharing one index, one host thread each (dg_clone)")
     ap.add_argument("--cache", default=os.environ.get("DART_BENCH_CACHE", "/tmp/dart_bench_cache"))
@@ -153,19 +154,25 @@ def main():
             torch.cuda.current_stream().synchronize()
 
     import threading
+    stagger_ms = args.stagger_ms
     def run_steps(n_steps, acc, ctxs=ctxs):
         done = [threading.Semaphore(0) for _ in ctxs]       # a step of this context has finished
         free = [threading.Semaphore(0) for _ in ctxs]       # its records have been gathered, the next step may start
         errs = []
         def worker(j):
             try:
+                # start the contexts a quarter of a step apart: in lock step all batches are in the same stage at the same
+                # time (four k_seed, then four k_report ...) and compete for the same resource instead of complementing each other
+                if stagger_ms > 0 and j:
+                    time.sleep(j * stagger_ms * 1e-3)
                 for k in range(j, n_steps, len(ctxs)):
                     ctxs[j].run()
                     if acc is not None:
                         for name, ms in ctxs[j].timings():
                             acc[name] = acc.get(name, 0.0) + ms
                     done[j].release()
-                    free[j].acquire()
+                    if dist is not None:                # only the N>1 gather needs the records to stay put
+                        free[j].acquire()
             except Exception as e:                          # surface the failure instead of hanging the main thread
                 errs.append(e)
                 done[j].release()

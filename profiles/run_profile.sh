@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1 || true   # builds and caches the index outside the profiler
-# the default command (8 steps, 4 warm-up, 4 batches in flight), minus the CPU leg
+# the default command (24 steps, 8 warm-up, 4 batches in flight), minus the CPU leg
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 # counters: one batch in flight (the profiler serialises dispatches anyway), separate passes
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 2 --warmup 0 --inflight 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
