@@ -613,6 +613,15 @@ __device__ inline int d_process_pair_small(LaneCtx &cx, DSeed &sp, int mode, uin
         for (int i = 0; i < m; i++) if (((A >> (8 * i)) & 0xFF) != ((B >> (8 * i)) & 0xFF)) nm++;     // CalFragPairMismatchBases :40-47
         if (nm <= 2 && nm <= (int)(m * 0.2)) { cig[nc++] = CIG(m, OP_M); return m - nm; }
     }
+    if (m == 1 && n == 1) {
+        // the commonest pair by far (one substituted base between two exact seeds): nw_alignment of two different
+        // characters.  s[1][1] = tr(-1.5) = -1 beats r = t = -3 whatever the characters are, so the traceback is the
+        // diagonal: one M column with unequal characters, in every mode (one state change, one mismatch: the local
+        // quality check passes and nothing is trimmed)
+        cx.n_nw++; cx.nw_cells += 1;
+        cig[nc++] = CIG(1, OP_M);
+        return 0;
+    }
     // nw_alignment, one strip of 8 columns, rows in registers
     cx.n_nw++; cx.nw_cells += (unsigned long long)m * (unsigned long long)n;
     int sp_[NW_STRIP], tp_[NW_STRIP];
