@@ -233,3 +233,33 @@ def test_gpu_reference_equivalent_counters(workdir):
     # interval's two rows straddle a 128-row block (1 in 128 steps), so the figure is a lower bound, < 1 % under
     assert 0 <= oc["n_occ_blocks"] - (c["occ_blocks"] + c["lf_steps"]) <= 1e-2 * oc["n_occ_blocks"]
     gpu.close(); orc.close()
+
+
+def test_gpu_full_size_batch_matches_oracle(workdir):
+    """BASELINE configs[1] at full size: chr20-sized genome, 1 M pairs 2x101 in ONE batch, every record field, CIGAR op and
+    splice-junction tuple against the oracle (16 threads, a few seconds)."""
+    import bench
+    cache = os.path.join(workdir, "bench_cache")
+    prefix, g = bench.prepare_index(cache, bench.CHR20_LEN, 0, lambda: None)
+    m1, m2 = synth.make_reads(g, 1000000, rlen=101, seed=1000, sub_rate=0.01, indel_frac=0.02, n_frac=0.002)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
+    assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=16))
+    gpu.close(); orc.close()
+
+
+def test_gpu_spliced_2x151_batch_matches_oracle(workdir):
+    """BASELINE configs[4] shape on the chr20-sized genome: 2x151, 30 % of the reads span a planted intron of 200 b - 500 kb
+    (half with GT..AG), -max_intron 500000: the long-gap re-seeding and NW stress, 300 k pairs against the oracle."""
+    import bench
+    cache = os.path.join(workdir, "bench_cache")
+    prefix, g = bench.prepare_index(cache, bench.CHR20_LEN, 0, lambda: None, 20000)
+    m1, m2 = synth.make_reads(g, 300000, rlen=151, seed=1001, sub_rate=0.01, indel_frac=0.02, n_frac=0.002, spliced_frac=0.3)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5, max_intron=500000))
+    res = gpu.map_batch(so, rl, flat)
+    assert_same(res, orc.map_batch(orc.params(paired=1, max_mismatch=5, max_intron=500000), so, rl, flat, threads=16))
+    assert len(res.sj) > 10000                       # the junction path really ran
+    gpu.close(); orc.close()
