@@ -487,8 +487,17 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
     uint32_t pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;      // words of the reads being prefetched, in flight
     unsigned int pend_total = 0;
     uint32_t *const tab = sh + 2 * W * 64;             // rank in the batch -> lane | buffer << 8
-    auto rb = [&](int w) -> uint32_t { return w < W2 ? (USE_LDS ? sh[(cur * W + w) * 64 + lane] : enc[(size_t)r * W + w]) : 0u; };
-    auto rm = [&](int w) -> uint32_t { return w < W2 ? (USE_LDS ? sh[(cur * W + W2 + w) * 64 + lane] : enc[(size_t)r * W + W2 + w]) : 0xFFFFFFFFu; };
+    // unconditional reads with a clamped index + a select: `w < W2 ? load : const` would be a branch around every load
+    auto rb = [&](int w) -> uint32_t {
+        const int wc = w < W2 ? w : W2 - 1;
+        const uint32_t v = USE_LDS ? sh[(cur * W + wc) * 64 + lane] : enc[(size_t)(r < 0 ? 0 : r) * W + wc];
+        return w < W2 ? v : 0u;
+    };
+    auto rm = [&](int w) -> uint32_t {
+        const int wc = w < W2 ? w : W2 - 1;
+        const uint32_t v = USE_LDS ? sh[(cur * W + W2 + wc) * 64 + lane] : enc[(size_t)(r < 0 ? 0 : r) * W + W2 + wc];
+        return w < W2 ? v : 0xFFFFFFFFu;
+    };
     // guided self-scheduling: one atomic buys this wave a run of reads (many at the start, few near the end),
     // so 2 M reads cost thousands of atomics on `next_read`, not one per refill
     auto grab = [&]() {
@@ -659,8 +668,8 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
         __syncthreads();
         for (int w = lane; w < W; w += 64) sh[w] = enc[(size_t)r * W + w];
         __syncthreads();
-        auto rb = [&](int w) -> uint32_t { return w < W2 ? sh[w] : 0u; };
-        auto rm = [&](int w) -> uint32_t { return w < W2 ? sh[W2 + w] : 0xFFFFFFFFu; };
+        auto rb = [&](int w) -> uint32_t { const uint32_t v = sh[w < W2 ? w : W2 - 1]; return w < W2 ? v : 0u; };
+        auto rm = [&](int w) -> uint32_t { const uint32_t v = sh[W2 + (w < W2 ? w : W2 - 1)]; return w < W2 ? v : 0xFFFFFFFFu; };
         int pos = hv.pos, nh = hv.nh;
         uint32_t ns = hv.ns;
         while (pos < end_pos) {                      // uniform
