@@ -685,7 +685,9 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
                 if (acgt && direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
                 while (__ballot(acgt && s.mode != 0)) {
                     t.aux = T_NONE; ta.pa = ta.pb = ta.p16 = nullptr; ta.p8 = nullptr;
-                    if (acgt && s.mode != 0) d_trip_issue(ix, rm, len, direct, s, c, ta, t);
+                    // as in k_seed: the cheap locate mode every trip, and the fuller of the two heavy modes
+                    const int sel = __popcll(__ballot(acgt && s.mode == 1)) >= __popcll(__ballot(acgt && s.mode == 2)) ? 1 : 2;
+                    if (acgt && (s.mode == 3 || s.mode == sel)) d_trip_issue(ix, rm, len, direct, s, c, ta, t);
                     d_trip_load(ta, t);
                     if (t.aux != T_NONE) d_trip_finish(ix, pr, rb, rm, len, s, c, t);
                     if (acgt && direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
