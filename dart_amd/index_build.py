@@ -130,7 +130,122 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
     return sa
 
 
-def build_index(prefix: str, names, annos, seqs, device: str | None = None) -> dict:
+def suffix_array_bucketed(codes: torch.Tensor, log=None) -> torch.Tensor:
+    """Suffix array of codes+'$' for texts too large for `suffix_array` (which keeps ~9 arrays of N int64 alive:
+    150 GB at 2 G symbols): the suffixes are split by their first two symbols into <= 21 buckets whose relative order
+    is known, and prefix doubling runs bucket by bucket -- the sort temporaries are bucket-sized, only sa, rank and the
+    next round's rank are full-length (3 x 8 N bytes: 150 GB at GRCh38 size, N = 6.2 G).  After the first round only
+    the members of groups that are still tied are sorted again (Larsson-Sadakane style), so later rounds cost what the
+    repeats cost.  Same result as `suffix_array` (the suffix array is unique)."""
+    dev = codes.device
+    n = int(codes.numel())
+    N = n + 1
+    k0 = 16
+    t = torch.zeros(N + k0 + 1, dtype=torch.uint8, device=dev)
+    t[:n] = codes + 1                                            # '$' (and the padding behind it) = 0
+    bid = t[:N].to(torch.int16) * 5 + t[1:N + 1].to(torch.int16)
+    counts = torch.bincount(bid.to(torch.int64) if N < (1 << 24) else bid.to(torch.int32), minlength=25).to(torch.int64).cpu()
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)])
+    assert int(counts.max()) < (1 << 29), "a two-symbol bucket holds >= 2^29 suffixes: use three-symbol buckets"
+    sa = torch.empty(N, dtype=torch.int64, device=dev)
+    rank = torch.empty(N, dtype=torch.int64, device=dev)
+    pending = {}                                                  # bucket -> positions (in the bucket) still in tied groups
+
+    def regroup(sk, lo, members, pos_in_bucket, rank_out):
+        """sk: sorted keys of the processed elements (in order), members: their suffixes in that order,
+        pos_in_bucket: their (ascending) positions.  Writes ranks = absolute position of each group's first element;
+        returns the positions that are still tied."""
+        m = sk.numel()
+        flag = torch.ones(m, dtype=torch.bool, device=dev)
+        if m > 1:
+            flag[1:] = sk[1:] != sk[:-1]
+        start = torch.cummax(torch.where(flag, pos_in_bucket, torch.zeros_like(pos_in_bucket)), 0).values
+        rank_out[members] = start + lo
+        single = flag.clone()
+        if m > 1:
+            single[:-1] &= flag[1:]
+        return pos_in_bucket[~single]
+
+    for b in range(25):                                           # round 0: the first k0 symbols
+        m = int(counts[b])
+        if m == 0:
+            continue
+        lo = int(offs[b])
+        idx = torch.nonzero(bid == b).squeeze(1)
+        key = torch.zeros(m, dtype=torch.int64, device=dev)
+        for j in range(k0):
+            key = key * 5 + t[idx + j].to(torch.int64)
+        sk, order = torch.sort(key)
+        del key
+        members = idx[order]
+        del idx, order
+        sa[lo:lo + m] = members
+        rest = regroup(sk, lo, members, torch.arange(m, dtype=torch.int64, device=dev), rank)
+        del sk, members
+        if rest.numel():
+            pending[b] = rest
+        if log:
+            log("  bucket %2d: %d suffixes, %d still tied after %d symbols" % (b, m, int(rest.numel()), k0))
+    del bid
+    k = k0
+    while pending:
+        rank_new = rank.clone()
+        for b in sorted(pending):
+            lo = int(offs[b])
+            pos = pending[b]                                      # ascending positions inside the bucket
+            members = sa[lo + pos]
+            r1 = rank[members] - lo                               # < 2^29
+            nxt = members + k
+            r2 = torch.where(nxt < N, rank[nxt.clamp(max=N - 1)] + 1, torch.zeros_like(nxt))
+            key = (r1 << 34) | r2                                 # r2 <= N < 2^34
+            del r1, r2, nxt
+            sk, order = torch.sort(key)
+            del key
+            members = members[order]
+            del order
+            sa[lo + pos] = members                                # a tied group occupies the same positions before and after
+            rest = regroup(sk, lo, members, pos, rank_new)
+            del sk, members
+            if rest.numel():
+                pending[b] = rest
+            else:
+                del pending[b]
+        rank = rank_new
+        del rank_new
+        k *= 2
+        if log:
+            log("  after %d symbols: %d suffixes still tied" % (k, sum(int(v.numel()) for v in pending.values())))
+    return sa
+
+
+def _pack_bwt_occ(bwt: torch.Tensor, n: int):
+    """bwt: uint8 [n] on any device -> (blocks uint32 [nblk,16] numpy, occ_last uint64 [4]) in the .bwt layout, in chunks."""
+    dev = bwt.device
+    nblk = (n + 127) // 128
+    blocks = np.zeros((nblk, 16), dtype=np.uint32)
+    shifts = (30 - 2 * torch.arange(16, device=dev)).to(torch.int64)
+    run = torch.zeros(4, dtype=torch.int64, device=dev)
+    CH = 1 << 22                                                  # blocks per chunk (512 M symbols)
+    for b0 in range(0, nblk, CH):
+        b1 = min(nblk, b0 + CH)
+        seg = torch.zeros((b1 - b0) * 128, dtype=torch.uint8, device=dev)
+        s0, s1 = b0 * 128, min(n, b1 * 128)
+        seg[: s1 - s0] = bwt[s0:s1]
+        valid = torch.zeros((b1 - b0) * 128, dtype=torch.bool, device=dev)
+        valid[: s1 - s0] = True
+        words = (seg.view(-1, 16).to(torch.int64) << shifts).sum(dim=1).view(b1 - b0, 8)
+        b128, v128 = seg.view(b1 - b0, 128), valid.view(b1 - b0, 128)
+        per = torch.stack([((b128 == c) & v128).sum(dim=1) for c in range(4)], dim=1).to(torch.int64)   # [blocks,4]
+        cum = torch.cumsum(per, 0) + run                           # counts up to and including each block
+        before = cum - per
+        run = cum[-1].clone()
+        blocks[b0:b1, :8] = before.cpu().numpy().astype(np.uint64).view(np.uint32).reshape(b1 - b0, 8)
+        blocks[b0:b1, 8:] = words.cpu().numpy().astype(np.uint32)
+        del seg, valid, words, per, cum, before
+    return blocks, run.cpu().numpy().astype(np.uint64)
+
+
+def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=None) -> dict:
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
     fwd, holes, n_ambs = pack_sequences(seqs)
@@ -158,34 +273,34 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None) -> d
     # ---- text = forward + reverse complement ----
     text = np.concatenate([fwd, (3 - fwd)[::-1]])
     n = 2 * L
-    sa = suffix_array(torch.from_numpy(text).to(device))
-    primary = int(torch.nonzero(sa == 0)[0, 0])
     tt = torch.from_numpy(text).to(device)
-    prev = tt[(sa - 1).clamp(min=0)]
-    keep = torch.ones(n + 1, dtype=torch.bool, device=sa.device)
-    keep[primary] = False
-    bwt = prev[keep].cpu().numpy().astype(np.uint8)           # n symbols, '$' row removed
+    import os as _os
+    big = n >= (3 << 29) or _os.environ.get("DART_SA_BUCKETED") == "1"      # >= 1.6 G symbols: the lean sorter
+    sa = suffix_array_bucketed(tt, log) if big else suffix_array(tt)
+    primary = int(torch.nonzero(sa == 0)[0, 0])
     sa_s = sa[32::32].cpu().numpy().astype(np.uint64)         # rows 32, 64, ... of the (n+1)-row matrix
-    del sa, prev, keep, tt
-    cnt = np.bincount(text, minlength=4).astype(np.uint64)
+    # BWT with the '$' row removed, gathered in chunks (the index tensor of a one-shot gather is another N int64)
+    bwt = torch.empty(n, dtype=torch.uint8, device=tt.device)
+    CH = 1 << 28
+    for r0 in range(0, n + 1, CH):
+        r1 = min(n + 1, r0 + CH)
+        prev = tt[(sa[r0:r1] - 1).clamp(min=0)]
+        if r0 <= primary < r1:                                # rows after the primary shift up by one
+            bwt[r0:primary] = prev[: primary - r0]
+            bwt[primary:r1 - 1] = prev[primary - r0 + 1:]
+        elif r1 <= primary:
+            bwt[r0:r1] = prev
+        else:
+            bwt[r0 - 1:r1 - 1] = prev
+        del prev
+    del sa
+    cnt = torch.bincount(tt.to(torch.int64) if n < (1 << 24) else tt.to(torch.int32), minlength=4).cpu().numpy().astype(np.uint64)
+    del tt
     L2 = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
     # ---- Occ-interleaved .bwt ----
     nblk = (n + 127) // 128
-    bp = np.zeros(nblk * 128, dtype=np.uint8)
-    bp[:n] = bwt
-    w16 = bp.reshape(-1, 16).astype(np.uint32)
-    shifts = (30 - 2 * np.arange(16)).astype(np.uint32)
-    words = (w16 << shifts).sum(axis=1, dtype=np.uint64).astype(np.uint32).reshape(nblk, 8)
-    valid = np.zeros(nblk * 128, dtype=bool)
-    valid[:n] = True
-    occ = np.zeros((nblk + 1, 4), dtype=np.uint64)
-    b128 = bp.reshape(nblk, 128)
-    v128 = valid.reshape(nblk, 128)
-    for c in range(4):
-        occ[1:, c] = np.cumsum(((b128 == c) & v128).sum(axis=1)).astype(np.uint64)
-    blocks = np.zeros((nblk, 16), dtype=np.uint32)
-    blocks[:, :8] = occ[:-1].view(np.uint32).reshape(nblk, 8)
-    blocks[:, 8:] = words
+    blocks, occ_last = _pack_bwt_occ(bwt, n)
+    del bwt
     flat = blocks.reshape(-1)
     nwords = (n + 15) // 16
     body = flat[: (nblk - 1) * 16 + 8 + (nwords - (nblk - 1) * 8)] if nblk else flat[:0]
@@ -193,7 +308,7 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None) -> d
         f.write(np.array([primary], dtype=np.uint64).tobytes())
         f.write(L2[1:5].tobytes())
         f.write(body.tobytes())
-        f.write(occ[-1].tobytes())
+        f.write(occ_last.tobytes())
     with open(prefix + ".sa", "wb") as f:
         f.write(np.array([primary], dtype=np.uint64).tobytes())
         f.write(L2[1:5].tobytes())

@@ -107,3 +107,16 @@ def test_oracle_bwt_search_known_answers(oracles):
             assert got == freq
             if freq:
                 assert l.value == ln and out[:freq].tolist() == [int(x) for x in locs]
+
+
+def test_bucketed_suffix_sorter_gives_the_same_index(workdir, monkeypatch):
+    """the memory-lean sorter used for >= 1.6 G-symbol texts (dart_amd/index_build.py::suffix_array_bucketed) against the
+    plain prefix doubling, on a repeat-rich two-chromosome genome (several refinement rounds)"""
+    from dart_amd import synth, index_build
+    g = synth.make_genome([300000, 200000], seed=3, repeat_scale=30.0)
+    a, b = os.path.join(workdir, "sa_plain"), os.path.join(workdir, "sa_bucketed")
+    index_build.build_index_from_genome(g, a, device="cpu")
+    monkeypatch.setenv("DART_SA_BUCKETED", "1")
+    index_build.build_index_from_genome(g, b, device="cpu")
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert open(a + "." + ext, "rb").read() == open(b + "." + ext, "rb").read(), ext
