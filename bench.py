@@ -69,7 +69,7 @@ def prepare_index(cache_dir, genome_len, rank, barrier, n_introns=0):
         np.save(prefix + ".introns.npy", g.introns)
         log("[bench] genome %d bp generated in %.1f s" % (genome_len, time.time() - t))
         t = time.time()
-        index_build.build_index_from_genome(g, prefix)
+        index_build.build_index_from_genome(g, prefix, log=log)
         torch.cuda.empty_cache()
         log("[bench] index built in %.1f s" % (time.time() - t))
         open(done, "w").write("ok")

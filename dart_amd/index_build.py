@@ -143,8 +143,13 @@ def suffix_array_bucketed(codes: torch.Tensor, log=None) -> torch.Tensor:
     k0 = 16
     t = torch.zeros(N + k0 + 1, dtype=torch.uint8, device=dev)
     t[:n] = codes + 1                                            # '$' (and the padding behind it) = 0
-    bid = t[:N].to(torch.int16) * 5 + t[1:N + 1].to(torch.int16)
-    counts = torch.bincount(bid.to(torch.int64) if N < (1 << 24) else bid.to(torch.int32), minlength=25).to(torch.int64).cpu()
+    CHK = 1 << 30                                                 # torch.nonzero / bincount are limited to < 2^31 elements
+    bid = torch.empty(N, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(25, dtype=torch.int64)
+    for c0 in range(0, N, CHK):
+        c1 = min(N, c0 + CHK)
+        bid[c0:c1] = (t[c0:c1].to(torch.int16) * 5 + t[c0 + 1:c1 + 1].to(torch.int16)).to(torch.uint8)
+        counts += torch.bincount(bid[c0:c1].to(torch.int32), minlength=25).to(torch.int64).cpu()
     offs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)])
     assert int(counts.max()) < (1 << 29), "a two-symbol bucket holds >= 2^29 suffixes: use three-symbol buckets"
     sa = torch.empty(N, dtype=torch.int64, device=dev)
@@ -171,7 +176,7 @@ def suffix_array_bucketed(codes: torch.Tensor, log=None) -> torch.Tensor:
         if m == 0:
             continue
         lo = int(offs[b])
-        idx = torch.nonzero(bid == b).squeeze(1)
+        idx = torch.cat([torch.nonzero(bid[c0:min(N, c0 + CHK)] == b).squeeze(1) + c0 for c0 in range(0, N, CHK)])
         key = torch.zeros(m, dtype=torch.int64, device=dev)
         for j in range(k0):
             key = key * 5 + t[idx + j].to(torch.int64)
@@ -277,7 +282,7 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=
     import os as _os
     big = n >= (3 << 29) or _os.environ.get("DART_SA_BUCKETED") == "1"      # >= 1.6 G symbols: the lean sorter
     sa = suffix_array_bucketed(tt, log) if big else suffix_array(tt)
-    primary = int(torch.nonzero(sa == 0)[0, 0])
+    primary = int(torch.argmin(sa))                           # the row of suffix 0 (nonzero() is limited to < 2^31 elements)
     sa_s = sa[32::32].cpu().numpy().astype(np.uint64)         # rows 32, 64, ... of the (n+1)-row matrix
     # BWT with the '$' row removed, gathered in chunks (the index tensor of a one-shot gather is another N int64)
     bwt = torch.empty(n, dtype=torch.uint8, device=tt.device)
@@ -294,7 +299,7 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=
             bwt[r0 - 1:r1 - 1] = prev
         del prev
     del sa
-    cnt = torch.bincount(tt.to(torch.int64) if n < (1 << 24) else tt.to(torch.int32), minlength=4).cpu().numpy().astype(np.uint64)
+    cnt = sum(torch.bincount(tt[c0:min(n, c0 + (1 << 30))].to(torch.int32), minlength=4).to(torch.int64).cpu() for c0 in range(0, n, 1 << 30)).numpy().astype(np.uint64)
     del tt
     L2 = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
     # ---- Occ-interleaved .bwt ----
@@ -322,8 +327,8 @@ def build_index_from_fasta(fasta: str, prefix: str, device: str | None = None) -
     return build_index(prefix, names, annos, seqs, device)
 
 
-def build_index_from_genome(g, prefix: str, device: str | None = None) -> dict:
+def build_index_from_genome(g, prefix: str, device: str | None = None, log=None) -> dict:
     """g: dart_amd.synth.Genome (no FASTA round trip)."""
     asc = g.ascii()
     seqs = [asc[o:o + l].tobytes() for o, l in zip(g.offsets, g.lengths)]
-    return build_index(prefix, g.names, [""] * len(seqs), seqs, device)
+    return build_index(prefix, g.names, [""] * len(seqs), seqs, device, log)
