@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 static char g_init_error[512] = "";
@@ -427,8 +428,8 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
         if (intv >= 1 && intv < v->sa_intv && (intv & (intv - 1)) == 0 && v->seq_len < (1ull << 39)) {
             const uint64_t n_entries = v->seq_len / (uint64_t)intv + 1;
             if ((e = hipMalloc(&c->d_sa_dense, n_entries * 8)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc dense SA", e);
-            k_build_sa_dense<<<(unsigned)((n_entries + 255) / 256), 256, 0, c->stream>>>(c->ix, intv, n_entries, (uint64_t *)c->d_sa_dense);
-            if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_sa_dense", e);
+            k_build_sa_dense<<<(unsigned)std::min<uint64_t>((n_entries + 255) / 256, 1u << 22), 256, 0, c->stream>>>(c->ix, intv, n_entries, (uint64_t *)c->d_sa_dense);
+            if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_sa_dense", e);
             c->ix.sa_dense = (const uint64_t *)c->d_sa_dense; c->ix.sa_dense_intv = intv;
             for (int sh = 0; (1 << sh) < intv; sh++) c->ix.sa_dense_shift = sh + 1;
         }
@@ -443,8 +444,8 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
         if (K >= 2) {
             const size_t entries = (size_t)1 << (2 * K);
             if ((e = hipMalloc(&c->d_ktab, entries * 16)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc k-mer table", e);
-            k_build_ktab<<<(unsigned)((entries + 255) / 256), 256, 0, c->stream>>>(c->ix, K, (uint64_t *)c->d_ktab);
-            if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_ktab", e);
+            k_build_ktab<<<(unsigned)std::min<size_t>((entries + 255) / 256, (size_t)1 << 22), 256, 0, c->stream>>>(c->ix, K, (uint64_t *)c->d_ktab);
+            if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_ktab", e);
             c->ix.ktab = (const uint64_t *)c->d_ktab; c->ix.ktab_k = K;
         }
     }

@@ -216,8 +216,7 @@ __device__ __forceinline__ uint64_t d_lf_finish(const DIndex &ix, const OccBlock
 __global__ void __launch_bounds__(256)
 k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
 {
-    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (1ull << (2 * K))) return;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < (1ull << (2 * K)); id += (uint64_t)gridDim.x * blockDim.x) {   // grid-stride (K = 16: 2^32 entries)
     int c = (int)((id >> (2 * (K - 1))) & 3u);
     uint64_t x0 = d_L2(ix, c) + 1, x1 = d_L2(ix, 3 - c) + 1, x2 = d_L2(ix, c + 1) - d_L2(ix, c);
     uint32_t steps = 0, blocks = 0;
@@ -246,6 +245,7 @@ k_build_ktab(const DIndex ix, int K, uint64_t *__restrict__ tab)
     if (located) w1 |= 1ull << 62;
     if (x2 >> 31) w1 |= 1ull << 63;
     tab[id * 2 + 0] = w0; tab[id * 2 + 1] = w1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -738,13 +738,15 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
 __global__ void __launch_bounds__(256)
 k_build_sa_dense(const DIndex ix, int intv, uint64_t n_entries, uint64_t *__restrict__ dense)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_entries) return;
-    uint64_t k = i * (uint64_t)intv, steps = 0;
+    // grid-stride: a launch cannot have 2^32 work-items (the dispatch packet's grid size is 32 bits), a GRCh38-sized
+    // text has 6.2 G rows
     const uint64_t mask = (uint64_t)ix.sa_intv - 1;
-    while (k & mask) { k = d_lf(ix, k); steps++; }
-    const uint64_t pos = steps + ix.sa[k / (uint64_t)ix.sa_intv];      // sa[0] = -1 wraps as in the reference
-    dense[i] = ((pos + 1) & 0xFFFFFFFFFFull) | (steps << 40);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_entries; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = i * (uint64_t)intv, steps = 0;
+        while (k & mask) { k = d_lf(ix, k); steps++; }
+        const uint64_t pos = steps + ix.sa[k / (uint64_t)ix.sa_intv];      // sa[0] = -1 wraps as in the reference
+        dense[i] = ((pos + 1) & 0xFFFFFFFFFFull) | (steps << 40);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

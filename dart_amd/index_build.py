@@ -230,7 +230,7 @@ def _pack_bwt_occ(bwt: torch.Tensor, n: int):
     blocks = np.zeros((nblk, 16), dtype=np.uint32)
     shifts = (30 - 2 * torch.arange(16, device=dev)).to(torch.int64)
     run = torch.zeros(4, dtype=torch.int64, device=dev)
-    CH = 1 << 22                                                  # blocks per chunk (512 M symbols)
+    CH = 1 << 20                                                  # blocks per chunk (128 M symbols)
     for b0 in range(0, nblk, CH):
         b1 = min(nblk, b0 + CH)
         seg = torch.zeros((b1 - b0) * 128, dtype=torch.uint8, device=dev)
@@ -282,8 +282,11 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=
     import os as _os
     big = n >= (3 << 29) or _os.environ.get("DART_SA_BUCKETED") == "1"      # >= 1.6 G symbols: the lean sorter
     sa = suffix_array_bucketed(tt, log) if big else suffix_array(tt)
+    if log: log("  suffix array done")
     primary = int(torch.argmin(sa))                           # the row of suffix 0 (nonzero() is limited to < 2^31 elements)
+    if log: log("  primary = %d" % primary)
     sa_s = sa[32::32].cpu().numpy().astype(np.uint64)         # rows 32, 64, ... of the (n+1)-row matrix
+    if log: log("  SA sampled")
     # BWT with the '$' row removed, gathered in chunks (the index tensor of a one-shot gather is another N int64)
     bwt = torch.empty(n, dtype=torch.uint8, device=tt.device)
     CH = 1 << 28
@@ -299,12 +302,15 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=
             bwt[r0 - 1:r1 - 1] = prev
         del prev
     del sa
-    cnt = sum(torch.bincount(tt[c0:min(n, c0 + (1 << 30))].to(torch.int32), minlength=4).to(torch.int64).cpu() for c0 in range(0, n, 1 << 30)).numpy().astype(np.uint64)
+    if log: log("  BWT gathered")
+    cnt = np.array([sum(int((tt[c0:min(n, c0 + (1 << 30))] == c).sum()) for c0 in range(0, n, 1 << 30)) for c in range(4)], dtype=np.uint64)
     del tt
     L2 = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+    if log: log("  symbol counts done")
     # ---- Occ-interleaved .bwt ----
     nblk = (n + 127) // 128
     blocks, occ_last = _pack_bwt_occ(bwt, n)
+    if log: log("  Occ blocks packed")
     del bwt
     flat = blocks.reshape(-1)
     nwords = (n + 15) // 16
