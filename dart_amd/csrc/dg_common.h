@@ -98,6 +98,42 @@ __device__ __forceinline__ char d_refchar(const DIndex &ix, int64_t g)
     return (char)((rev ? 0x41434754u : 0x54474341u) >> (8u * c));     // "TGCA"[c] : "ACGT"[c] without a table in memory
 }
 
+typedef uint2 __attribute__((aligned(1))) uint2_a1;
+typedef uint32_t __attribute__((aligned(1))) uint32_a1;
+
+// up to 8 reference characters RefSequence[g0 .. g0+8) packed low byte first; positions outside the text give 0
+__device__ __forceinline__ uint64_t d_ref8(const DIndex &ix, int64_t g0)
+{
+    const int64_t L = ix.l_pac;
+    uint64_t out = 0;
+    if (g0 >= 0 && g0 + 8 <= L) {                              // forward strand: 8 bases = 16 bits out of 3 pac bytes
+        const uint32_t w = __builtin_bswap32(*(const uint32_a1 *)(ix.pac + (g0 >> 2))) << ((g0 & 3) << 1);
+#pragma unroll
+        for (int k = 0; k < 8; k++) out |= (uint64_t)((0x54474341u >> (8u * ((w >> (30 - 2 * k)) & 3u))) & 0xFFu) << (8 * k);
+        return out;
+    }
+    if (g0 >= L && g0 + 8 <= 2 * L) {                          // reverse strand: Ref[g0+k] = comp(fwd[f0-k])
+        const int64_t f0 = 2 * L - 1 - g0, lo = f0 - 7;        // fwd[lo..f0]
+        const uint32_t w = __builtin_bswap32(*(const uint32_a1 *)(ix.pac + (lo >> 2))) << ((lo & 3) << 1);   // fwd[lo+q] at bits 31-2q
+#pragma unroll
+        for (int k = 0; k < 8; k++) out |= (uint64_t)((0x41434754u >> (8u * ((w >> (16 + 2 * k)) & 3u))) & 0xFFu) << (8 * k);
+        return out;
+    }
+    for (int k = 0; k < 8; k++) out |= (uint64_t)(unsigned char)d_refchar(ix, g0 + k) << (8 * k);
+    return out;
+}
+
+// RefSequence[g0 .. g0+n) into dst, eight bases per pac fetch (a per-base d_refchar is a dependent load each, and on a
+// GRCh38-sized pac those miss the caches)
+__device__ __forceinline__ void d_ref_fill(const DIndex &ix, int64_t g0, int n, char *dst)
+{
+    for (int i = 0; i < n; i += 8) {
+        const uint64_t w = d_ref8(ix, g0 + i);
+        const int m = n - i < 8 ? n - i : 8;
+        for (int k = 0; k < m; k++) dst[i + k] = (char)(w >> (8 * k));
+    }
+}
+
 // ChrLocMap.lower_bound(g): index of the smallest key >= g
 __device__ __forceinline__ int d_loc_lower_bound(const DIndex &ix, int64_t g)
 {

@@ -313,7 +313,7 @@ __device__ inline int d_fill_gaps(LaneCtx &cx, DSeed *s, int n, const DSeed L, c
     int *Rv = (int *)ws_cig(cx), *Lv = Rv + rGaps + 1;      // the CIGAR scratch is idle at this stage
     const char *rd = (const char *)cx.seq + L.rPos + L.rLen;
     for (int i = 0; i <= rGaps; i++) Rv[i] = Lv[i] = 0;
-    for (int i = 0; i < rGaps; i++) g[i] = d_refchar(ix, L.gPos + L.gLen + i);
+    d_ref_fill(ix, L.gPos + L.gLen, rGaps, g);
     const int len = d_nw(cx, rd, rGaps, g, rGaps, f1, f2);
     int i = len - 1;
     while (i >= 0 && f2[i] == '-') i--;
@@ -321,7 +321,7 @@ __device__ inline int d_fill_gaps(LaneCtx &cx, DSeed *s, int n, const DSeed L, c
     for (i += 1; i < len; i++, gp++) f2[i] = d_refchar(ix, gp);
     int p = 0, sc = 0;
     for (i = 0; i < len; i++) { if (f1[i] == f2[i]) sc++; if (f1[i] != '-') p++; Rv[p] = sc; }
-    for (i = 0; i < rGaps; i++) g[i] = d_refchar(ix, R.gPos - rGaps + i);
+    d_ref_fill(ix, R.gPos - rGaps, rGaps, g);
     const int len3 = d_nw(cx, rd, rGaps, g, rGaps, f3, f4);
     i = 0;
     while (i < len3 && f4[i] == '-') i++;
@@ -366,7 +366,13 @@ __device__ __forceinline__ int d_shift_arr(int i) { return i == 0 ? 0 : ((i & 1)
 __device__ inline bool d_check_seq_fragment(const DIndex &ix, int64_t Lg, int64_t Rg, int shift)   // :702-730
 {
     if (shift <= 0) { shift = -shift; Lg -= shift; Rg -= shift; }
-    for (int i = 0; i < shift; i++, Lg++, Rg++) if (d_refchar(ix, Lg) != d_refchar(ix, Rg)) return false;
+    // shift <= 9 (ShiftArr): eight bases of each side in one fetch, the ninth on its own
+    const int n8 = shift < 8 ? shift : 8;
+    if (n8 > 0) {
+        const uint64_t m = n8 >= 8 ? ~0ull : ((1ull << (8 * n8)) - 1ull);
+        if ((d_ref8(ix, Lg) ^ d_ref8(ix, Rg)) & m) return false;
+    }
+    for (int i = 8; i < shift; i++) if (d_refchar(ix, Lg + i) != d_refchar(ix, Rg + i)) return false;
     return true;
 }
 
@@ -554,31 +560,6 @@ __device__ inline bool d_local_quality(const char *a1, const char *a2, int len) 
 // the genome, +4 = the two bases are the same character) -- no round trip through the lane's
 // scratch memory, which is what the generic path spends its time waiting for.
 // ---------------------------------------------------------------------------------------------
-typedef uint2 __attribute__((aligned(1))) uint2_a1;
-typedef uint32_t __attribute__((aligned(1))) uint32_a1;
-
-// up to 8 reference characters RefSequence[g0 .. g0+8) packed low byte first; positions outside the text give 0
-__device__ __forceinline__ uint64_t d_ref8(const DIndex &ix, int64_t g0)
-{
-    const int64_t L = ix.l_pac;
-    uint64_t out = 0;
-    if (g0 >= 0 && g0 + 8 <= L) {                              // forward strand: 8 bases = 16 bits out of 3 pac bytes
-        const uint32_t w = __builtin_bswap32(*(const uint32_a1 *)(ix.pac + (g0 >> 2))) << ((g0 & 3) << 1);
-#pragma unroll
-        for (int k = 0; k < 8; k++) out |= (uint64_t)((0x54474341u >> (8u * ((w >> (30 - 2 * k)) & 3u))) & 0xFFu) << (8 * k);
-        return out;
-    }
-    if (g0 >= L && g0 + 8 <= 2 * L) {                          // reverse strand: Ref[g0+k] = comp(fwd[f0-k])
-        const int64_t f0 = 2 * L - 1 - g0, lo = f0 - 7;        // fwd[lo..f0]
-        const uint32_t w = __builtin_bswap32(*(const uint32_a1 *)(ix.pac + (lo >> 2))) << ((lo & 3) << 1);   // fwd[lo+q] at bits 31-2q
-#pragma unroll
-        for (int k = 0; k < 8; k++) out |= (uint64_t)((0x41434754u >> (8u * ((w >> (16 + 2 * k)) & 3u))) & 0xFFu) << (8 * k);
-        return out;
-    }
-    for (int k = 0; k < 8; k++) out |= (uint64_t)(unsigned char)d_refchar(ix, g0 + k) << (8 * k);
-    return out;
-}
-
 __device__ __forceinline__ uint32_t d_colcode(uint64_t cols, int K, int p) { return (uint32_t)(cols >> (3 * (K - 1 - p))) & 7u; }
 
 __device__ inline int d_add_cigar_cols(uint64_t cols, int K, int p0, int p1, uint32_t *cig, int &nc)   // d_add_cigar on a column list
@@ -730,7 +711,7 @@ __device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t 
     }
     const char *rd = (const char *)cx.seq + sp.rPos;
     char *g = ws_str(cx, 0);
-    for (int i = 0; i < sp.gLen; i++) g[i] = d_refchar(ix, sp.gPos + i);
+    d_ref_fill(ix, sp.gPos, sp.gLen, g);
     if (sp.rLen == sp.gLen) {
         int n = 0;
         for (int i = 0; i < sp.rLen; i++) if (rd[i] != g[i]) n++;       // CalFragPairMismatchBases :40-47
