@@ -238,7 +238,9 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
          unsigned int *tops, unsigned char *ws, const WSLayout L, unsigned long long *ctr, int *err)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t lds_pm[64 * PM_LDS_WORDS];
     LaneCtx cx;
+    cx.lds = lds_pm + (threadIdx.x & 63) * PM_LDS_WORDS;
     cx.ix = &ix; cx.pr = &pr; cx.L = &L;
     cx.ws = ws + (size_t)lane * L.stride;
     cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
@@ -486,7 +488,8 @@ extern "C" int dg_batch_upload(dg_ctx *c, int n_reads, const uint32_t *seq_off, 
         if (rlen[i] > mx) mx = rlen[i];
     }
     c->n_reads = n_reads; c->max_rlen = mx; c->seq_bytes = bytes;
-    HIPCHK(c->seq.ensure(bytes + 16)); HIPCHK(c->seq_off.ensure((size_t)n_reads + 1)); HIPCHK(c->rlen.ensure((size_t)n_reads + 1));
+    HIPCHK(c->seq.ensure(bytes + 64));     /* the kernels read up to 24 bytes at a read position in one go */
+    HIPCHK(c->seq_off.ensure((size_t)n_reads + 1)); HIPCHK(c->rlen.ensure((size_t)n_reads + 1));
     if (n_reads) {
         HIPCHK(hipMemcpyAsync(c->seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->seq_off.p, seq_off, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
@@ -846,7 +849,7 @@ k_probe_nw(int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, c
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     LaneCtx cx;
-    cx.ix = &ix; cx.pr = &pr; cx.L = &L; cx.ws = ws + (size_t)i * L.stride; cx.seq = nullptr; cx.rlen = 0;
+    cx.ix = &ix; cx.pr = &pr; cx.L = &L; cx.ws = ws + (size_t)i * L.stride; cx.seq = nullptr; cx.rlen = 0; cx.lds = nullptr;
     cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
     out_len[i] = (uint32_t)d_nw(cx, a + a_off[i], (int)(a_off[i + 1] - a_off[i]), b + b_off[i], (int)(b_off[i + 1] - b_off[i]), out_a + out_off[i], out_b + out_off[i]);
 }

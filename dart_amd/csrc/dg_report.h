@@ -27,6 +27,7 @@ struct WSLayout {
 };
 
 struct LaneCtx {
+    uint32_t *lds;                // PM_LDS_WORDS words of LDS owned by this lane (d_pair_nw)
     const DIndex *ix;
     const DParams *pr;
     const unsigned char *seq;   // this read, ASCII
@@ -560,14 +561,26 @@ __device__ inline bool d_local_quality(const char *a1, const char *a2, int len) 
 // the genome, +4 = the two bases are the same character) -- no round trip through the lane's
 // scratch memory, which is what the generic path spends its time waiting for.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t d_colcode(uint64_t cols, int K, int p) { return (uint32_t)(cols >> (3 * (K - 1 - p))) & 7u; }
+// the gapped alignment as a column list, 4 bits per column, column 0 = the LAST column (traceback order)
+struct ColList { uint64_t w0, w1, w2; int K; };
+__device__ __forceinline__ uint32_t d_colcode(const ColList &c, int p)          // p counts from the first column
+{
+    const int k = c.K - 1 - p;
+    const uint64_t w = k < 16 ? c.w0 : (k < 32 ? c.w1 : c.w2);
+    return (uint32_t)(w >> ((k & 15) << 2)) & 7u;
+}
+__device__ __forceinline__ uint32_t d_byte3(uint64_t a0, uint64_t a1, uint64_t a2, int i)   // byte i of 24
+{
+    const uint64_t w = i < 8 ? a0 : (i < 16 ? a1 : a2);
+    return (uint32_t)(w >> ((i & 7) << 3)) & 0xFFu;
+}
 
-__device__ inline int d_add_cigar_cols(uint64_t cols, int K, int p0, int p1, uint32_t *cig, int &nc)   // d_add_cigar on a column list
+__device__ inline int d_add_cigar_cols(const ColList &cl, int p0, int p1, uint32_t *cig, int &nc)   // d_add_cigar on a column list
 {
     uint32_t state = 99;
     int c = 0, score = 0;
     for (int p = p0; p < p1; p++) {
-        const uint32_t cd = d_colcode(cols, K, p), ty = cd & 3u;
+        const uint32_t cd = d_colcode(cl, p), ty = cd & 3u;
         const uint32_t st = ty == 1 ? OP_D : (ty == 2 ? OP_I : OP_M);
         if (ty == 0 && (cd & 4u)) score++;
         if (state == st) c++;
@@ -577,48 +590,83 @@ __device__ inline int d_add_cigar_cols(uint64_t cols, int K, int p0, int p1, uin
     return score;
 }
 
-__device__ inline int d_process_pair_small(LaneCtx &cx, DSeed &sp, int mode, uint32_t *cig, int &nc, bool &handled)
+// ---------------------------------------------------------------------------------------------
+// ProcessNormal/Head/TailSequencePair for pairs of at most PM_MAX x PM_MAX bases, split in three so
+// that the nw_alignment calls of a wave's lanes can be executed TOGETHER (d_gen_mapping_report):
+//   d_pair_classify  the two strings as ASCII bytes in three register pairs each; the cheap
+//                    outcomes (equal length with <= 2 and <= 20 % mismatches -> M; 1 x 1) or
+//                    "needs nw_alignment"
+//   d_pair_nw        nw_alignment in strips of 8 columns held in registers (as d_nw), traceback
+//                    bits and strip boundary column in a 252-byte LDS slice of the lane, result =
+//                    a column list in three registers (4 bits per column: 0 = both bases, 1 = gap
+//                    in the read, 2 = gap in the genome, +4 = the two bases are the same character)
+//   d_pair_finish    AddNewCigarElements / CheckLocalAlignmentQuality / head and tail trimming on it
+// On a chr20-sized text almost every pair is 1 x 1 (a substituted base between two exact seeds);
+// on a GRCh38-sized one a chance 16-mer hit elsewhere usually follows the substitution (4^16 <
+// text length), the true locus resumes ~18 bases later and the typical pair is ~12 x 12: executed
+// one lane at a time, wherever each lane's loop happened to be, those alignments were 75 % of k_report.
+// ---------------------------------------------------------------------------------------------
+#define PM_MAX 24
+#define PM_LDS_WORDS 63          // per lane: 24 rows x 3 strips x u16 bits (144 B) + 2 x 25 x int16 boundary (100 B), odd stride
+#define PM_MAXQ 4                // nw_alignment results kept per candidate (more pairs than that: the rest run in place)
+struct PairStr { uint64_t A0, A1, A2, B0, B1, B2; };
+enum { PC_GENERIC = 0, PC_TRIVIAL, PC_EQUAL, PC_ONE, PC_NW };
+
+// which way does this pair go?  PC_GENERIC = too long or a literal '-' in the read (string path); PC_TRIVIAL = mode-2
+// early outs (tools.cpp:132-141); PC_EQUAL = equal length, few mismatches (*nm set); PC_ONE = 1 x 1; PC_NW
+__device__ inline int d_pair_classify(LaneCtx &cx, const DSeed &sp, int mode, PairStr &ps, int &nm)
 {
     const DIndex &ix = *cx.ix;
+    if (mode == 2 && (sp.gPos - sp.rPos == -1 || sp.rLen == 0 || sp.gLen == 0)) return PC_TRIVIAL;
     const int m = sp.rLen, n = sp.gLen;
-    handled = true;
-    const uint2 rq = *(const uint2_a1 *)(cx.seq + sp.rPos);
-    const uint64_t A = d_u64(rq.x, rq.y) & (m >= 8 ? ~0ull : ((1ull << (8 * m)) - 1ull));
-    {   // a literal '-' in the read changes what AddNewCigarElements sees: leave those to the generic path
-        const uint64_t z = A ^ 0x2D2D2D2D2D2D2D2Dull;
-        if (((z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull) & (m >= 8 ? ~0ull : ((1ull << (8 * m)) - 1ull))) { handled = false; return 0; }
+    if (m > PM_MAX || n > PM_MAX) return PC_GENERIC;
+    const unsigned char *rp = cx.seq + sp.rPos;
+    const uint2 r0 = *(const uint2_a1 *)rp, r1 = *(const uint2_a1 *)(rp + 8), r2 = *(const uint2_a1 *)(rp + 16);
+    auto keep = [](int len, int w) -> uint64_t { const int r = len - 8 * w; return r >= 8 ? ~0ull : (r <= 0 ? 0ull : ((1ull << (8 * r)) - 1ull)); };
+    ps.A0 = d_u64(r0.x, r0.y) & keep(m, 0); ps.A1 = d_u64(r1.x, r1.y) & keep(m, 1); ps.A2 = d_u64(r2.x, r2.y) & keep(m, 2);
+    {   // a literal '-' in the read changes what AddNewCigarElements sees: leave those to the string path
+        const uint64_t k = 0x2D2D2D2D2D2D2D2Dull, o = 0x0101010101010101ull, h = 0x8080808080808080ull;
+        const uint64_t z0 = ps.A0 ^ k, z1 = ps.A1 ^ k, z2 = ps.A2 ^ k;
+        if ((((z0 - o) & ~z0 & h) & keep(m, 0)) | (((z1 - o) & ~z1 & h) & keep(m, 1)) | (((z2 - o) & ~z2 & h) & keep(m, 2))) return PC_GENERIC;
     }
-    const uint64_t B = d_ref8(ix, sp.gPos) & (n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull));
+    ps.B0 = d_ref8(ix, sp.gPos) & keep(n, 0);
+    ps.B1 = n > 8 ? d_ref8(ix, sp.gPos + 8) & keep(n, 1) : 0ull;
+    ps.B2 = n > 16 ? d_ref8(ix, sp.gPos + 16) & keep(n, 2) : 0ull;
     if (m == n) {
-        int nm = 0;
-        for (int i = 0; i < m; i++) if (((A >> (8 * i)) & 0xFF) != ((B >> (8 * i)) & 0xFF)) nm++;     // CalFragPairMismatchBases :40-47
-        if (nm <= 2 && nm <= (int)(m * 0.2)) { cig[nc++] = CIG(m, OP_M); return m - nm; }
+        nm = 0;
+        for (int i = 0; i < m; i++) if (d_byte3(ps.A0, ps.A1, ps.A2, i) != d_byte3(ps.B0, ps.B1, ps.B2, i)) nm++;     // CalFragPairMismatchBases :40-47
+        if (nm <= 2 && nm <= (int)(m * 0.2)) return PC_EQUAL;
     }
-    if (m == 1 && n == 1) {
-        // the commonest pair by far (one substituted base between two exact seeds): nw_alignment of two different
-        // characters.  s[1][1] = tr(-1.5) = -1 beats r = t = -3 whatever the characters are, so the traceback is the
-        // diagonal: one M column with unequal characters, in every mode (one state change, one mismatch: the local
-        // quality check passes and nothing is trimmed)
-        cx.n_nw++; cx.nw_cells += 1;
-        cig[nc++] = CIG(1, OP_M);
-        return 0;
-    }
-    // nw_alignment, one strip of 8 columns, rows in registers
+    // 1 x 1 with two different characters: s[1][1] = tr(-1.5) = -1 beats r = t = -3 whatever the characters are, so the
+    // traceback is the diagonal: one M column with unequal characters, in every mode (one state change, one mismatch:
+    // the local quality check passes and nothing is trimmed)
+    if (m == 1 && n == 1) return PC_ONE;
+    return PC_NW;
+}
+
+__device__ inline void d_pair_nw(LaneCtx &cx, int m, int n, const PairStr &ps, ColList &cl)
+{
     cx.n_nw++; cx.nw_cells += (unsigned long long)m * (unsigned long long)n;
-    int sp_[NW_STRIP], tp_[NW_STRIP];
-    uint8_t cb[NW_STRIP];
+    uint16_t *bits = (uint16_t *)cx.lds;                     // bits[(i-1) * 3 + strip]
+    int16_t *colS = (int16_t *)(cx.lds + 36), *colR = colS + 25;
+    const int nstrips = (n + NW_STRIP - 1) / NW_STRIP;
+    for (int st = 0; st < nstrips; st++) {
+        const int j0 = st * NW_STRIP + 1;
+        const bool first = st == 0, last = st == nstrips - 1;
+        int sp_[NW_STRIP], tp_[NW_STRIP];
+        uint8_t cb[NW_STRIP];
 #pragma unroll
-    for (int q = 0; q < NW_STRIP; q++) {
-        sp_[q] = -2 - (q + 1); tp_[q] = -131072;
-        cb[q] = q < n ? d_nt4((unsigned char)(B >> (8 * q))) : 7;
-    }
-    uint32_t rb[4] = {0, 0, 0, 0};                              // traceback bits of row i at rb[(i-1)>>1], half (i-1)&1
-    int diag0 = 0;
-#pragma unroll
-    for (int i = 1; i <= 8; i++) {
-        if (i <= m) {
-            int left_s = -2 - i, left_r = -131072;
-            const uint8_t ca = d_nt4((unsigned char)(A >> (8 * (i - 1))));
+        for (int q = 0; q < NW_STRIP; q++) {
+            const int j = j0 + q;
+            sp_[q] = -2 - j; tp_[q] = -131072;
+            cb[q] = j <= n ? d_nt4((unsigned char)d_byte3(ps.B0, ps.B1, ps.B2, j - 1)) : 7;
+        }
+        int diag0 = first ? 0 : -2 - (j0 - 1);
+        for (int i = 1; i <= m; i++) {
+            int left_s, left_r;
+            if (first) { left_s = -2 - i; left_r = -131072; }
+            else { left_s = colS[i]; left_r = colR[i]; }
+            const uint8_t ca = d_nt4((unsigned char)d_byte3(ps.A0, ps.A1, ps.A2, i - 1));
             int diag = diag0;
             diag0 = left_s;
             uint32_t acc = 0;
@@ -636,36 +684,36 @@ __device__ inline int d_process_pair_small(LaneCtx &cx, DSeed &sp, int mode, uin
                 sp_[q] = sv; tp_[q] = t;
                 left_s = sv; left_r = r;
             }
-            rb[(i - 1) >> 1] |= acc << (16 * ((i - 1) & 1));
+            bits[(i - 1) * 3 + st] = (uint16_t)acc;
+            if (!last) { colS[i] = (int16_t)left_s; colR[i] = (int16_t)left_r; }
         }
     }
     // traceback :61-74 into the column list, last column first
-    uint64_t cols = 0;
-    int K = 0;
-    {
-        int i = m, j = n;
-        while (i > 0 || j > 0) {
-            uint32_t fl;
-            if (i == 0) fl = 1;
-            else if (j == 0) fl = 2;
-            else {
-                const int h = (i - 1) >> 1;
-                const uint32_t w = h == 0 ? rb[0] : (h == 1 ? rb[1] : (h == 2 ? rb[2] : rb[3]));
-                fl = ((w >> (16 * ((i - 1) & 1))) >> ((j - 1) << 1)) & 3u;
-            }
-            uint32_t code;
-            if (fl & 1u) { code = 1; j--; }
-            else if (fl & 2u) { code = 2; i--; }
-            else { code = (((A >> (8 * (i - 1))) & 0xFF) == ((B >> (8 * (j - 1))) & 0xFF)) ? 4u : 0u; i--; j--; }
-            cols |= (uint64_t)code << (3 * K);
-            K++;
-        }
+    cl.w0 = cl.w1 = cl.w2 = 0; cl.K = 0;
+    int i = m, j = n;
+    while (i > 0 || j > 0) {
+        uint32_t fl;
+        if (i == 0) fl = 1;
+        else if (j == 0) fl = 2;
+        else fl = ((uint32_t)bits[(i - 1) * 3 + ((j - 1) >> 3)] >> (((j - 1) & 7) << 1)) & 3u;
+        uint64_t code;
+        if (fl & 1u) { code = 1; j--; }
+        else if (fl & 2u) { code = 2; i--; }
+        else { code = d_byte3(ps.A0, ps.A1, ps.A2, i - 1) == d_byte3(ps.B0, ps.B1, ps.B2, j - 1) ? 4u : 0u; i--; j--; }
+        const int sh = (cl.K & 15) << 2;
+        if (cl.K < 16) cl.w0 |= code << sh; else if (cl.K < 32) cl.w1 |= code << sh; else cl.w2 |= code << sh;
+        cl.K++;
     }
-    if (mode == 2) return d_add_cigar_cols(cols, K, 0, K, cig, nc);
+}
+
+__device__ inline int d_pair_finish(const ColList &cl, DSeed &sp, int mode, uint32_t *cig, int &nc)
+{
+    const int K = cl.K;
+    if (mode == 2) return d_add_cigar_cols(cl, 0, K, cig, nc);
     {   // CheckLocalAlignmentQuality :166-201
         int nn = 0, mis = 0, type = -1, st = 0;
         for (int p = 0; p < K; p++) {
-            const uint32_t cd = d_colcode(cols, K, p), ty = cd & 3u;
+            const uint32_t cd = d_colcode(cl, p), ty = cd & 3u;
             if (ty == 1) { if (type != 0) { type = 0; st++; } }
             else if (ty == 2) { if (type != 1) { type = 1; st++; } }
             else { nn++; if (!(cd & 4u)) mis++; if (type != 2) { type = 2; st++; } }
@@ -674,20 +722,20 @@ __device__ inline int d_process_pair_small(LaneCtx &cx, DSeed &sp, int mode, uin
     }
     if (mode == 0) {
         int p0 = 0, p = 0;
-        while (p0 + p < K && (d_colcode(cols, K, p0 + p) & 3u) == 1) p++;
+        while (p0 + p < K && (d_colcode(cl, p0 + p) & 3u) == 1) p++;
         if (p > 0) { p0 += p; sp.gPos += p; sp.gLen -= p; }
         p = 0;
-        while (p0 + p < K && (d_colcode(cols, K, p0 + p) & 3u) == 2) p++;
+        while (p0 + p < K && (d_colcode(cl, p0 + p) & 3u) == 2) p++;
         if (p > 0) { p0 += p; sp.rPos += p; sp.rLen -= p; cig[nc++] = CIG(p, OP_S); }
-        return d_add_cigar_cols(cols, K, p0, K, cig, nc);
+        return d_add_cigar_cols(cl, p0, K, cig, nc);
     }
     int len = K, p = len - 1, c = 0;
-    while (p >= 0 && (d_colcode(cols, K, p) & 3u) == 1) { c++; p--; }
+    while (p >= 0 && (d_colcode(cl, p) & 3u) == 1) { c++; p--; }
     if (c > 0) { len -= c; sp.gLen -= c; }
     p = len - 1; c = 0;
-    while (p >= 0 && (d_colcode(cols, K, p) & 3u) == 2) { c++; p--; }
+    while (p >= 0 && (d_colcode(cl, p) & 3u) == 2) { c++; p--; }
     if (c > 0) { len -= c; sp.rLen -= c; }
-    const int score = d_add_cigar_cols(cols, K, 0, len, cig, nc);
+    const int score = d_add_cigar_cols(cl, 0, len, cig, nc);
     if (c > 0) cig[nc++] = CIG(c, OP_S);
     return score;
 }
@@ -703,11 +751,6 @@ __device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t 
             else if (sp.gLen > 0) cig[nc++] = CIG(sp.gLen, OP_D);
             return 0;
         }
-    }
-    if (sp.rLen <= 8 && sp.gLen <= 8) {
-        bool handled;
-        const int sc = d_process_pair_small(cx, sp, mode, cig, nc, handled);
-        if (handled) return sc;
     }
     const char *rd = (const char *)cx.seq + sp.rPos;
     char *g = ws_str(cx, 0);
@@ -802,6 +845,25 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, 
         const int num = n;
         if (num > 1 && !d_check_coordinate_validity(ix, s, num)) return;
         int nc = 1, mis_num = 0, aln = 0;                 // cig[0] is kept free for a leading soft clip
+        // (1) which pairs need nw_alignment?  (2) all lanes of the wave run their q-th alignment together;
+        // (3) the reference's loop (:1134-1160), consuming the stored column lists in order
+        uint32_t nwj = 0;                                 // seed indices (8 bits each) of the first PM_MAXQ alignments
+        int nq = 0;
+        for (int j = 0; j < num; j++) {
+            const DSeed &sd = s[j];
+            if ((sd.rLen == 0 && sd.gLen == 0) || (sd.flags & SEED_SIMPLE) || j > 254) continue;
+            PairStr ps; int nm;
+            if (nq < PM_MAXQ && d_pair_classify(cx, sd, j == 0 ? 0 : (j == num - 1 ? 1 : 2), ps, nm) == PC_NW) { nwj |= (uint32_t)j << (8 * nq); nq++; }
+        }
+        uint64_t *pmres = (uint64_t *)(cx.ws + cx.L->kmer_off);          // the k-mer list is idle at this stage: 4 u64 per result
+        for (int q = 0; q < nq; q++) {
+            const int j = (int)((nwj >> (8 * q)) & 255u);
+            PairStr ps; int nm; ColList cl;
+            d_pair_classify(cx, s[j], j == 0 ? 0 : (j == num - 1 ? 1 : 2), ps, nm);
+            d_pair_nw(cx, s[j].rLen, s[j].gLen, ps, cl);
+            pmres[4 * q] = cl.w0; pmres[4 * q + 1] = cl.w1; pmres[4 * q + 2] = cl.w2; pmres[4 * q + 3] = (uint64_t)cl.K;
+        }
+        int qn = 0;
         for (int j = 0; j < num; j++) {
             DSeed &sd = s[j];
             if (sd.rLen == 0 && sd.gLen == 0) continue;
@@ -809,7 +871,20 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, 
             if (j > 0 && (g = (int)(sd.gPos - (s[j - 1].gPos + s[j - 1].gLen))) > 0) cig[nc++] = CIG(g, OP_N);
             if (sd.flags & SEED_SIMPLE) { cig[nc++] = CIG(sd.rLen, OP_M); aln += sd.rLen; }
             else {
-                const int score = d_process_pair(cx, sd, j == 0 ? 0 : (j == num - 1 ? 1 : 2), cig, nc);
+                const int mode = j == 0 ? 0 : (j == num - 1 ? 1 : 2);
+                int score;
+                if (qn < nq && (int)((nwj >> (8 * qn)) & 255u) == j) {
+                    ColList cl; cl.w0 = pmres[4 * qn]; cl.w1 = pmres[4 * qn + 1]; cl.w2 = pmres[4 * qn + 2]; cl.K = (int)pmres[4 * qn + 3];
+                    qn++;
+                    score = d_pair_finish(cl, sd, mode, cig, nc);
+                } else {
+                    PairStr ps; int nm = 0;
+                    const int pc = d_pair_classify(cx, sd, mode, ps, nm);
+                    if (pc == PC_EQUAL) { cig[nc++] = CIG(sd.rLen, OP_M); score = sd.rLen - nm; }
+                    else if (pc == PC_ONE) { cx.n_nw++; cx.nw_cells += 1; cig[nc++] = CIG(1, OP_M); score = 0; }
+                    else if (pc == PC_NW) { ColList cl; d_pair_nw(cx, sd.rLen, sd.gLen, ps, cl); score = d_pair_finish(cl, sd, mode, cig, nc); }   // beyond PM_MAXQ
+                    else score = d_process_pair(cx, sd, mode, cig, nc);                                                               // trivial cases and the string path
+                }
                 aln += score;
                 mis_num += sd.rLen - score;
             }
