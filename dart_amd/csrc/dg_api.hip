@@ -254,13 +254,14 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
         base = lo + (unsigned int)__shfl((int)base, 0, 64);
         if (base >= hi) break;
         const unsigned int idx = base + (threadIdx.x & 63);
-        if (idx < hi) {
-            const int r = (int)perm[idx];
-            DRead rd;
-            rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0;           // defined start state
-            cx.seq = seq + seq_off[r]; cx.rlen = rlen[r];
-            d_gen_mapping_report(cx, paired ? (r & 1) == 0 : true, rd, cands + seed_off[r], (int)ncand[r], jobs, work,
-                                 reports + rep_off[r], rep_off[r], cigpool, tops + 0, cigcap, err);
+        const bool valid = idx < hi;                      // every lane enters d_gen_mapping_report (it has wave-wide steps)
+        const int r = valid ? (int)perm[idx] : 0;
+        DRead rd;
+        rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0;           // defined start state
+        cx.seq = seq + seq_off[r]; cx.rlen = rlen[r];
+        d_gen_mapping_report(cx, valid, paired ? (r & 1) == 0 : true, rd, cands + seed_off[r], valid ? (int)ncand[r] : 0, jobs, work,
+                             reports + rep_off[r], rep_off[r], cigpool, tops + 0, cigcap, err);
+        if (valid) {
             dg_read_out o;
             o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
             o.n_rep = rd.CanNum; o.best = rd.iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;

@@ -740,8 +740,97 @@ __device__ inline int d_pair_finish(const ColList &cl, DSeed &sp, int mode, uint
     return score;
 }
 
+// ---------------------------------------------------------------------------------------------
+// nw_alignment of ONE large pair by the whole wave (all 64 lanes call it with the same arguments):
+// anti-diagonal wavefront, lane = column (blocks of 64 columns), the three values a cell needs from
+// its left neighbour come by shuffle.  A 30 x 50 alignment is 80 steps of ~45 instructions instead of
+// 1500 cells x 30 in one lane while 63 lanes wait: on a GRCh38-sized text those large pairs (a chance
+// 16-mer hit elsewhere after a substitution, the true locus resuming ~30 bases later) hold 88 % of all
+// nw_alignment cells.  Output: traceback bits in the OWNER lane's scratch, column-major:
+// tb[(j-1) * RW + (i-1)/16], 2 bits per cell; the owner then runs the traceback itself.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void d_nw_coop(const DIndex &ix, const unsigned char *a, int m, int64_t gPos, int n, unsigned char *ows, const WSLayout &L, int lane)
+{
+    uint32_t *tb = (uint32_t *)(ows + L.nwbits_off);
+    int *colS = (int *)(ows + L.rows_off), *colR = colS + L.row_cap;   // s, r of the previous block's last column
+    const int RW = (m + 15) >> 4;
+    for (int j0 = 1; j0 <= n; j0 += 64) {
+        const int nb = n - j0 + 1 < 64 ? n - j0 + 1 : 64;
+        const int j = j0 + lane;
+        const bool col_ok = lane < nb, firstblk = j0 == 1, lastblk = j0 + 64 > n;
+        const uint8_t cb = col_ok ? d_nt4((unsigned char)d_refchar(ix, gPos + j - 1)) : 7;
+        int up_s = -2 - j, up_t = -131072;                 // s[0][j], t[0][j]
+        int cur_s = 0, cur_r = 0, prev_s = 0;              // this lane's cell of the previous step (row i) and the one before
+        uint32_t acc = 0;
+        __syncthreads();                                   // the previous block's boundary column is in memory
+        for (int t = 1; t <= m + nb - 1; t++) {
+            const int nl_cur_s = __shfl_up(cur_s, 1, 64), nl_cur_r = __shfl_up(cur_r, 1, 64), nl_prev_s = __shfl_up(prev_s, 1, 64);
+            const int i = t - lane;
+            if (col_ok && i >= 1 && i <= m) {
+                int left_s, left_r, diag;
+                if (lane == 0) {
+                    if (firstblk) { left_s = -2 - i; left_r = -131072; diag = i == 1 ? 0 : -2 - (i - 1); }
+                    else { left_s = colS[i]; left_r = colR[i]; diag = i == 1 ? -2 - (j0 - 1) : colS[i - 1]; }
+                } else { left_s = nl_cur_s; left_r = nl_cur_r; diag = i == 1 ? -2 - (j - 1) : nl_prev_s; }
+                const uint8_t ca = d_nt4(a[i - 1]);
+                int x = left_r - 1, y = left_s - 3;
+                const int r = x > y ? x : y;
+                x = up_t - 1; y = up_s - 3;
+                const int tt = x > y ? x : y;
+                const int d = d_tr2(diag + (ca == cb ? 3 : -3));
+                const int rr = d_tr2(r), t2 = d_tr2(tt);
+                const int sv = d > rr ? (d > t2 ? d : t2) : (rr > t2 ? rr : t2);
+                acc |= ((sv == r ? 1u : 0u) | (sv == tt ? 2u : 0u)) << (((i - 1) & 15) << 1);
+                if (((i - 1) & 15) == 15 || i == m) { tb[(size_t)(j - 1) * RW + ((i - 1) >> 4)] = acc; acc = 0; }
+                prev_s = cur_s; cur_s = sv; cur_r = r; up_s = sv; up_t = tt;
+                if (!lastblk && lane == 63) { colS[i] = sv; colR[i] = r; }
+            }
+        }
+    }
+    __syncthreads();                                       // the owner reads tb next
+}
+
+// traceback (nw_alignment.cpp:61-74) from the column-major bits of d_nw_coop into the two gapped strings
+__device__ inline int d_tb_traceback(LaneCtx &cx, const char *a, int m, const char *b, int n, char *oa, char *ob)
+{
+    const uint32_t *tb = (const uint32_t *)(cx.ws + cx.L->nwbits_off);
+    const int RW = (m + 15) >> 4;
+    cx.n_nw++; cx.nw_cells += (unsigned long long)m * (unsigned long long)n;
+    int i = m, j = n, k = 0;
+    while (i > 0 || j > 0) {
+        uint32_t fl;
+        if (i == 0) fl = 1;
+        else if (j == 0) fl = 2;
+        else fl = (tb[(size_t)(j - 1) * RW + ((i - 1) >> 4)] >> (((i - 1) & 15) << 1)) & 3u;
+        if (fl & 1u) { oa[k] = '-'; ob[k] = b[j - 1]; j--; }
+        else if (fl & 2u) { oa[k] = a[i - 1]; ob[k] = '-'; i--; }
+        else { oa[k] = a[i - 1]; ob[k] = b[j - 1]; i--; j--; }
+        k++;
+    }
+    for (int p = 0, q = k - 1; p < q; p++, q--) {
+        char c = oa[p]; oa[p] = oa[q]; oa[q] = c;
+        c = ob[p]; ob[p] = ob[q]; ob[q] = c;
+    }
+    return k;
+}
+
+// does the string path reach nw_alignment for this pair (tools.cpp:130-164,203-300 up to the call)?
+__device__ inline bool d_big_needs_nw(LaneCtx &cx, const DSeed &sp, int mode)
+{
+    if (mode == 2 && (sp.gPos - sp.rPos == -1 || sp.rLen == 0 || sp.gLen == 0)) return false;
+    if (sp.rLen != sp.gLen) return true;
+    int nm = 0;
+    const unsigned char *rd = cx.seq + sp.rPos;
+    for (int i = 0; i < sp.rLen; i += 8) {
+        const uint64_t w = d_ref8(*cx.ix, sp.gPos + i);
+        const int e = sp.rLen - i < 8 ? sp.rLen - i : 8;
+        for (int k = 0; k < e; k++) if (rd[i + k] != (unsigned char)(w >> (8 * k))) nm++;
+    }
+    return !(nm <= 2 && nm <= (int)(sp.rLen * 0.2));
+}
+
 // mode 0 = head (ProcessHeadSequencePair :203-249), 1 = tail (:251-300), 2 = normal (:130-164)
-__device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t *cig, int &nc)
+__device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t *cig, int &nc, bool have_tb = false)
 {
     const DIndex &ix = *cx.ix;
     if (mode == 2) {
@@ -761,7 +850,7 @@ __device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t 
         if (n <= 2 && n <= (int)(sp.rLen * 0.2)) { cig[nc++] = CIG(sp.rLen, OP_M); return sp.rLen - n; }
     }
     char *o1 = ws_str(cx, 1), *o2 = ws_str(cx, 3);     // each spans two string slots (rLen+gLen chars)
-    int len = d_nw(cx, rd, sp.rLen, g, sp.gLen, o1, o2);
+    int len = have_tb ? d_tb_traceback(cx, rd, sp.rLen, g, sp.gLen, o1, o2) : d_nw(cx, rd, sp.rLen, g, sp.gLen, o1, o2);
     if (mode == 2) return d_add_cigar(o1, o2, len, cig, nc);
     if (!d_local_quality(o1, o2, len)) { cig[nc++] = CIG(sp.rLen, OP_S); return 0; }
     if (mode == 0) {
@@ -790,144 +879,172 @@ struct DRead {
     int score, sub_score, mis_num, mapq, CanNum, iBest;
 };
 
-// GenMappingReport :1079-1207 for one read.  reports = this read's dg_report_out slots
+// GenMappingReport :1079-1207 for one read per lane.  reports = this read's dg_report_out slots
 // (n_rep = max(ncand,1)); cands/seeds = this read's candidates and the global seed array;
 // work = global working-seed pool; cigpool/cigtop = bump pool for merged CIGAR ops.
+// CALLED BY ALL 64 LANES OF THE WAVE TOGETHER (valid = false: a lane without a read): the candidate loop
+// runs to the wave's largest candidate count with per-lane guards, because in its middle the wave
+// aligns the lanes' LARGE segment pairs cooperatively, one after the other (d_nw_coop).
 template <typename ReportT>
-__device__ inline void d_gen_mapping_report(LaneCtx &cx, bool first, DRead &rd, DCand *cands, int ncand, const DJob *jobs,
+__device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first, DRead &rd, DCand *cands, int ncand, const DJob *jobs,
                                             DSeed *work, ReportT *rep, uint32_t rep_index0, uint32_t *cigpool, unsigned int *cigtop, uint32_t cigcap, int *err)
 {
     const DIndex &ix = *cx.ix;
+    const int lane = threadIdx.x & 63;
     rd.score = rd.iBest = 0;
-    if (ncand == 0) {
-        rd.CanNum = 1;
+    if (!valid) ncand = 0;
+    rd.CanNum = ncand > 0 ? ncand : 1;
+    if (valid && ncand == 0) {
         ReportT rp;
         rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = -1; rp.chr = -1; rp.bdir = 0;
         rp.pos = 0; rp.cigar_off = 0; rp.n_cigar = 0;
         rep[0] = rp;
-        return;
     }
-    rd.CanNum = ncand;
+    int nmax = ncand;
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
     uint32_t *cig = ws_cig(cx);
-    for (int i = 0; i < ncand; i++) {
-        DCand &c = cands[i];
-        // the record is assembled in registers and stored once (field-by-field stores were ~10 L2 requests per report)
+    for (int i = 0; i < nmax; i++) {
+        const bool act = i < ncand;
+        // ---- part 1 (per lane): everything up to knowing which segment pairs need nw_alignment ----
         ReportT rp;
-        rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = c.PairedIdx; rp.chr = -1; rp.bdir = 0; rp.pos = 0;
+        rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = -1; rp.chr = -1; rp.bdir = 0; rp.pos = 0;
         rp.cigar_off = 0; rp.n_cigar = 0;
-        int final_n = 0;
-        [&]() {
-        if (c.Score == 0) return;
-        // the working region already went through k_prep (tandem / translocation clean-up);
-        // IdentifyMissingSeeds :685-700: append the seeds k_reseed found, then re-sort
-        DSeed *s = work + c.work_off;
-        int n = c.n_a;
-        {
-            const int num = n;
-            for (int q = 0; q < c.job_count; q++) {
-                const DJob jb = jobs[c.job_first + q];
-                if (jb.found == 1) {
-                    DSeed ns; ns.gPos = jb.gPos; ns.rPos = jb.rPos; ns.rLen = ns.gLen = jb.len; ns.flags = SEED_SIMPLE;
-                    s[n++] = ns;
-                } else if (jb.found < 0) {               // read gap too long for the cooperative kernel
-                    DSeed ns;
-                    if (d_reseed(cx, jb.rBegin, jb.rBegin + jb.rl, jb.Lb, jb.Lb + jb.glen, &ns)) s[n++] = ns;
+        int final_n = 0, num = 0, nq = 0, bigj = -1;
+        uint32_t nwj = 0;                                 // seed indices (8 bits each) of the first PM_MAXQ small alignments
+        DSeed *s = work;
+        bool go = false;
+        if (act) {
+            DCand &c = cands[i];
+            rp.paired_idx = c.PairedIdx;
+            if (c.Score != 0) {
+                // the working region already went through k_prep (tandem / translocation clean-up);
+                // IdentifyMissingSeeds :685-700: append the seeds k_reseed found, then re-sort
+                s = work + c.work_off;
+                int n = c.n_a;
+                {
+                    const int n0 = n;
+                    for (int q = 0; q < c.job_count; q++) {
+                        const DJob jb = jobs[c.job_first + q];
+                        if (jb.found == 1) {
+                            DSeed ns; ns.gPos = jb.gPos; ns.rPos = jb.rPos; ns.rLen = ns.gLen = jb.len; ns.flags = SEED_SIMPLE;
+                            s[n++] = ns;
+                        } else if (jb.found < 0) {               // read gap too long for the cooperative kernel
+                            DSeed ns;
+                            if (d_reseed(cx, jb.rBegin, jb.rBegin + jb.rl, jb.Lb, jb.Lb + jb.glen, &ns)) s[n++] = ns;
+                        }
+                    }
+                    if (n > n0) d_insertion_sort_seeds(s, n);
+                }
+                n = d_seed_extension(cx, s, n);
+                int2 *vec = (int2 *)(s + n + 1);
+                rp.sj_type = c.SJtype = d_check_splice(cx, s, n, vec);
+                n = d_identify_normal_pairs(s, n);
+                final_n = num = n;
+                go = !(num > 1 && !d_check_coordinate_validity(ix, s, num));
+                if (go) {
+                    for (int j = 0; j < num; j++) {
+                        const DSeed &sd = s[j];
+                        if ((sd.rLen == 0 && sd.gLen == 0) || (sd.flags & SEED_SIMPLE) || j > 254) continue;
+                        const int mode = j == 0 ? 0 : (j == num - 1 ? 1 : 2);
+                        if (sd.rLen > PM_MAX || sd.gLen > PM_MAX) {              // large: the first one is aligned by the whole wave
+                            if (bigj < 0 && sd.gLen <= 64 * 64 && d_big_needs_nw(cx, sd, mode)) bigj = j;
+                            continue;
+                        }
+                        PairStr ps; int nm;
+                        if (nq < PM_MAXQ && d_pair_classify(cx, sd, mode, ps, nm) == PC_NW) { nwj |= (uint32_t)j << (8 * nq); nq++; }
+                    }
                 }
             }
-            if (n > num) d_insertion_sort_seeds(s, n);
         }
-        n = d_seed_extension(cx, s, n);
-        int2 *vec;
-        vec = (int2 *)(s + n + 1);
-        rp.sj_type = c.SJtype = d_check_splice(cx, s, n, vec);
-        n = d_identify_normal_pairs(s, n);
-        final_n = n;
-        const int num = n;
-        if (num > 1 && !d_check_coordinate_validity(ix, s, num)) return;
-        int nc = 1, mis_num = 0, aln = 0;                 // cig[0] is kept free for a leading soft clip
-        // (1) which pairs need nw_alignment?  (2) all lanes of the wave run their q-th alignment together;
-        // (3) the reference's loop (:1134-1160), consuming the stored column lists in order
-        uint32_t nwj = 0;                                 // seed indices (8 bits each) of the first PM_MAXQ alignments
-        int nq = 0;
-        for (int j = 0; j < num; j++) {
-            const DSeed &sd = s[j];
-            if ((sd.rLen == 0 && sd.gLen == 0) || (sd.flags & SEED_SIMPLE) || j > 254) continue;
-            PairStr ps; int nm;
-            if (nq < PM_MAXQ && d_pair_classify(cx, sd, j == 0 ? 0 : (j == num - 1 ? 1 : 2), ps, nm) == PC_NW) { nwj |= (uint32_t)j << (8 * nq); nq++; }
+        // ---- the wave aligns the lanes' large pairs, one owner after the other ----
+        unsigned long long todo = __ballot(bigj >= 0);
+        while (todo) {
+            const int owner = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const DSeed sd = s[bigj < 0 ? 0 : bigj];     // only the owner's copy is used
+            const unsigned long long ap = (unsigned long long)(cx.seq + sd.rPos), wp = (unsigned long long)cx.ws;
+            const unsigned long long a_o = ((unsigned long long)(uint32_t)__shfl((int)(ap >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)ap, owner, 64);
+            const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)wp, owner, 64);
+            const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)sd.gPos >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)sd.gPos, owner, 64);
+            const int m_o = __shfl((int)sd.rLen, owner, 64), n_o = __shfl((int)sd.gLen, owner, 64);
+            d_nw_coop(ix, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
         }
-        uint64_t *pmres = (uint64_t *)(cx.ws + cx.L->kmer_off);          // the k-mer list is idle at this stage: 4 u64 per result
-        for (int q = 0; q < nq; q++) {
-            const int j = (int)((nwj >> (8 * q)) & 255u);
-            PairStr ps; int nm; ColList cl;
-            d_pair_classify(cx, s[j], j == 0 ? 0 : (j == num - 1 ? 1 : 2), ps, nm);
-            d_pair_nw(cx, s[j].rLen, s[j].gLen, ps, cl);
-            pmres[4 * q] = cl.w0; pmres[4 * q + 1] = cl.w1; pmres[4 * q + 2] = cl.w2; pmres[4 * q + 3] = (uint64_t)cl.K;
-        }
-        int qn = 0;
-        for (int j = 0; j < num; j++) {
-            DSeed &sd = s[j];
-            if (sd.rLen == 0 && sd.gLen == 0) continue;
-            int g;
-            if (j > 0 && (g = (int)(sd.gPos - (s[j - 1].gPos + s[j - 1].gLen))) > 0) cig[nc++] = CIG(g, OP_N);
-            if (sd.flags & SEED_SIMPLE) { cig[nc++] = CIG(sd.rLen, OP_M); aln += sd.rLen; }
-            else {
-                const int mode = j == 0 ? 0 : (j == num - 1 ? 1 : 2);
-                int score;
-                if (qn < nq && (int)((nwj >> (8 * qn)) & 255u) == j) {
-                    ColList cl; cl.w0 = pmres[4 * qn]; cl.w1 = pmres[4 * qn + 1]; cl.w2 = pmres[4 * qn + 2]; cl.K = (int)pmres[4 * qn + 3];
-                    qn++;
-                    score = d_pair_finish(cl, sd, mode, cig, nc);
-                } else {
-                    PairStr ps; int nm = 0;
-                    const int pc = d_pair_classify(cx, sd, mode, ps, nm);
-                    if (pc == PC_EQUAL) { cig[nc++] = CIG(sd.rLen, OP_M); score = sd.rLen - nm; }
-                    else if (pc == PC_ONE) { cx.n_nw++; cx.nw_cells += 1; cig[nc++] = CIG(1, OP_M); score = 0; }
-                    else if (pc == PC_NW) { ColList cl; d_pair_nw(cx, sd.rLen, sd.gLen, ps, cl); score = d_pair_finish(cl, sd, mode, cig, nc); }   // beyond PM_MAXQ
-                    else score = d_process_pair(cx, sd, mode, cig, nc);                                                               // trivial cases and the string path
+        // ---- part 2 (per lane): the lanes' small alignments together, then the reference's loop (:1134-1160) ----
+        if (act && go) {
+            int nc = 1, mis_num = 0, aln = 0;                 // cig[0] is kept free for a leading soft clip
+            uint64_t *pmres = (uint64_t *)(cx.ws + cx.L->kmer_off);          // the k-mer list is idle at this stage: 4 u64 per result
+            for (int q = 0; q < nq; q++) {
+                const int j = (int)((nwj >> (8 * q)) & 255u);
+                PairStr ps; int nm; ColList cl;
+                d_pair_classify(cx, s[j], j == 0 ? 0 : (j == num - 1 ? 1 : 2), ps, nm);
+                d_pair_nw(cx, s[j].rLen, s[j].gLen, ps, cl);
+                pmres[4 * q] = cl.w0; pmres[4 * q + 1] = cl.w1; pmres[4 * q + 2] = cl.w2; pmres[4 * q + 3] = (uint64_t)cl.K;
+            }
+            int qn = 0;
+            for (int j = 0; j < num; j++) {
+                DSeed &sd = s[j];
+                if (sd.rLen == 0 && sd.gLen == 0) continue;
+                int g;
+                if (j > 0 && (g = (int)(sd.gPos - (s[j - 1].gPos + s[j - 1].gLen))) > 0) cig[nc++] = CIG(g, OP_N);
+                if (sd.flags & SEED_SIMPLE) { cig[nc++] = CIG(sd.rLen, OP_M); aln += sd.rLen; }
+                else {
+                    const int mode = j == 0 ? 0 : (j == num - 1 ? 1 : 2);
+                    int score;
+                    if (j == bigj) score = d_process_pair(cx, sd, mode, cig, nc, true);          // traceback bits are ready
+                    else if (qn < nq && (int)((nwj >> (8 * qn)) & 255u) == j) {
+                        ColList cl; cl.w0 = pmres[4 * qn]; cl.w1 = pmres[4 * qn + 1]; cl.w2 = pmres[4 * qn + 2]; cl.K = (int)pmres[4 * qn + 3];
+                        qn++;
+                        score = d_pair_finish(cl, sd, mode, cig, nc);
+                    } else {
+                        PairStr ps; int nm = 0;
+                        const int pc = d_pair_classify(cx, sd, mode, ps, nm);
+                        if (pc == PC_EQUAL) { cig[nc++] = CIG(sd.rLen, OP_M); score = sd.rLen - nm; }
+                        else if (pc == PC_ONE) { cx.n_nw++; cx.nw_cells += 1; cig[nc++] = CIG(1, OP_M); score = 0; }
+                        else if (pc == PC_NW) { ColList cl; d_pair_nw(cx, sd.rLen, sd.gLen, ps, cl); score = d_pair_finish(cl, sd, mode, cig, nc); }   // beyond PM_MAXQ
+                        else score = d_process_pair(cx, sd, mode, cig, nc);                                                               // trivial cases and the string path
+                    }
+                    aln += score;
+                    mis_num += sd.rLen - score;
                 }
-                aln += score;
-                mis_num += sd.rLen - score;
+            }
+            int c0 = 1;
+            if (num > 0) {
+                int j;
+                if ((j = s[0].rPos) > 0) { cig[0] = CIG(j, OP_S); c0 = 0; }
+                if ((j = cx.rlen - (s[num - 1].rPos + s[num - 1].rLen)) > 0) cig[nc++] = CIG(j, OP_S);
+            }
+            if (mis_num > cx.pr->max_mismatch || nc - c0 == 0) aln = 0;
+            for (int j = c0; j < nc; j++) if ((cig[j] & 15u) == OP_N && (int)(cig[j] >> 4) < cx.pr->min_intron) { aln = 0; break; }   // CheckMinIntronSize :1052
+            if (aln > 0) {
+                const int64_t gPos = s[0].gPos, end_gPos = s[num - 1].gPos + s[num - 1].gLen - 1;   // GenCoordinateInfo :83-116
+                const int lb = d_loc_lower_bound(ix, gPos);
+                rp.chr = ix.loc_chr[lb];
+                if (gPos < ix.l_pac) { rp.bdir = first ? 1 : 0; rp.pos = gPos + 1 - ix.chr_off[rp.chr]; }
+                else { rp.bdir = first ? 0 : 1; rp.pos = ix.loc_key[lb] - end_gPos + 1; }
+                if (rp.pos <= 0) aln = 0;
+                else {
+                    if (gPos >= ix.l_pac) for (int a = c0, b = nc - 1; a < b; a++, b--) { const uint32_t t = cig[a]; cig[a] = cig[b]; cig[b] = t; }
+                    // GenerateCIGAR :37-61: merge equal neighbours, drop zero-length runs, in place
+                    int m = 0, cnt = 0;
+                    uint32_t state = 99;
+                    for (int j = c0; j < nc; j++) {
+                        const uint32_t op = cig[j] & 15u, ln = cig[j] >> 4;
+                        if (op != state) { if (cnt > 0) cig[m++] = CIG(cnt, state); cnt = (int)ln; state = op; }
+                        else cnt += (int)ln;
+                    }
+                    if (cnt > 0) cig[m++] = CIG(cnt, state);
+                    // every report owns CIG_SLOT ops of the pool (no atomic: one hot bump counter serialises at ~6 ns per wave
+                    // update); the rare longer CIGAR goes to the bump-allocated overflow area behind the slots
+                    const unsigned int off = m <= CIG_SLOT ? (rep_index0 + (unsigned int)i) * CIG_SLOT : atomicAdd(cigtop, (unsigned int)m);
+                    if (off + (unsigned int)m > cigcap) { *err = 1; rp.n_cigar = 0; }
+                    else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
+                }
+                rp.aln_score = aln;
+                if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis_num; rd.sub_score = rd.score; rd.score = aln; }
+                else if (aln == rd.score) rd.sub_score = rd.score;
             }
         }
-        int c0 = 1;
-        if (num > 0) {
-            int j;
-            if ((j = s[0].rPos) > 0) { cig[0] = CIG(j, OP_S); c0 = 0; }
-            if ((j = cx.rlen - (s[num - 1].rPos + s[num - 1].rLen)) > 0) cig[nc++] = CIG(j, OP_S);
-        }
-        if (mis_num > cx.pr->max_mismatch || nc - c0 == 0) aln = 0;
-        for (int j = c0; j < nc; j++) if ((cig[j] & 15u) == OP_N && (int)(cig[j] >> 4) < cx.pr->min_intron) { aln = 0; break; }   // CheckMinIntronSize :1052
-        if (aln > 0) {
-            const int64_t gPos = s[0].gPos, end_gPos = s[num - 1].gPos + s[num - 1].gLen - 1;   // GenCoordinateInfo :83-116
-            const int lb = d_loc_lower_bound(ix, gPos);
-            rp.chr = ix.loc_chr[lb];
-            if (gPos < ix.l_pac) { rp.bdir = first ? 1 : 0; rp.pos = gPos + 1 - ix.chr_off[rp.chr]; }
-            else { rp.bdir = first ? 0 : 1; rp.pos = ix.loc_key[lb] - end_gPos + 1; }
-            if (rp.pos <= 0) aln = 0;
-            else {
-                if (gPos >= ix.l_pac) for (int a = c0, b = nc - 1; a < b; a++, b--) { const uint32_t t = cig[a]; cig[a] = cig[b]; cig[b] = t; }
-                // GenerateCIGAR :37-61: merge equal neighbours, drop zero-length runs, in place
-                int m = 0, cnt = 0;
-                uint32_t state = 99;
-                for (int j = c0; j < nc; j++) {
-                    const uint32_t op = cig[j] & 15u, ln = cig[j] >> 4;
-                    if (op != state) { if (cnt > 0) cig[m++] = CIG(cnt, state); cnt = (int)ln; state = op; }
-                    else cnt += (int)ln;
-                }
-                if (cnt > 0) cig[m++] = CIG(cnt, state);
-                // every report owns CIG_SLOT ops of the pool (no atomic: one hot bump counter serialises at ~6 ns per wave
-                // update); the rare longer CIGAR goes to the bump-allocated overflow area behind the slots
-                const unsigned int off = m <= CIG_SLOT ? (rep_index0 + (unsigned int)i) * CIG_SLOT : atomicAdd(cigtop, (unsigned int)m);
-                if (off + (unsigned int)m > cigcap) { *err = 1; rp.n_cigar = 0; }
-                else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
-            }
-            rp.aln_score = aln;
-            if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis_num; rd.sub_score = rd.score; rd.score = aln; }
-            else if (aln == rd.score) rd.sub_score = rd.score;
-        }
-        }();
-        c.final_n = final_n;
-        rep[i] = rp;
+        if (act) { cands[i].final_n = final_n; rep[i] = rp; }
     }
 }
 
