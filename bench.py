@@ -299,6 +299,18 @@ def main():
                         "algorithm (own_requested_*), so the algorithmic rate can exceed the HBM peak; measured_random_64B_ceiling = "
                         "profiles/probes/tlb_probe.hip (50-60 G random 64-byte lines/s on this chip at any footprint and occupancy)"}
 
+    # the seeding stage carries ~98 % of the path's algorithmic bytes: its roofline is reported too whenever another
+    # kernel is the longest (on a GRCh38-sized text k_report is: chance 16-mer hits make the segment pairs ~10x larger)
+    roofline_seeding = None
+    if dom != "k_seed":
+        sb = alg["k_seed"]
+        roofline_seeding = {"bound": "hbm", "kernel": "k_seed", "achieved": round(sb / (kern["k_seed"] * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(sb / (kern["k_seed"] * 1e-3) / 1e9 / 8000.0, 5), "traffic": (json.load(open(tpath)).get("k_seed") if os.path.exists(tpath) else None),
+                            "algorithmic_bytes_per_launch": int(sb), "kernel_ms": round(kern["k_seed"], 4),
+                            "kernel_ms_one_batch_in_flight": round(iso.get("k_seed", 0.0), 4),
+                            "achieved_one_batch_in_flight": round(sb / (iso["k_seed"] * 1e-3) / 1e9, 2) if iso.get("k_seed") else None,
+                            "own_requested_bytes_per_launch": int(own["k_seed"])}
+
     # ---- CPU baseline: the oracle ("port") on a bounded sample of the same reads, all host cores ----
     cpu = None
     if not args.no_cpu_baseline:
@@ -336,6 +348,7 @@ def main():
         "kernels_ms_one_batch_in_flight": {k: round(v, 4) for k, v in iso.items()},
         "counters_per_launch": counters,
         "roofline": roofline,
+        "roofline_seeding": roofline_seeding,
         "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
