@@ -511,7 +511,7 @@ static WSLayout make_ws_layout(int R)
     L.nwbits_off = o; L.nwbits_words = ((uint32_t)R + 1u) * ((nmax + 7u) / 8u); o = al(o + L.nwbits_words * 4u);
     L.rows_off = o; L.row_cap = (uint32_t)R + 8u; o = al(o + 2u * L.row_cap * 4u);          // strip boundary column: s and r per row
     L.str_off = o; L.str_cap = al(3u * (uint32_t)R + 64u); o = al(o + 6u * L.str_cap);
-    L.kmer_off = o; L.kmer_cap = (uint32_t)R + 8u; o = al(o + L.kmer_cap * 8u);
+    L.kmer_off = o; L.kmer_cap = (uint32_t)R + 8u > 48u ? (uint32_t)R + 8u : 48u; o = al(o + L.kmer_cap * 8u);   // also holds 4 x (4 + 6) u64 of pair strings/results
     uint32_t rd = 64; while (rd < (uint32_t)R + 1u) rd <<= 1;
     L.ring_diag = rd; L.ring_words = ((uint32_t)R + 64u) / 64u; L.ring_off = o; o = al(o + rd * L.ring_words * 8u);
     L.stride = (o + 255u) & ~255u;

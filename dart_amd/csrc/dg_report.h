@@ -763,16 +763,19 @@ __device__ inline void d_nw_coop(const DIndex &ix, const unsigned char *a, int m
         int cur_s = 0, cur_r = 0, prev_s = 0;              // this lane's cell of the previous step (row i) and the one before
         uint32_t acc = 0;
         __syncthreads();                                   // the previous block's boundary column is in memory
+        unsigned char a_nxt = (1 - lane >= 1 && 1 - lane <= m) ? a[1 - lane - 1] : 0;   // the row's read character, fetched a step ahead
         for (int t = 1; t <= m + nb - 1; t++) {
             const int nl_cur_s = __shfl_up(cur_s, 1, 64), nl_cur_r = __shfl_up(cur_r, 1, 64), nl_prev_s = __shfl_up(prev_s, 1, 64);
             const int i = t - lane;
+            const unsigned char a_cur = a_nxt;
+            a_nxt = (i + 1 >= 1 && i + 1 <= m) ? a[i] : 0;
             if (col_ok && i >= 1 && i <= m) {
                 int left_s, left_r, diag;
                 if (lane == 0) {
                     if (firstblk) { left_s = -2 - i; left_r = -131072; diag = i == 1 ? 0 : -2 - (i - 1); }
                     else { left_s = colS[i]; left_r = colR[i]; diag = i == 1 ? -2 - (j0 - 1) : colS[i - 1]; }
                 } else { left_s = nl_cur_s; left_r = nl_cur_r; diag = i == 1 ? -2 - (j - 1) : nl_prev_s; }
-                const uint8_t ca = d_nt4(a[i - 1]);
+                const uint8_t ca = d_nt4(a_cur);
                 int x = left_r - 1, y = left_s - 3;
                 const int r = x > y ? x : y;
                 x = up_t - 1; y = up_s - 3;
@@ -951,7 +954,11 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                             continue;
                         }
                         PairStr ps; int nm;
-                        if (nq < PM_MAXQ && d_pair_classify(cx, sd, mode, ps, nm) == PC_NW) { nwj |= (uint32_t)j << (8 * nq); nq++; }
+                        if (nq < PM_MAXQ && d_pair_classify(cx, sd, mode, ps, nm) == PC_NW) {
+                            uint64_t *pin = (uint64_t *)(cx.ws + cx.L->kmer_off) + 16 + 6 * nq;     // the strings, for the alignment pass
+                            pin[0] = ps.A0; pin[1] = ps.A1; pin[2] = ps.A2; pin[3] = ps.B0; pin[4] = ps.B1; pin[5] = ps.B2;
+                            nwj |= (uint32_t)j << (8 * nq); nq++;
+                        }
                     }
                 }
             }
@@ -972,11 +979,12 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
         // ---- part 2 (per lane): the lanes' small alignments together, then the reference's loop (:1134-1160) ----
         if (act && go) {
             int nc = 1, mis_num = 0, aln = 0;                 // cig[0] is kept free for a leading soft clip
-            uint64_t *pmres = (uint64_t *)(cx.ws + cx.L->kmer_off);          // the k-mer list is idle at this stage: 4 u64 per result
+            uint64_t *pmres = (uint64_t *)(cx.ws + cx.L->kmer_off);          // the k-mer list is idle at this stage: 4 u64 per result, then 6 per input
             for (int q = 0; q < nq; q++) {
                 const int j = (int)((nwj >> (8 * q)) & 255u);
-                PairStr ps; int nm; ColList cl;
-                d_pair_classify(cx, s[j], j == 0 ? 0 : (j == num - 1 ? 1 : 2), ps, nm);
+                PairStr ps; ColList cl;
+                const uint64_t *pin = pmres + 16 + 6 * q;
+                ps.A0 = pin[0]; ps.A1 = pin[1]; ps.A2 = pin[2]; ps.B0 = pin[3]; ps.B1 = pin[4]; ps.B2 = pin[5];
                 d_pair_nw(cx, s[j].rLen, s[j].gLen, ps, cl);
                 pmres[4 * q] = cl.w0; pmres[4 * q + 1] = cl.w1; pmres[4 * q + 2] = cl.w2; pmres[4 * q + 3] = (uint64_t)cl.K;
             }
