@@ -912,8 +912,9 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
         ReportT rp;
         rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = -1; rp.chr = -1; rp.bdir = 0; rp.pos = 0;
         rp.cigar_off = 0; rp.n_cigar = 0;
-        int final_n = 0, num = 0, nq = 0, bigj = -1;
+        int final_n = 0, num = 0, nq = 0, bigj = -1, npl = 0;
         uint32_t nwj = 0;                                 // seed indices (8 bits each) of the first PM_MAXQ small alignments
+        uint64_t pcl = 0;                                 // outcome of d_pair_classify for the first 12 pairs, 5 bits each (class | mismatches << 3)
         DSeed *s = work;
         bool go = false;
         if (act) {
@@ -951,10 +952,14 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                         const int mode = j == 0 ? 0 : (j == num - 1 ? 1 : 2);
                         if (sd.rLen > PM_MAX || sd.gLen > PM_MAX) {              // large: the first one is aligned by the whole wave
                             if (bigj < 0 && sd.gLen <= 64 * 64 && d_big_needs_nw(cx, sd, mode)) bigj = j;
+                            npl++;                                               // (slot stays PC_GENERIC)
                             continue;
                         }
-                        PairStr ps; int nm;
-                        if (nq < PM_MAXQ && d_pair_classify(cx, sd, mode, ps, nm) == PC_NW) {
+                        PairStr ps; int nm = 0;
+                        const int pc = d_pair_classify(cx, sd, mode, ps, nm);
+                        if (npl < 12) pcl |= (uint64_t)(pc | ((pc == PC_EQUAL ? nm : 0) << 3)) << (5 * npl);
+                        npl++;
+                        if (nq < PM_MAXQ && pc == PC_NW) {
                             uint64_t *pin = (uint64_t *)(cx.ws + cx.L->kmer_off) + 16 + 6 * nq;     // the strings, for the alignment pass
                             pin[0] = ps.A0; pin[1] = ps.A1; pin[2] = ps.A2; pin[3] = ps.B0; pin[4] = ps.B1; pin[5] = ps.B2;
                             nwj |= (uint32_t)j << (8 * nq); nq++;
@@ -988,7 +993,7 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                 d_pair_nw(cx, s[j].rLen, s[j].gLen, ps, cl);
                 pmres[4 * q] = cl.w0; pmres[4 * q + 1] = cl.w1; pmres[4 * q + 2] = cl.w2; pmres[4 * q + 3] = (uint64_t)cl.K;
             }
-            int qn = 0;
+            int qn = 0, pi = 0;
             for (int j = 0; j < num; j++) {
                 DSeed &sd = s[j];
                 if (sd.rLen == 0 && sd.gLen == 0) continue;
@@ -1004,13 +1009,16 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                         qn++;
                         score = d_pair_finish(cl, sd, mode, cig, nc);
                     } else {
-                        PairStr ps; int nm = 0;
-                        const int pc = d_pair_classify(cx, sd, mode, ps, nm);
+                        PairStr ps; int nm = 0, pc;
+                        const int slot = j > 254 ? 99 : pi;      // pairs are numbered as in part 1 (which skips j > 254)
+                        if (slot < 12 && ((pcl >> (5 * slot)) & 7u) != PC_NW) { pc = (int)((pcl >> (5 * slot)) & 7u); nm = (int)((pcl >> (5 * slot + 3)) & 3u); }
+                        else pc = d_pair_classify(cx, sd, mode, ps, nm);
                         if (pc == PC_EQUAL) { cig[nc++] = CIG(sd.rLen, OP_M); score = sd.rLen - nm; }
                         else if (pc == PC_ONE) { cx.n_nw++; cx.nw_cells += 1; cig[nc++] = CIG(1, OP_M); score = 0; }
                         else if (pc == PC_NW) { ColList cl; d_pair_nw(cx, sd.rLen, sd.gLen, ps, cl); score = d_pair_finish(cl, sd, mode, cig, nc); }   // beyond PM_MAXQ
                         else score = d_process_pair(cx, sd, mode, cig, nc);                                                               // trivial cases and the string path
                     }
+                    if (j <= 254) pi++;
                     aln += score;
                     mis_num += sd.rLen - score;
                 }
