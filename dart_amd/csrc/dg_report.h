@@ -765,7 +765,9 @@ __device__ inline void d_nw_coop(const DIndex &ix, const unsigned char *a, int m
         __syncthreads();                                   // the previous block's boundary column is in memory
         unsigned char a_nxt = (1 - lane >= 1 && 1 - lane <= m) ? a[1 - lane - 1] : 0;   // the row's read character, fetched a step ahead
         for (int t = 1; t <= m + nb - 1; t++) {
-            const int nl_cur_s = __shfl_up(cur_s, 1, 64), nl_cur_r = __shfl_up(cur_r, 1, 64), nl_prev_s = __shfl_up(prev_s, 1, 64);
+            // the left neighbour's values: a DPP wave shift by one lane (wave_shr:1), not a ds_bpermute round trip through LDS
+            const int nl_cur_s = __builtin_amdgcn_update_dpp(0, cur_s, 0x138, 0xF, 0xF, false), nl_cur_r = __builtin_amdgcn_update_dpp(0, cur_r, 0x138, 0xF, 0xF, false),
+                      nl_prev_s = __builtin_amdgcn_update_dpp(0, prev_s, 0x138, 0xF, 0xF, false);
             const int i = t - lane;
             const unsigned char a_cur = a_nxt;
             a_nxt = (i + 1 >= 1 && i + 1 <= m) ? a[i] : 0;
