@@ -1,4 +1,5 @@
-"""End-to-end timing of the product's `dart` command line (FASTQ on /tmp -> SAM on /tmp) on the bench workload, and a
+"""Usage: python profiles/probes/cli_e2e.py [pairs] [chr20|grch38|<bp>]
+End-to-end timing of the product's `dart` command line (FASTQ on /tmp -> SAM on /tmp) on the bench workload, and a
 byte comparison of its SAM / junctions with the oracle's command line.  Usage: python profiles/probes/cli_e2e.py [pairs]"""
 import os, sys, time, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,12 +8,14 @@ import bench
 from dart_amd import synth
 import oracle_py
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-prefix, g = bench.prepare_index("/tmp/dart_bench_cache", bench.CHR20_LEN, 0, lambda: None)
+label, gnames, glens = bench.genome_spec(sys.argv[2] if len(sys.argv) > 2 else "chr20")
+print(label + ")")
+prefix, g = bench.prepare_index("/tmp/dart_bench_cache", (gnames, glens), 0, lambda: None)
 m1, m2 = synth.make_reads(g, pairs, rlen=101, seed=1000, sub_rate=0.01, indel_frac=0.02, n_frac=0.002)
 d = "/tmp/cli_e2e"; os.makedirs(d, exist_ok=True)
 synth.write_fastq(os.path.join(d, "1.fq"), m1, 1); synth.write_fastq(os.path.join(d, "2.fq"), m2, 2)
 dart = os.path.join(ROOT, "dart_amd", "dart")
-for env_extra in ({"DART_INFLIGHT": "1"}, {"DART_INFLIGHT": "2"}, {"DART_INFLIGHT": "3"}):
+for env_extra in ({"DART_INFLIGHT": "1"}, {"DART_INFLIGHT": "2"}):
     env = dict(os.environ, DART_TIMING="1", **env_extra)
     t = time.time()
     r = subprocess.run([dart, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-o", "gpu.sam", "-j", "gpu.j", "-t", "16", "-mis", "5"], cwd=d, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
