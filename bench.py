@@ -157,7 +157,8 @@ def main():
     gpu = host.DartGPU(ix, params, device=local)
 
     t = time.time()
-    m1, m2 = synth.make_reads(g, args.pairs, rlen=args.rlen, seed=1000 + rank, sub_rate=0.01, indel_frac=0.02, n_frac=0.002, spliced_frac=args.spliced)
+    m1, m2, truth = synth.make_reads(g, args.pairs, rlen=args.rlen, seed=1000 + rank, sub_rate=0.01, indel_frac=0.02, n_frac=0.002, spliced_frac=args.spliced,
+                                     return_truth=True)
     arr = host.interleave_pairs(m1, m2)
     so, rl, flat = host.pack_reads(arr)
     gpu.upload(so, rl, flat)                       # inputs resident in HBM before the timed region
@@ -336,6 +337,28 @@ def main():
                "gpu_records_identical_on_sample": same}
         log("[bench] oracle counters on sample:", orc.counters)
 
+    # accuracy beside parity (the reference's Evaluation/eva idea): of the plain fragments (no planted indel or
+    # intron), how many reads' best alignment starts within 10 bp of where the read was taken from?  Outside every timed region.
+    accuracy = None
+    try:
+        res_a = gpu.download()
+        rd_, rp_ = res_a.reads, res_a.reports
+        best = rp_[np.clip(rd_["rep_off"] + rd_["best"], 0, len(rp_) - 1)]
+        npair = len(rd_) // 2
+        tp = np.stack([truth["pos1"][:npair], truth["pos2"][:npair]], 1).reshape(-1)
+        tc = np.repeat(truth["chr"][:npair], 2)
+        plain = np.repeat(truth["plain"][:npair], 2)
+        mapped = rd_["score"] > 0
+        cg = res_a.cigar
+        first_op = cg[np.clip(best["cigar_off"], 0, max(len(cg) - 1, 0))] if len(cg) else np.zeros(len(best), np.uint32)
+        lead_s = np.where((best["n_cigar"] > 0) & ((first_op & 15) == 4), first_op >> 4, 0).astype(np.int64)     # leading soft clip
+        ok = mapped & (best["chr"] == tc) & (np.abs(best["pos"] - lead_s - tp) <= 10)
+        accuracy = {"reads": int(plain.sum()), "mapped_frac": round(float(mapped[plain].mean()), 5),
+                    "correct_frac": round(float(ok[plain].mean()), 5), "tolerance_bp": 10,
+                    "note": "plain fragments of batch 0; (POS - leading soft clip) of the best report vs the position the read was sampled from; the rest are reads from planted repeat families placed at another copy"}
+    except Exception as e:
+        log("[bench] accuracy not computed:", repr(e))
+
     line = {
         "metric": "M paired-end reads/sec (2x101 bp), hot path seed->locate->chain->report, records bit-identical to CPU dart",
         "value": round(value, 4), "unit": "M reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -350,6 +373,7 @@ def main():
         "roofline": roofline,
         "roofline_seeding": roofline_seeding,
         "cpu_baseline": cpu,
+        "accuracy": accuracy,
     }
     print(json.dumps(line), flush=True)
     if dist is not None:

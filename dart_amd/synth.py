@@ -132,9 +132,11 @@ def make_genome(lengths, seed=20, repeat_scale=1.0, n_introns=0, names=None) -> 
 
 def make_reads(g: Genome, n_pairs: int, rlen: int = 101, seed: int = 7, sub_rate: float = 0.01,
                indel_frac: float = 0.02, spliced_frac: float = 0.0, n_frac: float = 0.002,
-               paired: bool = True, frag_mean: float = 350.0, frag_sd: float = 40.0):
+               paired: bool = True, frag_mean: float = 350.0, frag_sd: float = 40.0, return_truth: bool = False):
     """Returns (seq1, seq2) as uint8 [n_pairs, rlen] ASCII arrays (seq2 None when not paired).
-    seq2 is the mate as sequenced (i.e. NOT yet reverse-complemented by the loader)."""
+    seq2 is the mate as sequenced (i.e. NOT yet reverse-complemented by the loader).
+    return_truth: also a dict with, per pair, the chromosome index, the 1-based leftmost forward-strand position of each
+    mate's footprint, and `plain` = the pair is a plain fragment (no planted indel / splice: its truth is exact)."""
     rng = np.random.default_rng(seed)
     asc = g.ascii()
     total = g.total
@@ -219,6 +221,12 @@ def make_reads(g: Genome, n_pairs: int, rlen: int = 101, seed: int = 7, sub_rate
         rows = rng.integers(0, n_pairs, size=n_n)
         cols = rng.integers(0, rlen, size=n_n)
         m2[rows, cols] = ord("N")
+    if return_truth:
+        lo1 = np.where(flip, start + flen - rlen, start)
+        lo2 = np.where(flip, start, start + flen - rlen)
+        truth = {"chr": ci.astype(np.int32), "pos1": (lo1 - g.offsets[ci] + 1).astype(np.int64),
+                 "pos2": (lo2 - g.offsets[ci] + 1).astype(np.int64), "plain": ~special}
+        return (m1, m2, truth) if paired else (m1, None, truth)
     return (m1, m2) if paired else (m1, None)
 
 
