@@ -154,7 +154,11 @@ def main():
         prefix, g = prepare_index(args.cache, (gnames, glens), rank, barrier, args.introns)
     ix = host.Index(prefix)
     params = host.default_params(paired=1, max_mismatch=args.mis)
+    t = time.time()
     gpu = host.DartGPU(ix, params, device=local)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("[bench] dg_init (upload + Occ relayout + prefix table + full SA) %.2f s" % (time.time() - t))
 
     t = time.time()
     m1, m2, truth = synth.make_reads(g, args.pairs, rlen=args.rlen, seed=1000 + rank, sub_rate=0.01, indel_frac=0.02, n_frac=0.002, spliced_frac=args.spliced,

@@ -431,7 +431,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
         if (intv >= 1 && intv < v->sa_intv && (intv & (intv - 1)) == 0 && v->seq_len < (1ull << 39)) {
             const uint64_t n_entries = v->seq_len / (uint64_t)intv + 1;
             if ((e = hipMalloc(&c->d_sa_dense, n_entries * 8)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc dense SA", e);
-            k_build_sa_dense<<<(unsigned)std::min<uint64_t>((n_entries + 255) / 256, 1u << 22), 256, 0, c->stream>>>(c->ix, intv, n_entries, (uint64_t *)c->d_sa_dense);
+            k_build_sa_dense<<<(unsigned)std::min<uint64_t>(((uint64_t)v->n_sa + 255) / 256, 1u << 22), 256, 0, c->stream>>>(c->ix, intv, n_entries, (uint64_t *)c->d_sa_dense);
             if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_sa_dense", e);
             c->ix.sa_dense = (const uint64_t *)c->d_sa_dense; c->ix.sa_dense_intv = intv;
             for (int sh = 0; (1 << sh) < intv; sh++) c->ix.sa_dense_shift = sh + 1;

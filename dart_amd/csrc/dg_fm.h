@@ -731,21 +731,34 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_build_sa_dense (once per dg_init): SA of every `intv`-th row, derived from the reference's
-// SA/32 by the reference's own walk (bwt_sa :127-137), so results cannot change.  Each entry
-// also remembers how many LF steps the reference needs from that row (algorithmic-byte accounting).
+// k_build_sa_dense (once per dg_init): SA of every `intv`-th row (intv = 1: the full suffix array),
+// derived from the reference's SA/32 so that every entry is exactly what the reference's walk
+// (bwt_sa :127-137: LF steps to the next sampled row, then sa[] + steps) returns -- and each entry
+// also remembers that step count (algorithmic-byte accounting).
+// One thread per SAMPLED row r0: the rows LF(r0), LF^2(r0), ... up to the next sampled row r_T are
+// exactly the rows whose reference walk ends at r_T, after T-1, T-2, ... steps.  So the chain is
+// walked twice (once to find T and r_T, once to write) -- 2 LF evaluations per row instead of the
+// 15.5 on average that a walk from every row costs (GRCh38-sized: 3.3 s -> see DESIGN.md).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_build_sa_dense(const DIndex ix, int intv, uint64_t n_entries, uint64_t *__restrict__ dense)
 {
-    // grid-stride: a launch cannot have 2^32 work-items (the dispatch packet's grid size is 32 bits), a GRCh38-sized
-    // text has 6.2 G rows
-    const uint64_t mask = (uint64_t)ix.sa_intv - 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_entries; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t k = i * (uint64_t)intv, steps = 0;
-        while (k & mask) { k = d_lf(ix, k); steps++; }
-        const uint64_t pos = steps + ix.sa[k / (uint64_t)ix.sa_intv];      // sa[0] = -1 wraps as in the reference
-        dense[i] = ((pos + 1) & 0xFFFFFFFFFFull) | (steps << 40);
+    const uint64_t smask = (uint64_t)ix.sa_intv - 1, dmask = (uint64_t)intv - 1;
+    const uint64_t n_sampled = (ix.seq_len + (uint64_t)ix.sa_intv) / (uint64_t)ix.sa_intv;      // rows 0, 32, 64, ... <= seq_len
+    int dsh = 0;
+    while ((1 << dsh) < intv) dsh++;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_sampled; q += (uint64_t)gridDim.x * blockDim.x) {   // grid-stride: 2^32 work-items do not fit a launch
+        const uint64_t r0 = q * (uint64_t)ix.sa_intv;
+        if ((r0 >> dsh) < n_entries) dense[r0 >> dsh] = ((ix.sa[q] + 1) & 0xFFFFFFFFFFull);    // a sampled row: 0 steps (sa[0] = -1 wraps as in the reference)
+        uint64_t k = d_lf(ix, r0), T = 1;
+        while (k & smask) { k = d_lf(ix, k); T++; }
+        const uint64_t base = ix.sa[k / (uint64_t)ix.sa_intv];
+        k = d_lf(ix, r0);
+        for (uint64_t t = 1; t < T; t++) {
+            const uint64_t steps = T - t;
+            if (!(k & dmask) && (k >> dsh) < n_entries) dense[k >> dsh] = ((steps + base + 1) & 0xFFFFFFFFFFull) | (steps << 40);
+            k = d_lf(ix, k);
+        }
     }
 }
 
