@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--rlen", type=int, default=101)
     ap.add_argument("--spliced", type=float, default=0.0, help="fraction of reads spanning a planted intron (BASELINE config 5 shape: --rlen 151 --spliced 0.3 --introns 20000)")
     ap.add_argument("--introns", type=int, default=0, help="introns planted in the synthetic genome")
+    ap.add_argument("--sub-rate", type=float, default=0.01, help="per-base substitution rate of the synthetic reads (experiments only; the bench line is quoted at the default)")
+    ap.add_argument("--indel-frac", type=float, default=0.02, help="fraction of reads carrying one short indel (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("DART_BENCH_STAGGER_MS", "0")))
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "4")),
@@ -161,7 +163,7 @@ def main():
         log("[bench] dg_init (upload + Occ relayout + prefix table + full SA) %.2f s" % (time.time() - t))
 
     t = time.time()
-    m1, m2, truth = synth.make_reads(g, args.pairs, rlen=args.rlen, seed=1000 + rank, sub_rate=0.01, indel_frac=0.02, n_frac=0.002, spliced_frac=args.spliced,
+    m1, m2, truth = synth.make_reads(g, args.pairs, rlen=args.rlen, seed=1000 + rank, sub_rate=args.sub_rate, indel_frac=args.indel_frac, n_frac=0.002, spliced_frac=args.spliced,
                                      return_truth=True)
     arr = host.interleave_pairs(m1, m2)
     so, rl, flat = host.pack_reads(arr)

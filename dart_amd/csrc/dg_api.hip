@@ -35,7 +35,7 @@ struct dg_ctx {
     int device = 0;
     bool owns_index = true;       // false for dg_clone()d contexts: the index arrays belong to the parent
     hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     float reseed_ms = 0;
     char err[512] = "";
     DIndex ix{};
@@ -228,39 +228,67 @@ k_cost_scatter(int n_reads, int n_blocks, const uint8_t *__restrict__ key, const
 // k_report: persistent waves; one lane = one read at a time (GenMappingReport,
 // AlignmentCandidates.cpp:1079-1207); results go to the read's dg_read_out / dg_report_out slots
 // ------------------------------------------------------------------------------------------
+#ifdef DG_PROFILE_CLASSES          // diagnostic build only (profiles/probes/class_profile.sh): shader cycles per cost class
+__device__ unsigned long long g_class_cycles[COST_CLASSES + 1], g_class_chunks[COST_CLASSES + 1];
+__device__ const uint8_t *g_costkey;
+#endif
 template <int MINW>
 __global__ void __launch_bounds__(64, MINW)
 k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsigned char *__restrict__ seq,
          const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ seed_off,
          const DJob *__restrict__ jobs, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
          const uint32_t *__restrict__ rep_off, DSeed *__restrict__ work, const uint32_t *__restrict__ perm,
-         const uint32_t *__restrict__ n_jobreads_p, int job_part, dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
+         const uint32_t *__restrict__ n_jobreads_p, const uint32_t *__restrict__ heavy_end_p, int job_part, dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
          unsigned int *tops, unsigned char *ws, const WSLayout L, unsigned long long *ctr, int *err)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t lds_pm[64 * PM_LDS_WORDS];
     LaneCtx cx;
+#ifdef DG_PROFILE_CLASSES
+    __shared__ unsigned long long ph_acc[17 * DG_NPHASE], cls_acc[2 * 17];
+    for (int q = threadIdx.x; q < 17 * DG_NPHASE; q += 64) ph_acc[q] = 0;
+    if (threadIdx.x < 34) cls_acc[threadIdx.x] = 0;
+    __syncthreads();
+    cx.ph = ph_acc;
+#endif
     cx.lds = lds_pm + (threadIdx.x & 63) * PM_LDS_WORDS;
     cx.ix = &ix; cx.pr = &pr; cx.L = &L;
     cx.ws = ws + (size_t)lane * L.stride;
     cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
-    // perm = [reads that wait for k_reseed | all other reads, heaviest class first]; this launch takes one part
+    // perm = [reads that wait for k_reseed | all other reads, heaviest class first]; this launch takes one part.
+    // The heavy head of the part (all job reads; classes 1-3 of the rest: many seeds AND a long segment pair) is handed
+    // out in groups of g < 64 reads, g ~ one group per wave: 64 such reads in ONE wave were the kernel's critical
+    // path (one chunk = 7 M cycles, as long as everything else together).
     const unsigned int n_jobreads = *n_jobreads_p;
     const unsigned int lo = job_part ? 0u : n_jobreads, hi = job_part ? n_jobreads : (unsigned int)n_reads;
+    const unsigned int n_heavy = job_part ? hi - lo : *heavy_end_p - n_jobreads;
+    unsigned int g = 8;
+    while (g < 64 && (unsigned long long)g * gridDim.x < n_heavy) g <<= 1;
+    const unsigned int hgroups = (n_heavy + g - 1) / g;
     unsigned int *next = tops + (job_part ? 4 : 3);
     while (true) {
-        unsigned int base = 0;
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(next, 64u);
-        base = lo + (unsigned int)__shfl((int)base, 0, 64);
+        unsigned int ticket = 0;
+        if ((threadIdx.x & 63) == 0) ticket = atomicAdd(next, 1u);
+        ticket = (unsigned int)__shfl((int)ticket, 0, 64);
+        unsigned int base, cnt;
+        if (ticket < hgroups) { base = lo + ticket * g; cnt = n_heavy - ticket * g < g ? n_heavy - ticket * g : g; }
+        else { base = lo + n_heavy + (ticket - hgroups) * 64u; cnt = 64; }
         if (base >= hi) break;
         const unsigned int idx = base + (threadIdx.x & 63);
-        const bool valid = idx < hi;                      // every lane enters d_gen_mapping_report (it has wave-wide steps)
+        const bool valid = (threadIdx.x & 63) < cnt && idx < hi;   // every lane enters d_gen_mapping_report (it has wave-wide steps)
         const int r = valid ? (int)perm[idx] : 0;
         DRead rd;
         rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0;           // defined start state
         cx.seq = seq + seq_off[r]; cx.rlen = rlen[r];
+#ifdef DG_PROFILE_CLASSES
+        const long long t_begin = clock64();
+        cx.cls = g_costkey[perm[base]]; cx.t_last = t_begin;
+#endif
         d_gen_mapping_report(cx, valid, paired ? (r & 1) == 0 : true, rd, cands + seed_off[r], valid ? (int)ncand[r] : 0, jobs, work,
                              reports + rep_off[r], rep_off[r], cigpool, tops + 0, cigcap, err);
+#ifdef DG_PROFILE_CLASSES
+        if ((threadIdx.x & 63) == 0) { cls_acc[cx.cls] += (unsigned long long)(clock64() - t_begin); cls_acc[17 + cx.cls] += 1ull; }
+#endif
         if (valid) {
             dg_read_out o;
             o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
@@ -268,6 +296,11 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
             rout[r] = o;
         }
     }
+#ifdef DG_PROFILE_CLASSES
+    __syncthreads();
+    for (int q = threadIdx.x; q < 17 * DG_NPHASE; q += 64) if (ph_acc[q]) atomicAdd(&g_phase[q / DG_NPHASE][q % DG_NPHASE], ph_acc[q]);
+    if (threadIdx.x < 17 && cls_acc[17 + threadIdx.x]) { atomicAdd(&g_class_cycles[threadIdx.x], cls_acc[threadIdx.x]); atomicAdd(&g_class_chunks[threadIdx.x], cls_acc[17 + threadIdx.x]); }
+#endif
     d_wave_add(ctr + CTR_NW, cx.n_nw);
     d_wave_add(ctr + CTR_NWCELLS, cx.nw_cells);
     d_wave_add(ctr + CTR_RESEED, cx.n_reseed);
@@ -350,6 +383,8 @@ extern "C" void dg_destroy(dg_ctx *c)
     c->ws.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_reseed0) (void)hipEventDestroy(c->ev_reseed0);
     if (c->ev_reseed1) (void)hipEventDestroy(c->ev_reseed1);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -376,7 +411,8 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     c->device = device;
     for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) return bail(DG_ERR_HIP, "hipStreamCreate", e);
-    if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess) return bail(DG_ERR_HIP, "hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev_fork)) != hipSuccess || (e = hipEventCreate(&c->ev_join)) != hipSuccess) return bail(DG_ERR_HIP, "hipEventCreate", e);
     for (int i = 0; i <= N_TIMERS; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail(DG_ERR_HIP, "hipEventCreate", e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -470,7 +506,8 @@ extern "C" dg_ctx *dg_clone(dg_ctx *parent, int *status)
     c->ix = parent->ix; c->pr = parent->pr;
     for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
     bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipStreamCreate(&c->stream2) == hipSuccess &&
-              hipEventCreate(&c->ev_prep) == hipSuccess && hipEventCreate(&c->ev_reseed0) == hipSuccess && hipEventCreate(&c->ev_reseed1) == hipSuccess;
+              hipEventCreate(&c->ev_prep) == hipSuccess && hipEventCreate(&c->ev_reseed0) == hipSuccess && hipEventCreate(&c->ev_reseed1) == hipSuccess &&
+              hipEventCreate(&c->ev_fork) == hipSuccess && hipEventCreate(&c->ev_join) == hipSuccess;
     for (int i = 0; ok && i <= N_TIMERS; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8) == hipSuccess && hipMalloc((void **)&c->d_tops, 64) == hipSuccess && hipMalloc((void **)&c->d_err, 4) == hipSuccess;
     if (!ok) { snprintf(g_init_error, sizeof g_init_error, "dg_clone: stream/event/counter allocation failed"); dg_destroy(c); if (status) *status = DG_ERR_HIP; return nullptr; }
@@ -587,10 +624,15 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     TICK("k_locate");
     HIPCHK(c->heavy.ensure((size_t)n_units + 16));
     k_heavy_list<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(n_units, paired, c->seed_off.p, c->heavy.p, c->d_tops + 5);
+    // the heavy units (a wave each) and the ordinary ones (a lane each) write disjoint slots: the two kernels run side by side
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    k_chain_heavy<<<c->n_cu * 8, 64, 0, c->stream2>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p,
+                                                      c->nrep.p, c->work_need.p, c->heavy.p, c->d_tops + 5, c->d_ctr);
+    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
     k_chain<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p,
                                                                   c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->d_ctr);
-    k_chain_heavy<<<c->n_cu * 8, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p,
-                                                     c->nrep.p, c->work_need.p, c->heavy.p, c->d_tops + 5, c->d_ctr);
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     HIPCHK(hipGetLastError());
     TICK("k_chain");
     HIPCHK(scan_u32(c, c->nrep.p, c->rep_off.p, (uint32_t)n));
@@ -634,17 +676,37 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(scan_u32(c, c->hist.p, class_offs, COST_CLASSES * nb));
     k_cost_scatter<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->costkey.p, class_offs, c->perm.p);
     const uint32_t *n_jobreads_p = class_offs + (size_t)1 * nb;       // start of class 1 = number of class-0 (job) reads
+    const uint32_t *heavy_end_p = class_offs + (size_t)4 * nb;        // start of class 4 = end of the heavy classes 1-3
     TICK("order");
     // one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves
     const int blocks_main = blocks > c->n_cu * 4 ? blocks - c->n_cu : blocks;
+#ifdef DG_PROFILE_CLASSES
+    { const uint8_t *kp = c->costkey.p; HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_costkey), &kp, sizeof kp, 0, hipMemcpyHostToDevice, c->stream)); }
+#endif
     k_report<2><<<blocks_main, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
-                                               c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, 0, c->reads_out.p, c->reports.p, c->cigpool.p,
+                                               c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, heavy_end_p, 0, c->reads_out.p, c->reports.p, c->cigpool.p,
                                                (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
+#ifdef DG_PROFILE_CLASSES
+    {
+        unsigned long long cyc[COST_CLASSES + 1], cnt[COST_CLASSES + 1], z[COST_CLASSES + 1] = {0};
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_class_cycles), sizeof cyc)); HIPCHK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_class_chunks), sizeof cnt));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_class_cycles), z, sizeof z)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_class_chunks), z, sizeof z));
+        unsigned long long tot = 0; for (int k = 0; k <= COST_CLASSES; k++) tot += cyc[k];
+        unsigned long long ph[17][DG_NPHASE], zp[17][DG_NPHASE] = {{0}};
+        HIPCHK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof ph)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zp, sizeof zp));
+        for (int k = 0; k < COST_CLASSES; k++) if (cnt[k]) {
+            fprintf(stderr, "[class %2d] chunks %7llu  cycles/chunk %8llu  share %5.1f %%  phases/chunk:", k, cnt[k], cyc[k] / cnt[k], 100.0 * cyc[k] / (tot ? tot : 1));
+            for (int q = 0; q < DG_NPHASE; q++) fprintf(stderr, " %llu", ph[k][q] / cnt[k]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     TICK("k_report");
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_reseed1, 0));
     k_report<2><<<blocks_main < c->n_cu ? blocks_main : c->n_cu, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
-                                               c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, 1, c->reads_out.p, c->reports.p, c->cigpool.p,
+                                               c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, heavy_end_p, 1, c->reads_out.p, c->reports.p, c->cigpool.p,
                                                (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_report_jobs");

@@ -27,6 +27,9 @@ struct WSLayout {
 };
 
 struct LaneCtx {
+#ifdef DG_PROFILE_CLASSES
+    int cls; long long t_last; unsigned long long *ph;
+#endif
     uint32_t *lds;                // PM_LDS_WORDS words of LDS owned by this lane (d_pair_nw)
     const DIndex *ix;
     const DParams *pr;
@@ -878,6 +881,13 @@ __device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t 
     return score;
 }
 
+#ifdef DG_PROFILE_CLASSES
+#define DG_NPHASE 12
+__device__ unsigned long long g_phase[17][DG_NPHASE];
+#define PH(k) do { if ((threadIdx.x & 63) == 0) { const long long t_now = clock64(); cx.ph[cx.cls * DG_NPHASE + (k)] += (unsigned long long)(t_now - cx.t_last); cx.t_last = t_now; } } while (0)
+#else
+#define PH(k) do { } while (0)
+#endif
 // device-side per-read state (ReadItem_t)
 #define CIG_SLOT 8
 struct DRead {
@@ -908,6 +918,7 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
     int nmax = ncand;
     for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
     uint32_t *cig = ws_cig(cx);
+    PH(0);
     for (int i = 0; i < nmax; i++) {
         const bool act = i < ncand;
         // ---- part 1 (per lane): everything up to knowing which segment pairs need nw_alignment ----
@@ -941,12 +952,16 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                     }
                     if (n > n0) d_insertion_sort_seeds(s, n);
                 }
+                PH(1);
                 n = d_seed_extension(cx, s, n);
+                PH(2);
                 int2 *vec = (int2 *)(s + n + 1);
                 rp.sj_type = c.SJtype = d_check_splice(cx, s, n, vec);
+                PH(3);
                 n = d_identify_normal_pairs(s, n);
                 final_n = num = n;
                 go = !(num > 1 && !d_check_coordinate_validity(ix, s, num));
+                PH(4);
                 if (go) {
                     for (int j = 0; j < num; j++) {
                         const DSeed &sd = s[j];
@@ -970,6 +985,7 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                 }
             }
         }
+        PH(5);
         // ---- the wave aligns the lanes' large pairs, one owner after the other ----
         unsigned long long todo = __ballot(bigj >= 0);
         while (todo) {
@@ -983,6 +999,7 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
             const int m_o = __shfl((int)sd.rLen, owner, 64), n_o = __shfl((int)sd.gLen, owner, 64);
             d_nw_coop(ix, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
         }
+        PH(6);
         // ---- part 2 (per lane): the lanes' small alignments together, then the reference's loop (:1134-1160) ----
         if (act && go) {
             int nc = 1, mis_num = 0, aln = 0;                 // cig[0] is kept free for a leading soft clip
@@ -995,6 +1012,7 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                 d_pair_nw(cx, s[j].rLen, s[j].gLen, ps, cl);
                 pmres[4 * q] = cl.w0; pmres[4 * q + 1] = cl.w1; pmres[4 * q + 2] = cl.w2; pmres[4 * q + 3] = (uint64_t)cl.K;
             }
+            PH(7);
             int qn = 0, pi = 0;
             for (int j = 0; j < num; j++) {
                 DSeed &sd = s[j];
@@ -1025,6 +1043,7 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                     mis_num += sd.rLen - score;
                 }
             }
+            PH(8);
             int c0 = 1;
             if (num > 0) {
                 int j;
@@ -1062,7 +1081,9 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                 else if (aln == rd.score) rd.sub_score = rd.score;
             }
         }
+        PH(9);
         if (act) { cands[i].final_n = final_n; rep[i] = rp; }
+        PH(10);
     }
 }
 

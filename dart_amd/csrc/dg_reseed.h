@@ -52,15 +52,15 @@ k_prep(const DParams pr, int n_reads, const uint32_t *__restrict__ seed_off, con
         n = d_remove_transloc(s, n, vec);
         c.n_a = n;
         int cnt = 0;                                     // IdentifyMissingSeeds :691-697, enumeration only
-        int big = n > 0 && (s[0].rPos > 8 || (int)rlen[r] - (s[n - 1].rPos + s[n - 1].rLen) > 8) ? 1 : 0;
+        int big = n > 0 && (s[0].rPos > PM_MAX || (int)rlen[r] - (s[n - 1].rPos + s[n - 1].rLen) > PM_MAX) ? 1 : 0;
         for (int k = 1; k < n; k++) {
             const int pd = (int)((s[k].gPos - s[k].rPos) - (s[k - 1].gPos - s[k - 1].rPos));
             const int rGaps = s[k].rPos - s[k - 1].rPos - s[k - 1].rLen;
             if (pd > pr.max_gaps && rGaps > 20) cnt++;
-            if (rGaps > 8 || pd != 0) big = 1;
+            if (rGaps > PM_MAX || rGaps + pd > PM_MAX) big = 1;
         }
         c.final_n = big;                                 // scheduling hint for k_cost only (k_report sets the real value):
-                                                         // this candidate will need more than the register-only pair path
+                                                         // some segment pair is longer than PM_MAX: string path, maybe a wave-wide alignment
         if (cnt == 0) continue;
         const unsigned int first = atomicAdd(jobtop, (unsigned int)cnt);
         if (first + (unsigned int)cnt > jobcap) { *err = 3; continue; }
