@@ -168,7 +168,7 @@ __global__ void k_compact_sj(dg_read_out *rd, uint32_t n, const uint32_t *new_of
 // list.  Lanes of one wave then walk similar paths (less divergence) and the heavy tail starts
 // first (longest-processing-time scheduling).
 // ------------------------------------------------------------------------------------------
-#define COST_CLASSES 16
+#define COST_CLASSES 32
 // pass 1: class of every read + per-(class, block) counts, laid out class-major for one scan
 __global__ void __launch_bounds__(256)
 k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
@@ -184,15 +184,20 @@ k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const D
         const int nc = (int)ncand[r];
         // Reads of one class do the same things in the same order, so a wave's lanes stay converged in k_report:
         // 0 = waits for k_reseed; 1-4 = some pair is too big for the register-only path (by seed count);
-        // 5-14 = small pairs only, by (live candidates, seeds); 15 = nothing to report
-        uint32_t tot = 0, live = 0; bool has_jobs = false, big = false;
-        for (int i = 0; i < nc; i++) if (cd[i].Score > 0) { live++; tot += (uint32_t)cd[i].n_a; has_jobs = has_jobs || cd[i].job_count > 0; big = big || cd[i].final_n != 0; }
+        // 5-14 = small pairs only, by (live candidates, seeds); 15 = nothing to report  (x 2, see below)
+        // every class is split in two: first the reads with two seeds on different diagonals (an nw_alignment is certain: about one
+        // read in eight, but met in every 64-read chunk while they were mixed in), then the rest
+        uint32_t tot = 0, live = 0; bool has_jobs = false, big = false, nw = false;
+        for (int i = 0; i < nc; i++) if (cd[i].Score > 0) {
+            live++; tot += (uint32_t)cd[i].n_a; has_jobs = has_jobs || cd[i].job_count > 0; big = big || (cd[i].final_n & 1) != 0; nw = nw || (cd[i].final_n & 2) != 0;
+        }
         if (has_jobs) k = 0;
         else if (live == 0) k = 15;
         else if (big) k = tot > 12 ? 1u : tot > 6 ? 2u : tot > 3 ? 3u : 4u;
         else if (live >= 3) k = tot > 8 ? 5u : 6u;
         else if (live == 2) k = tot > 4 ? 7u : tot > 2 ? 8u : 9u;
         else k = tot >= 5 ? 10u : tot == 4 ? 11u : tot == 3 ? 12u : tot == 2 ? 13u : 14u;
+        k = 2 * k + (nw ? 0u : 1u);
         key[r] = (uint8_t)k;
     }
     for (uint32_t c = 0; c < COST_CLASSES; c++) {
@@ -245,9 +250,9 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
     __shared__ uint32_t lds_pm[64 * PM_LDS_WORDS];
     LaneCtx cx;
 #ifdef DG_PROFILE_CLASSES
-    __shared__ unsigned long long ph_acc[17 * DG_NPHASE], cls_acc[2 * 17];
-    for (int q = threadIdx.x; q < 17 * DG_NPHASE; q += 64) ph_acc[q] = 0;
-    if (threadIdx.x < 34) cls_acc[threadIdx.x] = 0;
+    __shared__ unsigned long long ph_acc[DG_NCLS * DG_NPHASE], cls_acc[2 * DG_NCLS];
+    for (int q = threadIdx.x; q < DG_NCLS * DG_NPHASE; q += 64) ph_acc[q] = 0;
+    for (int q = threadIdx.x; q < 2 * DG_NCLS; q += 64) cls_acc[q] = 0;
     __syncthreads();
     cx.ph = ph_acc;
 #endif
@@ -262,8 +267,10 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
     const unsigned int n_jobreads = *n_jobreads_p;
     const unsigned int lo = job_part ? 0u : n_jobreads, hi = job_part ? n_jobreads : (unsigned int)n_reads;
     const unsigned int n_heavy = job_part ? hi - lo : *heavy_end_p - n_jobreads;
-    unsigned int g = 8;
-    while (g < 64 && (unsigned long long)g * gridDim.x < n_heavy) g <<= 1;
+    // few heavy reads (the usual case: some dozens per million): ONE read per wave, lane = candidate
+    const bool cpar = n_heavy <= 2u * gridDim.x;
+    unsigned int g = cpar ? 1 : 8;
+    while (!cpar && g < 64 && (unsigned long long)g * gridDim.x < n_heavy) g <<= 1;
     const unsigned int hgroups = (n_heavy + g - 1) / g;
     unsigned int *next = tops + (job_part ? 4 : 3);
     while (true) {
@@ -274,8 +281,9 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
         if (ticket < hgroups) { base = lo + ticket * g; cnt = n_heavy - ticket * g < g ? n_heavy - ticket * g : g; }
         else { base = lo + n_heavy + (ticket - hgroups) * 64u; cnt = 64; }
         if (base >= hi) break;
-        const unsigned int idx = base + (threadIdx.x & 63);
-        const bool valid = (threadIdx.x & 63) < cnt && idx < hi;   // every lane enters d_gen_mapping_report (it has wave-wide steps)
+        const bool wave_read = cpar && ticket < hgroups;
+        const unsigned int idx = wave_read ? base : base + (threadIdx.x & 63);
+        const bool valid = wave_read || ((threadIdx.x & 63) < cnt && idx < hi);   // every lane enters d_gen_mapping_report (it has wave-wide steps)
         const int r = valid ? (int)perm[idx] : 0;
         DRead rd;
         rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0;           // defined start state
@@ -285,11 +293,11 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
         cx.cls = g_costkey[perm[base]]; cx.t_last = t_begin;
 #endif
         d_gen_mapping_report(cx, valid, paired ? (r & 1) == 0 : true, rd, cands + seed_off[r], valid ? (int)ncand[r] : 0, jobs, work,
-                             reports + rep_off[r], rep_off[r], cigpool, tops + 0, cigcap, err);
+                             reports + rep_off[r], rep_off[r], cigpool, tops + 0, cigcap, err, wave_read ? (int)(threadIdx.x & 63) : 0, wave_read ? 64 : 1);
 #ifdef DG_PROFILE_CLASSES
-        if ((threadIdx.x & 63) == 0) { cls_acc[cx.cls] += (unsigned long long)(clock64() - t_begin); cls_acc[17 + cx.cls] += 1ull; }
+        if ((threadIdx.x & 63) == 0) { cls_acc[cx.cls] += (unsigned long long)(clock64() - t_begin); cls_acc[DG_NCLS + cx.cls] += 1ull; }
 #endif
-        if (valid) {
+        if (valid && (!wave_read || (threadIdx.x & 63) == 0)) {
             dg_read_out o;
             o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
             o.n_rep = rd.CanNum; o.best = rd.iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
@@ -298,8 +306,8 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
     }
 #ifdef DG_PROFILE_CLASSES
     __syncthreads();
-    for (int q = threadIdx.x; q < 17 * DG_NPHASE; q += 64) if (ph_acc[q]) atomicAdd(&g_phase[q / DG_NPHASE][q % DG_NPHASE], ph_acc[q]);
-    if (threadIdx.x < 17 && cls_acc[17 + threadIdx.x]) { atomicAdd(&g_class_cycles[threadIdx.x], cls_acc[threadIdx.x]); atomicAdd(&g_class_chunks[threadIdx.x], cls_acc[17 + threadIdx.x]); }
+    for (int q = threadIdx.x; q < DG_NCLS * DG_NPHASE; q += 64) if (ph_acc[q]) atomicAdd(&g_phase[q / DG_NPHASE][q % DG_NPHASE], ph_acc[q]);
+    if (threadIdx.x < DG_NCLS && cls_acc[DG_NCLS + threadIdx.x]) { atomicAdd(&g_class_cycles[threadIdx.x], cls_acc[threadIdx.x]); atomicAdd(&g_class_chunks[threadIdx.x], cls_acc[DG_NCLS + threadIdx.x]); }
 #endif
     d_wave_add(ctr + CTR_NW, cx.n_nw);
     d_wave_add(ctr + CTR_NWCELLS, cx.nw_cells);
@@ -675,8 +683,8 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     uint32_t *class_offs = c->hist.p + (size_t)COST_CLASSES * nb + 8;
     HIPCHK(scan_u32(c, c->hist.p, class_offs, COST_CLASSES * nb));
     k_cost_scatter<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->costkey.p, class_offs, c->perm.p);
-    const uint32_t *n_jobreads_p = class_offs + (size_t)1 * nb;       // start of class 1 = number of class-0 (job) reads
-    const uint32_t *heavy_end_p = class_offs + (size_t)4 * nb;        // start of class 4 = end of the heavy classes 1-3
+    const uint32_t *n_jobreads_p = class_offs + (size_t)2 * nb;       // start of class 1 (key 2) = number of class-0 (job) reads
+    const uint32_t *heavy_end_p = class_offs + (size_t)8 * nb;        // start of class 4 (key 8) = end of the heavy classes 1-3
     TICK("order");
     // one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves
     const int blocks_main = blocks > c->n_cu * 4 ? blocks - c->n_cu : blocks;
@@ -694,7 +702,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
         HIPCHK(hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_class_cycles), sizeof cyc)); HIPCHK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_class_chunks), sizeof cnt));
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_class_cycles), z, sizeof z)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_class_chunks), z, sizeof z));
         unsigned long long tot = 0; for (int k = 0; k <= COST_CLASSES; k++) tot += cyc[k];
-        unsigned long long ph[17][DG_NPHASE], zp[17][DG_NPHASE] = {{0}};
+        unsigned long long ph[DG_NCLS][DG_NPHASE], zp[DG_NCLS][DG_NPHASE] = {{0}};
         HIPCHK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof ph)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zp, sizeof zp));
         for (int k = 0; k < COST_CLASSES; k++) if (cnt[k]) {
             fprintf(stderr, "[class %2d] chunks %7llu  cycles/chunk %8llu  share %5.1f %%  phases/chunk:", k, cnt[k], cyc[k] / cnt[k], 100.0 * cyc[k] / (tot ? tot : 1));

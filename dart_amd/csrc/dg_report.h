@@ -798,6 +798,85 @@ __device__ inline void d_nw_coop(const DIndex &ix, const unsigned char *a, int m
     __syncthreads();                                       // the owner reads tb next
 }
 
+// ---------------------------------------------------------------------------------------------
+// nw_alignment of up to EIGHT pairs at once: the wave's 64 lanes form 8 groups of 8, a group aligns one
+// pair of n <= 64 columns.  Lane k of a group owns the c = ceil(n / 8) columns [k*c, (k+1)*c) for every
+// row (their s/t values of the previous row stay in registers, as in d_nw's strips) and the group is a
+// software pipeline along the rows: at step t lane k computes row t - k, taking the three values its
+// first column needs from lane k-1 (which computed that row one step earlier) by a DPP row shift.
+// A 35 x 35 pair costs 42 steps of ~170 instructions for 8 pairs, against 70 steps of ~45 for ONE pair in
+// d_nw_coop: the per-phase profile (profiles/r01/i_k_report_class_profile.txt) had the one-pair-at-a-time
+// loop at 60 % of the large-pair class.  Same output as d_nw_coop: traceback bits, column-major, in the
+// owner lane's scratch.  All 64 lanes call it; the arguments are the GROUP's pair (has = false: none).
+// ---------------------------------------------------------------------------------------------
+#define NWG_LANES 8
+#define NWG_MAXN  64
+__device__ inline void d_nw_group(const DIndex &ix, bool has, const unsigned char *a, int m, int64_t gPos, int n, unsigned char *ows, const WSLayout &L, int lane)
+{
+    const int k = lane & (NWG_LANES - 1);
+    const int c = has ? (n + NWG_LANES - 1) / NWG_LANES : 0;
+    const int j_first = k * c + 1;
+    int cn = has ? n - k * c : 0;                                  // this lane's valid columns
+    cn = cn < 0 ? 0 : (cn > c ? c : cn);
+    int steps = has ? m + NWG_LANES - 1 : 0, cmax = c;
+    for (int o = 32; o > 0; o >>= 1) {
+        const int v = __shfl_xor(steps, o, 64); steps = v > steps ? v : steps;
+        const int w = __shfl_xor(cmax, o, 64); cmax = w > cmax ? w : cmax;
+    }
+    uint32_t *tb = (uint32_t *)(ows + L.nwbits_off);
+    const int RW = (m + 15) >> 4;
+    int up_s[8], up_t[8];
+    uint32_t acc[8], cbp = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int j = j_first + q;
+        up_s[q] = -2 - j; up_t[q] = -131072; acc[q] = 0;
+        const uint32_t cb = q < cn ? (uint32_t)d_nt4((unsigned char)d_refchar(ix, gPos + j - 1)) : 7u;
+        cbp |= cb << (4 * q);
+    }
+    int cur_s = 0, cur_r = 0, prev_s = 0;                          // s, r of this lane's LAST column in the row of the previous step; s one row earlier
+    unsigned char a_nxt = (has && 1 - k >= 1 && 1 - k <= m) ? a[1 - k - 1] : 0;
+    for (int t = 1; t <= steps; t++) {
+        const int nl_cur_s = __builtin_amdgcn_update_dpp(0, cur_s, 0x111, 0xF, 0xF, false), nl_cur_r = __builtin_amdgcn_update_dpp(0, cur_r, 0x111, 0xF, 0xF, false),
+                  nl_prev_s = __builtin_amdgcn_update_dpp(0, prev_s, 0x111, 0xF, 0xF, false);      // row_shr:1 (lane 8 of a row ignores what it gets: k == 0)
+        const int i = t - k;
+        const unsigned char a_cur = a_nxt;
+        a_nxt = (has && i + 1 >= 1 && i + 1 <= m) ? a[i] : 0;
+        if (cn > 0 && i >= 1 && i <= m) {
+            int left_s, left_r, diag;
+            if (k == 0) { left_s = -2 - i; left_r = -131072; diag = i == 1 ? 0 : -2 - (i - 1); }
+            else { left_s = nl_cur_s; left_r = nl_cur_r; diag = i == 1 ? -2 - (j_first - 1) : nl_prev_s; }
+            const uint32_t ca = d_nt4(a_cur);
+            const int sh = ((i - 1) & 15) << 1;
+            int new_prev = prev_s;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (q >= cmax) break;                              // wave-uniform
+                if (q < cn) {
+                    int x = left_r - 1, y = left_s - 3;
+                    const int r = x > y ? x : y;
+                    x = up_t[q] - 1; y = up_s[q] - 3;
+                    const int tt = x > y ? x : y;
+                    const int d = d_tr2(diag + (ca == ((cbp >> (4 * q)) & 15u) ? 3 : -3));
+                    const int rr = d_tr2(r), t2 = d_tr2(tt);
+                    const int sv = d > rr ? (d > t2 ? d : t2) : (rr > t2 ? rr : t2);
+                    acc[q] |= ((sv == r ? 1u : 0u) | (sv == tt ? 2u : 0u)) << sh;
+                    diag = up_s[q];
+                    new_prev = diag;                               // after the last valid column: s[i-1][last]
+                    up_s[q] = sv; up_t[q] = tt;
+                    left_s = sv; left_r = r;
+                }
+            }
+            prev_s = new_prev; cur_s = left_s; cur_r = left_r;
+            if (sh == 30 || i == m) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (q < cn) { tb[(size_t)(j_first + q - 1) * RW + ((i - 1) >> 4)] = acc[q]; acc[q] = 0; }
+            }
+        }
+    }
+    __syncthreads();                                               // the owners read tb next
+}
+
 // traceback (nw_alignment.cpp:61-74) from the column-major bits of d_nw_coop into the two gapped strings
 __device__ inline int d_tb_traceback(LaneCtx &cx, const char *a, int m, const char *b, int n, char *oa, char *ob)
 {
@@ -883,7 +962,8 @@ __device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t 
 
 #ifdef DG_PROFILE_CLASSES
 #define DG_NPHASE 12
-__device__ unsigned long long g_phase[17][DG_NPHASE];
+#define DG_NCLS 33
+__device__ unsigned long long g_phase[DG_NCLS][DG_NPHASE];
 #define PH(k) do { if ((threadIdx.x & 63) == 0) { const long long t_now = clock64(); cx.ph[cx.cls * DG_NPHASE + (k)] += (unsigned long long)(t_now - cx.t_last); cx.t_last = t_now; } } while (0)
 #else
 #define PH(k) do { } while (0)
@@ -900,26 +980,32 @@ struct DRead {
 // CALLED BY ALL 64 LANES OF THE WAVE TOGETHER (valid = false: a lane without a read): the candidate loop
 // runs to the wave's largest candidate count with per-lane guards, because in its middle the wave
 // aligns the lanes' LARGE segment pairs cooperatively, one after the other (d_nw_coop).
+// Two lane layouts: one read per lane (cstride = 1, cstart = 0: the lane walks its read's candidates in order), or ONE read
+// for the whole wave with lane = candidate (cstride = 64, cstart = lane; the few reads with dozens of candidates that
+// otherwise set the kernel's critical path).  In the second layout the running best/second-best state of
+// :1161-1172 is replayed in candidate order by lane 0 afterwards (rd is valid in lane 0 only).
 template <typename ReportT>
 __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first, DRead &rd, DCand *cands, int ncand, const DJob *jobs,
-                                            DSeed *work, ReportT *rep, uint32_t rep_index0, uint32_t *cigpool, unsigned int *cigtop, uint32_t cigcap, int *err)
+                                            DSeed *work, ReportT *rep, uint32_t rep_index0, uint32_t *cigpool, unsigned int *cigtop, uint32_t cigcap, int *err,
+                                            int cstart = 0, int cstride = 1)
 {
     const DIndex &ix = *cx.ix;
     const int lane = threadIdx.x & 63;
     rd.score = rd.iBest = 0;
     if (!valid) ncand = 0;
     rd.CanNum = ncand > 0 ? ncand : 1;
-    if (valid && ncand == 0) {
+    if (valid && ncand == 0 && cstart == 0) {
         ReportT rp;
         rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = -1; rp.chr = -1; rp.bdir = 0;
         rp.pos = 0; rp.cigar_off = 0; rp.n_cigar = 0;
         rep[0] = rp;
     }
-    int nmax = ncand;
+    int nmax = ncand > cstart ? (ncand - cstart + cstride - 1) / cstride : 0;      // this lane's iterations
     for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
     uint32_t *cig = ws_cig(cx);
     PH(0);
-    for (int i = 0; i < nmax; i++) {
+    for (int it = 0; it < nmax; it++) {
+        const int i = cstart + it * cstride;
         const bool act = i < ncand;
         // ---- part 1 (per lane): everything up to knowing which segment pairs need nw_alignment ----
         ReportT rp;
@@ -986,18 +1072,35 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
             }
         }
         PH(5);
-        // ---- the wave aligns the lanes' large pairs, one owner after the other ----
-        unsigned long long todo = __ballot(bigj >= 0);
-        while (todo) {
-            const int owner = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const DSeed sd = s[bigj < 0 ? 0 : bigj];     // only the owner's copy is used
+        // ---- the wave aligns the lanes' large pairs: eight at a time (<= 64 columns), the rest one after the other ----
+        if (__ballot(bigj >= 0)) {
+            const DSeed sd = s[bigj < 0 ? 0 : bigj];         // only an owner's copy is used
             const unsigned long long ap = (unsigned long long)(cx.seq + sd.rPos), wp = (unsigned long long)cx.ws;
-            const unsigned long long a_o = ((unsigned long long)(uint32_t)__shfl((int)(ap >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)ap, owner, 64);
-            const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)wp, owner, 64);
-            const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)sd.gPos >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)sd.gPos, owner, 64);
-            const int m_o = __shfl((int)sd.rLen, owner, 64), n_o = __shfl((int)sd.gLen, owner, 64);
-            d_nw_coop(ix, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
+            unsigned long long todo = __ballot(bigj >= 0 && sd.gLen <= NWG_MAXN);
+            while (todo) {
+                int own = -1;
+                for (int q = 0; q < 64 / NWG_LANES; q++) {   // group q takes the q-th owner
+                    const int b = todo ? __ffsll((long long)todo) - 1 : -1;
+                    if (q == (lane >> 3)) own = b;
+                    todo &= todo - 1;                        // (0 stays 0)
+                }
+                const int src = own < 0 ? 0 : own;
+                const unsigned long long a_o = ((unsigned long long)(uint32_t)__shfl((int)(ap >> 32), src, 64) << 32) | (uint32_t)__shfl((int)ap, src, 64);
+                const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), src, 64) << 32) | (uint32_t)__shfl((int)wp, src, 64);
+                const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)sd.gPos >> 32), src, 64) << 32) | (uint32_t)__shfl((int)sd.gPos, src, 64);
+                const int m_o = __shfl((int)sd.rLen, src, 64), n_o = __shfl((int)sd.gLen, src, 64);
+                d_nw_group(ix, own >= 0, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
+            }
+            todo = __ballot(bigj >= 0 && sd.gLen > NWG_MAXN);
+            while (todo) {
+                const int owner = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const unsigned long long a_o = ((unsigned long long)(uint32_t)__shfl((int)(ap >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)ap, owner, 64);
+                const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)wp, owner, 64);
+                const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)sd.gPos >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)sd.gPos, owner, 64);
+                const int m_o = __shfl((int)sd.rLen, owner, 64), n_o = __shfl((int)sd.gLen, owner, 64);
+                d_nw_coop(ix, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
+            }
         }
         PH(6);
         // ---- part 2 (per lane): the lanes' small alignments together, then the reference's loop (:1134-1160) ----
@@ -1077,13 +1180,27 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                     else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
                 }
                 rp.aln_score = aln;
-                if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis_num; rd.sub_score = rd.score; rd.score = aln; }
+                if (cstride != 1) rp.flag = mis_num;               // parked for the replay below
+                else if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis_num; rd.sub_score = rd.score; rd.score = aln; }
                 else if (aln == rd.score) rd.sub_score = rd.score;
             }
         }
         PH(9);
         if (act) { cands[i].final_n = final_n; rep[i] = rp; }
         PH(10);
+    }
+    if (cstride != 1) {
+        __syncthreads();                                           // the other lanes' reports are in memory
+        if (lane == 0) {
+            for (int i = 0; i < ncand; i++) {
+                const int aln = rep[i].aln_score;
+                if (aln <= 0) continue;                            // (an aln the reference zeroes late changes nothing: score and sub_score are 0 or stay)
+                const int mis_num = rep[i].flag;
+                rep[i].flag = 0;
+                if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis_num; rd.sub_score = rd.score; rd.score = aln; }
+                else if (aln == rd.score) rd.sub_score = rd.score;
+            }
+        }
     }
 }
 

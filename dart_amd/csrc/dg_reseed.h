@@ -52,15 +52,17 @@ k_prep(const DParams pr, int n_reads, const uint32_t *__restrict__ seed_off, con
         n = d_remove_transloc(s, n, vec);
         c.n_a = n;
         int cnt = 0;                                     // IdentifyMissingSeeds :691-697, enumeration only
-        int big = n > 0 && (s[0].rPos > PM_MAX || (int)rlen[r] - (s[n - 1].rPos + s[n - 1].rLen) > PM_MAX) ? 1 : 0;
+        int big = n > 0 && (s[0].rPos > PM_MAX || (int)rlen[r] - (s[n - 1].rPos + s[n - 1].rLen) > PM_MAX) ? 1 : 0, indel = 0;
         for (int k = 1; k < n; k++) {
             const int pd = (int)((s[k].gPos - s[k].rPos) - (s[k - 1].gPos - s[k - 1].rPos));
             const int rGaps = s[k].rPos - s[k - 1].rPos - s[k - 1].rLen;
             if (pd > pr.max_gaps && rGaps > 20) cnt++;
             if (rGaps > PM_MAX || rGaps + pd > PM_MAX) big = 1;
+            if (pd != 0) indel = 2;
         }
-        c.final_n = big;                                 // scheduling hint for k_cost only (k_report sets the real value):
-                                                         // some segment pair is longer than PM_MAX: string path, maybe a wave-wide alignment
+        c.final_n = big | indel;                         // scheduling hints for k_cost only (k_report sets the real value): bit 0 = some
+                                                         // segment pair is longer than PM_MAX (string path, maybe a wave-wide alignment),
+                                                         // bit 1 = two seeds on different diagonals (an nw_alignment is certain)
         if (cnt == 0) continue;
         const unsigned int first = atomicAdd(jobtop, (unsigned int)cnt);
         if (first + (unsigned int)cnt > jobcap) { *err = 3; continue; }
