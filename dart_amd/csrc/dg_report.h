@@ -877,6 +877,41 @@ __device__ inline void d_nw_group(const DIndex &ix, bool has, const unsigned cha
     __syncthreads();                                               // the owners read tb next
 }
 
+// Wave-wide nw_alignment service: every lane may ask for one alignment (has; read characters a[0..m), genome
+// gPos..gPos+n); requests of <= 64 columns run eight at a time (d_nw_group), wider ones one after the other
+// (d_nw_coop).  Traceback bits land in each requesting lane's own scratch.  Called by all 64 lanes.
+__device__ inline void d_nw_wave(LaneCtx &cx, bool has, const unsigned char *a, int m, int64_t gPos, int n, int lane)
+{
+    if (!__ballot(has)) return;
+    const DIndex &ix = *cx.ix;
+    const unsigned long long ap = (unsigned long long)a, wp = (unsigned long long)cx.ws;
+    unsigned long long todo = __ballot(has && n <= NWG_MAXN);
+    while (todo) {
+        int own = -1;
+        for (int q = 0; q < 64 / NWG_LANES; q++) {           // group q takes the q-th requester
+            const int b = todo ? __ffsll((long long)todo) - 1 : -1;
+            if (q == (lane >> 3)) own = b;
+            todo &= todo - 1;                                // (0 stays 0)
+        }
+        const int src = own < 0 ? 0 : own;
+        const unsigned long long a_o = ((unsigned long long)(uint32_t)__shfl((int)(ap >> 32), src, 64) << 32) | (uint32_t)__shfl((int)ap, src, 64);
+        const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), src, 64) << 32) | (uint32_t)__shfl((int)wp, src, 64);
+        const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)gPos >> 32), src, 64) << 32) | (uint32_t)__shfl((int)gPos, src, 64);
+        const int m_o = __shfl(m, src, 64), n_o = __shfl(n, src, 64);
+        d_nw_group(ix, own >= 0, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
+    }
+    todo = __ballot(has && n > NWG_MAXN);
+    while (todo) {
+        const int owner = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const unsigned long long a_o = ((unsigned long long)(uint32_t)__shfl((int)(ap >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)ap, owner, 64);
+        const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)wp, owner, 64);
+        const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)gPos >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)gPos, owner, 64);
+        const int m_o = __shfl(m, owner, 64), n_o = __shfl(n, owner, 64);
+        d_nw_coop(ix, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
+    }
+}
+
 // traceback (nw_alignment.cpp:61-74) from the column-major bits of d_nw_coop into the two gapped strings
 __device__ inline int d_tb_traceback(LaneCtx &cx, const char *a, int m, const char *b, int n, char *oa, char *ob)
 {
@@ -899,6 +934,73 @@ __device__ inline int d_tb_traceback(LaneCtx &cx, const char *a, int m, const ch
         c = ob[p]; ob[p] = ob[q]; ob[q] = c;
     }
     return k;
+}
+
+// SeedExtension :577-594 for the wave's lanes together (live = this lane has a candidate to extend).  The two
+// nw_alignment calls of every FillGapsBetweenAdjacentSeeds (d_fill_gaps above, the one-lane form) are served by
+// d_nw_wave; the lane then reads its traceback, exactly the strings d_nw would have produced.  On spliced reads
+// these rGaps x rGaps alignments, one lane at a time, were most of k_report (and on plain reads the tail of
+// the job reads: one lane, 1.9 M cycles).
+__device__ inline int d_seed_extension_wave(LaneCtx &cx, bool live, DSeed *s, int n, int lane)
+{
+    const DIndex &ix = *cx.ix;
+    const int num = live ? n : 0;
+    int i = 1;
+    while (true) {
+        bool has = false;
+        for (; i < num; i++) {
+            const int pd = (int)((s[i].gPos - s[i].rPos) - (s[i - 1].gPos - s[i - 1].rPos));
+            if (pd > cx.pr->min_intron && s[i].rPos > s[i - 1].rPos + s[i - 1].rLen) { has = true; break; }
+        }
+        if (!__ballot(has)) break;
+        DSeed Ls = s[has ? i - 1 : 0], Rs = s[has ? i : 0];
+        int rGaps = has ? Rs.rPos - (Ls.rPos + Ls.rLen) : 0;
+        const unsigned char *rdp = cx.seq + Ls.rPos + Ls.rLen;
+        char *g = ws_str(cx, 0), *f1 = ws_str(cx, 1), *f2 = ws_str(cx, 2), *f3 = ws_str(cx, 3), *f4 = ws_str(cx, 4);
+        int *Rv = (int *)ws_cig(cx), *Lv = Rv + rGaps + 1;      // the CIGAR scratch is idle at this stage
+        int len = 0;
+        d_nw_wave(cx, has, rdp, rGaps, Ls.gPos + Ls.gLen, rGaps, lane);
+        if (has) {
+            for (int q = 0; q <= rGaps; q++) Rv[q] = Lv[q] = 0;
+            d_ref_fill(ix, Ls.gPos + Ls.gLen, rGaps, g);
+            len = d_tb_traceback(cx, (const char *)rdp, rGaps, g, rGaps, f1, f2);
+            int q = len - 1;
+            while (q >= 0 && f2[q] == '-') q--;
+            int64_t gp = Ls.gPos + Ls.gLen + rGaps;
+            for (q += 1; q < len; q++, gp++) f2[q] = d_refchar(ix, gp);
+            int p = 0, sc = 0;
+            for (q = 0; q < len; q++) { if (f1[q] == f2[q]) sc++; if (f1[q] != '-') p++; Rv[p] = sc; }
+        }
+        d_nw_wave(cx, has, rdp, rGaps, Rs.gPos - rGaps, rGaps, lane);
+        if (has) {
+            d_ref_fill(ix, Rs.gPos - rGaps, rGaps, g);
+            const int len3 = d_tb_traceback(cx, (const char *)rdp, rGaps, g, rGaps, f3, f4);
+            int q = 0;
+            while (q < len3 && f4[q] == '-') q++;
+            int64_t gp = Rs.gPos - rGaps;
+            for (q -= 1; q >= 0; q--, gp--) f4[q] = d_refchar(ix, gp);
+            int p = 0, sc = 0;
+            for (q = len3 - 1; q >= 0; q--) { if (f3[q] == f4[q]) sc++; if (f3[q] != '-') p++; Lv[rGaps - p] = sc; }
+            int max_score = 0, bp = 0;
+            for (q = 0; q <= rGaps; q++) { const int v = Rv[q] + Lv[q]; if (v > max_score) { max_score = v; bp = q; } }
+            int right_ext = 0, left_ext = 0;
+            if (!(max_score < (int)(rGaps * 0.8) || (rGaps - max_score) > cx.pr->max_mismatch)) {
+                for (p = bp, q = 0; p > 0; q++) { if (f1[q] != '-') p--; if (f2[q] != '-') right_ext++; }
+                for (p = rGaps - bp, q = len3 - 1; p > 0; q--) { if (f3[q] != '-') p--; if (f4[q] != '-') left_ext++; }
+            }
+            if (bp > 0) {
+                DSeed x; x.flags = 0; x.rPos = Ls.rPos + Ls.rLen; x.gPos = Ls.gPos + Ls.gLen; x.rLen = bp; x.gLen = right_ext;
+                s[n++] = x;
+            }
+            if ((rGaps -= bp) > 0) {
+                DSeed x; x.flags = 0; x.rLen = rGaps; x.gLen = left_ext; x.rPos = Rs.rPos - x.rLen; x.gPos = Rs.gPos - x.gLen;
+                s[n++] = x;
+            }
+            i++;
+        }
+    }
+    if (live && n > num) d_insertion_sort_seeds(s, n);
+    return n;
 }
 
 // does the string path reach nw_alignment for this pair (tools.cpp:130-164,203-300 up to the call)?
@@ -1015,32 +1117,37 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
         uint32_t nwj = 0;                                 // seed indices (8 bits each) of the first PM_MAXQ small alignments
         uint64_t pcl = 0;                                 // outcome of d_pair_classify for the first 12 pairs, 5 bits each (class | mismatches << 3)
         DSeed *s = work;
-        bool go = false;
+        bool go = false, live = false;
+        int n = 0;
         if (act) {
             DCand &c = cands[i];
             rp.paired_idx = c.PairedIdx;
             if (c.Score != 0) {
                 // the working region already went through k_prep (tandem / translocation clean-up);
                 // IdentifyMissingSeeds :685-700: append the seeds k_reseed found, then re-sort
+                live = true;
                 s = work + c.work_off;
-                int n = c.n_a;
-                {
-                    const int n0 = n;
-                    for (int q = 0; q < c.job_count; q++) {
-                        const DJob jb = jobs[c.job_first + q];
-                        if (jb.found == 1) {
-                            DSeed ns; ns.gPos = jb.gPos; ns.rPos = jb.rPos; ns.rLen = ns.gLen = jb.len; ns.flags = SEED_SIMPLE;
-                            s[n++] = ns;
-                        } else if (jb.found < 0) {               // read gap too long for the cooperative kernel
-                            DSeed ns;
-                            if (d_reseed(cx, jb.rBegin, jb.rBegin + jb.rl, jb.Lb, jb.Lb + jb.glen, &ns)) s[n++] = ns;
-                        }
+                n = c.n_a;
+                const int n0 = n;
+                for (int q = 0; q < c.job_count; q++) {
+                    const DJob jb = jobs[c.job_first + q];
+                    if (jb.found == 1) {
+                        DSeed ns; ns.gPos = jb.gPos; ns.rPos = jb.rPos; ns.rLen = ns.gLen = jb.len; ns.flags = SEED_SIMPLE;
+                        s[n++] = ns;
+                    } else if (jb.found < 0) {               // read gap too long for the cooperative kernel
+                        DSeed ns;
+                        if (d_reseed(cx, jb.rBegin, jb.rBegin + jb.rl, jb.Lb, jb.Lb + jb.glen, &ns)) s[n++] = ns;
                     }
-                    if (n > n0) d_insertion_sort_seeds(s, n);
                 }
-                PH(1);
-                n = d_seed_extension(cx, s, n);
-                PH(2);
+                if (n > n0) d_insertion_sort_seeds(s, n);
+            }
+        }
+        PH(1);
+        n = d_seed_extension_wave(cx, live, s, n, lane);      // wave-wide: the gap-filling alignments of all lanes together
+        PH(2);
+        if (live) {
+            {
+                DCand &c = cands[i];
                 int2 *vec = (int2 *)(s + n + 1);
                 rp.sj_type = c.SJtype = d_check_splice(cx, s, n, vec);
                 PH(3);
@@ -1074,33 +1181,8 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
         PH(5);
         // ---- the wave aligns the lanes' large pairs: eight at a time (<= 64 columns), the rest one after the other ----
         if (__ballot(bigj >= 0)) {
-            const DSeed sd = s[bigj < 0 ? 0 : bigj];         // only an owner's copy is used
-            const unsigned long long ap = (unsigned long long)(cx.seq + sd.rPos), wp = (unsigned long long)cx.ws;
-            unsigned long long todo = __ballot(bigj >= 0 && sd.gLen <= NWG_MAXN);
-            while (todo) {
-                int own = -1;
-                for (int q = 0; q < 64 / NWG_LANES; q++) {   // group q takes the q-th owner
-                    const int b = todo ? __ffsll((long long)todo) - 1 : -1;
-                    if (q == (lane >> 3)) own = b;
-                    todo &= todo - 1;                        // (0 stays 0)
-                }
-                const int src = own < 0 ? 0 : own;
-                const unsigned long long a_o = ((unsigned long long)(uint32_t)__shfl((int)(ap >> 32), src, 64) << 32) | (uint32_t)__shfl((int)ap, src, 64);
-                const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), src, 64) << 32) | (uint32_t)__shfl((int)wp, src, 64);
-                const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)sd.gPos >> 32), src, 64) << 32) | (uint32_t)__shfl((int)sd.gPos, src, 64);
-                const int m_o = __shfl((int)sd.rLen, src, 64), n_o = __shfl((int)sd.gLen, src, 64);
-                d_nw_group(ix, own >= 0, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
-            }
-            todo = __ballot(bigj >= 0 && sd.gLen > NWG_MAXN);
-            while (todo) {
-                const int owner = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const unsigned long long a_o = ((unsigned long long)(uint32_t)__shfl((int)(ap >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)ap, owner, 64);
-                const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)wp, owner, 64);
-                const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)sd.gPos >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)sd.gPos, owner, 64);
-                const int m_o = __shfl((int)sd.rLen, owner, 64), n_o = __shfl((int)sd.gLen, owner, 64);
-                d_nw_coop(ix, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
-            }
+            const DSeed sd = s[bigj < 0 ? 0 : bigj];         // only a requesting lane's copy is used
+            d_nw_wave(cx, bigj >= 0, cx.seq + sd.rPos, sd.rLen, sd.gPos, sd.gLen, lane);
         }
         PH(6);
         // ---- part 2 (per lane): the lanes' small alignments together, then the reference's loop (:1134-1160) ----
