@@ -18,6 +18,11 @@ import os
 import sys
 import time
 
+# the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); a mapping context uses two streams, so the
+# batches in flight shared queues and waited for each other (399 -> 465 M reads/s, profiles/probes/hwq_sweep.sh).  Read at HIP
+# initialisation: must be set before torch / libdartgpu touch the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -117,7 +122,7 @@ def main():
     ap.add_argument("--indel-frac", type=float, default=0.02, help="fraction of reads carrying one short indel (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("DART_BENCH_STAGGER_MS", "0")))
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "4")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "8")),
                     help="batches in flight per GPU: contexts sharing one index, one host thread each (dg_clone)")
     ap.add_argument("--cache", default=os.environ.get("DART_BENCH_CACHE", "/tmp/dart_bench_cache"))
     args = ap.parse_args()

@@ -503,6 +503,11 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
 // A second context on the same device that shares the parent's index (no copy): its own streams, batch buffers
 // and counters, so that two batches can be in flight at once (one host thread per context).  The parent must
 // outlive its clones.
+// A context drives two HIP streams and a host keeps several contexts in flight (dg_clone); the runtime's default of 4 hardware
+// queues makes those streams wait for each other.  The variable is read when the HIP runtime initialises, so this only helps a
+// host that loads the library before its first HIP call; others export GPU_MAX_HW_QUEUES themselves.
+__attribute__((constructor)) static void dg_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" dg_ctx *dg_clone(dg_ctx *parent, int *status)
 {
     if (status) *status = DG_ERR_ARG;
@@ -642,6 +647,16 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
                                                                   c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->d_ctr);
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     HIPCHK(hipGetLastError());
+#ifdef DG_PROFILE_CLASSES
+    {
+        unsigned long long v[3], z = 0;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(g_chain_max), 8)); HIPCHK(hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(g_chain_units), 8)); HIPCHK(hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(g_chain_cycles), 8));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_max), &z, 8)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_units), &z, 8)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_cycles), &z, 8));
+        fprintf(stderr, "[chain_heavy] units %llu  mean cycles %llu  max cycles %llu (seeds %llu/%llu cands %llu/%llu)\n", v[1], v[1] ? v[2] / v[1] : 0, v[0] >> 40,
+                (v[0] >> 30) & 1023, (v[0] >> 20) & 1023, (v[0] >> 10) & 1023, v[0] & 1023);
+    }
+#endif
     TICK("k_chain");
     HIPCHK(scan_u32(c, c->nrep.p, c->rep_off.p, (uint32_t)n));
     HIPCHK(scan_u32(c, c->work_need.p, c->work_off.p, (uint32_t)n));

@@ -234,6 +234,9 @@ __device__ inline void d_bitonic_sort_lds(DSeed *a, int n, int lane)   // n <= C
     }
 }
 
+#ifdef DG_PROFILE_CLASSES
+__device__ unsigned long long g_chain_max, g_chain_units, g_chain_cycles;
+#endif
 __global__ void __launch_bounds__(64)
 k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const uint16_t *__restrict__ rlen,
               const uint32_t *__restrict__ seed_off, DSeed *__restrict__ seeds, DCand *__restrict__ cands,
@@ -249,6 +252,9 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
     for (unsigned int hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
         const int u = (int)heavy_list[hi];
         const int nm = paired ? 2 : 1;
+#ifdef DG_PROFILE_CLASSES
+        const long long t_begin = clock64();
+#endif
         const int r1 = paired ? 2 * u : u;
         uint32_t b[2], n[2];
         bool fits = true;
@@ -327,6 +333,12 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
                 ncand[r1 + m] = (uint32_t)nc; nrep[r1 + m] = nc > 0 ? (uint32_t)nc : 1u; work_need[r1 + m] = w;
                 nc_total += (unsigned long long)nc;
             }
+#ifdef DG_PROFILE_CLASSES
+            const unsigned long long cyc = (unsigned long long)(clock64() - t_begin);
+            auto cl = [](unsigned long long v) { return v > 1023 ? 1023ull : v; };
+            atomicMax(&g_chain_max, (cyc << 40) | (cl(n[0]) << 30) | (cl(paired ? n[1] : 0) << 20) | (cl(n1) << 10) | cl(n2));
+            atomicAdd(&g_chain_units, 1ull); atomicAdd(&g_chain_cycles, cyc);
+#endif
         }
     }
     if (lane == 0 && nc_total) atomicAdd(d_ctr_stripe(ctr) + CTR_CANDS, nc_total);

@@ -409,6 +409,7 @@ static void format_range(const Reads &R, int lo, int hi, int n_pair_mode, const 
 
 int main(int argc, char *argv[])
 {
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);      // before the first HIP call: a hardware queue per stream of the contexts in flight
     Options o;
     dg_params_default(&o.p);
     if (argc == 1 || strcmp(argv[1], "-h") == 0) { usage(argv[0], o); return 0; }

@@ -10,4 +10,4 @@ set -e
 mkdir -p gpurun_out
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -DDG_PROFILE_CLASSES -o dart_amd/libdartgpu.so dart_amd/csrc/dg_api.hip
 python bench.py --no-cpu-baseline --inflight 1 --steps 1 --warmup 1 "$@" > gpurun_out/class_profile.json 2> gpurun_out/class_profile.err
-grep "class" gpurun_out/class_profile.err | tail -16 | tee gpurun_out/class_profile.txt
+grep -E "class|chain_heavy" gpurun_out/class_profile.err | tail -30 | tee gpurun_out/class_profile.txt
