@@ -120,6 +120,20 @@ __global__ void k_relayout_bwt(const uint32_t *__restrict__ src, uint64_t src_wo
 // One thread per output word: neighbouring lanes read neighbouring 16-byte groups and store contiguously.
 // ---------------------------------------------------------------------------------------------
 typedef uint4 __attribute__((aligned(1))) uint4_a1;
+// four characters at once (SWAR): x = 4 ASCII bytes in string order, keep = 0xFF in the bytes that belong to the read.
+// b8 = their four 2-bit codes, first character in the top bits; m8 = 0b11 where the character is not A/C/G/T (either case).
+// (One base at a time through nst_nt4_table this kernel was 278 M wave-instructions per 2 M reads, half of k_seed's.)
+__device__ __forceinline__ void d_enc4(uint32_t x, uint32_t keep, uint32_t &b8, uint32_t &m8)
+{
+    const uint32_t u = x & 0xDFDFDFDFu;                                             // upper case
+    auto nz = [](uint32_t z) { return ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z; };     // bit 7 of a byte set <=> the byte is not zero
+    const uint32_t none = nz(u ^ 0x41414141u) & nz(u ^ 0x43434343u) & nz(u ^ 0x47474747u) & nz(u ^ 0x54545454u);
+    const uint32_t inv = ((none & 0x80808080u) >> 7) | (~keep & 0x01010101u);       // 1 in every byte that is not a base of the read
+    const uint32_t code = ((u >> 1) ^ (u >> 2)) & 0x03030303u & ~(inv * 3u);        // d_nt4's formula, byte-wise (the mask keeps bits that came from the same byte)
+    b8 = (code * 0x40100401u) >> 24;                                                // bytes b0..b3 -> b0<<6 | b1<<4 | b2<<2 | b3 (no two partial products meet)
+    m8 = ((inv * 0x40100401u) >> 24) * 3u;
+}
+
 __global__ void __launch_bounds__(256)
 k_encode(const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen,
          int n_reads, int W, int lg, uint32_t *__restrict__ enc)
@@ -130,20 +144,14 @@ k_encode(const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq
     const int ww = (int)(t & ((1u << lg) - 1u));
     if (rr >= (size_t)n_reads || ww >= W2) return;
     const int r = (int)rr;
-    const unsigned char *s = seq + seq_off[r] + ww * 16;
     const int left = (int)rlen[r] - ww * 16;                            // bases of the read from this group on
-    uint32_t ch[4] = {0, 0, 0, 0};
-    if (left >= 16) { const uint4 q = *(const uint4_a1 *)s; ch[0] = q.x; ch[1] = q.y; ch[2] = q.z; ch[3] = q.w; }
-    else for (int j = 0; j < left; j++) ch[j >> 2] |= (uint32_t)s[j] << (8 * (j & 3));
-    uint32_t vb = 0, vm = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint32_t c = j < left ? d_nt4((unsigned char)(ch[j >> 2] >> (8 * (j & 3)))) : 4u;
-        vb |= (c > 3 ? 0u : c) << (30 - 2 * j);
-        vm |= (c > 3 ? 3u : 0u) << (30 - 2 * j);
-    }
-    enc[(size_t)r * W + ww] = vb;
-    enc[(size_t)r * W + W2 + ww] = vm;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (left > 0) q = *(const uint4_a1 *)(seq + seq_off[r] + ww * 16);  // may run up to 15 bytes past the read: the batch buffer is padded
+    auto keep = [left](int w) -> uint32_t { const int k = left - 4 * w; return k >= 4 ? 0xFFFFFFFFu : (k <= 0 ? 0u : (1u << (8 * k)) - 1u); };
+    uint32_t b0, b1, b2, b3, m0, m1, m2, m3;
+    d_enc4(q.x, keep(0), b0, m0); d_enc4(q.y, keep(1), b1, m1); d_enc4(q.z, keep(2), b2, m2); d_enc4(q.w, keep(3), b3, m3);
+    enc[(size_t)r * W + ww] = (b0 << 24) | (b1 << 16) | (b2 << 8) | b3;
+    enc[(size_t)r * W + W2 + ww] = (m0 << 24) | (m1 << 16) | (m2 << 8) | m3;
 }
 
 // one step of BWT_Search (:152-170) with base c, given the already loaded Occ blocks of rows kk and ll
