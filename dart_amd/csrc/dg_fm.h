@@ -475,7 +475,7 @@ template <bool USE_LDS>
 __global__ void __launch_bounds__(64)
 k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H,
        DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
-       DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips)
+       DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int both_thr)
 {
     extern __shared__ uint32_t sh[];
     const int lane = threadIdx.x;
@@ -539,13 +539,21 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
         // in; the lanes in the other heavy mode wait a trip.  Running every mode's code in every trip made the kernel
         // instruction-fetch bound (the I-cache of a CU pair was busy 85 % of the time); serving only the single fullest
         // mode left 58 % of the lanes idle per trip.
-        int sel;
+        uint32_t serve;                                       // bit m: mode m's code runs in this trip
         {
             const int n1 = __popcll(__ballot(r >= 0 && s.mode == 1)), n2 = __popcll(__ballot(r >= 0 && s.mode == 2));
-            sel = n1 >= n2 ? 1 : 2;
+            if (both_thr <= 0) serve = 0x9u | (n1 >= n2 ? 2u : 4u);
+            else {                                            // experimental: a mode's code runs only for at least both_thr lanes (else the fullest mode)
+                const int n0 = __popcll(__ballot(r >= 0 && s.mode == 0)), n3 = __popcll(__ballot(r >= 0 && s.mode == 3));
+                serve = (n0 >= both_thr ? 1u : 0u) | (n1 >= both_thr ? 2u : 0u) | (n2 >= both_thr ? 4u : 0u) | (n3 >= both_thr ? 8u : 0u);
+                if (!serve) {
+                    const int m01 = n0 >= n1 ? n0 : n1, m23 = n2 >= n3 ? n2 : n3;
+                    serve = m01 >= m23 ? (n0 >= n1 ? 1u : 2u) : (n2 >= n3 ? 4u : 8u);
+                }
+            }
         }
         // ---- issue phase: every chosen lane computes its address and issues its load, nobody waits ----
-        if (r >= 0 && (s.mode == sel || s.mode == 0 || s.mode == 3)) {
+        if (r >= 0 && ((serve >> s.mode) & 1u)) {
             trips++;
             live = true;
             if (s.mode == 0) {                       // IdentifySeedPairs :191-211: next start
