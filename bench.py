@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--introns", type=int, default=0, help="introns planted in the synthetic genome")
     ap.add_argument("--sub-rate", type=float, default=0.01, help="per-base substitution rate of the synthetic reads (experiments only; the bench line is quoted at the default)")
     ap.add_argument("--indel-frac", type=float, default=0.02, help="fraction of reads carrying one short indel (experiments only)")
+    ap.add_argument("--gather", action="store_true", help="N>1 only: also gather every step's per-read records to rank 0 inside the timed region "
+                    "(models ONE ordered SAM writer; the mapping path itself has no exchange step, so the default has no data-path collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("DART_BENCH_STAGGER_MS", "0")))
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "8")),
@@ -177,7 +179,7 @@ def main():
         log("[bench] %d pairs generated + uploaded in %.1f s" % (args.pairs, time.time() - t))
 
     # `inflight` contexts share the index; each holds one resident batch and is driven by its own host thread, the way
-    # the reference runs ReadMapping in -t threads.  Step k runs on context k % inflight; the N>1 gather of step k's
+    # the reference runs ReadMapping in -t threads.  Step k runs on context k % inflight; with --gather the N>1 gather of step k's
     # records is done by the main thread in step order (one collective sequence on every rank).
     ctxs = [gpu] + [gpu.clone() for _ in range(max(1, args.inflight) - 1)]
     for cx in ctxs[1:]:
@@ -197,6 +199,7 @@ def main():
             torch.cuda.current_stream().synchronize()
 
     import threading
+    do_gather = dist is not None and args.gather
     stagger_ms = args.stagger_ms
     def run_steps(n_steps, acc, ctxs=ctxs):
         done = [threading.Semaphore(0) for _ in ctxs]       # a step of this context has finished
@@ -214,7 +217,7 @@ def main():
                         for name, ms in ctxs[j].timings():
                             acc[name] = acc.get(name, 0.0) + ms
                     done[j].release()
-                    if dist is not None:                # only the N>1 gather needs the records to stay put
+                    if do_gather:                       # only the N>1 gather needs the records to stay put
                         free[j].acquire()
             except Exception as e:                          # surface the failure instead of hanging the main thread
                 errs.append(e)
@@ -227,7 +230,7 @@ def main():
             done[j].acquire()
             if errs:
                 break
-            if dist is not None:
+            if do_gather:
                 gather(ctxs[j])
             free[j].release()
         for j in range(len(ctxs)):
@@ -377,7 +380,7 @@ def main():
         "vs_baseline": None, "dtype": "u64/u8 integer", "data": "synthetic",
         "config": {"workload": label + ", i.i.d. + planted repeats), %d pairs 2x101 bp per GPU and step, -mis %d" % (args.pairs, args.mis) if args.rlen == 101 else
                                label + ", %d planted introns), %d pairs 2x%d bp per GPU and step, %.0f %% spliced, -mis %d" % (args.introns, args.pairs, args.rlen, 100 * args.spliced, args.mis),
-                   "pairs_per_gpu": args.pairs, "read_len": args.rlen, "spliced_fraction": args.spliced, "batches_in_flight_per_gpu": len(ctxs), "parallelism": "reads sharded x%d, RCCL gather of records" % world},
+                   "pairs_per_gpu": args.pairs, "read_len": args.rlen, "spliced_fraction": args.spliced, "batches_in_flight_per_gpu": len(ctxs), "parallelism": ("reads sharded x%d, index replicated" % world) + (", RCCL gather of records to rank 0" if do_gather else ", no data-path collective")},
         "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
         "kernels_ms_one_batch_in_flight": {k: round(v, 4) for k, v in iso.items()},
         "counters_per_launch": counters,
