@@ -1275,10 +1275,9 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
         __syncthreads();                                           // the other lanes' reports are in memory
         if (lane == 0) {
             for (int i = 0; i < ncand; i++) {
-                const int aln = rep[i].aln_score;
-                if (aln <= 0) continue;                            // (an aln the reference zeroes late changes nothing: score and sub_score are 0 or stay)
-                const int mis_num = rep[i].flag;
-                rep[i].flag = 0;
+                const int aln = rep[i].aln_score, mis_num = rep[i].flag;
+                rep[i].flag = 0;                                   // (also where the reference zeroes aln late, :1157: the parked value must not stay)
+                if (aln <= 0) continue;                            // such an aln changes nothing: score and sub_score are 0 or stay
                 if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis_num; rd.sub_score = rd.score; rd.score = aln; }
                 else if (aln == rd.score) rd.sub_score = rd.score;
             }
