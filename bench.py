@@ -109,7 +109,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--pairs", type=int, default=1000000, help="pairs per GPU per step")
     ap.add_argument("--genome", default=os.environ.get("DART_BENCH_GENOME", "grch38"),
                     help="grch38 (default: 24 chromosomes with GRCh38 sizes, 3.09 Gbp) | chr20 | <bp> (one chromosome)")
@@ -124,7 +124,7 @@ def main():
                     "(models ONE ordered SAM writer; the mapping path itself has no exchange step, so the default has no data-path collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("DART_BENCH_STAGGER_MS", "0")))
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "8")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "12")),
                     help="batches in flight per GPU: contexts sharing one index, one host thread each (dg_clone)")
     ap.add_argument("--cache", default=os.environ.get("DART_BENCH_CACHE", "/tmp/dart_bench_cache"))
     args = ap.parse_args()
@@ -184,6 +184,8 @@ def main():
     ctxs = [gpu] + [gpu.clone() for _ in range(max(1, args.inflight) - 1)]
     for cx in ctxs[1:]:
         cx.upload(so, rl, flat)
+    for cx in ctxs:
+        cx.run()                                   # sizes every context's device buffers (hipMalloc) before any counted step, whatever W and K are
     gather_buf = None
     def gather(cx):
         nonlocal gather_buf
