@@ -482,10 +482,15 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
         }
     }
     {   // K-mer prefix table: the smallest K with 4^K >= text length (so that most K-mers are unique or absent and a
-        // search needs the table plus a step or two), 8 <= K <= 15: 16 bytes per entry = 4.3 GB at K = 14 (chr20),
-        // 17 GB at K = 15 (human).  DG_KTAB_K=0 turns it off, =2..16 forces K (16 = 69 GB).
+        // search needs the table plus a step or two), 8 <= K <= 16: 16 bytes per entry = 4.3 GB at K = 14 (chr20),
+        // 69 GB at K = 16 (human; K = 15, 17 GB: k_seed 2.47 instead of 2.18 ms).  DG_KTAB_K=0 turns it off, =2..16 forces K.
         int K = 8;
-        while (K < 15 && (1ull << (2 * K)) < v->seq_len) K++;
+        while (K < 16 && (1ull << (2 * K)) < v->seq_len) K++;
+        {   // the table must leave room for the batches in flight: step down while it would not leave 48 GB free
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                while (K > 8 && ((size_t)16 << (2 * K)) + ((size_t)48 << 30) > free_b) K--;
+        }
         if (getenv("DG_KTAB_K")) K = atoi(getenv("DG_KTAB_K"));
         if (K > 16) K = 16;
         if (K >= 2) {
