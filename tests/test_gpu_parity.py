@@ -263,3 +263,27 @@ def test_gpu_spliced_2x151_batch_matches_oracle(workdir):
     assert_same(res, orc.map_batch(orc.params(paired=1, max_mismatch=5, max_intron=500000), so, rl, flat, threads=16))
     assert len(res.sj) > 10000                       # the junction path really ran
     gpu.close(); orc.close()
+
+
+def test_gpu_noisy_long_reads_wave_nw_paths(workdir):
+    """Stress of the wave-wide alignment service and of the wave-per-read layout: a repeat-rich 3 Mbp genome, 2x250 reads with
+    4 % substitutions and an indel in a third of them (segment pairs wider than 64 columns: one pair per wave; up to 64: eight
+    per wave; gap filling on spliced reads), reads from repeat families (dozens of candidates), then 76-base single-end
+    reads; every record against the oracle."""
+    g = synth.make_genome([2000000, 1000000], seed=51, repeat_scale=200.0, n_introns=600)
+    prefix = os.path.join(workdir, "noisy")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); gpu = host.DartGPU(ix); orc = oracle_py.Oracle(prefix)
+    m1, m2 = synth.make_reads(g, 30000, rlen=250, seed=52, sub_rate=0.04, indel_frac=0.35, spliced_frac=0.25, n_frac=0.01, frag_mean=600.0)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    for flags in (["-mis", "30"], ["-mis", "30", "-m", "-max_dup", "1000"]):
+        p, _ = common.parse_flags(flags)
+        gpu.set_params(host.default_params(paired=1, **p))
+        res = gpu.map_batch(so, rl, flat)
+        assert_same(res, orc.map_batch(orc.params(paired=1, **p), so, rl, flat, threads=16))
+        assert gpu.counters()["nw_cells"] > 50 * gpu.counters()["nw_calls"]        # large matrices really occurred
+    s1, _ = synth.make_reads(g, 40000, rlen=76, seed=53, sub_rate=0.03, indel_frac=0.2, spliced_frac=0.2, paired=False)
+    so, rl, flat = host.pack_reads(s1)
+    gpu.set_params(host.default_params(paired=0, max_mismatch=10))
+    assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=0, max_mismatch=10), so, rl, flat, threads=16))
+    gpu.close(); orc.close()
