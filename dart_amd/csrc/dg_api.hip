@@ -49,7 +49,7 @@ struct dg_ctx {
     DBuf<unsigned char> seq; DBuf<uint32_t> seq_off; DBuf<uint16_t> rlen; DBuf<uint32_t> enc;
     // pipeline buffers
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, nrep, rep_off, work_need, work_off, tile_sums, tmp_u32, tmp_off;
-    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> costkey; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy;
+    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> costkey; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy, seed_left; DBuf<uint32_t> seed_list; DBuf<RState> seed_state;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<unsigned char> ws;
@@ -386,7 +386,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     for (void *p : own) if (p) (void)hipFree(p);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->nrep.release(); c->rep_off.release(); c->work_need.release(); c->work_off.release();
-    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->costkey.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
+    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->costkey.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_left.release(); c->seed_list.release(); c->seed_state.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -593,8 +593,32 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     if ((size_t)blocks * 64 > (size_t)n) blocks = (unsigned)((n + 63) / 64);
     const int bail_trips = getenv("DG_SEED_BAIL_TRIPS") ? atoi(getenv("DG_SEED_BAIL_TRIPS")) : 128;
     const int both_thr = getenv("DG_SEED_BOTH") ? atoi(getenv("DG_SEED_BOTH")) : 0;
-    if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips, both_thr);
-    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips, both_thr);
+    // Rounds (k_seed_round, DG_SEED_ROUNDS=1..6; default 0 = the general kernel does everything): search number r of every read
+    // that has one, lanes in lock step; what does not fit the common case is left to the general kernel.  Needs the prefix table
+    // and the dense SA.  Measured (GRCh38-sized): 426 M instead of 518 M wave-instructions per 2 M reads, but the
+    // rounds wait for memory 85 % of their cycles and the step as a whole is slower (467 against 504 M reads/s), so it is off.
+    int rounds = getenv("DG_SEED_ROUNDS") ? atoi(getenv("DG_SEED_ROUNDS")) : 0;
+    if (rounds > 6) rounds = 6;
+    if (!c->ix.ktab || !c->ix.sa_dense || W > 40) rounds = 0;                 // (W x 1 KB of LDS per block)
+    const DHeavy *items = nullptr;
+    const unsigned int *n_items_p = nullptr;
+    if (rounds > 0) {
+        const int max_steps = getenv("DG_SEED_ROUND_STEPS") ? atoi(getenv("DG_SEED_ROUND_STEPS")) : 4;
+        if ((e = c->seed_left.ensure((size_t)n + 16)) != hipSuccess || (e = c->seed_list.ensure((size_t)2 * n + 16)) != hipSuccess ||
+            (e = c->seed_state.ensure((size_t)n + 16)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(c->d_tops + 8, 0, 32, c->stream)) != hipSuccess) return e;      // d_tops[8..13]: list sizes after rounds 1..6, [14]: leftovers
+        unsigned rb = (unsigned)c->n_cu * (getenv("DG_SEED_ROUND_BPC") ? (unsigned)atoi(getenv("DG_SEED_ROUND_BPC")) : 16u);
+        if ((size_t)rb * 256 > (size_t)n) rb = (unsigned)((n + 255) / 256);
+        for (int r = 1; r <= rounds; r++) {
+            const uint32_t *lin = r == 1 ? nullptr : c->seed_list.p + (size_t)((r - 1) & 1) * n;
+            uint32_t *lout = c->seed_list.p + (size_t)(r & 1) * n;
+            k_seed_round<<<rb, 256, (size_t)W * 256 * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, lin, r == 1 ? nullptr : c->d_tops + 8 + (r - 2), W, H, max_steps, r == rounds ? 1 : 0,
+                                                    c->hits.p, c->nhits.p, c->nseeds.p, c->seed_state.p, lout, c->d_tops + 8 + (r - 1), c->seed_left.p, c->d_tops + 14, c->d_ctr);
+        }
+        items = c->seed_left.p; n_items_p = c->d_tops + 14;
+    }
+    if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips, both_thr, items, n_items_p);
+    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips, both_thr, items, n_items_p);
     k_seed_heavy<<<(unsigned)c->n_cu * 8u, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, c->d_tops + 7, c->d_ctr);
     return hipGetLastError();
 }

@@ -287,3 +287,25 @@ def test_gpu_noisy_long_reads_wave_nw_paths(workdir):
     gpu.set_params(host.default_params(paired=0, max_mismatch=10))
     assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=0, max_mismatch=10), so, rl, flat, threads=16))
     gpu.close(); orc.close()
+
+
+def test_gpu_seeding_rounds_variant_matches_oracle(workdir, monkeypatch):
+    """DG_SEED_ROUNDS (k_seed_round: one lock-step search per read and launch, leftovers to the general kernel; off by default):
+    same records and same reference-equivalent counters as the oracle, on plain, spliced and N-rich reads."""
+    g = synth.make_genome([2000000, 1000000], seed=61, repeat_scale=100.0, n_introns=300)
+    prefix = os.path.join(workdir, "rounds")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
+    m1, m2 = synth.make_reads(g, 40000, rlen=101, seed=62, sub_rate=0.02, indel_frac=0.05, spliced_frac=0.15, n_frac=0.02)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    want = orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=16)
+    base = gpu.map_batch(so, rl, flat); base_ctr = gpu.counters()
+    assert_same(base, want)
+    for rounds, steps in (("6", "4"), ("2", "1"), ("3", "16")):
+        monkeypatch.setenv("DG_SEED_ROUNDS", rounds); monkeypatch.setenv("DG_SEED_ROUND_STEPS", steps)
+        assert_same(gpu.map_batch(so, rl, flat), want)
+        ctr = gpu.counters()
+        for k in ("steps", "lf_steps", "sa_lookups", "seeds", "occ_blocks"):
+            assert ctr[k] == base_ctr[k], k
+    gpu.close(); orc.close()
