@@ -307,6 +307,9 @@ def main():
                 "own_requested_bytes_per_launch": int(own.get(dom, dom_bytes)),
                 "own_requested_GBps": round(own.get(dom, dom_bytes) / (kern[dom] * 1e-3) / 1e9, 2),
                 "fm_bytes_per_read": round(per_read_B, 1),
+                # SURVEY 8d's whole-job form: reads/s x algorithmic bytes per read (this GPU's share of `value`), against the same 8 TB/s
+                "whole_job_algorithmic_GBps_per_gpu": round(value / world * 1e6 * per_read_B / 1e9, 1),
+                "whole_job_frac_per_gpu": round(value / world * 1e6 * per_read_B / 8e12, 4),
                 "measured_random_64B_ceiling_GBps": 3820.0,
                 "own_frac_of_measured_ceiling": round(own.get(dom, dom_bytes) / (kern[dom] * 1e-3) / 1e9 / 3820.0, 4),
                 "note": "achieved = reference-algorithm bytes of one launch (SURVEY 8d: what bwt_2occ4/bwt_sa would fetch for these reads) / "
