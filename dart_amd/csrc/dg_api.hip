@@ -169,6 +169,7 @@ __global__ void k_compact_sj(dg_read_out *rd, uint32_t n, const uint32_t *new_of
 // first (longest-processing-time scheduling).
 // ------------------------------------------------------------------------------------------
 #define COST_CLASSES 32
+#define DIAG_DONE 31           // key of the reads k_report_diag has finished (they sort behind every other class)
 // pass 1: class of every read + per-(class, block) counts, laid out class-major for one scan
 __global__ void __launch_bounds__(256)
 k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
@@ -187,19 +188,18 @@ k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const D
         // 5-14 = small pairs only, by (live candidates, seeds); 15 = nothing to report  (x 2, see below)
         // every class is split in two: first the reads with two seeds on different diagonals (an nw_alignment is certain: about one
         // read in eight, but met in every 64-read chunk while they were mixed in), then the rest
-        uint32_t tot = 0, live = 0; bool has_jobs = false, big = false, nw = false, all1 = true;
-        for (int i = 0; i < nc; i++) if (cd[i].Score != 0) {
+        uint32_t tot = 0, live = 0; bool has_jobs = false, big = false, nw = false;
+        const bool done = key[r] == DIAG_DONE;            // k_report_diag has written this read's records already
+        if (!done) for (int i = 0; i < nc; i++) if (cd[i].Score != 0) {
             live++; tot += (uint32_t)cd[i].n_a; has_jobs = has_jobs || cd[i].job_count > 0; big = big || (cd[i].final_n & 1) != 0; nw = nw || (cd[i].final_n & 2) != 0;
-            all1 = all1 && cd[i].n_a == 1;
         }
         if (has_jobs) k = 0;
         else if (live == 0) k = 15;
-        else if (all1) { k = 14; nw = false; }           // every scored candidate is ONE exact seed: nothing to align (k_report_single)
         else if (big) k = tot > 12 ? 1u : tot > 6 ? 2u : tot > 3 ? 3u : 4u;
         else if (live >= 3) k = tot > 8 ? 5u : 6u;
         else if (live == 2) k = tot > 4 ? 7u : tot > 2 ? 8u : 9u;
         else k = tot >= 5 ? 10u : tot == 4 ? 11u : tot == 3 ? 12u : tot == 2 ? 13u : 14u;
-        k = 2 * k + (nw ? 0u : 1u);
+        k = done ? (uint32_t)DIAG_DONE : 2 * k + ((nw || k == 15) ? 0u : 1u);    // (class 15 not done cannot occur; its key 30 keeps 31 for the done reads)
         key[r] = (uint8_t)k;
     }
     for (uint32_t c = 0; c < COST_CLASSES; c++) {
@@ -267,7 +267,7 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
     // out in groups of g < 64 reads, g ~ one group per wave: 64 such reads in ONE wave were the kernel's critical
     // path (one chunk = 7 M cycles, as long as everything else together).
     const unsigned int n_jobreads = *n_jobreads_p;
-    const unsigned int lo = job_part ? 0u : n_jobreads, hi = job_part ? n_jobreads : *single_first_p;   // classes 14, 15: k_report_single
+    const unsigned int lo = job_part ? 0u : n_jobreads, hi = job_part ? n_jobreads : *single_first_p;   // key 31: finished by k_report_diag
     const unsigned int n_heavy = job_part ? hi - lo : *heavy_end_p - n_jobreads;
     // few heavy reads (the usual case: some dozens per million): ONE read per wave, lane = candidate
     const bool cpar = n_heavy <= 2u * gridDim.x;
@@ -318,72 +318,118 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
 }
 
 // ------------------------------------------------------------------------------------------
-// k_report_single: GenMappingReport for the reads whose scored candidates are all ONE exact seed (classes 14, 15 of the
-// work order: 40-55 % of a DNA batch -- error-free reads, and reads with no candidate at all).  For such a candidate every
-// stage of GenMappingReport is the identity (SeedExtension, CheckSpliceJunction and IdentifyNormalPairs need two seeds;
-// :1134-1160 sees one simple pair), the CIGAR is [S] M [S] and the score the seed length, so a lane = one read needs a
-// handful of loads and no workspace: 40 VGPRs instead of k_report's 251, and the loads that k_report could only wait
-// for (two waves per SIMD) overlap across many waves here.
+// k_report_diag: GenMappingReport for the reads whose scored candidates are all "exact seeds on ONE diagonal with
+// substitutions between them" -- the error-free read (one seed), the read with one or a few substituted bases (two or
+// three seeds, the bases between them equal in number on both sides and at most 2 / 20 % different, or 1 x 1) -- and the
+// reads with nothing scored: 70-90 % of a DNA batch.  For such a candidate SeedExtension, CheckSpliceJunction and the
+// overlap clean-up are the identity (they act on diagonal changes), IdentifyNormalPairs inserts one equal-length pair per
+// gap, ProcessNormalSequencePair turns it into M (tools.cpp:130-141; a 1 x 1 pair goes through nw_alignment: counted),
+// and the CIGAR is [S] M [S].  One lane = one read, a handful of loads, no workspace: 8 waves per SIMD where k_report
+// (251 VGPRs, two waves per SIMD) could only wait for the same loads.  The kernel runs BEFORE the work order is built and
+// marks what it finished (key 31); a read with ANY candidate outside the pattern is left entirely to k_report
+// (which overwrites whatever this kernel wrote for its earlier candidates).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_report_single(const DIndex ix, const DParams pr, int n_reads, int paired, const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ seed_off,
-                DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ rep_off, const DSeed *__restrict__ work,
-                const uint32_t *__restrict__ perm, const uint32_t *__restrict__ first_p, dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports,
-                uint32_t *__restrict__ cigpool, uint32_t cigcap, int *err)
+k_report_diag(const DIndex ix, const DParams pr, int n_reads, int paired, const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off,
+              const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ seed_off, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
+              const uint32_t *__restrict__ rep_off, const DSeed *__restrict__ work, uint8_t *__restrict__ key, dg_read_out *__restrict__ rout,
+              dg_report_out *__restrict__ reports, uint32_t *__restrict__ cigpool, uint32_t cigcap, unsigned long long *ctr, int *err)
 {
-    const unsigned int idx = *first_p + blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (unsigned int)n_reads) return;
-    const int r = (int)perm[idx];
-    const bool first = paired ? (r & 1) == 0 : true;
-    const int nc_r = (int)ncand[r], len = rlen[r];
-    DCand *cd = cands + seed_off[r];
-    dg_report_out *rep = reports + rep_off[r];
-    DRead rd;
-    rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0; rd.score = 0; rd.iBest = 0;
-    rd.CanNum = nc_r > 0 ? nc_r : 1;
-    for (int i = 0; i < (nc_r > 0 ? nc_r : 1); i++) {
-        dg_report_out rp;
-        rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = -1; rp.chr = -1; rp.bdir = 0; rp.pos = 0; rp.cigar_off = 0; rp.n_cigar = 0;
-        if (i < nc_r) {
-            DCand &c = cd[i];
-            rp.paired_idx = c.PairedIdx;
-            int final_n = 0;
-            if (c.Score != 0) {
-                const DSeed sd = work[c.work_off];
-                if (c.n_a != 1 || c.job_count != 0 || !(sd.flags & SEED_SIMPLE)) { *err = 4; return; }     // not this kernel's class: a scheduling bug
-                c.SJtype = -1;
-                final_n = 1;
-                uint32_t cig[3];
-                int m = 0;
-                const int head = sd.rPos, tail = len - (sd.rPos + sd.rLen);
-                if (head > 0) cig[m++] = CIG(head, OP_S);
-                cig[m++] = CIG(sd.rLen, OP_M);
-                if (tail > 0) cig[m++] = CIG(tail, OP_S);
-                int aln = sd.rLen;                                         // mis_num = 0 <= MaxMismatch, no N element
-                const int64_t gPos = sd.gPos, end_gPos = sd.gPos + sd.gLen - 1;   // GenCoordinateInfo :83-116
-                const int lb = d_loc_lower_bound(ix, gPos);
-                rp.chr = ix.loc_chr[lb];
-                if (gPos < ix.l_pac) { rp.bdir = first ? 1 : 0; rp.pos = gPos + 1 - ix.chr_off[rp.chr]; }
-                else { rp.bdir = first ? 0 : 1; rp.pos = ix.loc_key[lb] - end_gPos + 1; }
-                if (rp.pos <= 0) aln = 0;
-                else {
-                    if (gPos >= ix.l_pac && m > 1) { const uint32_t t = cig[0]; cig[0] = cig[m - 1]; cig[m - 1] = t; }   // reversed CIGAR (3 elements: the middle one stays)
-                    const unsigned int off = (rep_off[r] + (unsigned int)i) * CIG_SLOT;      // S, M, S never merge (GenerateCIGAR :37-61)
-                    if (off + (unsigned int)m > cigcap) { *err = 1; rp.n_cigar = 0; }
-                    else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n_nw = 0;                                   // 1 x 1 pairs: nw_alignment calls of one cell each
+    bool ok = r < n_reads;
+    if (ok) {
+        const bool first = paired ? (r & 1) == 0 : true;
+        const int nc_r = (int)ncand[r], len = rlen[r];
+        const int64_t L = ix.l_pac;
+        DCand *cd = cands + seed_off[r];
+        dg_report_out *rep = reports + rep_off[r];
+        const unsigned char *rd_seq = seq + seq_off[r];
+        DRead rd;
+        rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0; rd.score = 0; rd.iBest = 0;
+        rd.CanNum = nc_r > 0 ? nc_r : 1;
+        for (int i = 0; ok && i < (nc_r > 0 ? nc_r : 1); i++) {
+            dg_report_out rp;
+            rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = -1; rp.chr = -1; rp.bdir = 0; rp.pos = 0; rp.cigar_off = 0; rp.n_cigar = 0;
+            if (i < nc_r) {
+                DCand &c = cd[i];
+                rp.paired_idx = c.PairedIdx;
+                int final_n = 0;
+                if (c.Score != 0) {
+                    const int n = c.n_a;
+                    if (c.job_count != 0 || n < 1 || n > 16) { ok = false; break; }
+                    const DSeed *s = work + c.work_off;
+                    const DSeed s0 = s[0];
+                    DSeed prev = s0;
+                    const int64_t diag = s0.gPos - s0.rPos;
+                    if (!(s0.flags & SEED_SIMPLE) || (n > 1 && diag == -1)) { ok = false; break; }
+                    int aln = s0.rLen, mis = 0;
+                    unsigned long long ones = 0;
+                    for (int k = 1; k < n; k++) {
+                        const DSeed sk = s[k];
+                        const int g = sk.rPos - (prev.rPos + prev.rLen);
+                        if (!(sk.flags & SEED_SIMPLE) || sk.gPos - sk.rPos != diag || g < 1 || g > PM_MAX) { ok = false; break; }
+                        // the pair IdentifyNormalPairs inserts: g read bases against g genome bases (d_pair_classify)
+                        const unsigned char *a = rd_seq + prev.rPos + prev.rLen;
+                        const int64_t gp = prev.gPos + prev.gLen;
+                        int nm = 0;
+                        bool dash = false;
+                        for (int q = 0; q < g; q += 8) {
+                            const uint64_t w = d_ref8(ix, gp + q);
+                            const int e = g - q < 8 ? g - q : 8;
+                            for (int t = 0; t < e; t++) { const unsigned char ch = a[q + t]; dash = dash || ch == '-'; if (ch != (unsigned char)(w >> (8 * t))) nm++; }
+                        }
+                        if (dash) { ok = false; break; }                              // a literal '-' in the read: the string path's business
+                        if (nm <= 2 && nm <= (int)(g * 0.2)) { aln += g - nm; mis += nm; }   // CalFragPairMismatchBases :40-47 -> M
+                        else if (g == 1) { ones++; mis += 1; }                        // 1 x 1, different characters: nw_alignment, one M column, score 0
+                        else { ok = false; break; }                                   // needs a real alignment
+                        aln += sk.rLen;
+                        prev = sk;
+                    }
+                    if (!ok) break;
+                    const int64_t gPos = s0.gPos, end_gPos = prev.gPos + prev.gLen - 1;
+                    if (n > 1 && ((gPos < L) != (end_gPos < L))) { ok = false; break; }   // CheckCoordinateValidity fails: left to the general path
+                    n_nw += ones;
+                    c.SJtype = -1;
+                    final_n = 2 * n - 1;
+                    uint32_t cig[3];
+                    int m = 0;
+                    const int head = s0.rPos, tail = len - (prev.rPos + prev.rLen);
+                    if (head > 0) cig[m++] = CIG(head, OP_S);
+                    cig[m++] = CIG(prev.rPos + prev.rLen - s0.rPos, OP_M);
+                    if (tail > 0) cig[m++] = CIG(tail, OP_S);
+                    if (mis > pr.max_mismatch) aln = 0;
+                    if (aln > 0) {
+                        const int lb = d_loc_lower_bound(ix, gPos);                    // GenCoordinateInfo :83-116
+                        rp.chr = ix.loc_chr[lb];
+                        if (gPos < L) { rp.bdir = first ? 1 : 0; rp.pos = gPos + 1 - ix.chr_off[rp.chr]; }
+                        else { rp.bdir = first ? 0 : 1; rp.pos = ix.loc_key[lb] - end_gPos + 1; }
+                        if (rp.pos <= 0) aln = 0;
+                        else {
+                            if (gPos >= L && m > 1) { const uint32_t t = cig[0]; cig[0] = cig[m - 1]; cig[m - 1] = t; }   // reversed CIGAR (the middle element stays)
+                            const unsigned int off = (rep_off[r] + (unsigned int)i) * CIG_SLOT;      // S, M, S never merge (GenerateCIGAR :37-61)
+                            if (off + (unsigned int)m > cigcap) { *err = 1; rp.n_cigar = 0; }
+                            else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
+                        }
+                        rp.aln_score = aln;
+                        if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis; rd.sub_score = rd.score; rd.score = aln; }
+                        else if (aln == rd.score) rd.sub_score = rd.score;
+                    }
                 }
-                rp.aln_score = aln;
-                if (aln > rd.score) { rd.iBest = i; rd.mis_num = 0; rd.sub_score = rd.score; rd.score = aln; }
-                else if (aln == rd.score) rd.sub_score = rd.score;
+                c.final_n = final_n;
             }
-            c.final_n = final_n;
+            rep[i] = rp;
         }
-        rep[i] = rp;
+        if (ok) {
+            dg_read_out o;
+            o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
+            o.n_rep = rd.CanNum; o.best = rd.iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
+            rout[r] = o;
+        } else n_nw = 0;
+        key[r] = ok ? (uint8_t)DIAG_DONE : (uint8_t)0xFF;
     }
-    dg_read_out o;
-    o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
-    o.n_rep = rd.CanNum; o.best = rd.iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
-    rout[r] = o;
+    d_wave_add(ctr + CTR_NW, n_nw);
+    d_wave_add(ctr + CTR_NWCELLS, n_nw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -795,16 +841,16 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_reseed1, c->stream2));
     HIPCHK(c->costkey.ensure((size_t)n + 16)); HIPCHK(c->perm.ensure((size_t)n + 16)); HIPCHK(c->hist.ensure((size_t)COST_CLASSES * nb * 2 + 16));
+    k_report_diag<<<nb, 256, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->cands.p, c->ncand.p, c->rep_off.p, c->work.p,
+                                             c->costkey.p, c->reads_out.p, c->reports.p, c->cigpool.p, (uint32_t)cigcap, c->d_ctr, c->d_err);
     k_cost<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->seed_off.p, c->cands.p, c->ncand.p, c->costkey.p, c->hist.p);
     uint32_t *class_offs = c->hist.p + (size_t)COST_CLASSES * nb + 8;
     HIPCHK(scan_u32(c, c->hist.p, class_offs, COST_CLASSES * nb));
     k_cost_scatter<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->costkey.p, class_offs, c->perm.p);
     const uint32_t *n_jobreads_p = class_offs + (size_t)2 * nb;       // start of class 1 (key 2) = number of class-0 (job) reads
     const uint32_t *heavy_end_p = class_offs + (size_t)8 * nb;        // start of class 4 (key 8) = end of the heavy classes 1-3
-    const uint32_t *single_first_p = class_offs + (size_t)28 * nb;    // start of class 14 (key 28): single-seed candidates only, then class 15 (nothing scored)
+    const uint32_t *single_first_p = class_offs + (size_t)DIAG_DONE * nb;   // start of key 31: the reads k_report_diag finished
     TICK("order");
-    k_report_single<<<nb, 256, 0, c->stream>>>(c->ix, c->pr, n, paired, c->rlen.p, c->seed_off.p, c->cands.p, c->ncand.p, c->rep_off.p, c->work.p, c->perm.p,
-                                               single_first_p, c->reads_out.p, c->reports.p, c->cigpool.p, (uint32_t)cigcap, c->d_err);
     // one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves
     const int blocks_main = blocks > c->n_cu * 4 ? blocks - c->n_cu : blocks;
 #ifdef DG_PROFILE_CLASSES
@@ -871,7 +917,6 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
         c->counters[k] = v;
     }
     c->counters[CTR_SEEDS] = total_seeds;
-    if (derr == 4) { snprintf(c->err, 512, "k_report_single was handed a read outside its class (work order bug)"); return DG_ERR_INTERNAL; }
     if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == 1 ? "cigar" : (derr == 2 ? "splice junction" : "reseed jobs")); return DG_ERR_INTERNAL; }
     c->used[0] = total_rep; c->used[1] = total_cig; c->used[2] = total_sj;
     if (used) { used[0] = total_rep; used[1] = total_cig; used[2] = total_sj; }
