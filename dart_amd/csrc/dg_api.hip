@@ -320,7 +320,7 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
 // ------------------------------------------------------------------------------------------
 // k_report_diag: GenMappingReport for the reads whose scored candidates are all "exact seeds on ONE diagonal with
 // substitutions between them" -- the error-free read (one seed), the read with one or a few substituted bases (two or
-// three seeds, the bases between them equal in number on both sides and at most 2 / 20 % different, or 1 x 1) -- and the
+// more seeds, the bases between them equal in number on both sides and at most 2 / 20 % different -- any length --, or 1 x 1) -- and the
 // reads with nothing scored: 70-90 % of a DNA batch.  For such a candidate SeedExtension, CheckSpliceJunction and the
 // overlap clean-up are the identity (they act on diagonal changes), IdentifyNormalPairs inserts one equal-length pair per
 // gap, ProcessNormalSequencePair turns it into M (tools.cpp:130-141; a 1 x 1 pair goes through nw_alignment: counted),
@@ -368,7 +368,7 @@ k_report_diag(const DIndex ix, const DParams pr, int n_reads, int paired, const 
                     for (int k = 1; k < n; k++) {
                         const DSeed sk = s[k];
                         const int g = sk.rPos - (prev.rPos + prev.rLen);
-                        if (!(sk.flags & SEED_SIMPLE) || sk.gPos - sk.rPos != diag || g < 1 || g > PM_MAX) { ok = false; break; }
+                        if (!(sk.flags & SEED_SIMPLE) || sk.gPos - sk.rPos != diag || g < 1) { ok = false; break; }
                         // the pair IdentifyNormalPairs inserts: g read bases against g genome bases (d_pair_classify)
                         const unsigned char *a = rd_seq + prev.rPos + prev.rLen;
                         const int64_t gp = prev.gPos + prev.gLen;
@@ -379,9 +379,10 @@ k_report_diag(const DIndex ix, const DParams pr, int n_reads, int paired, const 
                             const int e = g - q < 8 ? g - q : 8;
                             for (int t = 0; t < e; t++) { const unsigned char ch = a[q + t]; dash = dash || ch == '-'; if (ch != (unsigned char)(w >> (8 * t))) nm++; }
                         }
-                        if (dash) { ok = false; break; }                              // a literal '-' in the read: the string path's business
-                        if (nm <= 2 && nm <= (int)(g * 0.2)) { aln += g - nm; mis += nm; }   // CalFragPairMismatchBases :40-47 -> M
-                        else if (g == 1) { ones++; mis += 1; }                        // 1 x 1, different characters: nw_alignment, one M column, score 0
+                        // equal length with <= 2 and <= 20 % mismatches -> M, whatever the length and the characters (tools.cpp:137-141: the
+                        // register path, the string path and a read with a literal '-' all end in this comparison)
+                        if (nm <= 2 && nm <= (int)(g * 0.2)) { aln += g - nm; mis += nm; }
+                        else if (g == 1 && !dash) { ones++; mis += 1; }               // 1 x 1, different characters: nw_alignment, one M column, score 0
                         else { ok = false; break; }                                   // needs a real alignment
                         aln += sk.rLen;
                         prev = sk;
