@@ -391,7 +391,6 @@ k_report_diag(const DIndex ix, const DParams pr, int n_reads, int paired, const 
                     const int64_t gPos = s0.gPos, end_gPos = prev.gPos + prev.gLen - 1;
                     if (n > 1 && ((gPos < L) != (end_gPos < L))) { ok = false; break; }   // CheckCoordinateValidity fails: left to the general path
                     n_nw += ones;
-                    c.SJtype = -1;
                     final_n = 2 * n - 1;
                     uint32_t cig[3];
                     int m = 0;
@@ -417,11 +416,17 @@ k_report_diag(const DIndex ix, const DParams pr, int n_reads, int paired, const 
                         else if (aln == rd.score) rd.sub_score = rd.score;
                     }
                 }
-                c.final_n = final_n;
+                (void)final_n;
             }
             rep[i] = rp;
         }
         if (ok) {
+            // candidate fields GenMappingReport leaves behind (only now: a read handed on to k_report keeps k_prep's scheduling hints)
+            for (int i = 0; i < nc_r; i++) {
+                const bool live = cd[i].Score != 0;
+                cd[i].final_n = live ? 2 * cd[i].n_a - 1 : 0;
+                if (live) cd[i].SJtype = -1;
+            }
             dg_read_out o;
             o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
             o.n_rep = rd.CanNum; o.best = rd.iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
