@@ -293,75 +293,6 @@ __device__ inline void d_insertion_sort_seeds(DSeed *a, int n)
     }
 }
 
-__device__ inline int d_identify_missing(LaneCtx &cx, DSeed *s, int n)   // :685-700
-{
-    const int num = n;
-    for (int i = 1; i < num; i++) {
-        const int pd = (int)((s[i].gPos - s[i].rPos) - (s[i - 1].gPos - s[i - 1].rPos));
-        const int rGaps = s[i].rPos - s[i - 1].rPos - s[i - 1].rLen;
-        if (pd > cx.pr->max_gaps && rGaps > 20) {
-            DSeed ns;
-            if (d_reseed(cx, s[i - 1].rPos + s[i - 1].rLen, s[i].rPos, s[i - 1].gPos + s[i - 1].gLen, s[i].gPos, &ns)) s[n++] = ns;
-        }
-    }
-    if (n > num) d_insertion_sort_seeds(s, n);
-    return n;
-}
-
-// IdentifyBestGappedPartition :385-467 + FillGapsBetweenAdjacentSeeds :547-575; appends at s[n..]
-__device__ inline int d_fill_gaps(LaneCtx &cx, DSeed *s, int n, const DSeed L, const DSeed R)
-{
-    const DIndex &ix = *cx.ix;
-    int rGaps = R.rPos - (L.rPos + L.rLen);
-    char *g = ws_str(cx, 0), *f1 = ws_str(cx, 1), *f2 = ws_str(cx, 2), *f3 = ws_str(cx, 3), *f4 = ws_str(cx, 4);
-    int *Rv = (int *)ws_cig(cx), *Lv = Rv + rGaps + 1;      // the CIGAR scratch is idle at this stage
-    const char *rd = (const char *)cx.seq + L.rPos + L.rLen;
-    for (int i = 0; i <= rGaps; i++) Rv[i] = Lv[i] = 0;
-    d_ref_fill(ix, L.gPos + L.gLen, rGaps, g);
-    const int len = d_nw(cx, rd, rGaps, g, rGaps, f1, f2);
-    int i = len - 1;
-    while (i >= 0 && f2[i] == '-') i--;
-    int64_t gp = L.gPos + L.gLen + rGaps;
-    for (i += 1; i < len; i++, gp++) f2[i] = d_refchar(ix, gp);
-    int p = 0, sc = 0;
-    for (i = 0; i < len; i++) { if (f1[i] == f2[i]) sc++; if (f1[i] != '-') p++; Rv[p] = sc; }
-    d_ref_fill(ix, R.gPos - rGaps, rGaps, g);
-    const int len3 = d_nw(cx, rd, rGaps, g, rGaps, f3, f4);
-    i = 0;
-    while (i < len3 && f4[i] == '-') i++;
-    gp = R.gPos - rGaps;
-    for (i -= 1; i >= 0; i--, gp--) f4[i] = d_refchar(ix, gp);
-    p = 0; sc = 0;
-    for (i = len3 - 1; i >= 0; i--) { if (f3[i] == f4[i]) sc++; if (f3[i] != '-') p++; Lv[rGaps - p] = sc; }
-    int max_score = 0, bp = 0;
-    for (i = 0; i <= rGaps; i++) { const int v = Rv[i] + Lv[i]; if (v > max_score) { max_score = v; bp = i; } }
-    int right_ext = 0, left_ext = 0;
-    if (!(max_score < (int)(rGaps * 0.8) || (rGaps - max_score) > cx.pr->max_mismatch)) {
-        for (p = bp, i = 0; p > 0; i++) { if (f1[i] != '-') p--; if (f2[i] != '-') right_ext++; }
-        for (p = rGaps - bp, i = len3 - 1; p > 0; i--) { if (f3[i] != '-') p--; if (f4[i] != '-') left_ext++; }
-    }
-    if (bp > 0) {
-        DSeed x; x.flags = 0; x.rPos = L.rPos + L.rLen; x.gPos = L.gPos + L.gLen; x.rLen = bp; x.gLen = right_ext;
-        s[n++] = x;
-    }
-    if ((rGaps -= bp) > 0) {
-        DSeed x; x.flags = 0; x.rLen = rGaps; x.gLen = left_ext; x.rPos = R.rPos - x.rLen; x.gPos = R.gPos - x.gLen;
-        s[n++] = x;
-    }
-    return n;
-}
-
-__device__ inline int d_seed_extension(LaneCtx &cx, DSeed *s, int n)   // :577-594
-{
-    const int num = n;
-    for (int i = 1; i < num; i++) {
-        const int pd = (int)((s[i].gPos - s[i].rPos) - (s[i - 1].gPos - s[i - 1].rPos));
-        if (pd > cx.pr->min_intron && s[i].rPos > s[i - 1].rPos + s[i - 1].rLen) n = d_fill_gaps(cx, s, n, s[i - 1], s[i]);
-    }
-    if (n > num) d_insertion_sort_seeds(s, n);
-    return n;
-}
-
 // ---------------------------------------------------------------------------------------------
 // splice junctions (:6,702-815; main.cpp:18)
 // ---------------------------------------------------------------------------------------------
