@@ -528,6 +528,7 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
         if (pool_next == pool_end) exhausted = true;
     };
     const unsigned int w_magic = (65536u + (unsigned int)W - 1u) / (unsigned int)W;      // i / W == (i * w_magic) >> 16 for i < 256
+    const unsigned int refill_cap = 256u / (unsigned int)W ? 256u / (unsigned int)W : 1u;      // reads per prefetch batch (4 words per lane in flight); a division: once, not per event
     while (true) {
         const unsigned long long idle = __ballot(r < 0);
         bool event = false;
@@ -600,7 +601,7 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
                 const unsigned long long need = __ballot(r_nxt < 0);
                 if (need && !exhausted) {
                     if (pool_next == pool_end) grab();
-                    const unsigned int avail = pool_end - pool_next, cap = 256u / (unsigned int)W ? 256u / (unsigned int)W : 1u;
+                    const unsigned int avail = pool_end - pool_next, cap = refill_cap;
                     unsigned int take = (unsigned int)__popcll(need);
                     take = take < avail ? take : avail; take = take < cap ? take : cap;
                     const unsigned int rank = (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
