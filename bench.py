@@ -319,6 +319,19 @@ def main():
                         "algorithm (own_requested_*), so the algorithmic rate can exceed the HBM peak; measured_random_64B_ceiling = "
                         "profiles/probes/tlb_probe.hip (50-60 G random 64-byte lines/s on this chip at any footprint and occupancy)"}
 
+    # the same kernel's average duration in the committed rocprofv3 kernel trace of this command (profiles/run_profile.sh): it
+    # excludes the time a launch queues behind other streams' kernels, which the HIP-event interval above includes
+    try:
+        import csv
+        kpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "j_final_kernel_stats.csv")
+        pref = {"k_seed": ("void k_seed<", "k_seed_heavy("), "k_report": ("void k_report<",), "k_chain": ("k_chain(", "k_chain_heavy("), "k_locate": ("k_locate(",)}[dom]
+        ms = sum(float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(kpath)) if r["Name"].startswith(pref))
+        if ms > 0:
+            roofline["rocprof_kernel_ms_profile_run"] = round(ms, 4)
+            roofline["achieved_by_rocprof_duration"] = round(dom_bytes / (ms * 1e-3) / 1e9, 2)
+    except Exception:
+        pass
+
     # the seeding stage carries ~98 % of the path's algorithmic bytes: its roofline is reported too whenever another
     # kernel is the longest (on a GRCh38-sized text k_report is: chance 16-mer hits make the segment pairs ~10x larger)
     roofline_seeding = None
