@@ -78,7 +78,7 @@ struct DParams {
 enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, CTR_NWCELLS, CTR_RESEED, CTR_RESEEDW,
        CTR_STEPS_ACT, CTR_BLOCKS_ACT, CTR_KTAB, CTR_LF_ACT, CTR_DIRECT, CTR_MAXTRIPS, CTR_WTRIPS_MAX, CTR_WTRIPS_SUM, CTR_N };   // *_ACT: steps/blocks this implementation really executed
 
-__device__ __forceinline__ uint8_t d_nt4(unsigned char c)   // nst_nt4_table, BWT_Index/bntseq.c:40: ACGT/acgt -> 0..3, '-' -> 5, else 4
+__host__ __device__ __forceinline__ uint8_t d_nt4(unsigned char c)   // nst_nt4_table, BWT_Index/bntseq.c:40: ACGT/acgt -> 0..3, '-' -> 5, else 4
 {
     // branch-free (a switch compiles to a tree of divergent branches): A=0x41 C=0x43 G=0x47 T=0x54 after clearing the case bit
     const uint32_t u = c & 0xDFu;

@@ -123,7 +123,7 @@ typedef uint4 __attribute__((aligned(1))) uint4_a1;
 // four characters at once (SWAR): x = 4 ASCII bytes in string order, keep = 0xFF in the bytes that belong to the read.
 // b8 = their four 2-bit codes, first character in the top bits; m8 = 0b11 where the character is not A/C/G/T (either case).
 // (One base at a time through nst_nt4_table this kernel was 278 M wave-instructions per 2 M reads, half of k_seed's.)
-__device__ __forceinline__ void d_enc4(uint32_t x, uint32_t keep, uint32_t &b8, uint32_t &m8)
+__host__ __device__ __forceinline__ void d_enc4(uint32_t x, uint32_t keep, uint32_t &b8, uint32_t &m8)
 {
     const uint32_t u = x & 0xDFDFDFDFu;                                             // upper case
     auto nz = [](uint32_t z) { return ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z; };     // bit 7 of a byte set <=> the byte is not zero

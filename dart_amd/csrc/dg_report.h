@@ -50,7 +50,7 @@ struct LaneCtx {
 __device__ __forceinline__ uint32_t *ws_cig(LaneCtx &cx) { return (uint32_t *)(cx.ws + cx.L->cig_off); }
 __device__ __forceinline__ char *ws_str(LaneCtx &cx, int i) { return (char *)(cx.ws + cx.L->str_off + (uint32_t)i * cx.L->str_cap); }
 
-__device__ __forceinline__ int d_tr2(int v2) { return (int)(((unsigned)v2 + ((unsigned)v2 >> 31)) & ~1u); }   // 2*trunc(v2/2)
+__host__ __device__ __forceinline__ int d_tr2(int v2) { return (int)(((unsigned)v2 + ((unsigned)v2 >> 31)) & ~1u); }   // 2*trunc(v2/2)
 
 // ---------------------------------------------------------------------------------------------
 // nw_alignment (nw_alignment.cpp:18-82) restated on integers x2: s is built from

@@ -1,0 +1,36 @@
+// Host-side checks of the pure arithmetic helpers of the kernels (compiled with hipcc, run WITHOUT a GPU: no HIP API call).
+// Test infrastructure only: `python -m pytest tests -m "not gpu"` builds and runs it (tests/test_kernel_arith_host.py).
+#include <cstdio>
+#include <cstdint>
+#include "../../dart_amd/csrc/dg_fm.h"
+#include "../../dart_amd/csrc/dg_report.h"
+
+static int ref_nt4(unsigned char c)      // nst_nt4_table as BWT_Index/bntseq.c:40 defines it
+{
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case '-': return 5; default: return 4; }
+}
+
+int main()
+{
+    long bad = 0;
+    for (int c = 0; c < 256; c++) if (d_nt4((unsigned char)c) != ref_nt4((unsigned char)c)) { printf("d_nt4(%d)\n", c); bad++; }
+    // d_tr2: the x2 restatement of a float truncated to short (nw_alignment.cpp): 2*trunc(v/2) for v = 2*value
+    for (int v = -70000; v <= 70000; v++) { const int want = 2 * (v / 2); if (d_tr2(v) != want) { if (bad < 5) printf("d_tr2(%d) = %d want %d\n", v, d_tr2(v), want); bad++; } }
+    // d_enc4 against one base at a time
+    uint64_t s = 88172645463325252ull;
+    const char *al = "ACGTacgtNn-\0\xC1\x21XB";
+    for (long it = 0; it < 4000000; it++) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        unsigned char c[4];
+        for (int k = 0; k < 4; k++) c[k] = (it & 1) ? (unsigned char)(s >> (8 * k)) : (unsigned char)al[(s >> (8 * k)) & 15];
+        const int nk = (int)((s >> 40) % 5);
+        const uint32_t keep = nk >= 4 ? 0xFFFFFFFFu : (nk <= 0 ? 0u : (1u << (8 * nk)) - 1u);
+        const uint32_t x = c[0] | (uint32_t)c[1] << 8 | (uint32_t)c[2] << 16 | (uint32_t)c[3] << 24;
+        uint32_t b8, m8, eb = 0, em = 0;
+        d_enc4(x, keep, b8, m8);
+        for (int k = 0; k < 4; k++) { const int v = k < nk ? ref_nt4(c[k]) : 4; eb |= (uint32_t)(v > 3 ? 0 : v) << (6 - 2 * k); em |= (uint32_t)(v > 3 ? 3 : 0) << (6 - 2 * k); }
+        if (eb != b8 || em != m8) { if (bad < 5) printf("d_enc4 x=%08x keep=%08x got %02x %02x want %02x %02x\n", x, keep, b8, m8, eb, em); bad++; }
+    }
+    printf("bad=%ld\n", bad);
+    return bad ? 1 : 0;
+}
