@@ -88,7 +88,7 @@ __host__ __device__ __forceinline__ uint8_t d_nt4(unsigned char c)   // nst_nt4_
 }
 
 // RefSequence[g] (bwt_index.cpp:193-212,252) computed from the forward 2-bit pac; 0 outside [0,2L)
-__device__ __forceinline__ char d_refchar(const DIndex &ix, int64_t g)
+__host__ __device__ __forceinline__ char d_refchar(const DIndex &ix, int64_t g)
 {
     const int64_t L = ix.l_pac;
     if (g < 0 || g >= 2 * L) return 0;
@@ -102,7 +102,7 @@ typedef uint2 __attribute__((aligned(1))) uint2_a1;
 typedef uint32_t __attribute__((aligned(1))) uint32_a1;
 
 // up to 8 reference characters RefSequence[g0 .. g0+8) packed low byte first; positions outside the text give 0
-__device__ __forceinline__ uint64_t d_ref8(const DIndex &ix, int64_t g0)
+__host__ __device__ __forceinline__ uint64_t d_ref8(const DIndex &ix, int64_t g0)
 {
     const int64_t L = ix.l_pac;
     uint64_t out = 0;
@@ -125,7 +125,7 @@ __device__ __forceinline__ uint64_t d_ref8(const DIndex &ix, int64_t g0)
 
 // RefSequence[g0 .. g0+n) into dst, eight bases per pac fetch (a per-base d_refchar is a dependent load each, and on a
 // GRCh38-sized pac those miss the caches)
-__device__ __forceinline__ void d_ref_fill(const DIndex &ix, int64_t g0, int n, char *dst)
+__host__ __device__ __forceinline__ void d_ref_fill(const DIndex &ix, int64_t g0, int n, char *dst)
 {
     for (int i = 0; i < n; i += 8) {
         const uint64_t w = d_ref8(ix, g0 + i);

@@ -2,6 +2,7 @@
 // Test infrastructure only: `python -m pytest tests -m "not gpu"` builds and runs it (tests/test_kernel_arith_host.py).
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 #include "../../dart_amd/csrc/dg_fm.h"
 #include "../../dart_amd/csrc/dg_report.h"
 
@@ -30,6 +31,32 @@ int main()
         d_enc4(x, keep, b8, m8);
         for (int k = 0; k < 4; k++) { const int v = k < nk ? ref_nt4(c[k]) : 4; eb |= (uint32_t)(v > 3 ? 0 : v) << (6 - 2 * k); em |= (uint32_t)(v > 3 ? 3 : 0) << (6 - 2 * k); }
         if (eb != b8 || em != m8) { if (bad < 5) printf("d_enc4 x=%08x keep=%08x got %02x %02x want %02x %02x\n", x, keep, b8, m8, eb, em); bad++; }
+    }
+    // RefSequence windows (bwt_index.cpp:193-212): d_ref8 / d_ref_fill against one d_refchar per base, and d_refchar against the
+    // definition (forward strand from the 2-bit pac, reverse half = complement of the mirrored base, 0 outside), across both
+    // strand boundaries and the ends of the text
+    {
+        const int64_t L = 1003;                                     // odd on purpose: the last pac byte is partial
+        static unsigned char pac[(1003 + 3) / 4 + 8];
+        static char fwd[1003];
+        for (int64_t i = 0; i < L; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; const int b = (int)(s & 3); fwd[i] = "ACGT"[b]; pac[i >> 2] |= (unsigned char)(b << ((~i & 3) << 1)); }
+        DIndex ix; memset(&ix, 0, sizeof ix); ix.pac = pac; ix.l_pac = L;
+        auto want = [&](int64_t g) -> char {
+            if (g < 0 || g >= 2 * L) return 0;
+            if (g < L) return fwd[g];
+            const char c = fwd[2 * L - 1 - g];
+            return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+        };
+        for (int64_t g = -20; g < 2 * L + 20; g++) {
+            if (d_refchar(ix, g) != want(g)) { if (bad < 5) printf("d_refchar(%ld)\n", (long)g); bad++; }
+            const uint64_t w = d_ref8(ix, g);
+            for (int k = 0; k < 8; k++) if ((char)(w >> (8 * k)) != want(g + k)) { if (bad < 5) printf("d_ref8(%ld) byte %d\n", (long)g, k); bad++; }
+            char buf[40];
+            for (int n = 0; n <= 37; n += 37) {
+                d_ref_fill(ix, g, n, buf);
+                for (int k = 0; k < n; k++) if (buf[k] != want(g + k)) { if (bad < 5) printf("d_ref_fill(%ld,%d) at %d\n", (long)g, n, k); bad++; }
+            }
+        }
     }
     printf("bad=%ld\n", bad);
     return bad ? 1 : 0;

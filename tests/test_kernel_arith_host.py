@@ -1,5 +1,5 @@
 """CPU suite: the pure arithmetic helpers the kernels are built from (nst_nt4 restatement, the x2 truncation of nw_alignment,
-the four-characters-at-once read encoder), compiled for the host with hipcc and run without a GPU (no HIP API call)."""
+the four-characters-at-once read encoder, the RefSequence window fetches across both strand boundaries), compiled for the host with hipcc and run without a GPU (no HIP API call)."""
 import os, shutil, subprocess
 import pytest
 import common
