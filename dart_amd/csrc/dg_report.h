@@ -63,7 +63,7 @@ __host__ __device__ __forceinline__ int d_tr2(int v2) { return (int)(((unsigned)
 // a: m chars, b: n chars; oa/ob receive the gapped strings; returns their common length.
 // ---------------------------------------------------------------------------------------------
 #define NW_STRIP 8
-__device__ inline int d_nw(LaneCtx &cx, const char *a, int m, const char *b, int n, char *oa, char *ob)
+__host__ __device__ inline int d_nw(LaneCtx &cx, const char *a, int m, const char *b, int n, char *oa, char *ob)
 {
     uint32_t *bits = (uint32_t *)(cx.ws + cx.L->nwbits_off);         // bits[(i-1) * nstrips + strip]: 2 bits per cell
     int *colS = (int *)(cx.ws + cx.L->rows_off), *colR = colS + cx.L->row_cap;

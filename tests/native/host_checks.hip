@@ -5,6 +5,7 @@
 #include <cstring>
 #include "../../dart_amd/csrc/dg_fm.h"
 #include "../../dart_amd/csrc/dg_report.h"
+extern "C" int orc_nw(const char *s1, const char *s2, char *out1, char *out2, int cap);   // oracle/dart_oracle.h (the checker)
 
 static int ref_nt4(unsigned char c)      // nst_nt4_table as BWT_Index/bntseq.c:40 defines it
 {
@@ -57,6 +58,32 @@ int main()
                 for (int k = 0; k < n; k++) if (buf[k] != want(g + k)) { if (bad < 5) printf("d_ref_fill(%ld,%d) at %d\n", (long)g, n, k); bad++; }
             }
         }
+    }
+    // d_nw (the strip-in-registers restatement of nw_alignment, x2 integers) against the oracle's nw_alignment on random
+    // strings: same gapped strings, character for character (mixed case, N, '-' and odd characters included)
+    {
+        const int R = 96;
+        WSLayout Lw; memset(&Lw, 0, sizeof Lw);
+        Lw.nwbits_off = 0; Lw.nwbits_words = (R + 1) * ((2 * R + 32 + 7) / 8);
+        Lw.rows_off = Lw.nwbits_words * 4; Lw.row_cap = R + 8;
+        static unsigned char wsbuf[(96 + 1) * ((2 * 96 + 32 + 7) / 8) * 4 + 2 * (96 + 8) * 4 + 64];
+        LaneCtx cx; memset(&cx, 0, sizeof cx); cx.ws = wsbuf; cx.L = &Lw;
+        const char *alpha = "ACGTACGTACGTACGTacgtNn-X";
+        for (int it = 0; it < 20000; it++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            const int m = 1 + (int)(s % 60), n = 1 + (int)((s >> 20) % 90);
+            char a[128], b[128], oa[300], ob[300], ra[300], rb2[300];
+            uint64_t t = s;
+            for (int i = 0; i < m; i++) { t ^= t << 13; t ^= t >> 7; t ^= t << 17; a[i] = alpha[(it % 7 == 0) ? t % 24 : t % 16]; }
+            for (int i = 0; i < n; i++) { t ^= t << 13; t ^= t >> 7; t ^= t << 17; b[i] = (i < m && (t >> 8) % 10 < 7) ? a[i] : alpha[t % 16]; }
+            a[m] = 0; b[n] = 0;
+            const int len = d_nw(cx, a, m, b, n, oa, ob);
+            const int rlen = orc_nw(a, b, ra, rb2, 300);
+            bool same = len == rlen;
+            for (int i = 0; same && i < len; i++) same = oa[i] == ra[i] && ob[i] == rb2[i];
+            if (!same) { if (bad < 5) printf("d_nw differs from the oracle: m=%d n=%d len %d/%d\n", m, n, len, rlen); bad++; }
+        }
+        printf("d_nw: 20000 random alignments compared with the oracle\n");
     }
     printf("bad=%ld\n", bad);
     return bad ? 1 : 0;
