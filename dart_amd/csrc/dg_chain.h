@@ -13,7 +13,7 @@
 
 // in-place sort of a lane-private seed segment by (gPos,rPos): insertion sort for short lists,
 // heap sort beyond (both give the unique order of a total order up to identical elements)
-__device__ inline void d_sort_seeds(DSeed *a, int n)
+__host__ __device__ inline void d_sort_seeds(DSeed *a, int n)
 {
     if (n < 2) return;
     if (n == 2) { const DSeed x = a[0], y = a[1]; if (d_seed_less(y, x)) { a[0] = y; a[1] = x; } return; }
@@ -63,7 +63,7 @@ __device__ inline void d_sort_seeds(DSeed *a, int n)
 
 // GenerateAlignmentCandidate :241-288.  seeds = the read's sorted segment (absolute base `base`).
 // Every seed is fetched once (whole 24-byte record) and the chain tail is kept in registers.
-__device__ inline int d_gen_candidates(const DIndex &ix, const DParams &pr, int rlen, const DSeed *__restrict__ s, int num, uint32_t base, DCand *__restrict__ out)
+__host__ __device__ inline int d_gen_candidates(const DIndex &ix, const DParams &pr, int rlen, const DSeed *__restrict__ s, int num, uint32_t base, DCand *__restrict__ out)
 {
     int nc = 0;
     if (num == 0) return 0;
@@ -104,7 +104,7 @@ __device__ inline int d_gen_candidates(const DIndex &ix, const DParams &pr, int 
     return nc;
 }
 
-__device__ inline void d_remove_redundant(DCand *c, int n)   // Mapping.cpp:371-401
+__host__ __device__ inline void d_remove_redundant(DCand *c, int n)   // Mapping.cpp:371-401
 {
     if (n <= 1) return;
     int s1 = 0, s2 = 0;
@@ -119,7 +119,7 @@ __device__ inline void d_remove_redundant(DCand *c, int n)   // Mapping.cpp:371-
     for (int i = 0; i < n; i++) if (c[i].Score < thr) c[i].Score = 0;
 }
 
-__device__ inline bool d_check_paired(DCand *c1, int n1, DCand *c2, int n2)   // Mapping.cpp:403-450
+__host__ __device__ inline bool d_check_paired(DCand *c1, int n1, DCand *c2, int n2)   // Mapping.cpp:403-450
 {
     bool pairing = false;
     if (n1 * n2 > 1000) { d_remove_redundant(c1, n1); d_remove_redundant(c2, n2); }
@@ -146,7 +146,7 @@ __device__ inline bool d_check_paired(DCand *c1, int n1, DCand *c2, int n2)   //
     return pairing;
 }
 
-__device__ inline void d_remove_unmated(DCand *c1, int n1, DCand *c2, int n2)   // Mapping.cpp:452-477
+__host__ __device__ inline void d_remove_unmated(DCand *c1, int n1, DCand *c2, int n2)   // Mapping.cpp:452-477
 {
     for (int i = 0; i < n1; i++) {
         if (c1[i].PairedIdx == -1) c1[i].Score = 0;

@@ -135,14 +135,14 @@ __host__ __device__ __forceinline__ void d_ref_fill(const DIndex &ix, int64_t g0
 }
 
 // ChrLocMap.lower_bound(g): index of the smallest key >= g
-__device__ __forceinline__ int d_loc_lower_bound(const DIndex &ix, int64_t g)
+__host__ __device__ __forceinline__ int d_loc_lower_bound(const DIndex &ix, int64_t g)
 {
     int lo = 0, hi = 2 * ix.n_chr;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (ix.loc_key[mid] < g) lo = mid + 1; else hi = mid; }
     return lo;
 }
 
-__device__ __forceinline__ bool d_seed_less(const DSeed &a, const DSeed &b)   // CompByGenomePos, AlignmentCandidates.cpp:21-25
+__host__ __device__ __forceinline__ bool d_seed_less(const DSeed &a, const DSeed &b)   // CompByGenomePos, AlignmentCandidates.cpp:21-25
 {
     return a.gPos == b.gPos ? a.rPos < b.rPos : a.gPos < b.gPos;
 }
