@@ -5,6 +5,7 @@
 #include "dg_fm.h"
 #include "dg_chain.h"
 #include "dg_report.h"
+#include "dg_pair.h"
 #include "dg_reseed.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,13 +30,16 @@ template <typename T> struct DBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-#define N_TIMERS 16
+#define N_TIMERS 20
+#define N_TOPS 32               // small device counters of a batch (bump tops, tickets, list sizes), zeroed per run
+enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAVY_UNITS, TOP_SEED_NEXT, TOP_SEED_HEAVY, TOP_ROUNDS /* 8..14 */,
+       TOP_WORK = 16, TOP_TICKET_PAIR, TOP_TICKET_EMIT };
 
 struct dg_ctx {
     int device = 0;
     bool owns_index = true;       // false for dg_clone()d contexts: the index arrays belong to the parent
     hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr;
     float reseed_ms = 0;
     char err[512] = "";
     DIndex ix{};
@@ -46,21 +50,37 @@ struct dg_ctx {
     // batch inputs
     int n_reads = 0, max_rlen = 0;
     size_t seq_bytes = 0;
-    DBuf<unsigned char> seq; DBuf<uint32_t> seq_off; DBuf<uint16_t> rlen; DBuf<uint32_t> enc;
-    // pipeline buffers
-    DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, nrep, rep_off, work_need, work_off, tile_sums, tmp_u32, tmp_off;
-    DBuf<DSeed> seeds, work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> costkey; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy, seed_left; DBuf<uint32_t> seed_list; DBuf<RState> seed_state;
+    bool enc_ready = false;       // the packed entry point filled enc itself (no k_encode)
+    DBuf<unsigned char> seq; DBuf<uint32_t> seq_off; DBuf<uint16_t> rlen; DBuf<uint32_t> enc; DBuf<uint32_t> packed_in, nlist_in;
+    // pipeline buffers; the four whose size depends on the data have sticky capacities (cap_*): a batch is enqueued against
+    // them without asking the device for a size first, the device reports what it needed (DSizes) and flags an overflow
+    // (d_err >= DG_ABORT), in which case the host grows the buffer and runs the batch again
+    DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, rep_off, tile_sums, tile_read, slow_units;
+    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> done; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy, seed_left; DBuf<uint32_t> seed_list; DBuf<RState> seed_state;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<unsigned char> ws;
-    unsigned long long *d_ctr = nullptr; unsigned int *d_tops = nullptr; int *d_err = nullptr;
+    DBuf<unsigned long long> scan_state;
+    size_t cap_seeds = 0, cap_rep = 0, cap_work = 0, cap_cig = 0;
+    unsigned long long *d_ctr = nullptr; unsigned int *d_tops = nullptr; int *d_err = nullptr; DSizes *d_sizes = nullptr;
+    struct HostTail { DSizes sizes; int err; unsigned int tops[N_TOPS]; uint64_t ctr_stripes[CTR_STRIPES * CTR_STRIDE]; } *h_tail = nullptr;   // pinned
     size_t used[3] = {0, 0, 0};
+    bool enqueued = false;
     // timings
     hipEvent_t ev[N_TIMERS + 1]; const char *tname[N_TIMERS]; int n_t = 0; float tms[N_TIMERS];
     uint64_t counters[CTR_N];
-    uint64_t ctr_stripes[CTR_STRIPES * CTR_STRIDE];
-    int n_cu = 256;
+    int n_cu = 256, runs_of_last_batch = 0;
+    // environment switches, read once per context (not per batch)
+    int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_rounds = 0, env_round_steps = 4, env_round_bpc = 16, env_report_bpc = 8, env_no_fast = 0;
 };
+
+static void read_env(dg_ctx *c)
+{
+    auto geti = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
+    c->env_seed_waves = geti("DG_SEED_WAVES", 4); c->env_bail_trips = geti("DG_SEED_BAIL_TRIPS", 128); c->env_both = geti("DG_SEED_BOTH", 0);
+    c->env_rounds = geti("DG_SEED_ROUNDS", 0); c->env_round_steps = geti("DG_SEED_ROUND_STEPS", 4); c->env_round_bpc = geti("DG_SEED_ROUND_BPC", 16);
+    c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
+}
 
 static int fail(dg_ctx *c, int code, const char *what, hipError_t e)
 {
@@ -91,7 +111,7 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t *in, uint32_t
     for (int i = 0; i < 8; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
     if (threadIdx.x == 255) tile_sums[blockIdx.x] = sh[255];
 }
-__global__ void __launch_bounds__(256) k_scan_top(uint32_t *tile_sums, uint32_t n_tiles, uint32_t *total_out)
+__global__ void __launch_bounds__(256) k_scan_top(uint32_t *tile_sums, uint32_t n_tiles, uint32_t *total_out, uint32_t *total_copy, uint32_t cap, int *err, int code)
 {
     __shared__ uint32_t sh[256];
     __shared__ uint32_t carry;
@@ -113,7 +133,11 @@ __global__ void __launch_bounds__(256) k_scan_top(uint32_t *tile_sums, uint32_t 
         if (threadIdx.x == 255) carry += sh[255];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        if (total_copy) *total_copy = carry;
+        if (err && carry > cap) atomicMax(err, code);          // the consumers of this scan return at once (DG_ABORT)
+    }
 }
 __global__ void __launch_bounds__(256) k_scan_add(uint32_t *out, const uint32_t *tile_sums, uint32_t n)
 {
@@ -121,45 +145,17 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t *out, const uint32_t 
     if (i < n) out[i] += tile_sums[i / SCAN_TILE];
 }
 
-// out[0..n) = exclusive scan of in, out[n] = total
-static hipError_t scan_u32(dg_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n)
+// out[0..n) = exclusive scan of in, out[n] = total (also stored at total_copy; flagged in *err when it exceeds cap)
+static hipError_t scan_u32(dg_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total_copy = nullptr, uint32_t cap = 0, int code = 0)
 {
     if (n == 0) return hipMemsetAsync(out, 0, 4, c->stream);
     const uint32_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipError_t e = c->tile_sums.ensure(tiles + 1);
     if (e != hipSuccess) return e;
     k_scan_tiles<<<tiles, 256, 0, c->stream>>>(in, out, c->tile_sums.p, n);
-    k_scan_top<<<1, 256, 0, c->stream>>>(c->tile_sums.p, tiles, out + n);
+    k_scan_top<<<1, 256, 0, c->stream>>>(c->tile_sums.p, tiles, out + n, total_copy, cap, code ? c->d_err : nullptr, code);
     k_scan_add<<<(n + 255) / 256, 256, 0, c->stream>>>(out, c->tile_sums.p, n);
     return hipGetLastError();
-}
-
-__global__ void k_extract_ncigar(const dg_report_out *rep, uint32_t n, uint32_t *out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = rep[i].n_cigar;
-}
-__global__ void k_extract_nsj(const dg_read_out *rd, uint32_t n, uint32_t *out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (uint32_t)rd[i].n_sj;
-}
-// CIGAR ops leave the report kernel in a bump pool (arrival order); lay them out in report order
-__global__ void k_compact_cigar(dg_report_out *rep, uint32_t n, const uint32_t *new_off, const uint32_t *pool, uint32_t *fin)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t m = rep[i].n_cigar, src = rep[i].cigar_off, dst = new_off[i];
-    for (uint32_t k = 0; k < m; k++) fin[dst + k] = pool[src + k];
-    rep[i].cigar_off = dst;
-}
-__global__ void k_compact_sj(dg_read_out *rd, uint32_t n, const uint32_t *new_off, const dg_sj_out *pool, dg_sj_out *fin)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t m = (uint32_t)rd[i].n_sj, src = (uint32_t)rd[i].sj_off, dst = new_off[i];
-    for (uint32_t k = 0; k < m; k++) fin[dst + k] = pool[src + k];
-    rd[i].sj_off = (int32_t)dst;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -169,13 +165,14 @@ __global__ void k_compact_sj(dg_read_out *rd, uint32_t n, const uint32_t *new_of
 // first (longest-processing-time scheduling).
 // ------------------------------------------------------------------------------------------
 #define COST_CLASSES 32
-#define DIAG_DONE 31           // key of the reads k_report_diag has finished (they sort behind every other class)
+#define DIAG_DONE DONE_BY_PAIR  // key of the reads k_pair has finished (they sort behind every other class)
 // pass 1: class of every read + per-(class, block) counts, laid out class-major for one scan
 __global__ void __launch_bounds__(256)
 k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
-       uint8_t *__restrict__ key, uint32_t *__restrict__ counts)
+       uint8_t *__restrict__ key, uint32_t *__restrict__ counts, const int *__restrict__ abort_p)
 {
     __shared__ uint32_t sh[COST_CLASSES];
+    if (*abort_p >= DG_ABORT) return;
     if (threadIdx.x < COST_CLASSES) sh[threadIdx.x] = 0;
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -189,7 +186,7 @@ k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const D
         // every class is split in two: first the reads with two seeds on different diagonals (an nw_alignment is certain: about one
         // read in eight, but met in every 64-read chunk while they were mixed in), then the rest
         uint32_t tot = 0, live = 0; bool has_jobs = false, big = false, nw = false;
-        const bool done = key[r] == DIAG_DONE;            // k_report_diag has written this read's records already
+        const bool done = key[r] == DIAG_DONE;            // k_pair has written this read's records already
         if (!done) for (int i = 0; i < nc; i++) if (cd[i].Score != 0) {
             live++; tot += (uint32_t)cd[i].n_a; has_jobs = has_jobs || cd[i].job_count > 0; big = big || (cd[i].final_n & 1) != 0; nw = nw || (cd[i].final_n & 2) != 0;
         }
@@ -211,9 +208,10 @@ k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const D
 }
 // pass 2 (after an exclusive scan of counts): stable scatter -- inside a class reads keep index order
 __global__ void __launch_bounds__(256)
-k_cost_scatter(int n_reads, int n_blocks, const uint8_t *__restrict__ key, const uint32_t *__restrict__ offs, uint32_t *__restrict__ perm)
+k_cost_scatter(int n_reads, int n_blocks, const uint8_t *__restrict__ key, const uint32_t *__restrict__ offs, uint32_t *__restrict__ perm, const int *__restrict__ abort_p)
 {
     __shared__ uint32_t wave_cnt[4][COST_CLASSES];
+    if (*abort_p >= DG_ABORT) return;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
     const uint32_t k = r < n_reads ? key[r] : COST_CLASSES;
@@ -250,6 +248,7 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t lds_pm[64 * PM_LDS_WORDS];
+    if (*err >= DG_ABORT) return;
     LaneCtx cx;
 #ifdef DG_PROFILE_CLASSES
     __shared__ unsigned long long ph_acc[DG_NCLS * DG_NPHASE], cls_acc[2 * DG_NCLS];
@@ -318,161 +317,92 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
 }
 
 // ------------------------------------------------------------------------------------------
-// k_report_diag: GenMappingReport for the reads whose scored candidates are all "exact seeds on ONE diagonal with
-// substitutions between them" -- the error-free read (one seed), the read with one or a few substituted bases (two or
-// more seeds, the bases between them equal in number on both sides and at most 2 / 20 % different -- any length --, or 1 x 1) -- and the
-// reads with nothing scored: 70-90 % of a DNA batch.  For such a candidate SeedExtension, CheckSpliceJunction and the
-// overlap clean-up are the identity (they act on diagonal changes), IdentifyNormalPairs inserts one equal-length pair per
-// gap, ProcessNormalSequencePair turns it into M (tools.cpp:130-141; a 1 x 1 pair goes through nw_alignment: counted),
-// and the CIGAR is [S] M [S].  One lane = one read, a handful of loads, no workspace: 8 waves per SIMD where k_report
-// (251 VGPRs, two waves per SIMD) could only wait for the same loads.  The kernel runs BEFORE the work order is built and
-// marks what it finished (key 31); a read with ANY candidate outside the pattern is left entirely to k_report
-// (which overwrites whatever this kernel wrote for its earlier candidates).
+// k_finalize: one lane = one unit of the general path (slow_units[]): CheckPairedFinalAlignments, FLAGs, MAPQ,
+// splice-junction tuples (Mapping.cpp:74-206,479-565,615-621) on the records k_report left in memory
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_report_diag(const DIndex ix, const DParams pr, int n_reads, int paired, const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off,
-              const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ seed_off, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
-              const uint32_t *__restrict__ rep_off, const DSeed *__restrict__ work, uint8_t *__restrict__ key, dg_read_out *__restrict__ rout,
-              dg_report_out *__restrict__ reports, uint32_t *__restrict__ cigpool, uint32_t cigcap, unsigned long long *ctr, int *err)
+k_finalize(const DIndex ix, const DParams pr, int paired, const uint32_t *__restrict__ slow_units, const DSizes *__restrict__ sizes,
+           const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const DSeed *__restrict__ work,
+           dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, dg_sj_out *sjpool, uint32_t sjcap, unsigned int *tops, int *err)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long n_nw = 0;                                   // 1 x 1 pairs: nw_alignment calls of one cell each
-    bool ok = r < n_reads;
-    if (ok) {
-        const bool first = paired ? (r & 1) == 0 : true;
-        const int nc_r = (int)ncand[r], len = rlen[r];
-        const int64_t L = ix.l_pac;
-        DCand *cd = cands + seed_off[r];
-        dg_report_out *rep = reports + rep_off[r];
-        const unsigned char *rd_seq = seq + seq_off[r];
-        DRead rd;
-        rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0; rd.score = 0; rd.iBest = 0;
-        rd.CanNum = nc_r > 0 ? nc_r : 1;
-        for (int i = 0; ok && i < (nc_r > 0 ? nc_r : 1); i++) {
-            dg_report_out rp;
-            rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = -1; rp.chr = -1; rp.bdir = 0; rp.pos = 0; rp.cigar_off = 0; rp.n_cigar = 0;
-            if (i < nc_r) {
-                DCand &c = cd[i];
-                rp.paired_idx = c.PairedIdx;
-                int final_n = 0;
-                if (c.Score != 0) {
-                    const int n = c.n_a;
-                    if (c.job_count != 0 || n < 1 || n > 16) { ok = false; break; }
-                    const DSeed *s = work + c.work_off;
-                    const DSeed s0 = s[0];
-                    DSeed prev = s0;
-                    const int64_t diag = s0.gPos - s0.rPos;
-                    if (!(s0.flags & SEED_SIMPLE) || (n > 1 && diag == -1)) { ok = false; break; }
-                    int aln = s0.rLen, mis = 0;
-                    unsigned long long ones = 0;
-                    for (int k = 1; k < n; k++) {
-                        const DSeed sk = s[k];
-                        const int g = sk.rPos - (prev.rPos + prev.rLen);
-                        if (!(sk.flags & SEED_SIMPLE) || sk.gPos - sk.rPos != diag || g < 1) { ok = false; break; }
-                        // the pair IdentifyNormalPairs inserts: g read bases against g genome bases (d_pair_classify)
-                        const unsigned char *a = rd_seq + prev.rPos + prev.rLen;
-                        const int64_t gp = prev.gPos + prev.gLen;
-                        int nm = 0;
-                        bool dash = false;
-                        for (int q = 0; q < g; q += 8) {
-                            const uint64_t w = d_ref8(ix, gp + q);
-                            const int e = g - q < 8 ? g - q : 8;
-                            for (int t = 0; t < e; t++) { const unsigned char ch = a[q + t]; dash = dash || ch == '-'; if (ch != (unsigned char)(w >> (8 * t))) nm++; }
-                        }
-                        // equal length with <= 2 and <= 20 % mismatches -> M, whatever the length and the characters (tools.cpp:137-141: the
-                        // register path, the string path and a read with a literal '-' all end in this comparison)
-                        if (nm <= 2 && nm <= (int)(g * 0.2)) { aln += g - nm; mis += nm; }
-                        else if (g == 1 && !dash) { ones++; mis += 1; }               // 1 x 1, different characters: nw_alignment, one M column, score 0
-                        else { ok = false; break; }                                   // needs a real alignment
-                        aln += sk.rLen;
-                        prev = sk;
-                    }
-                    if (!ok) break;
-                    const int64_t gPos = s0.gPos, end_gPos = prev.gPos + prev.gLen - 1;
-                    if (n > 1 && ((gPos < L) != (end_gPos < L))) { ok = false; break; }   // CheckCoordinateValidity fails: left to the general path
-                    n_nw += ones;
-                    final_n = 2 * n - 1;
-                    uint32_t cig[3];
-                    int m = 0;
-                    const int head = s0.rPos, tail = len - (prev.rPos + prev.rLen);
-                    if (head > 0) cig[m++] = CIG(head, OP_S);
-                    cig[m++] = CIG(prev.rPos + prev.rLen - s0.rPos, OP_M);
-                    if (tail > 0) cig[m++] = CIG(tail, OP_S);
-                    if (mis > pr.max_mismatch) aln = 0;
-                    if (aln > 0) {
-                        const int lb = d_loc_lower_bound(ix, gPos);                    // GenCoordinateInfo :83-116
-                        rp.chr = ix.loc_chr[lb];
-                        if (gPos < L) { rp.bdir = first ? 1 : 0; rp.pos = gPos + 1 - ix.chr_off[rp.chr]; }
-                        else { rp.bdir = first ? 0 : 1; rp.pos = ix.loc_key[lb] - end_gPos + 1; }
-                        if (rp.pos <= 0) aln = 0;
-                        else {
-                            if (gPos >= L && m > 1) { const uint32_t t = cig[0]; cig[0] = cig[m - 1]; cig[m - 1] = t; }   // reversed CIGAR (the middle element stays)
-                            const unsigned int off = (rep_off[r] + (unsigned int)i) * CIG_SLOT;      // S, M, S never merge (GenerateCIGAR :37-61)
-                            if (off + (unsigned int)m > cigcap) { *err = 1; rp.n_cigar = 0; }
-                            else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
-                        }
-                        rp.aln_score = aln;
-                        if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis; rd.sub_score = rd.score; rd.score = aln; }
-                        else if (aln == rd.score) rd.sub_score = rd.score;
-                    }
-                }
-                (void)final_n;
-            }
-            rep[i] = rp;
+    if (*err >= DG_ABORT) return;
+    const unsigned int n_units = sizes->n_slow_units;
+    for (unsigned int it = blockIdx.x * blockDim.x + threadIdx.x; it < n_units; it += gridDim.x * blockDim.x) {
+        const int u = (int)slow_units[it];
+        const int nm = paired ? 2 : 1;
+        DRead rd[2];
+        dg_read_out o[2];
+        RepMem<dg_report_out> rp[2];
+        for (int m = 0; m < nm; m++) {
+            const int r = paired ? 2 * u + m : u;
+            o[m] = rout[r];
+            rd[m].score = o[m].score; rd[m].sub_score = o[m].sub_score; rd[m].mis_num = o[m].mis_num; rd[m].mapq = 0;
+            rd[m].CanNum = o[m].n_rep; rd[m].iBest = o[m].best;
+            rp[m].p = reports + o[m].rep_off;
         }
-        if (ok) {
-            // candidate fields GenMappingReport leaves behind (only now: a read handed on to k_report keeps k_prep's scheduling hints)
-            for (int i = 0; i < nc_r; i++) {
-                const bool live = cd[i].Score != 0;
-                cd[i].final_n = live ? 2 * cd[i].n_a - 1 : 0;
-                if (live) cd[i].SJtype = -1;
-            }
-            dg_read_out o;
-            o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
-            o.n_rep = rd.CanNum; o.best = rd.iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
-            rout[r] = o;
-        } else n_nw = 0;
-        key[r] = ok ? (uint8_t)DIAG_DONE : (uint8_t)0xFF;
+        if (paired) {
+            d_settle_pair(pr, rd[0], rp[0], rd[1], rp[1]);
+            d_flag_pair(rd[0], rp[0], rd[1], rp[1]);
+        } else d_flag_single(rd[0], rp[0]);
+        for (int m = 0; m < nm; m++) {
+            const int r = paired ? 2 * u + m : u;
+            d_mapq(rd[m], rp[m]);
+            o[m].score = rd[m].score; o[m].mapq = rd[m].mapq; o[m].best = rd[m].iBest;
+            if (ncand[r] > 0 && (rd[m].mapq == 50 || (pr.all_sj && rd[m].score > 0)))
+                d_collect_sj(ix, pr, cands[seed_off[r] + rd[m].iBest], work, r, sjpool, tops + TOP_SJ, sjcap, o[m].sj_off, o[m].n_sj, err);
+            rout[r] = o[m];
+        }
     }
-    d_wave_add(ctr + CTR_NW, n_nw);
-    d_wave_add(ctr + CTR_NWCELLS, n_nw);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_finalize: one lane = one pair (or single read): CheckPairedFinalAlignments, FLAGs, MAPQ,
-// splice-junction tuples (Mapping.cpp:74-206,479-565,615-621)
+// k_emit_slow: the variable-length records of the general path's reads, laid out deterministically behind k_pair's: one lane
+// = one read of slow_units[] (ascending); a single-pass scan (dg_scan.h) of (CIGAR ops, junction tuples) per read gives the
+// places; CIGAR ops move from the report kernel's pool to cigfinal[cig_fast + ...], tuples from the bump pool to sjfinal.
+// The grid covers the worst case (every unit on the list); workgroups beyond the list leave at once.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_finalize(const DIndex ix, const DParams pr, int n_units, int paired, const uint32_t *__restrict__ seed_off,
-           const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const DSeed *__restrict__ work,
-           dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, dg_sj_out *sjpool, uint32_t sjcap,
-           unsigned int *tops, int *err)
+k_emit_slow(int paired, const uint32_t *__restrict__ slow_units, DSizes *sizes, dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports,
+            const uint32_t *__restrict__ cigpool, uint32_t *__restrict__ cigfinal, uint32_t cap_cig, const dg_sj_out *__restrict__ sjpool, dg_sj_out *__restrict__ sjfinal,
+            TileScan ts, int *err)
 {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n_units) return;
-    const int nm = paired ? 2 : 1;
-    DRead rd[2];
-    dg_report_out *rp[2];
-    dg_read_out o[2];
-    for (int m = 0; m < nm; m++) {
-        const int r = paired ? 2 * u + m : u;
-        o[m] = rout[r];
-        rd[m].score = o[m].score; rd[m].sub_score = o[m].sub_score; rd[m].mis_num = o[m].mis_num; rd[m].mapq = 0;
-        rd[m].CanNum = o[m].n_rep; rd[m].iBest = o[m].best;
-        rp[m] = reports + o[m].rep_off;
+    __shared__ unsigned long long s_scan[16];
+    __shared__ unsigned int s_tile;
+    const int e0 = *err;
+    if (e0 >= DG_ABORT && e0 != DG_E_CIGFINAL) return;            // (DG_E_CIGFINAL may have been raised by an earlier workgroup of this launch)
+    const unsigned int tile = d_tile_ticket(ts, &s_tile);
+    const unsigned int n_items = sizes->n_slow_units * (paired ? 2u : 1u);
+    if (tile > 0 && tile * 256u >= n_items) return;
+    const unsigned int it = tile * 256u + threadIdx.x;
+    const bool on = it < n_items;
+    const int r = on ? (paired ? (int)(2u * slow_units[it >> 1] + (it & 1u)) : (int)slow_units[it]) : 0;
+    dg_read_out o;
+    o.n_rep = 0; o.rep_off = 0; o.n_sj = 0; o.sj_off = 0;
+    if (on) o = rout[r];
+    uint32_t ncig = 0;
+    for (int i = 0; i < (on ? o.n_rep : 0); i++) ncig += reports[o.rep_off + i].n_cigar;
+    Triple mine, tot;
+    mine.x = ncig; mine.y = on ? (uint32_t)o.n_sj : 0u; mine.z = 0;
+    const Triple inb = d_block_exclusive(mine, tot, s_scan);
+    const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 12, err);
+    const uint32_t cig_fast = sizes->cig_fast;
+    if (on) {
+        uint32_t dst = cig_fast + base.x + inb.x;
+        if ((uint64_t)dst + ncig > cap_cig) atomicMax(err, DG_E_CIGFINAL);
+        else for (int i = 0; i < o.n_rep; i++) {
+            dg_report_out &rp = reports[o.rep_off + i];
+            const uint32_t m = rp.n_cigar, src = rp.cigar_off;
+            for (uint32_t k = 0; k < m; k++) cigfinal[dst + k] = cigpool[src + k];
+            rp.cigar_off = dst; dst += m;
+        }
+        if (o.n_sj > 0) {
+            const uint32_t sd = base.y + inb.y;
+            for (int k = 0; k < o.n_sj; k++) sjfinal[sd + k] = sjpool[o.sj_off + k];
+            rout[r].sj_off = (int32_t)sd;
+        }
     }
-    if (paired) {
-        d_check_paired_final(pr, rd[0], rp[0], rd[1], rp[1]);
-        d_set_paired_flag(rd[0], rp[0], rd[1], rp[1]);
-    } else d_set_single_flag(rd[0], rp[0]);
-    for (int m = 0; m < nm; m++) {
-        const int r = paired ? 2 * u + m : u;
-        d_evaluate_mapq(rd[m], rp[m]);
-        o[m].score = rd[m].score; o[m].mapq = rd[m].mapq; o[m].best = rd[m].iBest;
-        if (ncand[r] > 0 && (rd[m].mapq == 50 || (pr.all_sj && rd[m].score > 0)))
-            d_collect_sj(ix, pr, cands[seed_off[r] + rd[m].iBest], work, r, sjpool, tops + 1, sjcap, o[m].sj_off, o[m].n_sj, err);
-        rout[r] = o[m];
-    }
+    const unsigned int last = n_items ? (n_items - 1u) / 256u : 0u;
+    if (tile == last && threadIdx.x == 0) { sizes->total_cig = cig_fast + base.x + tot.x; sizes->total_sj = base.y + tot.y; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -494,6 +424,7 @@ extern "C" int dg_set_params(dg_ctx *c, const dg_params *p)
 {
     if (!c || !p) return DG_ERR_ARG;
     set_params(c, p);
+    read_env(c);                    // the DG_* tuning switches are read here and at init, never per batch
     return DG_OK;
 }
 
@@ -503,24 +434,41 @@ extern "C" void dg_destroy(dg_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     void *ptrs[] = { c->d_ktab, c->d_sa_dense, c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff };
     if (c->owns_index) for (void *p : ptrs) if (p) (void)hipFree(p);
-    void *own[] = { c->d_ctr, c->d_tops, c->d_err };
+    void *own[] = { c->d_ctr, c->d_tops, c->d_err, c->d_sizes };
     for (void *p : own) if (p) (void)hipFree(p);
-    c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
-    c->seed_off.release(); c->ncand.release(); c->nrep.release(); c->rep_off.release(); c->work_need.release(); c->work_off.release();
-    c->tile_sums.release(); c->tmp_u32.release(); c->tmp_off.release(); c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->costkey.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_left.release(); c->seed_list.release(); c->seed_state.release();
+    if (c->h_tail) (void)hipHostFree(c->h_tail);
+    c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->packed_in.release(); c->nlist_in.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
+    c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
+    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_left.release(); c->seed_list.release(); c->seed_state.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
-    c->ws.release();
+    c->ws.release(); c->scan_state.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_reseed0) (void)hipEventDestroy(c->ev_reseed0);
     if (c->ev_reseed1) (void)hipEventDestroy(c->ev_reseed1);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+// per-context objects that dg_init and dg_clone both need
+static hipError_t make_ctx_objects(dg_ctx *c)
+{
+    hipError_t e;
+    for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) return e;
+    if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess) return e;
+    for (int i = 0; i <= N_TIMERS; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, N_TOPS * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess || (e = hipMalloc((void **)&c->d_sizes, sizeof(DSizes))) != hipSuccess) return e;
+    if ((e = hipHostMalloc((void **)&c->h_tail, sizeof(dg_ctx::HostTail), hipHostMallocDefault)) != hipSuccess) return e;
+    memset(c->h_tail, 0, sizeof(dg_ctx::HostTail));
+    read_env(c);
+    return hipSuccess;
 }
 
 extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int device, int *status)
@@ -540,11 +488,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(DG_ERR_HIP, "hipSetDevice", e);
     c = new dg_ctx();
     c->device = device;
-    for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
-    if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) return bail(DG_ERR_HIP, "hipStreamCreate", e);
-    if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev_fork)) != hipSuccess || (e = hipEventCreate(&c->ev_join)) != hipSuccess) return bail(DG_ERR_HIP, "hipEventCreate", e);
-    for (int i = 0; i <= N_TIMERS; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail(DG_ERR_HIP, "hipEventCreate", e);
+    if ((e = make_ctx_objects(c)) != hipSuccess) return bail(DG_ERR_HIP, "stream / event / counter allocation", e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
     set_params(c, p);
@@ -583,8 +527,6 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
             (e = hipMemcpy(c->d_locchr, chr.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_chroff, off.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload chr tables", e);
     }
-    if ((e = hipMalloc((void **)&c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, 64)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc counters", e);
     c->ix.bwt = (const uint4 *)c->d_bwt; c->ix.sa = (const uint64_t *)c->d_sa; c->ix.pac = (const uint8_t *)c->d_pac;
     c->ix.loc_key = (const int64_t *)c->d_lockey; c->ix.loc_chr = (const int32_t *)c->d_locchr; c->ix.chr_off = (const int64_t *)c->d_chroff;
     c->ix.primary = v->primary; for (int i = 0; i < 5; i++) c->ix.L2[i] = v->L2[i]; c->ix.seq_len = v->seq_len;
@@ -594,7 +536,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
         // 288 GB are for): locating a row is one load instead of a walk of up to 31 LF steps.  Texts too large for
         // that fall back to every 2nd / 4th row; DG_SA_DENSE=0 turns it off, =2/4/8/16 forces an interval
         int intv = v->seq_len <= (12ull << 30) ? 1 : (v->seq_len <= (24ull << 30) ? 2 : 4);
-        if (getenv("DG_SA_DENSE")) intv = atoi(getenv("DG_SA_DENSE"));
+        if (const char *v = getenv("DG_SA_DENSE")) intv = atoi(v);
         if (intv >= 1 && intv < v->sa_intv && (intv & (intv - 1)) == 0 && v->seq_len < (1ull << 39)) {
             const uint64_t n_entries = v->seq_len / (uint64_t)intv + 1;
             if ((e = hipMalloc(&c->d_sa_dense, n_entries * 8)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc dense SA", e);
@@ -614,7 +556,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
                 while (K > 8 && ((size_t)16 << (2 * K)) + ((size_t)48 << 30) > free_b) K--;
         }
-        if (getenv("DG_KTAB_K")) K = atoi(getenv("DG_KTAB_K"));
+        if (const char *v = getenv("DG_KTAB_K")) K = atoi(v);
         if (K > 16) K = 16;
         if (K >= 2) {
             const size_t entries = (size_t)1 << (2 * K);
@@ -645,28 +587,28 @@ extern "C" dg_ctx *dg_clone(dg_ctx *parent, int *status)
     dg_ctx *c = new dg_ctx();
     c->device = parent->device; c->owns_index = false; c->n_cu = parent->n_cu;
     c->ix = parent->ix; c->pr = parent->pr;
-    for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
-    bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipStreamCreate(&c->stream2) == hipSuccess &&
-              hipEventCreate(&c->ev_prep) == hipSuccess && hipEventCreate(&c->ev_reseed0) == hipSuccess && hipEventCreate(&c->ev_reseed1) == hipSuccess &&
-              hipEventCreate(&c->ev_fork) == hipSuccess && hipEventCreate(&c->ev_join) == hipSuccess;
-    for (int i = 0; ok && i <= N_TIMERS; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8) == hipSuccess && hipMalloc((void **)&c->d_tops, 64) == hipSuccess && hipMalloc((void **)&c->d_err, 4) == hipSuccess;
-    if (!ok) { snprintf(g_init_error, sizeof g_init_error, "dg_clone: stream/event/counter allocation failed"); dg_destroy(c); if (status) *status = DG_ERR_HIP; return nullptr; }
+    if ((e = make_ctx_objects(c)) != hipSuccess) {
+        snprintf(g_init_error, sizeof g_init_error, "dg_clone: %s", hipGetErrorString(e)); dg_destroy(c); if (status) *status = DG_ERR_HIP; return nullptr;
+    }
     if (status) *status = DG_OK;
     return c;
 }
 
-extern "C" int dg_batch_upload(dg_ctx *c, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq)
+// ------------------------------------------------------------------------------------------
+// batch input: ASCII reads (as the reference's ReadItem_t::seq) or packed reads (2 bit/base + a list of the non-ACGT positions)
+// ------------------------------------------------------------------------------------------
+static int enqueue_upload(dg_ctx *c, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq)
 {
     if (!c || n_reads < 0 || (n_reads > 0 && (!seq_off || !rlen || !seq))) return DG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     size_t bytes = 0; int mx = 0;
     for (int i = 0; i < n_reads; i++) {
-        if (rlen[i] > DG_MAX_RLEN) { snprintf(c->err, 512, "read %d longer than DG_MAX_RLEN", i); return DG_ERR_ARG; }
-        if ((size_t)seq_off[i] + rlen[i] > bytes) bytes = (size_t)seq_off[i] + rlen[i];
-        if (rlen[i] > mx) mx = rlen[i];
+        const size_t end = (size_t)seq_off[i] + rlen[i];
+        bytes = end > bytes ? end : bytes;
+        mx = rlen[i] > mx ? rlen[i] : mx;
     }
-    c->n_reads = n_reads; c->max_rlen = mx; c->seq_bytes = bytes;
+    if (mx > DG_MAX_RLEN) { snprintf(c->err, 512, "a read is longer than DG_MAX_RLEN (%d)", DG_MAX_RLEN); return DG_ERR_ARG; }
+    c->n_reads = n_reads; c->max_rlen = mx; c->seq_bytes = bytes; c->enc_ready = false; c->enqueued = false;
     HIPCHK(c->seq.ensure(bytes + 64));     /* the kernels read up to 24 bytes at a read position in one go */
     HIPCHK(c->seq_off.ensure((size_t)n_reads + 1)); HIPCHK(c->rlen.ensure((size_t)n_reads + 1));
     if (n_reads) {
@@ -674,9 +616,92 @@ extern "C" int dg_batch_upload(dg_ctx *c, int n_reads, const uint32_t *seq_off, 
         HIPCHK(hipMemcpyAsync(c->seq_off.p, seq_off, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->rlen.p, rlen, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->stream));
     }
+    return DG_OK;
+}
+
+extern "C" int dg_batch_upload(dg_ctx *c, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq)
+{
+    const int rc = enqueue_upload(c, n_reads, seq_off, rlen, seq);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return DG_OK;
 }
+
+// packed reads -> the ASCII buffer the report stage reads (A/C/G/T, then 'N' at the listed positions) and the 2-bit + mask
+// words the seeding stage reads (k_encode's format).  One thread = 16 bases = one input word.
+__global__ void __launch_bounds__(256)
+k_unpack(const uint32_t *__restrict__ words, int n_reads, int W2, int rlen_all, const uint16_t *rlen_in, unsigned char *__restrict__ seq,
+         uint32_t *__restrict__ seq_off, uint16_t *rlen_out, uint32_t *__restrict__ enc)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_reads * W2) return;
+    const int r = (int)(t / W2), ww = (int)(t - (size_t)r * W2);
+    const int len = rlen_in ? rlen_in[r] : rlen_all, left = len - 16 * ww;
+    const uint32_t w = words[t];
+    uint32_t out[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) x |= ((0x54474341u >> (8u * ((w >> (30 - 2 * (4 * q + k))) & 3u))) & 0xFFu) << (8 * k);     // "ACGT"[code]
+        out[q] = x;
+    }
+    *(uint4 *)(seq + (size_t)r * 16 * W2 + 16 * ww) = make_uint4(out[0], out[1], out[2], out[3]);       // (bases past the end: never read)
+    const uint32_t past = left >= 16 ? 0u : (left <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu >> (2 * left));          // mask 0b11 past the end, as k_encode
+    enc[(size_t)r * 2 * W2 + ww] = w & ~past;
+    enc[(size_t)r * 2 * W2 + W2 + ww] = past;
+    if (ww == 0) { seq_off[r] = (uint32_t)((size_t)r * 16 * W2); if (!rlen_in) rlen_out[r] = (uint16_t)len; }      // (given lengths are already in place)
+}
+__global__ void __launch_bounds__(256)
+k_unpack_n(const uint32_t *__restrict__ nlist, uint32_t n_n, int W2, unsigned char *__restrict__ seq, uint32_t *__restrict__ enc)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_n) return;
+    const uint32_t flat = nlist[i], per = 16u * (uint32_t)W2, r = flat / per, pos = flat - r * per;
+    seq[flat] = 'N';
+    const uint32_t bit = 3u << (30 - 2 * (pos & 15u));
+    atomicAnd(&enc[(size_t)r * 2 * W2 + (pos >> 4)], ~bit);
+    atomicOr(&enc[(size_t)r * 2 * W2 + W2 + (pos >> 4)], bit);
+}
+
+static int enqueue_upload_packed(dg_ctx *c, int n_reads, int rlen_all, const uint16_t *rlen, int words_per_read, const uint32_t *words, const uint32_t *nlist, size_t n_n)
+{
+    if (!c || n_reads < 0 || words_per_read < 1 || (n_reads > 0 && !words) || (n_n > 0 && !nlist)) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const int W2 = words_per_read;
+    int mx = rlen_all;
+    if (rlen) { mx = 0; for (int i = 0; i < n_reads; i++) mx = rlen[i] > mx ? rlen[i] : mx; }
+    if (mx > DG_MAX_RLEN || mx > 16 * W2 || (size_t)n_reads * 16 * W2 > 0xFFFFFFF0ull) { snprintf(c->err, 512, "packed batch: read length %d does not fit %d words (or exceeds DG_MAX_RLEN / 2^32 bases)", mx, W2); return DG_ERR_ARG; }
+    if (n_reads && (mx + 15) / 16 != W2) { snprintf(c->err, 512, "packed batch: words_per_read must be ceil(longest read / 16) = %d", (mx + 15) / 16); return DG_ERR_ARG; }
+    const size_t nw = (size_t)n_reads * W2, bytes = nw * 16;
+    c->n_reads = n_reads; c->max_rlen = mx; c->seq_bytes = bytes; c->enqueued = false;
+    HIPCHK(c->seq.ensure(bytes + 64)); HIPCHK(c->seq_off.ensure((size_t)n_reads + 1)); HIPCHK(c->rlen.ensure((size_t)n_reads + 1));
+    HIPCHK(c->enc.ensure(2 * nw + 16)); HIPCHK(c->packed_in.ensure(nw + 1)); HIPCHK(c->nlist_in.ensure(n_n + 1));
+    c->enc_ready = true;
+    if (n_reads == 0) return DG_OK;
+    HIPCHK(hipMemcpyAsync(c->packed_in.p, words, nw * 4, hipMemcpyHostToDevice, c->stream));
+    if (rlen) HIPCHK(hipMemcpyAsync(c->rlen.p, rlen, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->stream));
+    if (n_n) HIPCHK(hipMemcpyAsync(c->nlist_in.p, nlist, n_n * 4, hipMemcpyHostToDevice, c->stream));
+    k_unpack<<<(unsigned)((nw + 255) / 256), 256, 0, c->stream>>>(c->packed_in.p, n_reads, W2, rlen_all, rlen ? c->rlen.p : nullptr, c->seq.p, c->seq_off.p, c->rlen.p, c->enc.p);
+    if (n_n) k_unpack_n<<<(unsigned)((n_n + 255) / 256), 256, 0, c->stream>>>(c->nlist_in.p, (uint32_t)n_n, W2, c->seq.p, c->enc.p);
+    HIPCHK(hipGetLastError());
+    return DG_OK;
+}
+
+extern "C" int dg_batch_upload_packed(dg_ctx *c, int n_reads, int rlen_all, const uint16_t *rlen, int words_per_read, const uint32_t *words, const uint32_t *nlist, size_t n_n)
+{
+    const int rc = enqueue_upload_packed(c, n_reads, rlen_all, rlen, words_per_read, words, nlist, n_n);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DG_OK;
+}
+
+extern "C" void *dg_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+extern "C" void dg_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 static WSLayout make_ws_layout(int R)
 {
@@ -702,103 +727,109 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     const int W = 2 * ((c->max_rlen + 15) / 16 > 0 ? (c->max_rlen + 15) / 16 : 1);   // 2-bit words + N-mask words per read
     hipError_t e = c->enc.ensure((size_t)W * n + 16);
     if (e != hipSuccess) return e;
-    const unsigned nb = (unsigned)((n + 255) / 256);
     int lg = 0;
     while ((1 << lg) < W / 2) lg++;
-    k_encode<<<(unsigned)((((size_t)n << lg) + 255) / 256), 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, lg, c->enc.p);
+    if (!c->enc_ready) k_encode<<<(unsigned)((((size_t)n << lg) + 255) / 256), 256, 0, c->stream>>>(c->seq.p, c->seq_off.p, c->rlen.p, n, W, lg, c->enc.p);
     if (after_encode) { e = hipEventRecord(after_encode, c->stream); if (e != hipSuccess) return e; }
-    // persistent one-wave workgroups pulling reads from a queue (d_tops[6]); long walks go to d_tops[7]'s list
-    e = hipMemsetAsync(c->d_tops + 6, 0, 8, c->stream);
-    if (e != hipSuccess) return e;
+    // persistent one-wave workgroups pulling reads from a queue (TOP_SEED_NEXT); long walks go to TOP_SEED_HEAVY's list
     if ((e = c->seed_heavy.ensure((size_t)n + 16)) != hipSuccess) return e;
-    unsigned blocks = (unsigned)c->n_cu * (getenv("DG_SEED_WAVES") ? (unsigned)atoi(getenv("DG_SEED_WAVES")) : 4u);   // one wave per SIMD: the kernel is instruction-fetch bound, more waves add ~10 % alone but cost more than
-                                                                                             // that to the other batches in flight (measured 5.4 vs 6.0 ms per step with four batches)
+    unsigned blocks = (unsigned)c->n_cu * (unsigned)c->env_seed_waves;   // one wave per SIMD: the kernel is instruction-fetch bound, more waves add ~10 % alone but cost more than
+                                                                         // that to the other batches in flight (measured 5.4 vs 6.0 ms per step with four batches)
     if ((size_t)blocks * 64 > (size_t)n) blocks = (unsigned)((n + 63) / 64);
-    const int bail_trips = getenv("DG_SEED_BAIL_TRIPS") ? atoi(getenv("DG_SEED_BAIL_TRIPS")) : 128;
-    const int both_thr = getenv("DG_SEED_BOTH") ? atoi(getenv("DG_SEED_BOTH")) : 0;
+    const int bail_trips = c->env_bail_trips, both_thr = c->env_both;
     // Rounds (k_seed_round, DG_SEED_ROUNDS=1..6; default 0 = the general kernel does everything): search number r of every read
     // that has one, lanes in lock step; what does not fit the common case is left to the general kernel.  Needs the prefix table
     // and the dense SA.  Measured (GRCh38-sized): 426 M instead of 518 M wave-instructions per 2 M reads, but the
     // rounds wait for memory 85 % of their cycles and the step as a whole is slower (467 against 504 M reads/s), so it is off.
-    int rounds = getenv("DG_SEED_ROUNDS") ? atoi(getenv("DG_SEED_ROUNDS")) : 0;
+    int rounds = c->env_rounds;
     if (rounds > 6) rounds = 6;
     if (!c->ix.ktab || !c->ix.sa_dense || W > 40) rounds = 0;                 // (W x 1 KB of LDS per block)
     const DHeavy *items = nullptr;
     const unsigned int *n_items_p = nullptr;
+    unsigned int *tops = c->d_tops;
     if (rounds > 0) {
-        const int max_steps = getenv("DG_SEED_ROUND_STEPS") ? atoi(getenv("DG_SEED_ROUND_STEPS")) : 4;
+        const int max_steps = c->env_round_steps;
         if ((e = c->seed_left.ensure((size_t)n + 16)) != hipSuccess || (e = c->seed_list.ensure((size_t)2 * n + 16)) != hipSuccess ||
             (e = c->seed_state.ensure((size_t)n + 16)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(c->d_tops + 8, 0, 32, c->stream)) != hipSuccess) return e;      // d_tops[8..13]: list sizes after rounds 1..6, [14]: leftovers
-        unsigned rb = (unsigned)c->n_cu * (getenv("DG_SEED_ROUND_BPC") ? (unsigned)atoi(getenv("DG_SEED_ROUND_BPC")) : 16u);
+        unsigned rb = (unsigned)c->n_cu * (unsigned)c->env_round_bpc;
         if ((size_t)rb * 256 > (size_t)n) rb = (unsigned)((n + 255) / 256);
         for (int r = 1; r <= rounds; r++) {
             const uint32_t *lin = r == 1 ? nullptr : c->seed_list.p + (size_t)((r - 1) & 1) * n;
             uint32_t *lout = c->seed_list.p + (size_t)(r & 1) * n;
-            k_seed_round<<<rb, 256, (size_t)W * 256 * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, lin, r == 1 ? nullptr : c->d_tops + 8 + (r - 2), W, H, max_steps, r == rounds ? 1 : 0,
-                                                    c->hits.p, c->nhits.p, c->nseeds.p, c->seed_state.p, lout, c->d_tops + 8 + (r - 1), c->seed_left.p, c->d_tops + 14, c->d_ctr);
+            k_seed_round<<<rb, 256, (size_t)W * 256 * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, lin, r == 1 ? nullptr : tops + TOP_ROUNDS + (r - 2), W, H, max_steps, r == rounds ? 1 : 0,
+                                                    c->hits.p, c->nhits.p, c->nseeds.p, c->seed_state.p, lout, tops + TOP_ROUNDS + (r - 1), c->seed_left.p, tops + TOP_ROUNDS + 6, c->d_ctr);
         }
-        items = c->seed_left.p; n_items_p = c->d_tops + 14;
+        items = c->seed_left.p; n_items_p = tops + TOP_ROUNDS + 6;
     }
-    if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips, both_thr, items, n_items_p);
-    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->d_tops + 6, c->seed_heavy.p, c->d_tops + 7, c->d_ctr, bail_trips, both_thr, items, n_items_p);
-    k_seed_heavy<<<(unsigned)c->n_cu * 8u, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, c->d_tops + 7, c->d_ctr);
+    if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr, items, n_items_p);
+    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr, items, n_items_p);
+    k_seed_heavy<<<(unsigned)c->n_cu * 8u, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr);
     return hipGetLastError();
 }
 
-#define TICK(name) do { c->tname[c->n_t] = name; HIPCHK(hipEventRecord(c->ev[c->n_t + 1], c->stream)); c->n_t++; } while (0)
+#define TICK(name) do { if (c->n_t < N_TIMERS) { c->tname[c->n_t] = name; HIPCHK(hipEventRecord(c->ev[c->n_t + 1], c->stream)); c->n_t++; } } while (0)
 
-extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
+// the kernels of the seeding + locate stage up to the located, unsorted seeds (shared by dg_batch_run and dg_probe_seeds)
+static int enqueue_seeding(dg_ctx *c, int n, int H, bool timed)
 {
-    if (!c) return DG_ERR_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    const uint32_t nb = (uint32_t)((n + 255) / 256);
+    HIPCHK(c->hits.ensure((size_t)n * H)); HIPCHK(c->nhits.ensure(n)); HIPCHK(c->nseeds.ensure(n)); HIPCHK(c->seed_off.ensure((size_t)n + 1));
+    if (c->cap_seeds < (size_t)n * 3 + 1024) c->cap_seeds = (size_t)n * 3 + 1024;              // first guess: ~2.5 seeds per read; grows by itself
+    HIPCHK(c->seeds.ensure(c->cap_seeds + 1)); HIPCHK(c->cands.ensure(c->cap_seeds + 1)); HIPCHK(c->tile_read.ensure(c->cap_seeds / 64 + 16));
+    if (timed) c->tname[c->n_t] = "k_encode";
+    HIPCHK(launch_seed(c, n, H, timed ? c->ev[c->n_t + 1] : nullptr));
+    if (timed) { c->n_t++; TICK("k_seed"); }
+    HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n, &c->d_sizes->total_seeds, (uint32_t)c->cap_seeds, DG_E_SEEDS));
+    if (timed) TICK("scan_seeds");
+    k_tile_reads<<<nb, 256, 0, c->stream>>>(n, c->seed_off.p, c->tile_read.p, c->d_err);
+    k_locate<<<(unsigned)((c->cap_seeds + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->tile_read.p, c->seed_off.p, c->seeds.p, c->d_ctr, c->d_err);
+    HIPCHK(hipGetLastError());
+    if (timed) TICK("k_locate");
+    return DG_OK;
+}
+
+static int zero_batch_state(dg_ctx *c, int n_units)
+{
+    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_STRIPES * CTR_STRIDE * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_tops, 0, N_TOPS * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_sizes, 0, sizeof(DSizes), c->stream));
+    const size_t tiles = (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1, tiles2 = (size_t)(2 * n_units + 255) / 256 + 1;
+    HIPCHK(c->scan_state.ensure(2 * tiles + 2 * tiles2));
+    HIPCHK(hipMemsetAsync(c->scan_state.p, 0, (2 * tiles + 2 * tiles2) * 8, c->stream));
+    return DG_OK;
+}
+
+// Enqueues the whole path of the uploaded batch on the context's stream and returns without waiting: no size is read back
+// in between.  finish_run() waits, learns the sizes, and runs the batch again if a capacity was too small.
+static int enqueue_run(dg_ctx *c)
+{
     const int n = c->n_reads;
     const int paired = (c->pr.paired && (n % 2 == 0)) ? 1 : 0;      // Mapping.cpp:598
     const int n_units = paired ? n / 2 : n;
-    c->used[0] = c->used[1] = c->used[2] = 0;
     c->n_t = 0;
-    memset(c->counters, 0, sizeof c->counters);
-    if (used) used[0] = used[1] = used[2] = 0;
-    if (n == 0) return DG_OK;
     const int H = c->max_rlen / 16 + 1;
     const uint32_t nb = (uint32_t)((n + 255) / 256);
-    HIPCHK(c->hits.ensure((size_t)n * H)); HIPCHK(c->nhits.ensure(n)); HIPCHK(c->nseeds.ensure(n)); HIPCHK(c->seed_off.ensure((size_t)n + 1));
-    HIPCHK(c->ncand.ensure(n)); HIPCHK(c->nrep.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1));
-    HIPCHK(c->work_need.ensure(n)); HIPCHK(c->work_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n));
-    HIPCHK(c->tmp_u32.ensure(n)); HIPCHK(c->tmp_off.ensure((size_t)n + 1));
-    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_STRIPES * CTR_STRIDE * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_tops, 0, 64, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
+    { const int zr = zero_batch_state(c, n_units); if (zr) return zr; }
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    { const int rc = enqueue_seeding(c, n, H, true); if (rc) return rc; }
 
-    c->tname[c->n_t] = "k_encode";
-    HIPCHK(launch_seed(c, n, H, c->ev[c->n_t + 1]));
-    c->n_t++;
-    TICK("k_seed");
-    HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n));
-    uint32_t total_seeds = 0;
-    HIPCHK(hipMemcpyAsync(&total_seeds, c->seed_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    TICK("scan_seeds");
-    HIPCHK(c->seeds.ensure((size_t)total_seeds + 1)); HIPCHK(c->cands.ensure((size_t)total_seeds + 1));
-    if (total_seeds) {
-        HIPCHK(c->tmp_u32.ensure((size_t)total_seeds / 64 + 16));
-        k_tile_reads<<<nb, 256, 0, c->stream>>>(n, c->seed_off.p, c->tmp_u32.p);
-        k_locate<<<(unsigned)((total_seeds + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->tmp_u32.p, c->seed_off.p, c->seeds.p, c->d_ctr, total_seeds);
-        HIPCHK(hipGetLastError());
-    }
-    TICK("k_locate");
-    HIPCHK(c->heavy.ensure((size_t)n_units + 16));
-    k_heavy_list<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(n_units, paired, c->seed_off.p, c->heavy.p, c->d_tops + 5);
-    // the heavy units (a wave each) and the ordinary ones (a lane each) write disjoint slots: the two kernels run side by side
-    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    k_chain_heavy<<<c->n_cu * 8, 64, 0, c->stream2>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p,
-                                                      c->nrep.p, c->work_need.p, c->heavy.p, c->d_tops + 5, c->d_ctr);
-    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-    k_chain<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p,
-                                                                  c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->d_ctr);
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    // capacities of the data-dependent buffers (sticky; see dg_ctx)
+    if (c->cap_rep < (size_t)n + (size_t)n / 4 + 1024) c->cap_rep = (size_t)n + (size_t)n / 4 + 1024;
+    if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep;
+    if (c->cap_work < (size_t)n * 8 + 65536) c->cap_work = (size_t)n * 8 + 65536;
+    const size_t cigcap = (size_t)n * 48 + c->cap_rep * (16 + CIG_SLOT) + 4096, sjcap = (size_t)n * 4 + 1024;
+    HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n)); HIPCHK(c->done.ensure((size_t)n + 16));
+    HIPCHK(c->heavy.ensure((size_t)n_units + 16)); HIPCHK(c->slow_units.ensure((size_t)n_units + 16));
+    HIPCHK(c->reports.ensure(c->cap_rep + 1)); HIPCHK(c->work.ensure(c->cap_work + 16)); HIPCHK(c->jobs.ensure(c->cap_seeds + 16));
+    HIPCHK(c->cigpool.ensure(cigcap)); HIPCHK(c->cigfinal.ensure(c->cap_cig + 16)); HIPCHK(c->sjpool.ensure(sjcap)); HIPCHK(c->sjfinal.ensure(sjcap));
+    HIPCHK(c->perm.ensure((size_t)n + 16)); HIPCHK(c->hist.ensure((size_t)COST_CLASSES * nb * 2 + 16));
+    unsigned int *tops = c->d_tops;
+
+    // units with more seeds than a lane of k_pair holds: a wave each, before k_pair (which needs their candidate counts)
+    k_heavy_list<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(n_units, paired, c->seed_off.p, c->heavy.p, tops + TOP_HEAVY_UNITS, c->d_err);
+    k_chain_heavy<<<c->n_cu * 8, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p,
+                                                     c->heavy.p, tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
 #ifdef DG_PROFILE_CLASSES
     {
@@ -810,20 +841,20 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
                 (v[0] >> 30) & 1023, (v[0] >> 20) & 1023, (v[0] >> 10) & 1023, v[0] & 1023);
     }
 #endif
-    TICK("k_chain");
-    HIPCHK(scan_u32(c, c->nrep.p, c->rep_off.p, (uint32_t)n));
-    HIPCHK(scan_u32(c, c->work_need.p, c->work_off.p, (uint32_t)n));
-    uint32_t total_rep = 0, total_work = 0;
-    HIPCHK(hipMemcpyAsync(&total_rep, c->rep_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&total_work, c->work_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    TICK("scan_reports");
-    const size_t cigcap = (size_t)n * 48 + (size_t)total_rep * (16 + CIG_SLOT) + 4096, sjcap = (size_t)n * 4 + 1024;
-    HIPCHK(c->reports.ensure((size_t)total_rep + 1)); HIPCHK(c->work.ensure((size_t)total_work + 16));
-    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(c->d_tops + 0), (int)((size_t)total_rep * CIG_SLOT), 1, c->stream));   // overflow area starts behind the per-report slots
-    HIPCHK(c->cigpool.ensure(cigcap)); HIPCHK(c->cigfinal.ensure(cigcap)); HIPCHK(c->sjpool.ensure(sjcap)); HIPCHK(c->sjfinal.ensure(sjcap));
+    TICK("k_chain_heavy");
+    const size_t tiles = (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1, tiles2 = (size_t)(2 * n_units + 255) / 256 + 1;
+    TileScan ts_pair{c->scan_state.p, c->scan_state.p + tiles, tops + TOP_TICKET_PAIR};
+    TileScan ts_emit{c->scan_state.p + 2 * tiles, c->scan_state.p + 2 * tiles + tiles2, tops + TOP_TICKET_EMIT};
+    const int try_fast = (c->env_no_fast || c->ix.n_chr > 0xFFFF) ? 0 : 1;
+    k_pair<<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
+        c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p, c->done.p,
+        c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err);
+    HIPCHK(hipGetLastError());
+    TICK("k_pair");
+
+    // ---- the general path, on the units k_pair listed ----
     const WSLayout L = make_ws_layout(c->max_rlen < 32 ? 32 : c->max_rlen);
-    int blocks = c->n_cu * (getenv("DG_REPORT_BPC") ? atoi(getenv("DG_REPORT_BPC")) : 8);   // 8 one-wave workgroups per CU (2 per SIMD: the kernel needs ~220 VGPRs to stay out of scratch)
+    int blocks = c->n_cu * c->env_report_bpc;       // 8 one-wave workgroups per CU (2 per SIMD: the kernel needs ~220 VGPRs to stay out of scratch)
     if ((size_t)blocks * 64 > (size_t)n) blocks = (n + 63) / 64;
     {   // the lane workspace grows with the square of the longest read: keep it under ~12 GB by running fewer persistent waves
         const size_t budget = (size_t)12 << 30, per_block = (size_t)64 * L.stride;
@@ -831,40 +862,37 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
         if (blocks < 1) blocks = 1;
     }
     HIPCHK(c->ws.ensure((size_t)blocks * 64 * L.stride));
-    HIPCHK(c->jobs.ensure((size_t)total_seeds + 16));
-    k_prep<<<nb, 256, 0, c->stream>>>(c->pr, n, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work_off.p, c->work.p, c->jobs.p,
-                                        c->d_tops + 2, (uint32_t)c->jobs.cap, c->d_err, c->rlen.p);
+    unsigned slow_grid = (unsigned)c->n_cu * 4u;
+    if ((size_t)slow_grid * 256 > (size_t)n) slow_grid = nb;
+    k_prep<<<slow_grid, 256, 0, c->stream>>>(c->pr, paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work.p, tops + TOP_WORK,
+                                             (uint32_t)c->cap_work, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_err, c->rlen.p);
     HIPCHK(hipGetLastError());
     TICK("k_prep");
-    // k_reseed runs on a second stream, concurrently with the report of every read that has no
-    // re-seeding job (the 99 % case); only the job reads wait for it
+    // k_reseed runs on a second stream, concurrently with the report of every read that has no re-seeding job; only the job reads wait for it
     HIPCHK(hipEventRecord(c->ev_prep, c->stream));
     HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_prep, 0));
     HIPCHK(hipEventRecord(c->ev_reseed0, c->stream2));
-    k_reseed<1><<<c->n_cu * 8, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
-    k_reseed<2><<<c->n_cu * 5, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
-    k_reseed<4><<<c->n_cu * 3, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->d_tops + 2, c->d_ctr);
+    k_reseed<1><<<c->n_cu * 8, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_ctr, c->d_err);
+    k_reseed<2><<<c->n_cu * 5, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_ctr, c->d_err);
+    k_reseed<4><<<c->n_cu * 3, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_reseed1, c->stream2));
-    HIPCHK(c->costkey.ensure((size_t)n + 16)); HIPCHK(c->perm.ensure((size_t)n + 16)); HIPCHK(c->hist.ensure((size_t)COST_CLASSES * nb * 2 + 16));
-    k_report_diag<<<nb, 256, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->cands.p, c->ncand.p, c->rep_off.p, c->work.p,
-                                             c->costkey.p, c->reads_out.p, c->reports.p, c->cigpool.p, (uint32_t)cigcap, c->d_ctr, c->d_err);
-    k_cost<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->seed_off.p, c->cands.p, c->ncand.p, c->costkey.p, c->hist.p);
+    k_cost<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->seed_off.p, c->cands.p, c->ncand.p, c->done.p, c->hist.p, c->d_err);
     uint32_t *class_offs = c->hist.p + (size_t)COST_CLASSES * nb + 8;
     HIPCHK(scan_u32(c, c->hist.p, class_offs, COST_CLASSES * nb));
-    k_cost_scatter<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->costkey.p, class_offs, c->perm.p);
+    k_cost_scatter<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->done.p, class_offs, c->perm.p, c->d_err);
     const uint32_t *n_jobreads_p = class_offs + (size_t)2 * nb;       // start of class 1 (key 2) = number of class-0 (job) reads
     const uint32_t *heavy_end_p = class_offs + (size_t)8 * nb;        // start of class 4 (key 8) = end of the heavy classes 1-3
-    const uint32_t *single_first_p = class_offs + (size_t)DIAG_DONE * nb;   // start of key 31: the reads k_report_diag finished
+    const uint32_t *single_first_p = class_offs + (size_t)DIAG_DONE * nb;   // start of key 31: the reads k_pair finished
     TICK("order");
     // one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves
     const int blocks_main = blocks > c->n_cu * 4 ? blocks - c->n_cu : blocks;
 #ifdef DG_PROFILE_CLASSES
-    { const uint8_t *kp = c->costkey.p; HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_costkey), &kp, sizeof kp, 0, hipMemcpyHostToDevice, c->stream)); }
+    { const uint8_t *kp = c->done.p; HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_costkey), &kp, sizeof kp, 0, hipMemcpyHostToDevice, c->stream)); }
 #endif
     k_report<2><<<blocks_main, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
                                                c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, heavy_end_p, single_first_p, 0, c->reads_out.p, c->reports.p, c->cigpool.p,
-                                               (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
+                                               (uint32_t)cigcap, tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
 #ifdef DG_PROFILE_CLASSES
     {
@@ -886,46 +914,85 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_reseed1, 0));
     k_report<2><<<blocks_main < c->n_cu ? blocks_main : c->n_cu, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
                                                c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, heavy_end_p, single_first_p, 1, c->reads_out.p, c->reports.p, c->cigpool.p,
-                                               (uint32_t)cigcap, c->d_tops, c->ws.p, L, c->d_ctr, c->d_err);
+                                               (uint32_t)cigcap, tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_report_jobs");
-    k_finalize<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->seed_off.p, c->cands.p, c->ncand.p, c->work.p,
-                                                                     c->reads_out.p, c->reports.p, c->sjpool.p, (uint32_t)sjcap, c->d_tops, c->d_err);
+    k_finalize<<<slow_grid, 256, 0, c->stream>>>(c->ix, c->pr, paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->cands.p, c->ncand.p, c->work.p,
+                                                 c->reads_out.p, c->reports.p, c->sjpool.p, (uint32_t)sjcap, tops, c->d_err);
+    k_emit_slow<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->reads_out.p, c->reports.p, c->cigpool.p, c->cigfinal.p,
+                                                                    (uint32_t)c->cap_cig, c->sjpool.p, c->sjfinal.p, ts_emit, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_finalize");
-    // deterministic layout of the variable-length outputs
-    HIPCHK(c->tmp_u32.ensure((size_t)total_rep + 1)); HIPCHK(c->tmp_off.ensure((size_t)total_rep + 2));
-    uint32_t total_cig = 0, total_sj = 0;
-    if (total_rep) {
-        k_extract_ncigar<<<(total_rep + 255) / 256, 256, 0, c->stream>>>(c->reports.p, total_rep, c->tmp_u32.p);
-        HIPCHK(scan_u32(c, c->tmp_u32.p, c->tmp_off.p, total_rep));
-        k_compact_cigar<<<(total_rep + 255) / 256, 256, 0, c->stream>>>(c->reports.p, total_rep, c->tmp_off.p, c->cigpool.p, c->cigfinal.p);
-        HIPCHK(hipMemcpyAsync(&total_cig, c->tmp_off.p + total_rep, 4, hipMemcpyDeviceToHost, c->stream));
+    // the tail: sizes, status, counters -> pinned host memory, one copy each
+    HIPCHK(hipMemcpyAsync(&c->h_tail->sizes, c->d_sizes, sizeof(DSizes), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h_tail->err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_tail->tops, c->d_tops, N_TOPS * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_tail->ctr_stripes, c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
+    TICK("tail");
+    c->enqueued = true;
+    return DG_OK;
+}
+
+// waits for the enqueued batch; on a capacity overflow grows the buffer from what the device reported and runs the batch again
+static int finish_run(dg_ctx *c, size_t used[3])
+{
+    c->runs_of_last_batch = 0;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        c->runs_of_last_batch++;
         HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream2));
+        const DSizes &sz = c->h_tail->sizes;
+        const int derr = c->h_tail->err;
+        if (derr < DG_ABORT) break;
+        auto grow = [](size_t need) { return need + need / 4 + 1024; };
+        if (derr == DG_E_SEEDS) c->cap_seeds = grow(sz.total_seeds);
+        else if (derr == DG_E_REPORTS) { c->cap_rep = grow(sz.total_rep); if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep; }
+        else if (derr == DG_E_WORK) c->cap_work = grow(c->h_tail->tops[TOP_WORK]);
+        else if (derr == DG_E_CIGFINAL) c->cap_cig = grow(sz.total_cig > 2 * c->cap_cig ? sz.total_cig : 2 * c->cap_cig);
+        else { snprintf(c->err, 512, "device-side scan did not complete (status %d)", derr); return DG_ERR_INTERNAL; }
+        if (attempt == 5) { snprintf(c->err, 512, "buffer capacities did not converge (status %d)", derr); return DG_ERR_INTERNAL; }
+        const int rc = enqueue_run(c);
+        if (rc) return rc;
     }
-    HIPCHK(c->tmp_u32.ensure((size_t)n + 1)); HIPCHK(c->tmp_off.ensure((size_t)n + 2));
-    k_extract_nsj<<<nb, 256, 0, c->stream>>>(c->reads_out.p, (uint32_t)n, c->tmp_u32.p);
-    HIPCHK(scan_u32(c, c->tmp_u32.p, c->tmp_off.p, (uint32_t)n));
-    k_compact_sj<<<nb, 256, 0, c->stream>>>(c->reads_out.p, (uint32_t)n, c->tmp_off.p, c->sjpool.p, c->sjfinal.p);
-    HIPCHK(hipMemcpyAsync(&total_sj, c->tmp_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
-    int derr = 0;
-    HIPCHK(hipMemcpyAsync(&derr, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->ctr_stripes, c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    TICK("compact");
-    HIPCHK(hipEventSynchronize(c->ev[c->n_t]));
+    c->enqueued = false;
     for (int i = 0; i < c->n_t; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]); c->tms[i] = ms; }
-    if (c->n_t < N_TIMERS) { float ms = 0; (void)hipEventSynchronize(c->ev_reseed1); (void)hipEventElapsedTime(&ms, c->ev_reseed0, c->ev_reseed1); c->tname[c->n_t] = "k_reseed(overlapped)"; c->tms[c->n_t] = ms; c->n_t++; }
+    if (c->n_t < N_TIMERS) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_reseed0, c->ev_reseed1); c->tname[c->n_t] = "k_reseed(overlapped)"; c->tms[c->n_t] = ms; c->n_t++; }
     for (int k = 0; k < CTR_N; k++) {
         uint64_t v = 0;
         const bool is_max = k == CTR_MAXTRIPS || k == CTR_WTRIPS_MAX;
-        for (int s = 0; s < CTR_STRIPES; s++) { const uint64_t x = c->ctr_stripes[s * CTR_STRIDE + k]; v = is_max ? (x > v ? x : v) : v + x; }
+        for (int s = 0; s < CTR_STRIPES; s++) { const uint64_t x = c->h_tail->ctr_stripes[s * CTR_STRIDE + k]; v = is_max ? (x > v ? x : v) : v + x; }
         c->counters[k] = v;
     }
-    c->counters[CTR_SEEDS] = total_seeds;
-    if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == 1 ? "cigar" : (derr == 2 ? "splice junction" : "reseed jobs")); return DG_ERR_INTERNAL; }
-    c->used[0] = total_rep; c->used[1] = total_cig; c->used[2] = total_sj;
-    if (used) { used[0] = total_rep; used[1] = total_cig; used[2] = total_sj; }
+    const DSizes &sz = c->h_tail->sizes;
+    c->counters[CTR_SEEDS] = sz.total_seeds;
+    const int derr = c->h_tail->err;
+    if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == DG_E_CIGAR ? "cigar" : (derr == DG_E_SJ ? "splice junction" : "reseed jobs")); return DG_ERR_INTERNAL; }
+    c->used[0] = sz.total_rep; c->used[1] = sz.total_cig; c->used[2] = sz.total_sj;
+    if (used) { used[0] = c->used[0]; used[1] = c->used[1]; used[2] = c->used[2]; }
+    return DG_OK;
+}
+
+extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
+{
+    if (!c) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    c->used[0] = c->used[1] = c->used[2] = 0;
+    memset(c->counters, 0, sizeof c->counters);
+    if (used) used[0] = used[1] = used[2] = 0;
+    c->n_t = 0;
+    if (c->n_reads == 0) return DG_OK;
+    const int rc = enqueue_run(c);
+    if (rc) return rc;
+    return finish_run(c, used);
+}
+
+static int enqueue_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3])
+{
+    if (caps[0] < c->used[0] || caps[1] < c->used[1] || caps[2] < c->used[2]) { snprintf(c->err, 512, "output capacity too small"); return DG_ERR_CAPACITY; }
+    if (c->n_reads && ro) HIPCHK(hipMemcpyAsync(ro, c->reads_out.p, (size_t)c->n_reads * sizeof(dg_read_out), hipMemcpyDeviceToHost, c->stream));
+    if (c->used[0] && po) HIPCHK(hipMemcpyAsync(po, c->reports.p, c->used[0] * sizeof(dg_report_out), hipMemcpyDeviceToHost, c->stream));
+    if (c->used[1] && cig) HIPCHK(hipMemcpyAsync(cig, c->cigfinal.p, c->used[1] * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, c->stream));
     return DG_OK;
 }
 
@@ -933,19 +1000,30 @@ extern "C" int dg_batch_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, 
 {
     if (!c || !caps) return DG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    if (caps[0] < c->used[0] || caps[1] < c->used[1] || caps[2] < c->used[2]) { snprintf(c->err, 512, "output capacity too small"); return DG_ERR_CAPACITY; }
-    if (c->n_reads && ro) HIPCHK(hipMemcpyAsync(ro, c->reads_out.p, (size_t)c->n_reads * sizeof(dg_read_out), hipMemcpyDeviceToHost, c->stream));
-    if (c->used[0] && po) HIPCHK(hipMemcpyAsync(po, c->reports.p, c->used[0] * sizeof(dg_report_out), hipMemcpyDeviceToHost, c->stream));
-    if (c->used[1] && cig) HIPCHK(hipMemcpyAsync(cig, c->cigfinal.p, c->used[1] * 4, hipMemcpyDeviceToHost, c->stream));
-    if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, c->stream));
+    const int rc = enqueue_download(c, ro, po, cig, so, caps);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return DG_OK;
 }
 
+// host buffers in, host records out: the copies and the kernels are enqueued back to back (two waits per batch: sizes, then
+// records).  With page-locked caller buffers (dg_host_alloc) the copies are DMA transfers that overlap other contexts' kernels.
 extern "C" int dg_map_batch(dg_ctx *c, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
                             dg_read_out *ro, dg_report_out *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3], size_t used[3])
 {
-    int rc = dg_batch_upload(c, n_reads, seq_off, rlen, seq);
+    if (!c || !caps) return DG_ERR_ARG;
+    int rc = enqueue_upload(c, n_reads, seq_off, rlen, seq);
+    if (rc) return rc;
+    if ((rc = dg_batch_run(c, used))) return rc;
+    return dg_batch_download(c, ro, po, cig, so, caps);
+}
+
+extern "C" int dg_map_batch_packed(dg_ctx *c, int n_reads, int rlen_all, const uint16_t *rlen, int words_per_read, const uint32_t *words,
+                                   const uint32_t *nlist, size_t n_n, dg_read_out *ro, dg_report_out *po, uint32_t *cig, dg_sj_out *so,
+                                   const size_t caps[3], size_t used[3])
+{
+    if (!c || !caps) return DG_ERR_ARG;
+    int rc = enqueue_upload_packed(c, n_reads, rlen_all, rlen, words_per_read, words, nlist, n_n);
     if (rc) return rc;
     if ((rc = dg_batch_run(c, used))) return rc;
     return dg_batch_download(c, ro, po, cig, so, caps);
@@ -1041,6 +1119,9 @@ extern "C" int dg_last_counters(dg_ctx *c, uint64_t *out, int cap)
     if (!c) return 0;
     int k = CTR_N < cap ? CTR_N : cap;
     for (int i = 0; i < k; i++) out[i] = c->counters[i];
+    // [18] units that took the general path, [19] units chained by a wave each, [20] times the batch was enqueued (> 1: a buffer grew)
+    const uint64_t extra[3] = { c->h_tail ? c->h_tail->sizes.n_slow_units : 0u, c->h_tail ? c->h_tail->tops[TOP_HEAVY_UNITS] : 0u, (uint64_t)c->runs_of_last_batch };
+    for (int i = 0; i < 3 && k < cap; i++) out[k++] = extra[i];
     return k;
 }
 
@@ -1054,36 +1135,43 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
     if (used) *used = 0;
     if (n == 0) return DG_OK;
     const int H = c->max_rlen / 16 + 1;
-    HIPCHK(c->hits.ensure((size_t)n * H)); HIPCHK(c->nhits.ensure(n)); HIPCHK(c->nseeds.ensure(n)); HIPCHK(c->seed_off.ensure((size_t)n + 1));
-    HIPCHK(c->ncand.ensure(n)); HIPCHK(c->nrep.ensure(n)); HIPCHK(c->work_need.ensure(n));
-    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_STRIPES * CTR_STRIDE * 8, c->stream));
-    HIPCHK(launch_seed(c, n, H));
-    HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n));
     uint32_t total = 0;
-    HIPCHK(hipMemcpyAsync(&total, c->seed_off.p + n, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int attempt = 0; ; attempt++) {
+        c->n_t = 0;
+        if ((rc = zero_batch_state(c, n))) return rc;
+        if ((rc = enqueue_seeding(c, n, H, false))) return rc;
+        // the production sorters, every read on its own (unpaired): k_chain_heavy for the long lists, k_pair (candidate stage
+        // only, sorted seeds written back for every read) for the rest
+        HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n)); HIPCHK(c->done.ensure((size_t)n + 16));
+        HIPCHK(c->heavy.ensure((size_t)n + 16)); HIPCHK(c->slow_units.ensure((size_t)n + 16)); HIPCHK(c->reports.ensure(16)); HIPCHK(c->cigfinal.ensure(16));
+        k_heavy_list<<<(n + 255) / 256, 256, 0, c->stream>>>(n, 0, c->seed_off.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_err);
+        k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
+        const size_t tiles = (size_t)(n + PU_THREADS - 1) / PU_THREADS + 1;
+        TileScan ts{c->scan_state.p, c->scan_state.p + tiles, c->d_tops + TOP_TICKET_PAIR};
+        k_pair<<<(unsigned)((n + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
+            c->ix, c->pr, n, 0, 0, 1, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p, c->done.p,
+            c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, 0xFFFFFFFFu, 0xFFFFFFFFu, ts, c->d_sizes, c->d_tops + TOP_CIG, c->d_ctr, c->d_err);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&c->h_tail->sizes, c->d_sizes, sizeof(DSizes), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&c->h_tail->err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        total = c->h_tail->sizes.total_seeds;
+        if (c->h_tail->err == DG_E_SEEDS && attempt < 3) { c->cap_seeds = (size_t)total + total / 4 + 1024; continue; }
+        if (c->h_tail->err) { snprintf(c->err, 512, "dg_probe_seeds: device status %d", c->h_tail->err); return DG_ERR_INTERNAL; }
+        break;
+    }
     if (used) *used = total;
     if (total > cap) return DG_ERR_CAPACITY;
-    HIPCHK(c->seeds.ensure((size_t)total + 1)); HIPCHK(c->cands.ensure((size_t)total + 1));
-    if (total) {
-        HIPCHK(c->tmp_u32.ensure((size_t)total / 64 + 16));
-        k_tile_reads<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(n, c->seed_off.p, c->tmp_u32.p);
-        k_locate<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->tmp_u32.p, c->seed_off.p, c->seeds.p, c->d_ctr, total);
-    }
-    // the sort is the first half of k_chain; run it unpaired so every read is sorted on its own
-    HIPCHK(c->heavy.ensure((size_t)n + 16));
-    HIPCHK(hipMemsetAsync(c->d_tops, 0, 64, c->stream));
-    k_heavy_list<<<(n + 255) / 256, 256, 0, c->stream>>>(n, 0, c->seed_off.p, c->heavy.p, c->d_tops + 5);
-    k_chain<<<(n + 255) / 256, 256, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->d_ctr);
-    k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->nrep.p, c->work_need.p, c->heavy.p, c->d_tops + 5, c->d_ctr);
-    std::vector<DSeed> h(total);
+    std::vector<SKey> h(total);
     HIPCHK(hipMemcpyAsync(seed_off, c->seed_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    if (total) HIPCHK(hipMemcpyAsync(h.data(), c->seeds.p, (size_t)total * sizeof(DSeed), hipMemcpyDeviceToHost, c->stream));
+    if (total) HIPCHK(hipMemcpyAsync(h.data(), c->seeds.p, (size_t)total * sizeof(SKey), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (uint32_t i = 0; i < total; i++) { rpos[i] = h[i].rPos; slen[i] = h[i].rLen; gpos[i] = h[i].gPos; }
+    for (uint32_t i = 0; i < total; i++) { rpos[i] = sk_rpos(h[i]); slen[i] = sk_rlen(h[i]); gpos[i] = sk_gpos(h[i]); }
     return DG_OK;
 }
 
+// ---- nw_alignment probes: every form of nw_alignment.cpp:18-82 that runs in production, one pair per lane ----
+// mode 0: the serial strip form d_nw (string path of d_process_pair)
 __global__ void __launch_bounds__(64)
 k_probe_nw(int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b, const uint32_t *out_off,
            uint32_t *out_len, char *out_a, char *out_b, unsigned char *ws, const WSLayout L, const DIndex ix, const DParams pr)
@@ -1095,11 +1183,68 @@ k_probe_nw(int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, c
     cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
     out_len[i] = (uint32_t)d_nw(cx, a + a_off[i], (int)(a_off[i + 1] - a_off[i]), b + b_off[i], (int)(b_off[i + 1] - b_off[i]), out_a + out_off[i], out_b + out_off[i]);
 }
-
-extern "C" int dg_probe_nw(dg_ctx *c, int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b,
-                           uint32_t *out_off, uint32_t *out_len, char *out_a, char *out_b, size_t cap)
+// mode 1: the register-strip form d_pair_nw (pairs up to PM_MAX x PM_MAX: strings as bytes in registers, traceback bits in
+// the lane's LDS slice, result = a column list); the gapped strings are rebuilt from the column list
+__global__ void __launch_bounds__(64)
+k_probe_nw_strips(int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b, const uint32_t *out_off,
+                  uint32_t *out_len, char *out_a, char *out_b, const DIndex ix, const DParams pr)
 {
-    if (!c || n < 0) return DG_ERR_ARG;
+    __shared__ uint32_t lds_pm[64 * PM_LDS_WORDS];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    LaneCtx cx;
+    cx.ix = &ix; cx.pr = &pr; cx.L = nullptr; cx.ws = nullptr; cx.seq = nullptr; cx.rlen = 0; cx.lds = lds_pm + (threadIdx.x & 63) * PM_LDS_WORDS;
+    cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
+    const char *pa = a + a_off[i], *pb = b + b_off[i];
+    const int m = (int)(a_off[i + 1] - a_off[i]), nn = (int)(b_off[i + 1] - b_off[i]);
+    uint64_t w[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < m; k++) w[k >> 3] |= (uint64_t)(unsigned char)pa[k] << ((k & 7) << 3);
+    for (int k = 0; k < nn; k++) w[3 + (k >> 3)] |= (uint64_t)(unsigned char)pb[k] << ((k & 7) << 3);
+    PairStr ps; ps.A0 = w[0]; ps.A1 = w[1]; ps.A2 = w[2]; ps.B0 = w[3]; ps.B1 = w[4]; ps.B2 = w[5];
+    ColList cl;
+    d_pair_nw(cx, m, nn, ps, cl);
+    char *oa = out_a + out_off[i], *ob = out_b + out_off[i];
+    int x = 0, y = 0;
+    for (int p_ = 0; p_ < cl.K; p_++) {
+        const uint32_t ty = d_colcode(cl, p_) & 3u;
+        oa[p_] = ty == 1 ? '-' : pa[x++];
+        ob[p_] = ty == 2 ? '-' : pb[y++];
+    }
+    out_len[i] = (uint32_t)cl.K;
+}
+// modes 2 and 3: the wave-wide service d_nw_wave (8-lane groups up to 64 columns, the whole wave beyond; mode 3: the whole-wave
+// form for every pair) + the owner's traceback d_tb_traceback.  The genome side comes from a pac (here: the b strings packed
+// 2 bit/base), exactly as in k_report.
+__global__ void __launch_bounds__(64)
+k_probe_nw_wave(int n, int all_wide, const uint32_t *a_off, const uint32_t *b_off, const char *a, const uint32_t *out_off,
+                uint32_t *out_len, char *out_a, char *out_b, unsigned char *ws, const WSLayout L, const DIndex ix, const DParams pr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const bool has = i < n;
+    LaneCtx cx;
+    cx.ix = &ix; cx.pr = &pr; cx.L = &L; cx.ws = ws + (size_t)(has ? i : 0) * L.stride; cx.seq = nullptr; cx.rlen = 0; cx.lds = nullptr;
+    cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
+    const int m = has ? (int)(a_off[i + 1] - a_off[i]) : 0, nn = has ? (int)(b_off[i + 1] - b_off[i]) : 0;
+    const unsigned char *pa = (const unsigned char *)a + (has ? a_off[i] : 0);
+    const int64_t gPos = has ? (int64_t)b_off[i] : 0;
+    d_nw_wave(cx, has, pa, m, gPos, nn, lane, all_wide != 0);
+    if (has) {
+        char *g = ws_str(cx, 0);
+        d_ref_fill(ix, gPos, nn, g);
+        out_len[i] = (uint32_t)d_tb_traceback(cx, (const char *)pa, m, g, nn, out_a + out_off[i], out_b + out_off[i]);
+    }
+}
+
+struct DevTmp {                       // frees its device buffers on every return path
+    std::vector<void *> ptrs;
+    hipError_t alloc(void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) ptrs.push_back(*p); return e; }
+    ~DevTmp() { for (void *p : ptrs) (void)hipFree(p); }
+};
+
+extern "C" int dg_probe_nw_mode(dg_ctx *c, int mode, int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b,
+                                uint32_t *out_off, uint32_t *out_len, char *out_a, char *out_b, size_t cap)
+{
+    if (!c || n < 0 || mode < 0 || mode > 3) return DG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     if (n == 0) return DG_OK;
     size_t tot = 0; int mx = 32;
@@ -1108,22 +1253,49 @@ extern "C" int dg_probe_nw(dg_ctx *c, int n, const uint32_t *a_off, const uint32
         out_off[i] = (uint32_t)tot; tot += (size_t)m + nn;
         if (m > mx) mx = m;
         if ((nn + 1) / 2 > mx) mx = (nn + 1) / 2;      // workspace bit matrix holds 2R+32 columns
+        if (mode == 1 && (m > PM_MAX || nn > PM_MAX || m < 1 || nn < 1)) { snprintf(c->err, 512, "dg_probe_nw_mode 1: pair %d is not within %d x %d", i, PM_MAX, PM_MAX); return DG_ERR_ARG; }
     }
     if (tot > cap) return DG_ERR_CAPACITY;
-    const WSLayout L = make_ws_layout(mx);
-    unsigned char *d_ws = nullptr; char *d_a = nullptr, *d_b = nullptr, *d_oa = nullptr, *d_ob = nullptr; uint32_t *d_off = nullptr;
     const size_t la = a_off[n], lb = b_off[n];
-    HIPCHK(hipMalloc((void **)&d_ws, (size_t)n * L.stride)); HIPCHK(hipMalloc((void **)&d_a, la + 16)); HIPCHK(hipMalloc((void **)&d_b, lb + 16));
-    HIPCHK(hipMalloc((void **)&d_oa, tot + 16)); HIPCHK(hipMalloc((void **)&d_ob, tot + 16)); HIPCHK(hipMalloc((void **)&d_off, (size_t)(4 * n + 4) * 4));
+    std::vector<uint8_t> pac;
+    if (mode >= 2) {                                   // the genome side as a forward-strand pac (2 bit/base, first base on top)
+        pac.assign(lb / 4 + 1 + 64, 0);
+        for (size_t k = 0; k < lb; k++) {
+            const uint8_t code = d_nt4((unsigned char)b[k]);
+            if (code > 3) { snprintf(c->err, 512, "dg_probe_nw_mode %d: the genome side must be ACGT (RefSequence holds nothing else)", mode); return DG_ERR_ARG; }
+            pac[k >> 2] |= (uint8_t)(code << ((~k & 3) << 1));
+        }
+    }
+    const WSLayout L = make_ws_layout(mx);
+    DevTmp tmp;
+    unsigned char *d_ws = nullptr, *d_pac = nullptr; char *d_a = nullptr, *d_b = nullptr, *d_oa = nullptr, *d_ob = nullptr; uint32_t *d_off = nullptr;
+    const size_t lanes = ((size_t)n + 63) / 64 * 64;
+    if (mode != 1) HIPCHK(tmp.alloc((void **)&d_ws, lanes * L.stride));
+    HIPCHK(tmp.alloc((void **)&d_a, la + 16)); HIPCHK(tmp.alloc((void **)&d_b, lb + 16));
+    HIPCHK(tmp.alloc((void **)&d_oa, tot + 16)); HIPCHK(tmp.alloc((void **)&d_ob, tot + 16)); HIPCHK(tmp.alloc((void **)&d_off, (size_t)(4 * n + 4) * 4));
     uint32_t *d_aoff = d_off, *d_boff = d_off + (n + 1), *d_ooff = d_off + 2 * (n + 1), *d_olen = d_off + 3 * (n + 1);
     HIPCHK(hipMemcpy(d_a, a, la, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, b, lb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_aoff, a_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_boff, b_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_ooff, out_off, (size_t)n * 4, hipMemcpyHostToDevice));
-    k_probe_nw<<<(n + 63) / 64, 64, 0, c->stream>>>(n, d_aoff, d_boff, d_a, d_b, d_ooff, d_olen, d_oa, d_ob, d_ws, L, c->ix, c->pr);
+    const unsigned nblk = (unsigned)((n + 63) / 64);
+    if (mode == 0) k_probe_nw<<<nblk, 64, 0, c->stream>>>(n, d_aoff, d_boff, d_a, d_b, d_ooff, d_olen, d_oa, d_ob, d_ws, L, c->ix, c->pr);
+    else if (mode == 1) k_probe_nw_strips<<<nblk, 64, 0, c->stream>>>(n, d_aoff, d_boff, d_a, d_b, d_ooff, d_olen, d_oa, d_ob, c->ix, c->pr);
+    else {
+        HIPCHK(tmp.alloc((void **)&d_pac, pac.size()));
+        HIPCHK(hipMemcpy(d_pac, pac.data(), pac.size(), hipMemcpyHostToDevice));
+        DIndex fx = c->ix;                              // a text that is just the b strings, forward strand only
+        fx.pac = d_pac; fx.l_pac = (int64_t)lb;
+        k_probe_nw_wave<<<nblk, 64, 0, c->stream>>>(n, mode == 3 ? 1 : 0, d_aoff, d_boff, d_a, d_ooff, d_olen, d_oa, d_ob, d_ws, L, fx, c->pr);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out_len, d_olen, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_a, d_oa, tot, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_b, d_ob, tot, hipMemcpyDeviceToHost));
-    (void)hipFree(d_ws); (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_oa); (void)hipFree(d_ob); (void)hipFree(d_off);
     return DG_OK;
+}
+
+extern "C" int dg_probe_nw(dg_ctx *c, int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b,
+                           uint32_t *out_off, uint32_t *out_len, char *out_a, char *out_b, size_t cap)
+{
+    return dg_probe_nw_mode(c, 0, n, a_off, b_off, a, b, out_off, out_len, out_a, out_b, cap);
 }

@@ -1,233 +1,216 @@
-// dart_amd/csrc/dg_chain.h -- seeds -> alignment candidates, mate pairing, redundancy filter.
+// dart_amd/csrc/dg_chain.h -- seeds -> alignment candidates, mate pairing, redundancy filter: the pieces shared by
+// k_pair (dg_pair.h: one lane per unit, everything in LDS) and k_chain_heavy (here: one wave per unit with many seeds).
 //
-// Replaces the tail of IdentifySeedPairs (the sort, AlignmentCandidates.cpp:212),
-// GenerateAlignmentCandidate (:241-288), CheckPairedAlignmentCandidates (Mapping.cpp:403-450),
-// RemoveUnMatedAlignmentCandidates (:452-477) and RemoveRedundantCandidates (:371-401).
+// What the reference does at this stage: the tail of IdentifySeedPairs (sort by (gPos,rPos),
+// AlignmentCandidates.cpp:212), GenerateAlignmentCandidate (:241-288), CheckPairedAlignmentCandidates (Mapping.cpp:403-450),
+// RemoveUnMatedAlignmentCandidates (:452-477), RemoveRedundantCandidates (:371-401).
 //
-// One lane = one read pair (or one single read).  A candidate is a contiguous run of the
-// gPos-sorted seed list, so it is stored as (first,count) into the read's seed segment: nothing is
-// copied.  Per-read arrays are tiny (typically 1-5 seeds); the kernel is latency-, not
-// bandwidth-bound and costs a few percent of k_seed.
+// Seeds are SKey values (dg_common.h): sorting the 64-bit words is the reference's order.  A candidate is a run of the sorted
+// seed segment.  The three candidate-list rules are written once, against a small "view" interface
+//   n(), score(i), set_score(i, v), diag(i) [PosDiff], mate(i) [-1 = none], set_mate(i, v)
+// with one view over DCand arrays in memory (CandMem, below) and one over k_pair's packed LDS words (dg_pair.h).
 #pragma once
 #include "dg_common.h"
 
-// in-place sort of a lane-private seed segment by (gPos,rPos): insertion sort for short lists,
-// heap sort beyond (both give the unique order of a total order up to identical elements)
-__host__ __device__ inline void d_sort_seeds(DSeed *a, int n)
+// ---------------------------------------------------------------------------------------------
+// sorting SKey segments in memory (insertion for short lists, heap sort beyond)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline void d_sort_keys(SKey *a, int n)
 {
-    if (n < 2) return;
-    if (n == 2) { const DSeed x = a[0], y = a[1]; if (d_seed_less(y, x)) { a[0] = y; a[1] = x; } return; }
-    if (n == 3) {
-        DSeed x = a[0], y = a[1], z = a[2], t;
-        bool sw = false;
-        if (d_seed_less(y, x)) { t = x; x = y; y = t; sw = true; }
-        if (d_seed_less(z, y)) { t = y; y = z; z = t; sw = true; if (d_seed_less(y, x)) { t = x; x = y; y = t; } }
-        if (sw) { a[0] = x; a[1] = y; a[2] = z; }
-        return;
-    }
-    if (n <= 32) {
+    if (n <= 24) {
         for (int i = 1; i < n; i++) {
-            DSeed x = a[i];
+            const SKey x = a[i];
             int j = i;
-            while (j > 0 && d_seed_less(x, a[j - 1])) { a[j] = a[j - 1]; j--; }
+            for (; j > 0 && a[j - 1] > x; j--) a[j] = a[j - 1];
             a[j] = x;
         }
         return;
     }
-    for (int st = n / 2 - 1; st >= 0; st--) {          // heapify
-        int root = st;
-        DSeed x = a[root];
-        while (true) {
-            int ch = 2 * root + 1;
-            if (ch >= n) break;
-            if (ch + 1 < n && d_seed_less(a[ch], a[ch + 1])) ch++;
-            if (!d_seed_less(x, a[ch])) break;
+    auto sift = [&](SKey x, int root, int end) {
+        for (int ch = 2 * root + 1; ch < end; ch = 2 * root + 1) {
+            if (ch + 1 < end && a[ch] < a[ch + 1]) ch++;
+            if (!(x < a[ch])) break;
             a[root] = a[ch]; root = ch;
         }
         a[root] = x;
-    }
-    for (int end = n - 1; end > 0; end--) {
-        DSeed x = a[end];
-        a[end] = a[0];
-        int root = 0;
-        while (true) {
-            int ch = 2 * root + 1;
-            if (ch >= end) break;
-            if (ch + 1 < end && d_seed_less(a[ch], a[ch + 1])) ch++;
-            if (!d_seed_less(x, a[ch])) break;
-            a[root] = a[ch]; root = ch;
-        }
-        a[root] = x;
-    }
+    };
+    for (int st = n / 2 - 1; st >= 0; st--) sift(a[st], st, n);
+    for (int end = n - 1; end > 0; end--) { const SKey x = a[end]; a[end] = a[0]; sift(x, 0, end); }
 }
 
-// GenerateAlignmentCandidate :241-288.  seeds = the read's sorted segment (absolute base `base`).
-// Every seed is fetched once (whole 24-byte record) and the chain tail is kept in registers.
-__host__ __device__ inline int d_gen_candidates(const DIndex &ix, const DParams &pr, int rlen, const DSeed *__restrict__ s, int num, uint32_t base, DCand *__restrict__ out)
+// ---------------------------------------------------------------------------------------------
+// Clustering of a sorted seed segment into candidates (GenerateAlignmentCandidate :241-288).
+// The walk: seeds whose diagonal (gPos - rPos) is negative are skipped at the front; a cluster grows by the next seed while
+// the diagonals of the two neighbours differ by less than MaxGaps, or by less than MaxIntronSize when the next seed still lies
+// before the end of the chromosome half that holds the cluster's last seed (the smallest ChrLocMap key >= its gPos) and
+// further along the read; a cluster is a candidate when its seeds cover more than 30 % of the read.
+// key(i) -> SKey of seed i; emit(first, count, score, PosDiff) is called per candidate, in order.  Returns their number.
+// ---------------------------------------------------------------------------------------------
+template <class KeyAt, class Emit>
+__host__ __device__ inline int d_cluster_seeds(const DIndex &ix, const DParams &pr, int rlen, int num, KeyAt key, Emit emit)
 {
-    int nc = 0;
-    if (num == 0) return 0;
-    const int thr = (int)(rlen * 0.3);
-    int i = 0;
-    DSeed si = s[0];
-    while (si.gPos - si.rPos < 0) { if (++i >= num) return 0; si = s[i]; }
-    while (i < num) {
-        int score = si.rLen, k;
-        int64_t pd_j = si.gPos - si.rPos, g_j = si.gPos;
-        int r_j = si.rPos;
-        const int64_t pd0 = pd_j;
-        DSeed sk = si;
-        for (k = i + 1; k < num; k++) {
-            sk = s[k];
-            const int64_t pd_k = sk.gPos - sk.rPos;
-            int64_t pd = pd_k - pd_j;
-            if (pd < 0) pd = -pd;
-            bool ok = pd < pr.max_gaps;
-            if (!ok && pd < pr.max_intron) {
-                const int lb = d_loc_lower_bound(ix, g_j);
-                ok = sk.gPos < ix.loc_key[lb] && sk.rPos > r_j;
-            }
-            if (!ok) break;
-            score += sk.rLen;
-            pd_j = pd_k; g_j = sk.gPos; r_j = sk.rPos;
+    const int need = (int)(rlen * 0.3);
+    int made = 0, head = 0;
+    while (head < num && sk_diag(key(head)) < 0) head++;
+    while (head < num) {
+        SKey tail = key(head);
+        const int64_t d_head = sk_diag(tail);
+        int covered = sk_rlen(tail), next = head + 1;
+        for (; next < num; next++) {
+            const SKey cand = key(next);
+            int64_t jump = sk_diag(cand) - sk_diag(tail);
+            if (jump < 0) jump = -jump;
+            bool joins = jump < pr.max_gaps;
+            if (!joins && jump < pr.max_intron)
+                joins = sk_gpos(cand) < ix.loc_key[d_loc_lower_bound(ix, sk_gpos(tail))] && sk_rpos(cand) > sk_rpos(tail);
+            if (!joins) break;
+            covered += sk_rlen(cand);
+            tail = cand;
         }
-        if (score > thr) {
-            DCand c;
-            c.PosDiff = pd0 < 0 ? 0 : pd0;
-            c.first = (int32_t)(base + i); c.count = k - i; c.Score = score; c.PairedIdx = -1; c.SJtype = -1;
-            c.work_off = 0; c.final_n = 0; c.n_a = 0; c.job_first = 0; c.job_count = 0;
-            out[nc++] = c;
-        }
-        i = k;
-        si = sk;            // the seed that broke the chain starts the next one (unused when k == num)
+        if (covered > need) { emit(head, next - head, covered, d_head < 0 ? (int64_t)0 : d_head); made++; }
+        head = next;
     }
-    return nc;
+    return made;
 }
 
-__host__ __device__ inline void d_remove_redundant(DCand *c, int n)   // Mapping.cpp:371-401
+// ---------------------------------------------------------------------------------------------
+// The three list rules, over a view
+// ---------------------------------------------------------------------------------------------
+// RemoveRedundantCandidates (Mapping.cpp:371-401).  The scores are folded into (top, runner): a score above the runner
+// replaces it -- and pushes the old top down when it is at least the top --, a score EQUAL to the runner lifts the runner to
+// the top (the reference's tie rule: a second-best that occurs twice counts as a tie for first).  Candidates below the
+// cut are dropped (score 0); the cut is the top when top == runner or when they are more than 20 apart, else the runner.
+__host__ __device__ __forceinline__ void d_top2_push(int &top, int &runner, int sc)
 {
-    if (n <= 1) return;
-    int s1 = 0, s2 = 0;
-    for (int i = 0; i < n; i++) {
-        const int sc = c[i].Score;
-        if (sc > s2) {
-            if (sc >= s1) { s2 = s1; s1 = sc; }
-            else s2 = sc;
-        } else if (sc == s2) s2 = s1;
-    }
-    const int thr = (s1 == s2 || s1 - s2 > 20) ? s1 : s2;
-    for (int i = 0; i < n; i++) if (c[i].Score < thr) c[i].Score = 0;
+    if (sc == runner) runner = top;
+    else if (sc > runner) { const int t = top; top = t > sc ? t : sc; runner = t < sc ? t : sc; }
 }
-
-__host__ __device__ inline bool d_check_paired(DCand *c1, int n1, DCand *c2, int n2)   // Mapping.cpp:403-450
+template <class V>
+__host__ __device__ inline void d_keep_top(V &v)
 {
-    bool pairing = false;
-    if (n1 * n2 > 1000) { d_remove_redundant(c1, n1); d_remove_redundant(c2, n2); }
-    for (int i = 0; i < n1; i++) {
-        if (c1[i].Score == 0) continue;
-        int best = -1;
-        int64_t min_dist = 2000000;
-        for (int j = 0; j < n2; j++) {
-            if (c2[j].Score == 0 || c2[j].PosDiff < c1[i].PosDiff) continue;
-            const int64_t d = c2[j].PosDiff - c1[i].PosDiff;   // >= 0 here
-            if (d < min_dist) { best = j; min_dist = d; }
-        }
-        if (best != -1) {
-            const int j = best;
-            if (c2[j].PairedIdx == -1) {
-                pairing = true;
-                c1[i].PairedIdx = j; c2[j].PairedIdx = i;
-            } else if (c1[i].Score > c1[c2[j].PairedIdx].Score) {
-                c1[c2[j].PairedIdx].PairedIdx = -1;
-                c1[i].PairedIdx = j; c2[j].PairedIdx = i;
-            }
-        }
-    }
-    return pairing;
+    const int n = v.n();
+    if (n < 2) return;
+    int top = 0, runner = 0;
+    for (int i = 0; i < n; i++) d_top2_push(top, runner, v.score(i));
+    const int cut = (top == runner || top - runner > 20) ? top : runner;
+    for (int i = 0; i < n; i++) if (v.score(i) < cut) v.set_score(i, 0);
 }
 
-__host__ __device__ inline void d_remove_unmated(DCand *c1, int n1, DCand *c2, int n2)   // Mapping.cpp:452-477
+// CheckPairedAlignmentCandidates (Mapping.cpp:403-450): every live candidate of mate 1, in order, looks for the live candidate
+// of mate 2 that lies downstream of it (PosDiff not smaller) at the smallest distance below 2 000 000 (the first one wins a
+// tie).  A free partner is taken; a taken partner changes hands when the newcomer scores higher than its current holder.
+// Returns whether any pair was formed.
+template <class V1, class V2>
+__host__ __device__ inline bool d_pair_mates(V1 &a, V2 &b)
 {
-    for (int i = 0; i < n1; i++) {
-        if (c1[i].PairedIdx == -1) c1[i].Score = 0;
-        else { const int j = c1[i].PairedIdx; c1[i].Score = c2[j].Score = c1[i].Score + c2[j].Score; }
+    const int na = a.n(), nb = b.n();
+    if (na * nb > 1000) { d_keep_top(a); d_keep_top(b); }
+    bool formed = false;
+    for (int i = 0; i < na; i++) {
+        const int mine = a.score(i);
+        if (mine == 0) continue;
+        const int64_t here = a.diag(i);
+        int pick = -1;
+        int64_t reach = 2000000;
+        for (int j = 0; j < nb; j++) {
+            if (b.score(j) == 0) continue;
+            const int64_t ahead = b.diag(j) - here;
+            if (ahead >= 0 && ahead < reach) { reach = ahead; pick = j; }
+        }
+        if (pick < 0) continue;
+        const int holder = b.mate(pick);
+        if (holder < 0) formed = true;
+        else if (mine > a.score(holder)) a.set_mate(holder, -1);
+        else continue;
+        a.set_mate(i, pick); b.set_mate(pick, i);
     }
-    for (int j = 0; j < n2; j++) if (c2[j].PairedIdx == -1) c2[j].Score = 0;
+    return formed;
 }
 
-// working-region size of one candidate in the report stage: tandem/translocation clean-up never
-// grows the list; re-seeding adds <= n-1, gap filling <= 2 per adjacent pair, normal pairs <= 1 per
-// adjacent pair, plus merge slack -> 14n+8 seeds is a safe bound
-__device__ __forceinline__ uint32_t d_work_need(int count) { return 14u * (uint32_t)count + 8u; }
+// RemoveUnMatedAlignmentCandidates (Mapping.cpp:452-477): partners both get the sum of their scores, singles get 0
+template <class V1, class V2>
+__host__ __device__ inline void d_settle_mates(V1 &a, V2 &b)
+{
+    for (int i = 0, na = a.n(); i < na; i++) {
+        const int m = a.mate(i);
+        if (m < 0) { a.set_score(i, 0); continue; }
+        const int sum = a.score(i) + b.score(m);
+        a.set_score(i, sum); b.set_score(m, sum);
+    }
+    for (int j = 0, nb = b.n(); j < nb; j++) if (b.mate(j) < 0) b.set_score(j, 0);
+}
 
-// a unit (pair / single read) is "heavy" when a mate has more than CH_HEAVY seeds: repeat families.
-// Heavy units are a fraction of a percent of the input but their per-read arrays are 10-100x
-// longer; one lane walking them through global memory used to set the kernel's run time, so they
-// get a wave each (k_chain_heavy) and k_chain skips them.
-#define CH_HEAVY 16
+// the candidate stage of one unit after clustering: pairing (paired-end), then the redundancy filter per mate
+template <class V1, class V2>
+__host__ __device__ inline void d_candidate_rules(bool paired, V1 &a, V2 &b)
+{
+    if (paired) {
+        if (d_pair_mates(a, b)) d_settle_mates(a, b);
+        d_keep_top(a); d_keep_top(b);
+    } else d_keep_top(a);
+}
+
+// view over DCand records in memory (global or LDS)
+struct CandMem {
+    DCand *c; int cnt;
+    __host__ __device__ int n() const { return cnt; }
+    __host__ __device__ int score(int i) const { return c[i].Score; }
+    __host__ __device__ void set_score(int i, int v) { c[i].Score = v; }
+    __host__ __device__ int64_t diag(int i) const { return c[i].PosDiff; }
+    __host__ __device__ int mate(int i) const { return c[i].PairedIdx; }
+    __host__ __device__ void set_mate(int i, int v) { c[i].PairedIdx = v; }
+};
+
+__host__ __device__ __forceinline__ DCand d_new_cand(uint32_t first_abs, int count, int score, int64_t pos_diff)
+{
+    DCand c;
+    c.PosDiff = pos_diff; c.first = (int32_t)first_abs; c.count = count; c.Score = score; c.PairedIdx = -1; c.SJtype = -1;
+    c.work_off = 0; c.final_n = 0; c.n_a = 0; c.job_first = 0; c.job_count = 0;
+    return c;
+}
+
+// clustering of a segment that lies in memory, candidates appended to out[]
+__host__ __device__ inline int d_gen_candidates(const DIndex &ix, const DParams &pr, int rlen, const SKey *s, int num, uint32_t base, DCand *out)
+{
+    int k = 0;
+    return d_cluster_seeds(ix, pr, rlen, num, [&](int i) { return s[i]; },
+                           [&](int first, int count, int score, int64_t pd) { out[k++] = d_new_cand(base + (uint32_t)first, count, score, pd); });
+}
+
+// working-region size of one candidate in the report stage: tandem/translocation clean-up never grows the list; re-seeding
+// adds <= n-1, gap filling <= 2 per adjacent pair, normal pairs <= 1 per adjacent pair, plus merge slack -> 14n+8 seeds
+__host__ __device__ __forceinline__ uint32_t d_work_need(int count) { return 14u * (uint32_t)count + 8u; }
+
+// A unit (pair / single read) goes to k_chain_heavy when its seeds do not fit k_pair's per-lane LDS slice: reads from repeat
+// families.  They are a small share of the input but their lists are 10-100x longer; a wave each.
+#define UNIT_MAX_SEEDS 16
 __device__ __forceinline__ bool d_unit_is_heavy(const uint32_t *seed_off, int paired, int u)
 {
     const int r1 = paired ? 2 * u : u;
-    if (seed_off[r1 + 1] - seed_off[r1] > CH_HEAVY) return true;
-    return paired && seed_off[r1 + 2] - seed_off[r1 + 1] > CH_HEAVY;
-}
-
-__global__ void __launch_bounds__(256)
-k_chain(const DIndex ix, const DParams pr, int n_units, int paired, const uint16_t *__restrict__ rlen,
-        const uint32_t *__restrict__ seed_off, DSeed *__restrict__ seeds, DCand *__restrict__ cands,
-        uint32_t *__restrict__ ncand, uint32_t *__restrict__ nrep, uint32_t *__restrict__ work_need, unsigned long long *ctr)
-{
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long nc_total = 0;
-    if (u < n_units && !d_unit_is_heavy(seed_off, paired, u)) {
-        const int r1 = paired ? 2 * u : u;
-        const uint32_t b1 = seed_off[r1], e1 = seed_off[r1 + 1];
-        d_sort_seeds(seeds + b1, (int)(e1 - b1));
-        DCand *c1 = cands + b1;
-        const int n1 = d_gen_candidates(ix, pr, rlen[r1], seeds + b1, (int)(e1 - b1), b1, c1);
-        if (paired) {
-            const int r2 = r1 + 1;
-            const uint32_t b2 = seed_off[r2], e2 = seed_off[r2 + 1];
-            d_sort_seeds(seeds + b2, (int)(e2 - b2));
-            DCand *c2 = cands + b2;
-            const int n2 = d_gen_candidates(ix, pr, rlen[r2], seeds + b2, (int)(e2 - b2), b2, c2);
-            if (d_check_paired(c1, n1, c2, n2)) d_remove_unmated(c1, n1, c2, n2);
-            d_remove_redundant(c1, n1); d_remove_redundant(c2, n2);
-            uint32_t w = 0;
-            for (int i = 0; i < n2; i++) if (c2[i].Score > 0) w += d_work_need(c2[i].count);
-            ncand[r2] = (uint32_t)n2; nrep[r2] = n2 > 0 ? (uint32_t)n2 : 1u; work_need[r2] = w;
-            nc_total += (unsigned long long)n2;
-        } else d_remove_redundant(c1, n1);
-        uint32_t w = 0;
-        for (int i = 0; i < n1; i++) if (c1[i].Score > 0) w += d_work_need(c1[i].count);
-        ncand[r1] = (uint32_t)n1; nrep[r1] = n1 > 0 ? (uint32_t)n1 : 1u; work_need[r1] = w;
-        nc_total += (unsigned long long)n1;
-    }
-    d_wave_add(ctr + CTR_CANDS, nc_total);
+    return seed_off[r1 + (paired ? 2 : 1)] - seed_off[r1] > UNIT_MAX_SEEDS;
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_chain_heavy: one wave = one heavy unit.  Seeds of both mates are staged in LDS and sorted with
-// a wave-wide bitonic network; candidates are built by lane 0 from LDS; the O(n1*n2) mate search
-// of CheckPairedAlignmentCandidates runs 64 candidates at a time with a wave min-reduction that
-// keeps the reference's tie-break (first minimum).  Anything larger than the LDS staging
-// (> CH_MAXS seeds or > CH_MAXC candidates per mate) takes the serial global-memory route.
+// k_chain_heavy: one wave = one heavy unit.  Seeds of both mates are staged in LDS and sorted with a wave-wide bitonic
+// network; candidates are built by lane 0 from LDS; the O(n1*n2) mate search runs 64 candidates at a time with a wave
+// min-reduction that keeps the first-minimum rule.  Anything larger than the LDS staging (> CH_MAXS seeds or > CH_MAXC
+// candidates per mate) takes the serial route through global memory (same functions).
 // ---------------------------------------------------------------------------------------------
-#define CH_MAXS 512
+#define CH_MAXS 1024
 #define CH_MAXC 192
 
-__device__ inline void d_bitonic_sort_lds(DSeed *a, int n, int lane)   // n <= CH_MAXS, one wave
+__device__ inline void d_bitonic_sort_keys(SKey *a, int n, int lane)   // n <= CH_MAXS, one wave
 {
     int m = 1; while (m < n) m <<= 1;
-    for (int i = n + lane; i < m; i += 64) { a[i].gPos = 0x7FFFFFFFFFFFFFFFll; a[i].rPos = 0x7FFFFFFF; }
+    for (int i = n + lane; i < m; i += 64) a[i] = ~0ull;
     __syncthreads();
     for (int k = 2; k <= m; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = lane; t < m / 2; t += 64) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
                 const bool up = (i & k) == 0;
-                const DSeed x = a[i], y = a[l];
-                if (d_seed_less(y, x) == up) { a[i] = y; a[l] = x; }
+                const SKey x = a[i], y = a[l];
+                if ((y < x) == up) { a[i] = y; a[l] = x; }
             }
             __syncthreads();
         }
@@ -239,13 +222,14 @@ __device__ unsigned long long g_chain_max, g_chain_units, g_chain_cycles;
 #endif
 __global__ void __launch_bounds__(64)
 k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const uint16_t *__restrict__ rlen,
-              const uint32_t *__restrict__ seed_off, DSeed *__restrict__ seeds, DCand *__restrict__ cands,
-              uint32_t *__restrict__ ncand, uint32_t *__restrict__ nrep, uint32_t *__restrict__ work_need,
-              const uint32_t *__restrict__ heavy_list, const unsigned int *__restrict__ n_heavy_p, unsigned long long *ctr)
+              const uint32_t *__restrict__ seed_off, SKey *__restrict__ seeds, DCand *__restrict__ cands,
+              uint32_t *__restrict__ ncand, const uint32_t *__restrict__ heavy_list, const unsigned int *__restrict__ n_heavy_p,
+              unsigned long long *ctr, const int *__restrict__ abort_p)
 {
-    __shared__ DSeed ls[2][CH_MAXS];
+    __shared__ SKey ls[2][CH_MAXS];
     __shared__ DCand lc[2][CH_MAXC];
     __shared__ int s_n[2], s_pairing;
+    if (*abort_p >= DG_ABORT) return;
     const int lane = threadIdx.x;
     const unsigned int n_heavy = *n_heavy_p;
     unsigned long long nc_total = 0;
@@ -256,7 +240,7 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
         const long long t_begin = clock64();
 #endif
         const int r1 = paired ? 2 * u : u;
-        uint32_t b[2], n[2];
+        uint32_t b[2] = {0, 0}, n[2] = {0, 0};
         bool fits = true;
         for (int m = 0; m < nm; m++) { b[m] = seed_off[r1 + m]; n[m] = seed_off[r1 + m + 1] - b[m]; fits = fits && n[m] <= CH_MAXS; }
         __syncthreads();
@@ -264,18 +248,15 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
             for (int m = 0; m < nm; m++) {
                 for (uint32_t i = lane; i < n[m]; i += 64) ls[m][i] = seeds[b[m] + i];
                 __syncthreads();
-                d_bitonic_sort_lds(ls[m], (int)n[m], lane);
+                d_bitonic_sort_keys(ls[m], (int)n[m], lane);
                 for (uint32_t i = lane; i < n[m]; i += 64) seeds[b[m] + i] = ls[m][i];
             }
             __syncthreads();
         }
-        // candidates: lane 0, from LDS when staged (GenerateAlignmentCandidate :241-288)
         if (lane == 0) {
             for (int m = 0; m < nm; m++) {
-                if (!fits) d_sort_seeds(seeds + b[m], (int)n[m]);
-                const DSeed *src = fits ? ls[m] : seeds + b[m];
-                int nc = d_gen_candidates(ix, pr, rlen[r1 + m], src, (int)n[m], b[m], cands + b[m]);
-                s_n[m] = nc;
+                if (!fits) d_sort_keys(seeds + b[m], (int)n[m]);
+                s_n[m] = d_gen_candidates(ix, pr, rlen[r1 + m], fits ? ls[m] : seeds + b[m], (int)n[m], b[m], cands + b[m]);
             }
         }
         __syncthreads();
@@ -287,52 +268,46 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
                 for (int i = lane; i < n1; i += 64) lc[0][i] = c1[i];
                 for (int i = lane; i < n2; i += 64) lc[1][i] = c2[i];
                 __syncthreads();
-                DCand *a1 = lc[0], *a2 = lc[1];
-                if (n1 * n2 > 1000) { if (lane == 0) { d_remove_redundant(a1, n1); d_remove_redundant(a2, n2); } __syncthreads(); }
+                CandMem a1{lc[0], n1}, a2{lc[1], n2};
+                if (n1 * n2 > 1000) { if (lane == 0) { d_keep_top(a1); d_keep_top(a2); } __syncthreads(); }
                 if (lane == 0) s_pairing = 0;
                 __syncthreads();
-                for (int i = 0; i < n1; i++) {                       // CheckPairedAlignmentCandidates :416-448
-                    if (a1[i].Score == 0) continue;                  // uniform: read from LDS by every lane
-                    const int64_t pd1 = a1[i].PosDiff;
-                    int64_t best_d = 2000000; int best_j = 0x7FFFFFFF;
+                for (int i = 0; i < n1; i++) {                       // d_pair_mates with the inner search spread over the wave
+                    if (a1.score(i) == 0) continue;                  // uniform: read from LDS by every lane
+                    const int64_t here = a1.diag(i);
+                    int64_t reach = 2000000; int pick = 0x7FFFFFFF;
                     for (int j = lane; j < n2; j += 64) {
-                        if (a2[j].Score == 0 || a2[j].PosDiff < pd1) continue;
-                        const int64_t d = a2[j].PosDiff - pd1;
-                        if (d < best_d) { best_d = d; best_j = j; }   // per lane: first minimum in increasing j
+                        if (a2.score(j) == 0) continue;
+                        const int64_t ahead = a2.diag(j) - here;
+                        if (ahead >= 0 && ahead < reach) { reach = ahead; pick = j; }     // per lane: first minimum in increasing j
                     }
-                    for (int o = 32; o > 0; o >>= 1) {               // wave minimum of (dist, j): first minimum overall
-                        const int64_t od = __shfl_xor(best_d, o, 64); const int oj = __shfl_xor(best_j, o, 64);
-                        if (od < best_d || (od == best_d && oj < best_j)) { best_d = od; best_j = oj; }
+                    for (int o = 32; o > 0; o >>= 1) {               // wave minimum of (distance, j): first minimum overall
+                        const int64_t od = __shfl_xor(reach, o, 64); const int oj = __shfl_xor(pick, o, 64);
+                        if (od < reach || (od == reach && oj < pick)) { reach = od; pick = oj; }
                     }
-                    if (lane == 0 && best_d < 2000000) {
-                        const int j = best_j;
-                        if (a2[j].PairedIdx == -1) { s_pairing = 1; a1[i].PairedIdx = j; a2[j].PairedIdx = i; }
-                        else if (a1[i].Score > a1[a2[j].PairedIdx].Score) { a1[a2[j].PairedIdx].PairedIdx = -1; a1[i].PairedIdx = j; a2[j].PairedIdx = i; }
+                    if (lane == 0 && reach < 2000000) {
+                        const int holder = a2.mate(pick);
+                        bool take = true;
+                        if (holder < 0) s_pairing = 1;
+                        else if (a1.score(i) > a1.score(holder)) a1.set_mate(holder, -1);
+                        else take = false;
+                        if (take) { a1.set_mate(i, pick); a2.set_mate(pick, i); }
                     }
                     __syncthreads();
                 }
                 if (lane == 0) {
-                    if (s_pairing) d_remove_unmated(a1, n1, a2, n2);
-                    d_remove_redundant(a1, n1); d_remove_redundant(a2, n2);
+                    if (s_pairing) d_settle_mates(a1, a2);
+                    d_keep_top(a1); d_keep_top(a2);
                 }
                 __syncthreads();
                 for (int i = lane; i < n1; i += 64) c1[i] = lc[0][i];
                 for (int i = lane; i < n2; i += 64) c2[i] = lc[1][i];
-            } else if (lane == 0) {
-                if (d_check_paired(c1, n1, c2, n2)) d_remove_unmated(c1, n1, c2, n2);
-                d_remove_redundant(c1, n1); d_remove_redundant(c2, n2);
-            }
-        } else if (lane == 0) d_remove_redundant(c1, n1);
+            } else if (lane == 0) { CandMem a1{c1, n1}, a2{c2, n2}; d_candidate_rules(true, a1, a2); }
+        } else if (lane == 0) { CandMem a1{c1, n1}; d_keep_top(a1); }
         __syncthreads();
         if (lane == 0) {
-            for (int m = 0; m < nm; m++) {
-                const DCand *c = cands + b[m];
-                const int nc = m == 0 ? n1 : n2;
-                uint32_t w = 0;
-                for (int i = 0; i < nc; i++) if (c[i].Score > 0) w += d_work_need(c[i].count);
-                ncand[r1 + m] = (uint32_t)nc; nrep[r1 + m] = nc > 0 ? (uint32_t)nc : 1u; work_need[r1 + m] = w;
-                nc_total += (unsigned long long)nc;
-            }
+            ncand[r1] = (uint32_t)n1; nc_total += (unsigned long long)n1;
+            if (paired) { ncand[r1 + 1] = (uint32_t)n2; nc_total += (unsigned long long)n2; }
 #ifdef DG_PROFILE_CLASSES
             const unsigned long long cyc = (unsigned long long)(clock64() - t_begin);
             auto cl = [](unsigned long long v) { return v > 1023 ? 1023ull : v; };
@@ -346,8 +321,17 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
 
 // list of heavy units (order irrelevant: every unit writes only its own slots)
 __global__ void __launch_bounds__(256)
-k_heavy_list(int n_units, int paired, const uint32_t *__restrict__ seed_off, uint32_t *__restrict__ heavy_list, unsigned int *n_heavy)
+k_heavy_list(int n_units, int paired, const uint32_t *__restrict__ seed_off, uint32_t *__restrict__ heavy_list, unsigned int *n_heavy,
+             const int *__restrict__ abort_p)
 {
+    if (*abort_p >= DG_ABORT) return;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u < n_units && d_unit_is_heavy(seed_off, paired, u)) heavy_list[atomicAdd(n_heavy, 1u)] = (uint32_t)u;
+    const bool heavy = u < n_units && d_unit_is_heavy(seed_off, paired, u);
+    const unsigned long long m = __ballot(heavy);
+    if (!m) return;
+    unsigned int base = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_heavy, (unsigned int)__popcll(m));
+    base = (unsigned int)__shfl((int)base, __ffsll((long long)m) - 1, 64);
+    if (heavy) heavy_list[base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)u;
 }

@@ -6,6 +6,8 @@
 
 #define DG_WAVE 64
 
+__host__ __device__ __forceinline__ uint64_t d_u64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
 // One segment pair (SeedPair_t, structure.h:106-115).  PosDiff is not stored: every use in the
 // reference happens while PosDiff == gPos - rPos still holds, so it is derived.
 struct __attribute__((aligned(8))) DSeed {
@@ -17,6 +19,17 @@ struct __attribute__((aligned(8))) DSeed {
 };
 #define SEED_SIMPLE   1u
 #define SEED_ACCEPTOR 2u
+
+// An exact seed as it leaves the FM-index stage (bSimple, gLen == rLen), packed so that sorting the 64-bit values IS the
+// (gPos, rPos) order of CompByGenomePos (AlignmentCandidates.cpp:21-25): gPos < 2^40 (texts up to 10^12 symbols),
+// rPos, rLen < 4096.  k_locate writes these, the chain stage sorts them; DSeed (24 bytes) only exists in the working
+// regions of the candidates that go through the general report path.
+typedef uint64_t SKey;
+__host__ __device__ __forceinline__ SKey sk_make(int64_t gPos, int rPos, int rLen) { return ((uint64_t)gPos << 24) | ((uint64_t)(uint32_t)rPos << 12) | (uint64_t)(uint32_t)rLen; }
+__host__ __device__ __forceinline__ int64_t sk_gpos(SKey k) { return (int64_t)(k >> 24); }
+__host__ __device__ __forceinline__ int sk_rpos(SKey k) { return (int)((k >> 12) & 0xFFFu); }
+__host__ __device__ __forceinline__ int sk_rlen(SKey k) { return (int)(k & 0xFFFu); }
+__host__ __device__ __forceinline__ int64_t sk_diag(SKey k) { return sk_gpos(k) - sk_rpos(k); }      // PosDiff
 
 // One maximal exact match before SA lookup: the SA interval of BWT_Search (bwt_search.cpp:139-182)
 struct __attribute__((aligned(16))) DHit {
@@ -73,6 +86,22 @@ struct DIndex {
 struct DParams {
     int32_t max_gaps, max_dup, max_intron, min_intron, max_mismatch, multi_hit, all_sj, paired;
 };
+
+// Device-side status word of a batch (dg_ctx::d_err).  1..3: a bump pool ran out (results of this run are incomplete);
+// >= DG_ABORT: a capacity estimate was too small -- every later kernel of the batch returns at once, the host grows the
+// buffer from the sizes the device reported and runs the batch again (dg_batch_run never syncs mid-batch to learn a size).
+#define DG_E_CIGAR 1
+#define DG_E_SJ 2
+#define DG_E_JOBS 3
+#define DG_ABORT 10
+#define DG_E_SEEDS 10
+#define DG_E_REPORTS 11
+#define DG_E_WORK 12
+#define DG_E_CIGFINAL 13
+#define DG_E_SCAN 14
+#define DONE_BY_PAIR 31          // done[r]: k_pair finished this read's records (it sorts behind every class of the general path's work order)
+// sizes the device reports at the end of a batch (one small D2H copy)
+struct DSizes { uint32_t total_seeds, total_rep, total_work, total_cig, total_sj, n_jobs, n_slow_units, n_heavy_units, cig_fast, pad[3]; };
 
 // work counters (dg_last_counters)
 enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, CTR_NWCELLS, CTR_RESEED, CTR_RESEEDW,

@@ -40,7 +40,6 @@ __device__ __forceinline__ uint64_t d_L2(const DIndex &ix, int i)   // i in 0..4
 {
     return i == 4 ? ix.L2[4] : d_sel4(ix.L2[0], ix.L2[1], ix.L2[2], ix.L2[3], i);
 }
-__device__ __forceinline__ uint64_t d_u64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // in-block counts over symbols [0..o] of one block: P = #symbols with high bit == hi,
 // Q = #symbols with high bit == hi and low bit == 1
@@ -939,8 +938,9 @@ k_build_sa_dense(const DIndex ix, int intv, uint64_t n_entries, uint64_t *__rest
 // (read, hit, SA-interval row) order as in the reference.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_tile_reads(int n_reads, const uint32_t *__restrict__ seed_off, uint32_t *__restrict__ tile_read)
+k_tile_reads(int n_reads, const uint32_t *__restrict__ seed_off, uint32_t *__restrict__ tile_read, const int *__restrict__ abort_p)
 {
+    if (*abort_p >= DG_ABORT) return;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const uint32_t first = seed_off[r], end = seed_off[r + 1];
@@ -948,10 +948,13 @@ k_tile_reads(int n_reads, const uint32_t *__restrict__ seed_off, uint32_t *__res
     for (uint32_t t = (first + 63) >> 6; (t << 6) < end; t++) tile_read[t] = (uint32_t)r;
 }
 
+// grid = enough waves for the buffer's capacity; the real seed count is read from the scan (seed_off[n_reads])
 __global__ void __launch_bounds__(256)
 k_locate(const DIndex ix, int n_reads, int H, const DHit *__restrict__ hits, const uint32_t *__restrict__ tile_read,
-         const uint32_t *__restrict__ seed_off, DSeed *__restrict__ seeds, unsigned long long *ctr, uint32_t total)
+         const uint32_t *__restrict__ seed_off, SKey *__restrict__ seeds, unsigned long long *ctr, const int *__restrict__ abort_p)
 {
+    if (*abort_p >= DG_ABORT) return;
+    const uint32_t total = seed_off[n_reads];
     const int lane = threadIdx.x & 63;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t u = (tile << 6) + (uint32_t)lane;
@@ -998,10 +1001,7 @@ k_locate(const DIndex ix, int n_reads, int H, const DHit *__restrict__ hits, con
                 lf += steps; lf_act += steps;
             }
             nsa++;
-            DSeed s;
-            s.gPos = (int64_t)pos;
-            s.rPos = h->rPos; s.rLen = s.gLen = h->len; s.flags = SEED_SIMPLE;
-            seeds[u] = s;
+            seeds[u] = sk_make((int64_t)pos, (int)h->rPos, (int)h->len);
         }
     }
     d_wave_add(ctr + CTR_LF, lf);

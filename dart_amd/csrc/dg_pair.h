@@ -1,0 +1,442 @@
+// dart_amd/csrc/dg_pair.h -- k_pair: everything between the located seeds and the finished records for the units (read pairs,
+// or single reads) whose alignment is "exact seeds on one diagonal with substitutions between them" -- 70-98 % of a DNA batch --
+// in ONE kernel, lane = unit, all intermediate state in LDS.  Units outside that pattern leave k_pair as candidates in
+// memory, in the form the general path (k_prep / k_reseed / k_report / k_finalize) takes, on a compact list.
+//
+// Per unit the kernel does what the reference does in Mapping.cpp:598-639 for such a read pair:
+//   sort the seeds by (gPos,rPos)                         IdentifySeedPairs tail, AlignmentCandidates.cpp:212
+//   cluster them into candidates                          GenerateAlignmentCandidate :241-288
+//   pair the mates' candidates, drop unmated / redundant  Mapping.cpp:371-477
+//   report every live candidate                           GenMappingReport :1079-1207 where it reduces to [S] M [S]
+//   settle the pair, FLAG, MAPQ                           Mapping.cpp:74-206, 479-530
+// and writes dg_read_out / dg_report_out / CIGAR ops at their final places: the offsets (reports per read, CIGAR ops per
+// report, position on the list of units for the general path) come from a single-pass scan inside the kernel (dg_scan.h).
+//
+// Before this kernel the same work was k_chain -> 2 scans -> k_prep -> k_report_diag -> k_finalize -> CIGAR compaction, with
+// seeds, candidates, working regions and reports crossing HBM between them (3.4 GB per 2 M reads against 0.3 GB of input
+// and output).
+//
+// The pair-settling / FLAG / MAPQ rules are written once, against a "report view" (n, aln, set_aln, mate, set_mate, bdir,
+// set_flag, or_flag): RepLds over k_pair's packed LDS words, RepMem over dg_report_out records for the general path's k_finalize.
+#pragma once
+#include "../../include/dartgpu.h"
+#include "dg_common.h"
+#include "dg_chain.h"
+#include "dg_report.h"
+
+// ---------------------------------------------------------------------------------------------
+// pair settling, FLAG, MAPQ over a report view
+// ---------------------------------------------------------------------------------------------
+// CheckPairedFinalAlignments (Mapping.cpp:479-530).  If the two best reports are each other's mates nothing changes (unless
+// -m).  Otherwise, when both reads have a live report, the mated pair of live reports with the largest combined score
+// becomes the best of both reads (first such pair on a tie).  With a mated pair settled, read 1's reports that do not
+// carry the pair's scores lose their score and their link; without one, every link is cut and only reports scoring the
+// read's best stay alive.
+template <class R1, class R2>
+__host__ __device__ inline void d_settle_pair(const DParams &pr, DRead &m1, R1 &p1, DRead &m2, R2 &p2)
+{
+    bool linked = p1.mate(m1.iBest) == m2.iBest;
+    if (linked && !pr.multi_hit) return;
+    if (!linked && m1.score > 0 && m2.score > 0) {
+        int best_sum = 0;
+        for (int i = 0; i < m1.CanNum; i++) {
+            const int a = p1.aln(i), j = p1.mate(i);
+            if (a <= 0 || j < 0) continue;
+            const int b = p2.aln(j);
+            if (b <= 0) continue;
+            linked = true;
+            if (a + b > best_sum) { best_sum = a + b; m1.iBest = i; m1.score = a; m2.iBest = j; m2.score = b; }
+        }
+    }
+    if (linked) {
+        for (int i = 0; i < m1.CanNum; i++) {
+            const int j = p1.mate(i);
+            if (p1.aln(i) != m1.score || (j >= 0 && p2.aln(j) != m2.score)) { p1.set_aln(i, 0); p1.set_mate(i, -1); }
+        }
+        return;
+    }
+    for (int i = 0; i < m1.CanNum; i++) { p1.set_mate(i, -1); const int a = p1.aln(i); if (a > 0 && a != m1.score) p1.set_aln(i, 0); }
+    for (int j = 0; j < m2.CanNum; j++) { p2.set_mate(j, -1); const int b = p2.aln(j); if (b > 0 && b != m2.score) p2.set_aln(j, 0); }
+}
+
+template <class R>
+__host__ __device__ inline void d_flag_single(const DRead &r, R &p)   // SetSingleAlignmentFlag, Mapping.cpp:74-99
+{
+    if (r.score > r.sub_score) p.set_flag(r.iBest, p.bdir(r.iBest) ? 0 : 0x10);
+    else if (r.score > 0) { for (int i = 0; i < r.CanNum; i++) if (p.aln(i) > 0) p.set_flag(i, p.bdir(i) ? 0 : 0x10); }
+    else p.set_flag(0, 0x4);
+}
+
+// one read of a pair whose FLAGs are not both unique-best (Mapping.cpp:124-153 / :155-184); base = 0x41 or 0x81
+template <class RA, class RB>
+__host__ __device__ inline void d_flag_mate(const DRead &a, RA &pa, const DRead &b, RB &pb, int base)
+{
+    auto mapped = [&](int i) {
+        const int j = pa.mate(i);
+        pa.set_flag(i, base | (pa.bdir(i) ? 0x20 : 0x10) | ((j >= 0 && pb.aln(j) > 0) ? 0x2 : 0x8));
+    };
+    if (a.score > a.sub_score) mapped(a.iBest);
+    else if (a.score > 0) { for (int i = 0; i < a.CanNum; i++) if (pa.aln(i) > 0) mapped(i); }
+    else pa.set_flag(0, base | 0x4 | (b.score == 0 ? 0x8 : (pb.bdir(b.iBest) ? 0x10 : 0x20)));
+}
+
+template <class R1, class R2>
+__host__ __device__ inline void d_flag_pair(const DRead &r1, R1 &p1, const DRead &r2, R2 &p2)   // SetPairedAlignmentFlag, Mapping.cpp:101-186
+{
+    if (r1.score > r1.sub_score && r2.score > r2.sub_score) {
+        const int i = r1.iBest, j = r2.iBest;
+        const int proper = j == p1.mate(i) ? 0x2 : 0;
+        p1.set_flag(i, 0x41 | proper | (p1.bdir(i) ? 0x20 : 0x10));
+        p2.set_flag(j, 0x81 | proper | (p2.bdir(j) ? 0x20 : 0x10));
+    } else {
+        d_flag_mate(r1, p1, r2, p2, 0x41);
+        d_flag_mate(r2, p2, r1, p1, 0x81);
+    }
+}
+
+template <class R>
+__host__ __device__ inline void d_mapq(DRead &r, const R &p)   // EvaluateMAPQ, Mapping.cpp:188-206
+{
+    if (r.score == 0 || r.score == r.sub_score) r.mapq = 0;
+    else if (r.sub_score == 0 || r.score > r.sub_score) r.mapq = 50;
+    else {
+        int n = 0;
+        for (int i = 0; i < r.CanNum; i++) if (p.aln(i) == r.score) n++;
+        r.mapq = n >= 10 ? 0 : (n >= 4 ? 1 : (n == 3 ? 2 : (n == 2 ? 3 : 50)));
+    }
+}
+
+// view over dg_report_out records in memory
+template <typename ReportT>
+struct RepMem {
+    ReportT *p;
+    __host__ __device__ int aln(int i) const { return p[i].aln_score; }
+    __host__ __device__ void set_aln(int i, int v) { p[i].aln_score = v; }
+    __host__ __device__ int mate(int i) const { return p[i].paired_idx; }
+    __host__ __device__ void set_mate(int i, int v) { p[i].paired_idx = v; }
+    __host__ __device__ int bdir(int i) const { return p[i].bdir; }
+    __host__ __device__ void set_flag(int i, int v) { p[i].flag = v; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// k_pair's per-lane state: element e of a lane's array lives at base[e * S] (S = workgroup size on the device: neighbouring
+// lanes touch neighbouring banks; S = 1 in the host-compiled checks)
+//   key[16]  the unit's seeds, mate 1 then mate 2, each sorted
+//   cw[16]   candidate words, mate 1's then mate 2's:
+//            first seed (5, index inside the mate's segment) | seeds (5) << 5 | score (12) << 10 | mate (5, 31 = none) << 22 | slot (4, 15 = none) << 27
+//   rw[2*6]  report slots of the LIVE candidates (score != 0 after the candidate rules), two words each:
+//            w0 = POS (32) | chromosome (16) << 32 | AlnScore (12) << 48 | bDir << 60 | has coordinates << 61
+//            w1 = leading S (12) | M (12) << 12 | trailing S (12) << 24 | FLAG (12) << 36 | mismatches (12) << 48
+// ---------------------------------------------------------------------------------------------
+#define PU_THREADS 256
+#define PU_SEEDS UNIT_MAX_SEEDS
+#define PU_SLOTS 6            // 2 workgroups of 256 lanes per CU: (16 x 8 + 16 x 4 + 2 x 6 x 8) bytes per lane = 72 KB each
+
+__host__ __device__ __forceinline__ uint32_t cw_make(int first, int count, int score) { return (uint32_t)first | ((uint32_t)count << 5) | ((uint32_t)score << 10) | (31u << 22) | (15u << 27); }
+__host__ __device__ __forceinline__ int cw_first(uint32_t w) { return (int)(w & 31u); }
+__host__ __device__ __forceinline__ int cw_count(uint32_t w) { return (int)((w >> 5) & 31u); }
+__host__ __device__ __forceinline__ int cw_score(uint32_t w) { return (int)((w >> 10) & 0xFFFu); }
+__host__ __device__ __forceinline__ int cw_mate(uint32_t w) { const int m = (int)((w >> 22) & 31u); return m == 31 ? -1 : m; }
+__host__ __device__ __forceinline__ int cw_slot(uint32_t w) { return (int)((w >> 27) & 15u); }
+
+template <int S>
+struct CandLds {                      // candidate view (dg_chain.h rules) of one mate
+    const SKey *key; uint32_t *cw; int cnt;      // key, cw already point at the mate's first element
+    __host__ __device__ int n() const { return cnt; }
+    __host__ __device__ int score(int i) const { return cw_score(cw[i * S]); }
+    __host__ __device__ void set_score(int i, int v) { cw[i * S] = (cw[i * S] & ~(0xFFFu << 10)) | ((uint32_t)v << 10); }
+    __host__ __device__ int64_t diag(int i) const { const int64_t d = sk_diag(key[cw_first(cw[i * S]) * S]); return d < 0 ? 0 : d; }
+    __host__ __device__ int mate(int i) const { return cw_mate(cw[i * S]); }
+    __host__ __device__ void set_mate(int i, int v) { cw[i * S] = (cw[i * S] & ~(31u << 22)) | ((uint32_t)(v < 0 ? 31 : v) << 22); }
+};
+
+template <int S>
+struct RepLds {                       // report view of one mate: report i = candidate i (report 0 exists even without candidates)
+    uint32_t *cw; uint64_t *rw; int nc; int flag0;        // flag0: FLAG of report 0 when it has no slot (an unmapped read)
+    __host__ __device__ int slot(int i) const { return i < nc ? cw_slot(cw[i * S]) : 15; }
+    __host__ __device__ int aln(int i) const { const int s = slot(i); return s == 15 ? 0 : (int)((rw[(2 * s) * S] >> 48) & 0xFFFu); }
+    __host__ __device__ void set_aln(int i, int v) { const int s = slot(i); if (s != 15) rw[(2 * s) * S] = (rw[(2 * s) * S] & ~(0xFFFull << 48)) | ((uint64_t)(uint32_t)v << 48); }
+    __host__ __device__ int mate(int i) const { return i < nc ? cw_mate(cw[i * S]) : -1; }
+    __host__ __device__ void set_mate(int i, int v) { if (i < nc) cw[i * S] = (cw[i * S] & ~(31u << 22)) | ((uint32_t)(v < 0 ? 31 : v) << 22); }
+    __host__ __device__ int bdir(int i) const { const int s = slot(i); return s == 15 ? 0 : (int)((rw[(2 * s) * S] >> 60) & 1u); }
+    __host__ __device__ void set_flag(int i, int v) {
+        const int s = slot(i);
+        if (s != 15) rw[(2 * s + 1) * S] = (rw[(2 * s + 1) * S] & ~(0xFFFull << 36)) | ((uint64_t)(uint32_t)v << 36);
+        else if (i == 0) flag0 = v;
+    }
+    __host__ __device__ int flag(int i) const { const int s = slot(i); return s == 15 ? (i == 0 ? flag0 : 0) : (int)((rw[(2 * s + 1) * S] >> 36) & 0xFFFu); }
+};
+
+// what a unit looks like after d_unit_process
+struct UnitState {
+    DRead rd[2];
+    int nc[2];            // candidates per mate
+    int flag0[2];
+    bool fast;            // records complete in LDS; else: candidates go to the general path
+    uint32_t n_cig;       // CIGAR ops of its reports (fast only)
+    uint32_t n_one;       // 1 x 1 segment pairs met (each is an nw_alignment call of one cell in the reference: counters)
+};
+
+// insertion sort of a lane's seed segment in its LDS slice
+template <int S>
+__host__ __device__ __forceinline__ void d_unit_sort(SKey *key, int n)
+{
+    for (int i = 1; i < n; i++) {
+        const SKey x = key[i * S];
+        int j = i;
+        for (; j > 0 && key[(j - 1) * S] > x; j--) key[j * S] = key[(j - 1) * S];
+        key[j * S] = x;
+    }
+}
+
+// GenMappingReport for the live candidates of one mate, where it reduces to "[S] M [S]": every seed of the candidate exact and on
+// one diagonal, at least one read base between neighbours, and the bases between them either equal-length with <= 2 and <= 20 %
+// mismatches (ProcessNormalSequencePair's M shortcut, tools.cpp:137-141) or a single substituted base (a 1 x 1 nw_alignment).
+// Then the clean-up passes, re-seeding, gap filling, splice detection and overlap trimming are all the identity
+// (they act on repeated rPos, order inversions and diagonal changes).  Returns false when some live candidate is outside
+// the pattern (nothing of this unit is then kept: the general path redoes it).
+template <int S>
+__host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &pr, bool first, const unsigned char *seq, int len,
+                                               const SKey *key, uint32_t *cw, int nc, uint64_t *rw, int &n_slot, DRead &rd, uint32_t &n_cig, uint32_t &n_one)
+{
+    const int64_t L = ix.l_pac;
+    rd.score = rd.sub_score = rd.mis_num = rd.mapq = rd.iBest = 0;
+    rd.CanNum = nc > 0 ? nc : 1;
+    for (int i = 0; i < nc; i++) {
+        const uint32_t w = cw[i * S];
+        if (cw_score(w) == 0) continue;
+        const int n = cw_count(w), f = cw_first(w);
+        const SKey k0 = key[f * S];
+        const int64_t diag = sk_diag(k0);
+        if (n > 1 && diag == -1) return false;
+        SKey prev = k0;
+        int aln = sk_rlen(k0), mis = 0;
+        uint32_t ones = 0;
+        for (int k = 1; k < n; k++) {
+            const SKey cur = key[(f + k) * S];
+            const int from = sk_rpos(prev) + sk_rlen(prev), g = sk_rpos(cur) - from;
+            if (sk_diag(cur) != diag || g < 1) return false;
+            const int64_t gp = sk_gpos(prev) + sk_rlen(prev);
+            int nm = 0;
+            bool dash = false;
+            for (int q = 0; q < g; q += 8) {
+                const uint64_t ref = d_ref8(ix, gp + q);
+                const int e = g - q < 8 ? g - q : 8;
+                for (int t = 0; t < e; t++) { const unsigned char ch = seq[from + q + t]; dash = dash || ch == '-'; nm += ch != (unsigned char)(ref >> (8 * t)); }
+            }
+            if (nm <= 2 && nm <= (int)(g * 0.2)) { aln += g - nm; mis += nm; }
+            else if (g == 1 && !dash) { ones++; mis += 1; }
+            else return false;
+            aln += sk_rlen(cur);
+            prev = cur;
+        }
+        const int64_t gPos = sk_gpos(k0), end_gPos = sk_gpos(prev) + sk_rlen(prev) - 1;
+        if (n > 1 && ((gPos < L) != (end_gPos < L))) return false;          // CheckCoordinateValidity :136-163 would reject it
+        const int head = sk_rpos(k0), span = sk_rpos(prev) + sk_rlen(prev) - head, tail = len - head - span;
+        if (mis > pr.max_mismatch) aln = 0;
+        if (n_slot >= PU_SLOTS) return false;
+        const int slot = n_slot++;
+        uint64_t w0 = 0;
+        if (aln > 0) {                                                       // GenCoordinateInfo :83-116
+            const int lb = d_loc_lower_bound(ix, gPos);
+            const int chr = ix.loc_chr[lb];
+            int64_t pos; int bdir;
+            if (gPos < L) { bdir = first ? 1 : 0; pos = gPos + 1 - ix.chr_off[chr]; }
+            else { bdir = first ? 0 : 1; pos = ix.loc_key[lb] - end_gPos + 1; }
+            if (pos <= 0 || pos > 0xFFFFFFFFll || chr > 0xFFFF) return false;   // (a report the reference zeroes late, or fields too wide for the slot)
+            w0 = (uint64_t)pos | ((uint64_t)chr << 32) | ((uint64_t)aln << 48) | ((uint64_t)bdir << 60) | (1ull << 61);
+            n_cig += 1u + (head > 0) + (tail > 0);
+            if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis; rd.sub_score = rd.score; rd.score = aln; }
+            else if (aln == rd.score) rd.sub_score = rd.score;
+        }
+        rw[(2 * slot) * S] = w0;
+        rw[(2 * slot + 1) * S] = (uint64_t)head | ((uint64_t)span << 12) | ((uint64_t)tail << 24) | ((uint64_t)mis << 48);
+        cw[i * S] = (w & ~(15u << 27)) | ((uint32_t)slot << 27);
+        n_one += ones;
+    }
+    return true;
+}
+
+// One unit from sorted-or-not seeds in key[0 .. n1+n2) to either finished records in LDS (st.fast) or candidate words for the
+// general path.  try_fast = false: the candidate stage only (dg_probe_seeds, chr tables too wide for the slots).
+template <int S>
+__host__ __device__ inline void d_unit_process(const DIndex &ix, const DParams &pr, bool paired, int n1, int n2, int len1, int len2,
+                                               const unsigned char *seq1, const unsigned char *seq2, SKey *key, uint32_t *cw, uint64_t *rw,
+                                               bool try_fast, UnitState &st)
+{
+    d_unit_sort<S>(key, n1);
+    if (paired) d_unit_sort<S>(key + n1 * S, n2);
+    int k = 0;
+    st.nc[0] = d_cluster_seeds(ix, pr, len1, n1, [&](int i) { return key[i * S]; },
+                               [&](int first, int count, int score, int64_t) { cw[(k++) * S] = cw_make(first, count, score); });
+    st.nc[1] = 0;
+    CandLds<S> a{key, cw, st.nc[0]}, b{key + n1 * S, cw + st.nc[0] * S, 0};
+    if (paired) {
+        st.nc[1] = b.cnt = d_cluster_seeds(ix, pr, len2, n2, [&](int i) { return key[(n1 + i) * S]; },
+                                           [&](int first, int count, int score, int64_t) { cw[(k++) * S] = cw_make(first, count, score); });
+    }
+    d_candidate_rules(paired, a, b);
+    st.fast = false; st.n_cig = 0; st.n_one = 0; st.flag0[0] = st.flag0[1] = 0;
+    if (!try_fast) return;
+    int n_slot = 0;
+    uint32_t n_cig = 0, n_one = 0;
+    if (!d_unit_reports<S>(ix, pr, true, seq1, len1, key, cw, st.nc[0], rw, n_slot, st.rd[0], n_cig, n_one)) return;
+    if (paired && !d_unit_reports<S>(ix, pr, false, seq2, len2, key + n1 * S, cw + st.nc[0] * S, st.nc[1], rw, n_slot, st.rd[1], n_cig, n_one)) return;
+    RepLds<S> p1{cw, rw, st.nc[0], 0}, p2{cw + st.nc[0] * S, rw, st.nc[1], 0};
+    if (paired) {
+        d_settle_pair(pr, st.rd[0], p1, st.rd[1], p2);
+        d_flag_pair(st.rd[0], p1, st.rd[1], p2);
+        d_mapq(st.rd[1], p2);
+    } else d_flag_single(st.rd[0], p1);
+    d_mapq(st.rd[0], p1);
+    st.flag0[0] = p1.flag0; st.flag0[1] = p2.flag0;
+    st.fast = true; st.n_cig = n_cig; st.n_one = n_one;
+}
+
+// the records of one read of a fast unit, written at their final places; returns the CIGAR ops written
+template <int S>
+__host__ __device__ inline uint32_t d_unit_emit_read(bool first, const DRead &rd, const RepLds<S> &p, uint32_t rep_off, uint32_t cig_off,
+                                                     dg_read_out *rout_r, dg_report_out *reports, uint32_t *cigar)
+{
+    dg_read_out o;
+    o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = rd.mapq; o.n_rep = rd.CanNum; o.best = rd.iBest;
+    o.rep_off = (int32_t)rep_off; o.sj_off = 0; o.n_sj = 0;
+    *rout_r = o;
+    uint32_t used = 0;
+    for (int i = 0; i < rd.CanNum; i++) {
+        dg_report_out rp;
+        rp.aln_score = 0; rp.sj_type = -1; rp.flag = p.flag(i); rp.paired_idx = p.mate(i); rp.chr = -1; rp.bdir = 0; rp.pos = 0;
+        rp.cigar_off = cig_off + used; rp.n_cigar = 0;
+        const int s = p.slot(i);
+        if (s != 15) {
+            const uint64_t w0 = p.rw[(2 * s) * S], w1 = p.rw[(2 * s + 1) * S];
+            if ((w0 >> 61) & 1ull) {
+                rp.aln_score = (int32_t)((w0 >> 48) & 0xFFFu); rp.chr = (int32_t)((w0 >> 32) & 0xFFFFu); rp.bdir = (int32_t)((w0 >> 60) & 1u);
+                rp.pos = (int64_t)(w0 & 0xFFFFFFFFull);
+                const uint32_t head = (uint32_t)(w1 & 0xFFFu), span = (uint32_t)((w1 >> 12) & 0xFFFu), tail = (uint32_t)((w1 >> 24) & 0xFFFu);
+                const bool rev = (rp.bdir != 0) != first;                    // bDir = mate 1 on the forward half / mate 2 on the reverse half (:83-116);
+                                                                             // a candidate on the reverse half has its CIGAR reversed (:1179)
+                const uint32_t lead = rev ? tail : head, trail = rev ? head : tail;
+                uint32_t *c = cigar + cig_off + used;
+                uint32_t m = 0;
+                if (lead) c[m++] = CIG(lead, OP_S);
+                c[m++] = CIG(span, OP_M);
+                if (trail) c[m++] = CIG(trail, OP_S);
+                rp.n_cigar = m; used += m;
+            }
+        }
+        reports[rep_off + (uint32_t)i] = rp;
+    }
+    return used;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pair: lane = unit (workgroup t of arrival handles units [256 t, 256 t + 256): the ticket order IS the unit order, so the
+// scanned offsets are the read-order layout of the records).  Units with more than PU_SEEDS seeds were chained by
+// k_chain_heavy before this launch: they only take part in the scan (ncand from memory) and go on the general path's list.
+//   scan counters: x = reports of the unit, y = 1 if the unit goes to the general path, z = CIGAR ops of a finished unit
+// Outputs for every read: rep_off[r], done[r] (DONE_BY_PAIR: records complete; 0xFF: general path).  Finished units:
+// rout / reports / cigar.  Other units: slow_units[] (ascending), their sorted seeds, DCand records and ncand.
+// The workgroup that drew the last ticket also writes the totals (its inclusive prefix is the grand total).
+// ---------------------------------------------------------------------------------------------
+#include "dg_scan.h"
+
+__global__ void __launch_bounds__(PU_THREADS)
+k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast, int write_all_sorted,
+       const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen,
+       const uint32_t *__restrict__ seed_off, SKey *__restrict__ seeds, DCand *__restrict__ cands, uint32_t *__restrict__ ncand,
+       uint32_t *__restrict__ rep_off, uint8_t *__restrict__ done, uint32_t *__restrict__ slow_units,
+       dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *__restrict__ cigar,
+       uint32_t cap_rep, uint32_t cap_cig, TileScan ts, DSizes *sizes, unsigned int *pool_top, unsigned long long *ctr, int *err)
+{
+    __shared__ SKey s_key[PU_SEEDS * PU_THREADS];
+    __shared__ uint32_t s_cw[PU_SEEDS * PU_THREADS];
+    __shared__ uint64_t s_rw[2 * PU_SLOTS * PU_THREADS];
+    __shared__ unsigned long long s_scan[16];
+    __shared__ unsigned int s_tile;
+    if (*err == DG_E_SEEDS) return;                    // set before this launch (the only earlier abort); errors raised INSIDE this
+                                                       // launch never make a workgroup leave: its successors wait for its totals
+    const unsigned int tile = d_tile_ticket(ts, &s_tile);
+    const int u = (int)(tile * PU_THREADS + threadIdx.x);
+    const bool valid = u < n_units;
+    SKey *key = s_key + threadIdx.x;
+    uint32_t *cw = s_cw + threadIdx.x;
+    uint64_t *rw = s_rw + threadIdx.x;
+    UnitState st;
+    st.fast = false; st.n_cig = 0; st.n_one = 0; st.nc[0] = st.nc[1] = 0; st.flag0[0] = st.flag0[1] = 0;
+    int r1 = 0, n1 = 0, n2 = 0, len1 = 0, len2 = 0;
+    uint32_t b1 = 0;
+    bool heavy = false;
+    if (valid) {
+        r1 = paired ? 2 * u : u;
+        b1 = seed_off[r1];
+        const uint32_t e1 = seed_off[r1 + 1], e2 = paired ? seed_off[r1 + 2] : e1;
+        n1 = (int)(e1 - b1); n2 = (int)(e2 - e1);
+        heavy = n1 + n2 > PU_SEEDS;
+        if (!heavy) {
+            const SKey *src = seeds + b1;
+            const int nt = n1 + n2;
+            for (int i0 = 0; i0 < nt; i0 += 4) {      // four loads in flight
+                const SKey k0 = src[i0], k1 = i0 + 1 < nt ? src[i0 + 1] : 0, k2 = i0 + 2 < nt ? src[i0 + 2] : 0, k3 = i0 + 3 < nt ? src[i0 + 3] : 0;
+                key[i0 * PU_THREADS] = k0;
+                if (i0 + 1 < nt) key[(i0 + 1) * PU_THREADS] = k1;
+                if (i0 + 2 < nt) key[(i0 + 2) * PU_THREADS] = k2;
+                if (i0 + 3 < nt) key[(i0 + 3) * PU_THREADS] = k3;
+            }
+            len1 = rlen[r1]; len2 = paired ? rlen[r1 + 1] : 0;
+            d_unit_process<PU_THREADS>(ix, pr, paired != 0, n1, n2, len1, len2, seq + seq_off[r1], seq + seq_off[r1 + (paired ? 1 : 0)], key, cw, rw, try_fast != 0, st);
+        } else { st.nc[0] = (int)ncand[r1]; st.nc[1] = paired ? (int)ncand[r1 + 1] : 0; }
+    }
+    const uint32_t nrep1 = valid ? (uint32_t)(st.nc[0] > 0 ? st.nc[0] : 1) : 0u, nrep2 = (valid && paired) ? (uint32_t)(st.nc[1] > 0 ? st.nc[1] : 1) : 0u;
+    Triple mine, tot;
+    mine.x = nrep1 + nrep2; mine.y = (valid && !st.fast) ? 1u : 0u; mine.z = st.fast ? st.n_cig : 0u;
+    const Triple inb = d_block_exclusive(mine, tot, s_scan);
+    const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 12, err);
+    const uint32_t rep0 = base.x + inb.x, slow_at = base.y + inb.y;
+    const uint64_t cig0 = base.z + inb.z;
+    unsigned long long n_cands = 0, n_one = 0;
+    if (valid) {
+        rep_off[r1] = rep0;
+        if (paired) rep_off[r1 + 1] = rep0 + nrep1;
+        if (!heavy) n_cands = (unsigned long long)(st.nc[0] + st.nc[1]);
+        if (st.fast) {
+            done[r1] = DONE_BY_PAIR; if (paired) done[r1 + 1] = DONE_BY_PAIR;
+            if ((uint64_t)rep0 + mine.x > cap_rep) atomicMax(err, DG_E_REPORTS);
+            else if (cig0 + st.n_cig > cap_cig) atomicMax(err, DG_E_CIGFINAL);
+            else {
+                RepLds<PU_THREADS> p1{cw, rw, st.nc[0], st.flag0[0]}, p2{cw + st.nc[0] * PU_THREADS, rw, st.nc[1], st.flag0[1]};
+                const uint32_t c1 = d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar);
+                if (paired) d_unit_emit_read<PU_THREADS>(false, st.rd[1], p2, rep0 + nrep1, (uint32_t)cig0 + c1, rout + r1 + 1, reports, cigar);
+                n_one = st.n_one;
+            }
+        } else {
+            done[r1] = 0xFF; if (paired) done[r1 + 1] = 0xFF;
+            slow_units[slow_at] = (uint32_t)u;
+            if ((uint64_t)rep0 + mine.x > cap_rep) atomicMax(err, DG_E_REPORTS);       // its reports would not fit either
+        }
+        if (!heavy && (!st.fast || write_all_sorted)) {
+            const int nt = n1 + n2;
+            for (int i = 0; i < nt; i++) seeds[b1 + i] = key[i * PU_THREADS];
+            const uint32_t bm[2] = {b1, b1 + (uint32_t)n1};
+            int q = 0;
+            for (int m = 0; m < (paired ? 2 : 1); m++) {
+                for (int i = 0; i < st.nc[m]; i++, q++) {
+                    const uint32_t w = cw[q * PU_THREADS];
+                    const int64_t d = sk_diag(key[((m ? n1 : 0) + cw_first(w)) * PU_THREADS]);
+                    DCand c = d_new_cand(bm[m] + (uint32_t)cw_first(w), cw_count(w), cw_score(w), d < 0 ? 0 : d);
+                    c.PairedIdx = cw_mate(w);
+                    cands[bm[m] + i] = c;
+                }
+                ncand[r1 + m] = (uint32_t)st.nc[m];
+            }
+        } else if (!heavy) { ncand[r1] = (uint32_t)st.nc[0]; if (paired) ncand[r1 + 1] = (uint32_t)st.nc[1]; }
+    }
+    if (tile == gridDim.x - 1 && threadIdx.x == 0) {
+        sizes->total_rep = base.x + tot.x; sizes->n_slow_units = base.y + tot.y; sizes->cig_fast = (uint32_t)(base.z + tot.z);
+        sizes->total_cig = sizes->cig_fast;                          // (k_emit_slow adds the general path's)
+        *pool_top = (base.x + tot.x) * CIG_SLOT;                     // the report kernel's CIGAR pool: one slot group per report, overflow area behind
+    }
+    d_wave_add(ctr + CTR_CANDS, n_cands);
+    d_wave_add(ctr + CTR_NW, n_one);
+    d_wave_add(ctr + CTR_NWCELLS, n_one);
+}

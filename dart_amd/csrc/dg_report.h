@@ -229,58 +229,70 @@ __device__ inline bool d_reseed(LaneCtx &cx, int rBegin, int rEnd, int64_t Lb, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// clean-up of a candidate's seed list
+// clean-up of a candidate's seed list before re-seeding (GenMappingReport :1104-1110)
 // ---------------------------------------------------------------------------------------------
-__device__ inline int d_remove_null(DSeed *s, int n)   // RemoveNullSeeds :299-306
+__host__ __device__ inline int d_drop_dead_seeds(DSeed *s, int n)   // RemoveNullSeeds :299-306: seeds with rLen == 0 leave the list, order kept
 {
-    int k = 0;
-    for (int i = 0; i < n; i++) if (s[i].rLen != 0) { if (k != i) s[k] = s[i]; k++; }
-    return k;
+    int w = 0;
+    for (int i = 0; i < n; i++) { if (s[i].rLen == 0) continue; if (w != i) s[w] = s[i]; w++; }
+    return w;
 }
 
-// (rPos,index) pairs sorted by rPos; ties by index (ties are order-insensitive downstream)
-__device__ inline void d_sorted_rpos(const DSeed *s, int n, int2 *vec)
-{
-    for (int i = 0; i < n; i++) {
-        int2 x = make_int2(s[i].rPos, i);
-        int j = i;
-        while (j > 0 && (vec[j - 1].x > x.x)) { vec[j] = vec[j - 1]; j--; }
-        vec[j] = x;
-    }
-}
-
-__device__ inline int d_remove_tandem(DSeed *s, int n, int2 *vec)   // :817-842
+// RemoveTandemRepeatSeeds (:817-842) and RemoveTranslocatedSeeds (:844-902) in one entry point.  The list is in genome order.
+//  * Both passes are the identity when the read positions already increase along the list (every seed's rPos larger than
+//    its predecessor's): no two seeds share a read position and read order equals genome order.  That is the normal case
+//    and is decided with one look at each seed.
+//  * Otherwise, tandem pass: every seed whose rPos also belongs to another seed is dropped -- two bit sets over the read
+//    positions (seen / seen twice) instead of the reference's sort by rPos.
+//  * Then, translocation pass: ord[k] = list index of the seed with the k-th smallest rPos.  Where ord[k] != k a block of
+//    ranks [k, end] that is closed under ord is collected (end grows to the largest ord inside); its seeds that come EARLIER
+//    in the read than in the genome (k < ord[k]) are weighed against the others by read bases covered, and the lighter side's
+//    displaced seeds are dropped (ties drop the early side).
+// scratch: 2 * (rlen / 32 + 1) + n u32 words.
+__host__ __device__ inline int d_untangle_seeds(DSeed *s, int n, int rlen, uint32_t *scratch)
 {
     if (n < 2) return n;
-    d_sorted_rpos(s, n, vec);
-    bool any = false;
-    for (int i = 0; i < n;) {
-        int j = i + 1;
-        while (j < n && vec[j].x == vec[i].x) j++;
-        if (j - i > 1) { any = true; for (int k = i; k < j; k++) s[vec[k].y].rLen = s[vec[k].y].gLen = 0; }
-        i = j;
-    }
-    return any ? d_remove_null(s, n) : n;
-}
-
-__device__ inline int d_remove_transloc(DSeed *s, int n, int2 *vec)   // :844-902
-{
-    if (n < 2) return n;
-    d_sorted_rpos(s, n, vec);
-    bool any = false;
-    for (int i = 0; i < n; i++) {
-        if (vec[i].x != s[i].rPos) {
-            any = true;
-            int j = vec[i].y;
-            for (int q = i + 1; q <= j; q++) if (vec[q].y > j) j = vec[q].y;
-            int s1 = 0, s2 = 0;
-            for (int k = i; k <= j; k++) { if (k < vec[k].y) s1 += s[vec[k].y].rLen; else s2 += s[vec[k].y].rLen; }
-            if (s1 > s2) { for (int k = i; k <= j; k++) if (k > vec[k].y) s[vec[k].y].rLen = s[vec[k].y].gLen = 0; }
-            else { for (int k = i; k <= j; k++) if (k < vec[k].y) s[vec[k].y].rLen = s[vec[k].y].gLen = 0; }
-            i = j;
+    bool rising = true;
+    for (int i = 1; i < n && rising; i++) rising = s[i].rPos > s[i - 1].rPos;
+    if (rising) return n;
+    {   // tandem pass
+        const int words = rlen / 32 + 1;
+        uint32_t *once = scratch, *twice = scratch + words;
+        for (int w = 0; w < 2 * words; w++) scratch[w] = 0;
+        for (int i = 0; i < n; i++) {
+            const uint32_t bit = 1u << (s[i].rPos & 31), w = (uint32_t)s[i].rPos >> 5;
+            twice[w] |= once[w] & bit;
+            once[w] |= bit;
         }
+        bool any = false;
+        for (int i = 0; i < n; i++)
+            if ((twice[(uint32_t)s[i].rPos >> 5] >> (s[i].rPos & 31)) & 1u) { s[i].rLen = s[i].gLen = 0; any = true; }
+        if (any) n = d_drop_dead_seeds(s, n);
+        if (n < 2) return n;
     }
-    return any ? d_remove_null(s, n) : n;
+    // translocation pass: ranks by rPos (ties cannot occur any more; the index in the low bits keeps the sort stable anyway)
+    uint32_t *ord = scratch;
+    for (int i = 0; i < n; i++) {
+        const uint32_t x = ((uint32_t)s[i].rPos << 20) | (uint32_t)i;      // rPos < 4096, i < 2^20
+        int j = i;
+        for (; j > 0 && ord[j - 1] > x; j--) ord[j] = ord[j - 1];
+        ord[j] = x;
+    }
+    bool any = false;
+    for (int k = 0; k < n; k++) {
+        if ((int)(ord[k] >> 20) == s[k].rPos) continue;               // the k-th seed of the read is the k-th of the genome
+        int end = (int)(ord[k] & 0xFFFFFu);
+        for (int q = k + 1; q <= end; q++) { const int g = (int)(ord[q] & 0xFFFFFu); end = g > end ? g : end; }
+        int early = 0, rest = 0;
+        for (int q = k; q <= end; q++) { const int g = (int)(ord[q] & 0xFFFFFu); if (q < g) early += s[g].rLen; else rest += s[g].rLen; }
+        const bool keep_early = early > rest;
+        for (int q = k; q <= end; q++) {
+            const int g = (int)(ord[q] & 0xFFFFFu);
+            if (keep_early ? q > g : q < g) { s[g].rLen = s[g].gLen = 0; any = true; }
+        }
+        k = end;
+    }
+    return any ? d_drop_dead_seeds(s, n) : n;
 }
 
 __device__ inline void d_insertion_sort_seeds(DSeed *a, int n)
@@ -296,9 +308,9 @@ __device__ inline void d_insertion_sort_seeds(DSeed *a, int n)
 // ---------------------------------------------------------------------------------------------
 // splice junctions (:6,702-815; main.cpp:18)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int d_shift_arr(int i) { return i == 0 ? 0 : ((i & 1) ? (i + 1) / 2 : -(i / 2)); }   // ShiftArr :6
+__host__ __device__ __forceinline__ int d_shift_arr(int i) { return i == 0 ? 0 : ((i & 1) ? (i + 1) / 2 : -(i / 2)); }   // ShiftArr :6
 
-__device__ inline bool d_check_seq_fragment(const DIndex &ix, int64_t Lg, int64_t Rg, int shift)   // :702-730
+__host__ __device__ inline bool d_check_seq_fragment(const DIndex &ix, int64_t Lg, int64_t Rg, int shift)   // :702-730
 {
     if (shift <= 0) { shift = -shift; Lg -= shift; Rg -= shift; }
     // shift <= 9 (ShiftArr): eight bases of each side in one fetch, the ninth on its own
@@ -311,7 +323,7 @@ __device__ inline bool d_check_seq_fragment(const DIndex &ix, int64_t Lg, int64_
     return true;
 }
 
-__device__ inline int d_identify_sj(const DIndex &ix, int type, const DSeed &l, const DSeed &r)   // :732-756
+__host__ __device__ inline int d_identify_sj(const DIndex &ix, int type, const DSeed &l, const DSeed &r)   // :732-756
 {
     // SpliceJunctionArr = { "GT/AG", "CT/AC", "GC/AG", "CT/GC" }
     const char d0 = type == 0 ? 'G' : (type == 2 ? 'G' : 'C');
@@ -334,115 +346,120 @@ __device__ inline int d_identify_sj(const DIndex &ix, int type, const DSeed &l, 
     return i > j ? 10 : shift;
 }
 
-__device__ inline int d_check_splice(LaneCtx &cx, DSeed *s, int num, int2 *vec)   // :758-815
+// CheckSpliceJunction (:758-815).  A junction = two neighbouring exact seeds whose diagonals are more than MinIntronSize apart.
+// The four motifs are tried in their fixed order; a motif's cost is the sum of |boundary shift| over the junctions (a junction
+// without the motif costs 10) and it competes only if it fits at least one junction; the cheapest wins (the earlier one on
+// a tie) and the search stops at the first motif that fits every junction.  The winner's junctions get bAcceptorSite and
+// their boundary moved by the shift.  Returns the motif (SJtype) or -1.  trial/keep: 2 * num int2 of scratch.
+__host__ __device__ inline int d_check_splice(LaneCtx &cx, DSeed *s, int num, int2 *trial)
 {
     const DIndex &ix = *cx.ix;
-    int2 *best = vec + num + 1;
-    int min_cost = 1000, best_type = -1, nbest = 0;
-    for (int type = 0; type < 4; type++) {
-        int nvec = 0, mis = 0, c = 0;
-        for (int i = 1; i < num; i++) {
-            if (((s[i].gPos - s[i].rPos) - (s[i - 1].gPos - s[i - 1].rPos)) > cx.pr->min_intron && (s[i - 1].flags & SEED_SIMPLE) && (s[i].flags & SEED_SIMPLE)) {
-                const int shift = d_identify_sj(ix, type, s[i - 1], s[i]);
-                if (shift != 10) vec[nvec++] = make_int2(i, shift);
-                else mis++;
-                c += shift < 0 ? -shift : shift;
-            }
+    int2 *keep = trial + num + 1;
+    int kept = 0, kept_cost = 1000, motif_won = -1;
+    for (int motif = 0; motif < 4; motif++) {
+        int fits = 0, cost = 0, without = 0;
+        for (int j = 1; j < num; j++) {
+            const DSeed &up = s[j - 1], &dn = s[j];
+            if (!(up.flags & dn.flags & SEED_SIMPLE) || (dn.gPos - dn.rPos) - (up.gPos - up.rPos) <= cx.pr->min_intron) continue;
+            const int sh = d_identify_sj(ix, motif, up, dn);
+            cost += sh < 0 ? -sh : sh;
+            if (sh == 10) without++; else trial[fits++] = make_int2(j, sh);
         }
-        if (nvec > 0 && c < min_cost) { min_cost = c; best_type = type; nbest = nvec; for (int q = 0; q < nvec; q++) best[q] = vec[q]; }
-        if (mis == 0) break;
+        if (fits > 0 && cost < kept_cost) { kept_cost = cost; motif_won = motif; kept = fits; for (int q = 0; q < fits; q++) keep[q] = trial[q]; }
+        if (without == 0) break;
     }
-    if (best_type != -1) {
-        for (int q = 0; q < nbest; q++) {
-            const int j = best[q].x, shift = best[q].y;
-            s[j].flags |= SEED_ACCEPTOR;
-            if (shift != 0) {
-                s[j - 1].rLen += shift; s[j - 1].gLen += shift;
-                s[j].rLen -= shift; s[j].gLen -= shift;
-                s[j].rPos += shift; s[j].gPos += shift;
-            }
-        }
+    for (int q = 0; q < kept; q++) {
+        DSeed &up = s[keep[q].x - 1], &dn = s[keep[q].x];
+        const int sh = keep[q].y;
+        dn.flags |= SEED_ACCEPTOR;
+        up.rLen += sh; up.gLen += sh;                       // (sh == 0: nothing moves)
+        dn.rLen -= sh; dn.gLen -= sh; dn.rPos += sh; dn.gPos += sh;
     }
-    return best_type;
+    return motif_won;
 }
 
 // ---------------------------------------------------------------------------------------------
 // overlaps and normal pairs (:904-1035)
 // ---------------------------------------------------------------------------------------------
-__device__ inline bool d_check_seed_overlapping(DSeed &p1, DSeed &p2)   // :904-954
+// CheckSeedOverlapping (:904-954): `lo` precedes `hi` in the list.  First along the read, then (if both are still alive) along
+// the genome: when they overlap by ov, the shorter of the two in that dimension gives way -- `lo` loses its last ov bases,
+// `hi` its first ov (a seed not longer than ov dies).  A trimmed seed is exact, so its gLen follows its rLen.
+// Returns false when `lo` was the one that gave way (the caller then stops comparing it with later seeds).
+__host__ __device__ inline bool d_resolve_overlap(DSeed &lo, DSeed &hi)
 {
-    int ov;
-    bool master = true;
-    if ((ov = p1.rPos + p1.rLen - p2.rPos) > 0) {
-        if (p1.rLen < p2.rLen) {
-            master = false;
-            if (p1.rLen > ov) p1.gLen = (p1.rLen -= ov);
-            else p1.rLen = p1.gLen = 0;
-        } else {
-            if (p2.rLen > ov) { p2.rPos += ov; p2.gPos += ov; p2.gLen = (p2.rLen -= ov); }
-            else p2.rLen = p2.gLen = 0;
+    bool lo_intact = true;
+    auto trim_end = [](DSeed &x, int ov) { x.rLen = x.rLen > ov ? x.rLen - ov : 0; x.gLen = x.rLen; };
+    auto trim_front = [](DSeed &x, int ov) { if (x.rLen > ov) { x.rPos += ov; x.gPos += ov; x.rLen -= ov; x.gLen = x.rLen; } else x.rLen = x.gLen = 0; };
+    const int on_read = lo.rPos + lo.rLen - hi.rPos;
+    if (on_read > 0) {
+        if (lo.rLen < hi.rLen) { trim_end(lo, on_read); lo_intact = false; } else trim_front(hi, on_read);
+    }
+    if (lo.rLen > 0 && hi.rLen > 0) {
+        const int on_genome = (int)(lo.gPos + lo.gLen - hi.gPos);
+        if (on_genome > 0) {
+            if (lo.gLen < hi.gLen) { trim_end(lo, on_genome); lo_intact = false; } else trim_front(hi, on_genome);
         }
     }
-    if ((p1.rLen > 0 && p2.rLen > 0) && (ov = (int)(p1.gPos + p1.gLen - p2.gPos)) > 0) {
-        if (p1.gLen < p2.gLen) {
-            master = false;
-            if (p1.rLen > ov) p1.gLen = (p1.rLen -= ov);
-            else p1.rLen = p1.gLen = 0;
-        } else {
-            if (p2.rLen > ov) { p2.rPos += ov; p2.gPos += ov; p2.gLen = (p2.rLen -= ov); }
-            else p2.rLen = p2.gLen = 0;
-        }
-    }
-    return master;
+    return lo_intact;
 }
 
-__device__ inline int d_check_overlapping_seeds(DSeed *s, int num)   // :956-999
+// CheckOverlappingSeeds (:956-999): every live seed, in list order, is compared with the live seeds after it until one starts
+// beyond its end in both coordinates (the ends as they were when its turn began) or it gave way itself.  A seed that died on its
+// own turn sends the cursor back to the nearest live seed before it (or the list head), whose turn is taken again.
+__host__ __device__ inline int d_trim_overlaps(DSeed *s, int num)
 {
     if (num < 2) return num;
-    bool any = false;
-    for (int i = 0; i < num;) {
-        if (s[i].rLen > 0) {
-            const int rEnd = s[i].rPos + s[i].rLen - 1;
-            const int64_t gEnd = s[i].gPos + s[i].gLen - 1;
-            for (int j = i + 1; j < num; j++) {
-                if (s[j].rLen == 0) continue;
-                if (rEnd < s[j].rPos && gEnd < s[j].gPos) break;
-                if (!d_check_seed_overlapping(s[i], s[j])) break;
-            }
-            if (s[i].rLen == 0) {
-                any = true;
-                i = i - 1;
-                while (i > 0 && s[i].rLen == 0) i--;
-                if (i < 0) i = 0;
-            } else i++;
-        } else { any = true; i++; }
+    bool holes = false;
+    int at = 0;
+    while (at < num) {
+        if (s[at].rLen == 0) { holes = true; at++; continue; }
+        const int r_last = s[at].rPos + s[at].rLen - 1;
+        const int64_t g_last = s[at].gPos + s[at].gLen - 1;
+        for (int nx = at + 1; nx < num; nx++) {
+            if (s[nx].rLen == 0) continue;
+            if (s[nx].rPos > r_last && s[nx].gPos > g_last) break;
+            if (!d_resolve_overlap(s[at], s[nx])) break;
+        }
+        if (s[at].rLen != 0) { at++; continue; }
+        holes = true;
+        at--;
+        while (at > 0 && s[at].rLen == 0) at--;
+        if (at < 0) at = 0;
     }
-    return any ? d_remove_null(s, num) : num;
+    return holes ? d_drop_dead_seeds(s, num) : num;
 }
 
-__device__ inline int d_identify_normal_pairs(DSeed *s, int n)   // :1001-1035
+// IdentifyNormalPairs (:1001-1035): after the overlap trimming, every two neighbours that do not touch on the read get a
+// non-exact pair holding what lies between them: the read bases (none when the neighbours overlap there) and the genome bases
+// -- none when negative, and none when there are more than 30 AND more than twice the read bases (that gap becomes an N
+// in the CIGAR instead).  Pairs with nothing on either side are not made.  The new pairs are then merged into list order
+// (stable: behind every older element that is not greater).
+__host__ __device__ inline int d_identify_normal_pairs(DSeed *s, int n)
 {
-    if (n <= 1) return n;
-    n = d_check_overlapping_seeds(s, n);
-    const int num = n;
-    for (int i = 0, j = 1; j < num; i++, j++) {
-        if (s[j].rPos - s[i].rPos - s[i].rLen == 0) continue;
-        int rGaps = s[j].rPos - (s[i].rPos + s[i].rLen); if (rGaps < 0) rGaps = 0;
-        int gGaps = (int)(s[j].gPos - (s[i].gPos + s[i].gLen));
-        if (gGaps < 0) gGaps = 0; else if (gGaps > 30 && gGaps > (rGaps << 1)) gGaps = 0;
-        if (rGaps > 0 || gGaps > 0) {
-            DSeed x; x.flags = 0;
-            x.rPos = s[i].rPos + s[i].rLen; x.gPos = s[i].gPos + s[i].gLen; x.rLen = rGaps; x.gLen = gGaps;
-            s[n++] = x;
-        }
+    if (n < 2) return n;
+    n = d_trim_overlaps(s, n);
+    const int old = n;
+    for (int j = 1; j < old; j++) {
+        const DSeed &up = s[j - 1], &dn = s[j];
+        const int r_from = up.rPos + up.rLen, between_r = dn.rPos - r_from;
+        if (between_r == 0) continue;                                   // (also skips a genome-only gap: it will be an N or D later)
+        const int64_t g_from = up.gPos + up.gLen;
+        const int rG = between_r > 0 ? between_r : 0;
+        int gG = (int)(dn.gPos - g_from);
+        if (gG < 0 || (gG > 30 && gG > 2 * rG)) gG = 0;
+        if (rG == 0 && gG == 0) continue;
+        DSeed fill; fill.flags = 0; fill.rPos = r_from; fill.gPos = g_from; fill.rLen = rG; fill.gLen = gG;
+        s[n++] = fill;
     }
-    // inplace_merge(begin, begin+num, end) :1033 -- stable: an appended pair goes after every
-    // element of the first range that is not greater than it
-    for (int t = num; t < n; t++) {
-        DSeed x = s[t];
-        int j = t;
-        while (j > 0 && d_seed_less(x, s[j - 1])) { s[j] = s[j - 1]; j--; }
-        s[j] = x;
+    // the two-way merge of std::inplace_merge(begin, begin + old, end) (:1033), done in place: the new pairs are taken in the
+    // order they were made; each goes in front of the first not-yet-passed older element that is greater than it, and the
+    // walk over the older elements never goes back (so the result is the reference's even if the new pairs are not in order)
+    int at = 0;
+    for (int t = old; t < n; t++) {
+        const DSeed x = s[t];
+        while (at < t && !d_seed_less(x, s[at])) at++;
+        for (int j = t; j > at; j--) s[j] = s[j - 1];
+        s[at++] = x;
     }
     return n;
 }
@@ -811,12 +828,12 @@ __device__ inline void d_nw_group(const DIndex &ix, bool has, const unsigned cha
 // Wave-wide nw_alignment service: every lane may ask for one alignment (has; read characters a[0..m), genome
 // gPos..gPos+n); requests of <= 64 columns run eight at a time (d_nw_group), wider ones one after the other
 // (d_nw_coop).  Traceback bits land in each requesting lane's own scratch.  Called by all 64 lanes.
-__device__ inline void d_nw_wave(LaneCtx &cx, bool has, const unsigned char *a, int m, int64_t gPos, int n, int lane)
+__device__ inline void d_nw_wave(LaneCtx &cx, bool has, const unsigned char *a, int m, int64_t gPos, int n, int lane, bool all_wide = false)
 {
     if (!__ballot(has)) return;
     const DIndex &ix = *cx.ix;
     const unsigned long long ap = (unsigned long long)a, wp = (unsigned long long)cx.ws;
-    unsigned long long todo = __ballot(has && n <= NWG_MAXN);
+    unsigned long long todo = __ballot(has && n <= NWG_MAXN && !all_wide);      // all_wide (dg_probe_nw_mode 3 only): every pair takes the whole-wave form
     while (todo) {
         int own = -1;
         for (int q = 0; q < 64 / NWG_LANES; q++) {           // group q takes the q-th requester
@@ -831,7 +848,7 @@ __device__ inline void d_nw_wave(LaneCtx &cx, bool has, const unsigned char *a, 
         const int m_o = __shfl(m, src, 64), n_o = __shfl(n, src, 64);
         d_nw_group(ix, own >= 0, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
     }
-    todo = __ballot(has && n > NWG_MAXN);
+    todo = __ballot(has && (n > NWG_MAXN || all_wide));
     while (todo) {
         const int owner = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -1189,7 +1206,7 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                     // every report owns CIG_SLOT ops of the pool (no atomic: one hot bump counter serialises at ~6 ns per wave
                     // update); the rare longer CIGAR goes to the bump-allocated overflow area behind the slots
                     const unsigned int off = m <= CIG_SLOT ? (rep_index0 + (unsigned int)i) * CIG_SLOT : atomicAdd(cigtop, (unsigned int)m);
-                    if (off + (unsigned int)m > cigcap) { *err = 1; rp.n_cigar = 0; }
+                    if (off + (unsigned int)m > cigcap) { atomicMax(err, DG_E_CIGAR); rp.n_cigar = 0; }
                     else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
                 }
                 rp.aln_score = aln;
@@ -1216,100 +1233,6 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
     }
 }
 
-// CheckPairedFinalAlignments, Mapping.cpp:479-530
-template <typename ReportT>
-__device__ inline void d_check_paired_final(const DParams &pr, DRead &r1, ReportT *p1, DRead &r2, ReportT *p2)
-{
-    bool mated = p1[r1.iBest].paired_idx == r2.iBest;
-    if (!pr.multi_hit && mated) return;
-    if (!mated && r1.score > 0 && r2.score > 0) {
-        int s = 0;
-        for (int i = 0; i < r1.CanNum; i++) {
-            int j;
-            if (p1[i].aln_score > 0 && (j = p1[i].paired_idx) != -1 && p2[j].aln_score > 0) {
-                mated = true;
-                if (s < p1[i].aln_score + p2[j].aln_score) {
-                    s = p1[i].aln_score + p2[j].aln_score;
-                    r1.iBest = i; r1.score = p1[i].aln_score;
-                    r2.iBest = j; r2.score = p2[j].aln_score;
-                }
-            }
-        }
-    }
-    if (mated) {
-        for (int i = 0; i < r1.CanNum; i++) {
-            int j;
-            if (p1[i].aln_score != r1.score || ((j = p1[i].paired_idx) != -1 && p2[j].aln_score != r2.score)) { p1[i].aln_score = 0; p1[i].paired_idx = -1; }
-        }
-    } else {
-        for (int i = 0; i < r1.CanNum; i++) {
-            if (p1[i].paired_idx != -1) p1[i].paired_idx = -1;
-            if (p1[i].aln_score > 0 && p1[i].aln_score != r1.score) p1[i].aln_score = 0;
-        }
-        for (int j = 0; j < r2.CanNum; j++) {
-            if (p2[j].paired_idx != -1) p2[j].paired_idx = -1;
-            if (p2[j].aln_score > 0 && p2[j].aln_score != r2.score) p2[j].aln_score = 0;
-        }
-    }
-}
-
-template <typename ReportT>
-__device__ inline void d_set_single_flag(DRead &r, ReportT *p)   // Mapping.cpp:74-99
-{
-    if (r.score > r.sub_score) p[r.iBest].flag = p[r.iBest].bdir ? 0 : 0x10;
-    else if (r.score > 0) { for (int i = 0; i < r.CanNum; i++) if (p[i].aln_score > 0) p[i].flag = p[i].bdir ? 0 : 0x10; }
-    else p[0].flag = 0x4;
-}
-
-template <typename ReportT>
-__device__ inline void d_set_mate_flags(DRead &a, ReportT *pa, DRead &b, ReportT *pb, int base)   // Mapping.cpp:124-153 / :155-184
-{
-    int j;
-    if (a.score > a.sub_score) {
-        const int i = a.iBest;
-        pa[i].flag = base | (pa[i].bdir ? 0x20 : 0x10);
-        if ((j = pa[i].paired_idx) != -1 && pb[j].aln_score > 0) pa[i].flag |= 0x2; else pa[i].flag |= 0x8;
-    } else if (a.score > 0) {
-        for (int i = 0; i < a.CanNum; i++) {
-            if (pa[i].aln_score > 0) {
-                pa[i].flag = base | (pa[i].bdir ? 0x20 : 0x10);
-                if ((j = pa[i].paired_idx) != -1 && pb[j].aln_score > 0) pa[i].flag |= 0x2; else pa[i].flag |= 0x8;
-            }
-        }
-    } else {
-        pa[0].flag = base | 0x4;
-        if (b.score == 0) pa[0].flag |= 0x8;
-        else pa[0].flag |= (pb[b.iBest].bdir ? 0x10 : 0x20);
-    }
-}
-
-template <typename ReportT>
-__device__ inline void d_set_paired_flag(DRead &r1, ReportT *p1, DRead &r2, ReportT *p2)   // Mapping.cpp:101-186
-{
-    if (r1.score > r1.sub_score && r2.score > r2.sub_score) {
-        const int i = r1.iBest, j = r2.iBest;
-        p1[i].flag = 0x41; p2[j].flag = 0x81;
-        if (j == p1[i].paired_idx) { p1[i].flag |= 0x2; p2[j].flag |= 0x2; }
-        p1[i].flag |= (p1[i].bdir ? 0x20 : 0x10);
-        p2[j].flag |= (p2[j].bdir ? 0x20 : 0x10);
-    } else {
-        d_set_mate_flags(r1, p1, r2, p2, 0x41);
-        d_set_mate_flags(r2, p2, r1, p1, 0x81);
-    }
-}
-
-template <typename ReportT>
-__device__ inline void d_evaluate_mapq(DRead &r, const ReportT *p)   // Mapping.cpp:188-206
-{
-    if (r.score == 0 || r.score == r.sub_score) r.mapq = 0;
-    else if (r.sub_score == 0 || r.score > r.sub_score) r.mapq = 50;
-    else {
-        int n = 0;
-        for (int i = 0; i < r.CanNum; i++) if (p[i].aln_score == r.score) n++;
-        r.mapq = n >= 10 ? 0 : (n >= 4 ? 1 : (n == 3 ? 2 : (n == 2 ? 3 : 50)));
-    }
-}
-
 // UpdateLocalSJMap, Mapping.cpp:532-565: tuples of the best candidate -> bump pool
 template <typename SjT>
 __device__ inline void d_collect_sj(const DIndex &ix, const DParams &pr, const DCand &c, const DSeed *work, int read_idx,
@@ -1324,7 +1247,7 @@ __device__ inline void d_collect_sj(const DIndex &ix, const DParams &pr, const D
         if (pass == 1) {
             if (cnt == 0) return;
             off = atomicAdd(sjtop, (unsigned int)cnt);
-            if (off + (unsigned int)cnt > sjcap) { *err = 2; return; }
+            if (off + (unsigned int)cnt > sjcap) { atomicMax(err, DG_E_SJ); return; }
             sj_off = (int32_t)off; n_sj = cnt;
         }
         int k = 0;

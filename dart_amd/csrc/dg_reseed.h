@@ -29,56 +29,77 @@
 #define RS_RING     1024         // diagonals in the ring (>= span + 63 + RS_CHUNK live at any time): 32 KB of LDS, 4 waves per CU
 #define RS_WORDS    4
 
+// One thread per read of the general path's units (slow_units[], two reads per unit when paired).  Each live candidate gets its
+// private working region (bump-allocated per wave: the regions are internal, only the records' layout is deterministic), its
+// seeds unpacked into it, the clean-up passes, and its re-seeding jobs queued.
 __global__ void __launch_bounds__(256)
-k_prep(const DParams pr, int n_reads, const uint32_t *__restrict__ seed_off, const DSeed *__restrict__ seeds,
-       DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ work_off,
-       DSeed *__restrict__ work, DJob *__restrict__ jobs, unsigned int *jobtop, uint32_t jobcap, int *err, const uint16_t *__restrict__ rlen)
+k_prep(const DParams pr, int paired, const uint32_t *__restrict__ slow_units, const DSizes *__restrict__ sizes, const uint32_t *__restrict__ seed_off,
+       const SKey *__restrict__ seeds, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, DSeed *__restrict__ work, unsigned int *worktop, uint32_t workcap,
+       DJob *__restrict__ jobs, unsigned int *jobtop, uint32_t jobcap, int *err, const uint16_t *__restrict__ rlen)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    DCand *cd = cands + seed_off[r];
-    const int nc = (int)ncand[r];
-    uint32_t wo = work_off[r];
-    for (int i = 0; i < nc; i++) {
-        DCand &c = cd[i];
-        c.final_n = 0; c.n_a = 0; c.job_count = 0; c.job_first = 0;
-        if (c.Score == 0) continue;
-        c.work_off = wo; wo += d_work_need(c.count);
-        DSeed *s = work + c.work_off;
-        int n = c.count;
-        for (int q = 0; q < n; q++) s[q] = seeds[c.first + q];
-        int2 *vec = (int2 *)(s + 6 * c.count + 4);       // tail of the working region as int scratch
-        n = d_remove_tandem(s, n, vec);
-        n = d_remove_transloc(s, n, vec);
-        c.n_a = n;
-        int cnt = 0;                                     // IdentifyMissingSeeds :691-697, enumeration only
-        int big = n > 0 && (s[0].rPos > PM_MAX || (int)rlen[r] - (s[n - 1].rPos + s[n - 1].rLen) > PM_MAX) ? 1 : 0, indel = 0;
-        for (int k = 1; k < n; k++) {
-            const int pd = (int)((s[k].gPos - s[k].rPos) - (s[k - 1].gPos - s[k - 1].rPos));
-            const int rGaps = s[k].rPos - s[k - 1].rPos - s[k - 1].rLen;
-            if (pd > pr.max_gaps && rGaps > 20) cnt++;
-            if (rGaps > PM_MAX || rGaps + pd > PM_MAX) big = 1;
-            if (pd != 0) indel = 2;
-        }
-        c.final_n = big | indel;                         // scheduling hints for k_cost only (k_report sets the real value): bit 0 = some
-                                                         // segment pair is longer than PM_MAX (string path, maybe a wave-wide alignment),
-                                                         // bit 1 = two seeds on different diagonals (an nw_alignment is certain)
-        if (cnt == 0) continue;
-        const unsigned int first = atomicAdd(jobtop, (unsigned int)cnt);
-        if (first + (unsigned int)cnt > jobcap) { *err = 3; continue; }
-        c.job_first = first; c.job_count = cnt;
-        int w = 0;
-        for (int k = 1; k < n; k++) {
-            const int pd = (int)((s[k].gPos - s[k].rPos) - (s[k - 1].gPos - s[k - 1].rPos));
-            const int rGaps = s[k].rPos - s[k - 1].rPos - s[k - 1].rLen;
-            if (pd > pr.max_gaps && rGaps > 20) {
-                DJob j;
-                j.Lb = s[k - 1].gPos + s[k - 1].gLen;
-                j.glen = (int32_t)(s[k].gPos - j.Lb);
-                j.rBegin = s[k - 1].rPos + s[k - 1].rLen; j.rl = rGaps;
-                j.read = (uint32_t)r; j.found = rGaps > RS_MAX_RL ? -1 : 0;   // -1: left to the serial path in k_report
-                j.gPos = 0; j.rPos = 0; j.len = 0; j.pad = 0;
-                jobs[first + w++] = j;
+    if (*err >= DG_ABORT) return;
+    const unsigned int n_items = sizes->n_slow_units * (paired ? 2u : 1u);
+    const int lane = threadIdx.x & 63;
+    for (unsigned int base = blockIdx.x * blockDim.x; base < n_items; base += gridDim.x * blockDim.x) {   // uniform per workgroup
+        const unsigned int it = base + threadIdx.x;
+        const bool on = it < n_items;
+        const int r = on ? (paired ? (int)(2u * slow_units[it >> 1] + (it & 1u)) : (int)slow_units[it]) : 0;
+        DCand *cd = cands + seed_off[r];
+        const int nc = on ? (int)ncand[r] : 0;
+        uint32_t need = 0;
+        for (int i = 0; i < nc; i++) if (cd[i].Score != 0) need += d_work_need(cd[i].count);
+        // the wave's regions in one atomic
+        uint32_t incl = need;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        const uint32_t wave_total = __shfl(incl, 63, 64);
+        uint32_t wave_base = 0;
+        if (lane == 0 && wave_total) wave_base = atomicAdd(worktop, wave_total);
+        wave_base = __shfl(wave_base, 0, 64);
+        if ((uint64_t)wave_base + wave_total > workcap) { if (lane == 0) atomicMax(err, DG_E_WORK); continue; }   // (worktop keeps the need)
+        uint32_t wo = wave_base + incl - need;
+        for (int i = 0; i < nc; i++) {
+            DCand &c = cd[i];
+            c.final_n = 0; c.n_a = 0; c.job_count = 0; c.job_first = 0;
+            if (c.Score == 0) continue;
+            c.work_off = wo; wo += d_work_need(c.count);
+            DSeed *s = work + c.work_off;
+            int n = c.count;
+            for (int q = 0; q < n; q++) {
+                const SKey k = seeds[c.first + q];
+                DSeed x; x.gPos = sk_gpos(k); x.rPos = sk_rpos(k); x.rLen = x.gLen = sk_rlen(k); x.flags = SEED_SIMPLE;
+                s[q] = x;
+            }
+            n = d_untangle_seeds(s, n, (int)rlen[r], (uint32_t *)(s + 6 * c.count + 4));       // tail of the working region as scratch
+            c.n_a = n;
+            int cnt = 0;                                     // IdentifyMissingSeeds :691-697, enumeration only
+            int big = n > 0 && (s[0].rPos > PM_MAX || (int)rlen[r] - (s[n - 1].rPos + s[n - 1].rLen) > PM_MAX) ? 1 : 0, indel = 0;
+            for (int k = 1; k < n; k++) {
+                const int pd = (int)((s[k].gPos - s[k].rPos) - (s[k - 1].gPos - s[k - 1].rPos));
+                const int rGaps = s[k].rPos - s[k - 1].rPos - s[k - 1].rLen;
+                if (pd > pr.max_gaps && rGaps > 20) cnt++;
+                if (rGaps > PM_MAX || rGaps + pd > PM_MAX) big = 1;
+                if (pd != 0) indel = 2;
+            }
+            c.final_n = big | indel;                         // scheduling hints for k_cost only (k_report sets the real value): bit 0 = some
+                                                             // segment pair is longer than PM_MAX (string path, maybe a wave-wide alignment),
+                                                             // bit 1 = two seeds on different diagonals (an nw_alignment is certain)
+            if (cnt == 0) continue;
+            const unsigned int first = atomicAdd(jobtop, (unsigned int)cnt);
+            if (first + (unsigned int)cnt > jobcap) { atomicMax(err, DG_E_JOBS); continue; }
+            c.job_first = first; c.job_count = cnt;
+            int w = 0;
+            for (int k = 1; k < n; k++) {
+                const int pd = (int)((s[k].gPos - s[k].rPos) - (s[k - 1].gPos - s[k - 1].rPos));
+                const int rGaps = s[k].rPos - s[k - 1].rPos - s[k - 1].rLen;
+                if (pd > pr.max_gaps && rGaps > 20) {
+                    DJob j;
+                    j.Lb = s[k - 1].gPos + s[k - 1].gLen;
+                    j.glen = (int32_t)(s[k].gPos - j.Lb);
+                    j.rBegin = s[k - 1].rPos + s[k - 1].rLen; j.rl = rGaps;
+                    j.read = (uint32_t)r; j.found = rGaps > RS_MAX_RL ? -1 : 0;   // -1: left to the serial path in k_report
+                    j.gPos = 0; j.rPos = 0; j.len = 0; j.pad = 0;
+                    jobs[first + w++] = j;
+                }
             }
         }
     }
@@ -162,7 +183,7 @@ __device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, uint32_t
 template <int WORDS>
 __global__ void __launch_bounds__(64)
 k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off,
-         DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, unsigned long long *ctr)
+         DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, uint32_t jobcap, unsigned long long *ctr, const int *__restrict__ abort_p)
 {
     __shared__ unsigned char rs[RS_MAX_RL + 9];
     __shared__ uint64_t tmpk[RS_MAX_RL + 1], km[RS_MAX_RL + 1];
@@ -172,7 +193,8 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
     __shared__ uint32_t s_dirty;
     __shared__ int s_nk;
     const int lane = threadIdx.x;
-    const unsigned int njobs = *jobtop;
+    if (*abort_p >= DG_ABORT) return;
+    const unsigned int njobs = *jobtop < jobcap ? *jobtop : jobcap;
     const int64_t L = ix.l_pac;
     unsigned long long n_done = 0, w_done = 0;
     for (unsigned int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {

@@ -115,6 +115,11 @@ def _load_lib():
     vp = C.c_void_p
     lib.dg_map_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dg_batch_upload.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.dg_batch_upload_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_size_t]
+    lib.dg_map_batch_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
+    lib.dg_host_alloc.restype = C.c_void_p
+    lib.dg_host_alloc.argtypes = [C.c_size_t]
+    lib.dg_host_free.argtypes = [vp]
     lib.dg_batch_run.argtypes = [vp, vp]
     lib.dg_batch_download.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.dg_batch_device_ptrs.argtypes = [vp, vp]
@@ -122,7 +127,48 @@ def _load_lib():
     lib.dg_last_counters.argtypes = [vp, vp, C.c_int]
     lib.dg_probe_seeds.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.dg_probe_nw.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t]
+    lib.dg_probe_nw_mode.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t]
     return lib
+
+
+def pack_reads_2bit(arr: np.ndarray):
+    """[n, rlen] uint8 ASCII (A/C/G/T/N upper case only) -> (words u32 [n, ceil(rlen/16)], nlist u32) for dg_map_batch_packed:
+    16 bases per word, first base in the top bits; N stored as A and listed as flat index i * 16 * W + pos."""
+    n, l = arr.shape
+    W = (l + 15) // 16
+    code = np.full(256, 255, np.uint8)
+    for ch, v in zip(b"ACGTN", (0, 1, 2, 3, 0)):
+        code[ch] = v
+    c = code[arr]
+    if (c == 255).any():
+        raise ValueError("packed reads hold A, C, G, T, N only")
+    padded = np.zeros((n, 16 * W), np.uint32)
+    padded[:, :l] = c
+    sh = (30 - 2 * np.arange(16, dtype=np.uint32))
+    words = (padded.reshape(n, W, 16) << sh).sum(axis=2, dtype=np.uint64).astype(np.uint32)
+    ri, pi = np.nonzero(arr == ord("N"))
+    nlist = (ri.astype(np.uint64) * (16 * W) + pi.astype(np.uint64)).astype(np.uint32)
+    return np.ascontiguousarray(words), nlist
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory (dg_host_alloc): copies to/from it are DMA transfers"""
+
+    def __init__(self, lib, shape, dtype):
+        self.lib = lib
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        self.ptr = lib.dg_host_alloc(max(n * dt.itemsize, 64))
+        if not self.ptr:
+            raise MemoryError("dg_host_alloc failed")
+        buf = (C.c_char * (n * dt.itemsize)).from_address(self.ptr)
+        self.a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.a = None
+            self.lib.dg_host_free(self.ptr)
+            self.ptr = None
 
 
 def default_params(**kw) -> Params:
@@ -215,6 +261,22 @@ class DartGPU:
         self.run()
         return self.download()
 
+    def upload_packed(self, words, nlist, rlen_all, rlen=None):
+        self._n = int(words.shape[0])
+        w = np.ascontiguousarray(words, np.uint32); nl = np.ascontiguousarray(nlist, np.uint32)
+        rl = None if rlen is None else np.ascontiguousarray(rlen, np.uint16)
+        self._keep = (w, nl, rl)
+        self._chk(self.lib.dg_batch_upload_packed(self.ctx, self._n, int(rlen_all), None if rl is None else rl.ctypes.data, int(w.shape[1]) if w.ndim == 2 else 1,
+                                                  w.ctypes.data, nl.ctypes.data if len(nl) else None, len(nl)), "dg_batch_upload_packed")
+
+    def map_batch_packed(self, words, nlist, rlen_all, rlen=None) -> BatchResult:
+        self.upload_packed(words, nlist, rlen_all, rlen)
+        self.run()
+        return self.download()
+
+    def pinned(self, shape, dtype) -> "PinnedArray":
+        return PinnedArray(self.lib, shape, dtype)
+
     def device_reads_tensor(self):
         """torch uint8 view [n_reads, 36] of the per-read records in HBM (for RCCL collectives)."""
         import torch
@@ -237,7 +299,7 @@ class DartGPU:
         out = (C.c_uint64 * 32)()
         n = self.lib.dg_last_counters(self.ctx, out, 32)
         keys = ["steps", "occ_blocks", "lf_steps", "sa_lookups", "seeds", "candidates", "nw_calls", "nw_cells", "reseed_calls", "reseed_window",
-                "steps_executed", "occ_blocks_executed", "ktab_lookups", "lf_steps_executed", "direct_extensions", "k_seed_max_trips_per_read", "k_seed_wave_trips_max", "k_seed_wave_trips_sum"]
+                "steps_executed", "occ_blocks_executed", "ktab_lookups", "lf_steps_executed", "direct_extensions", "k_seed_max_trips_per_read", "k_seed_wave_trips_max", "k_seed_wave_trips_sum", "general_path_units", "wave_chained_units", "batch_runs"]
         return {keys[i]: int(out[i]) for i in range(min(n, len(keys)))}
 
     def probe_seeds(self, seq_off, rlen, flat):
@@ -256,7 +318,8 @@ class DartGPU:
             u = int(used.value)
             return so, rp[:u], sl[:u], gp[:u]
 
-    def probe_nw(self, pairs):
+    def probe_nw(self, pairs, mode: int = 0):
+        """nw_alignment of (a, b) byte pairs through form `mode` of the kernels (dg_probe_nw_mode)."""
         n = len(pairs)
         a_off = np.zeros(n + 1, np.uint32); b_off = np.zeros(n + 1, np.uint32)
         for i, (x, y) in enumerate(pairs):
@@ -266,8 +329,8 @@ class DartGPU:
         cap = int(a_off[n]) + int(b_off[n]) + 16
         out_off = np.zeros(n + 1, np.uint32); out_len = np.zeros(n + 1, np.uint32)
         oa = np.zeros(cap, np.uint8); ob = np.zeros(cap, np.uint8)
-        self._chk(self.lib.dg_probe_nw(self.ctx, n, a_off.ctypes.data, b_off.ctypes.data, a.ctypes.data, b.ctypes.data, out_off.ctypes.data,
-                                       out_len.ctypes.data, oa.ctypes.data, ob.ctypes.data, cap), "dg_probe_nw")
+        self._chk(self.lib.dg_probe_nw_mode(self.ctx, mode, n, a_off.ctypes.data, b_off.ctypes.data, a.ctypes.data, b.ctypes.data, out_off.ctypes.data,
+                                            out_len.ctypes.data, oa.ctypes.data, ob.ctypes.data, cap), "dg_probe_nw_mode")
         res = []
         for i in range(n):
             o, l = int(out_off[i]), int(out_len[i])

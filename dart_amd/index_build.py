@@ -3,8 +3,9 @@ reference's offline indexer (`bwt_index`, BWT_Index/bwtindex.c:77-148) for the s
 the tests and bench.py generate on the GPU box, where no reference binary exists.
 
 The index files are a pure function of the text, so any correct suffix sorter reproduces the
-reference's files byte for byte ("Format validated here"); tests/test_index_build.py
-checks that against oracle/_ref/bwt_index.  The suffix array comes from prefix doubling with
+reference's files byte for byte (SURVEY.md 8a, "Format validated here");
+tests/test_oracle_golden.py::test_index_builder_matches_reference_indexer checks that against the digests of
+oracle/_ref/bwt_index's files (CPU path) and tests/test_gpu_index.py does the same for the GPU path.  The suffix array comes from prefix doubling with
 torch.sort, which runs on the MI355X when one is present (chr20-sized text: seconds) and on the
 CPU otherwise (fine for the <= few-Mbp test genomes).  This is scope row 8f#1 ("next"), kept in
 Python on purpose: it is plumbing around the hot path, not the hot path.

@@ -79,15 +79,41 @@ int         dg_set_params(dg_ctx *, const dg_params *);
 
 /* ---- the path: host buffers in, host records out (replaces Mapping.cpp:598-639) ----
  * read i = seq[seq_off[i] .. +rlen[i]) ASCII as read from the file.
- * caps/used index: 0 = reports, 1 = cigar ops, 2 = sj tuples.                               */
+ * caps/used index: 0 = reports, 1 = cigar ops, 2 = sj tuples.
+ * Record layout: reports of read i are reports[rep_off .. rep_off + n_rep) and rep_off increases with i; a report's CIGAR
+ * ops are cigar_ops[cigar_off .. cigar_off + n_cigar) -- the layout is the same for the same input (deterministic), but
+ * cigar_off does NOT increase with the report index (reports finished by the fused kernel come first, then the others);
+ * sj tuples are grouped by read in read order.
+ * The whole batch is enqueued on the context's stream without asking the device for a size in between; the call waits twice:
+ * for the sizes, then for the records.  If a data-dependent buffer was too small the library grows it and runs the batch
+ * again before returning (first batches of a context, or a sudden change in the data).                                   */
 int dg_map_batch(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
                  dg_read_out *, dg_report_out *, uint32_t *cigar_ops, dg_sj_out *,
                  const size_t caps[3], size_t used[3]);
+
+/* Page-locked host memory for the arrays handed to dg_map_batch*: with it the copies in and out are DMA transfers that run
+ * beside other contexts' kernels; with ordinary memory the calls still work, the runtime stages the copies. */
+void *dg_host_alloc(size_t bytes);
+void  dg_host_free(void *);
+
+/* The same path for reads that hold nothing but A, C, G, T and N (upper case): 2 bit/base instead of a byte, which matters
+ * once the host link is the limit (202 MB -> 56 MB per million 2x101 pairs).
+ *   words   read i = words[i * words_per_read ..): 16 bases per word, FIRST base in the TOP two bits (A C G T = 0 1 2 3),
+ *           words_per_read = ceil(longest read / 16); an N is stored as any base and listed in nlist
+ *   nlist   the N positions as flat base indices  i * 16 * words_per_read + position  (n_n of them, any order)
+ *   rlen    per-read lengths, or NULL when every read has length rlen_all
+ * A read with any other character (lower case, IUPAC codes, '-') must go through dg_map_batch: the reference compares raw
+ * characters in places (tools.cpp:40-47), so such a read maps differently from its upper-case form.                          */
+int dg_map_batch_packed(dg_ctx *, int n_reads, int rlen_all, const uint16_t *rlen, int words_per_read, const uint32_t *words,
+                        const uint32_t *nlist, size_t n_n, dg_read_out *, dg_report_out *, uint32_t *cigar_ops, dg_sj_out *,
+                        const size_t caps[3], size_t used[3]);
 
 /* ---- the same path split so a caller can keep the batch resident in HBM (bench.py) ----
  * dg_batch_upload copies reads to the device; dg_batch_run runs the whole path on the device
  * leaving the result records in HBM (sizes in `used`); dg_batch_download copies them out.     */
 int dg_batch_upload(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq);
+int dg_batch_upload_packed(dg_ctx *, int n_reads, int rlen_all, const uint16_t *rlen, int words_per_read, const uint32_t *words,
+                           const uint32_t *nlist, size_t n_n);
 int dg_batch_run(dg_ctx *, size_t used[3]);
 int dg_batch_download(dg_ctx *, dg_read_out *, dg_report_out *, uint32_t *cigar_ops, dg_sj_out *, const size_t caps[3]);
 
@@ -103,7 +129,9 @@ int dg_last_timings(dg_ctx *, const char **names, float *ms, int cap);
  * [3] SA lookups [4] seeds [5] candidates [6] NW calls [7] NW cells [8] reseed calls
  * [9] reseed window bases -- [0..3] are counted as the REFERENCE's algorithm would execute them
  * (the basis of the algorithmic-byte figure); [10] Occ-pair steps and [11] Occ blocks this
- * implementation really executed, [12] k-mer prefix-table look-ups, [13] LF steps really executed */
+ * implementation really executed, [12] k-mer prefix-table look-ups, [13] LF steps really executed, [14..17] seeding statistics,
+ * [18] units (pairs / single reads) that took the general report path, [19] units chained by a wave each (> 16 seeds),
+ * [20] how many times the batch was enqueued (> 1: a capacity estimate was too small and the batch ran again)          */
 int dg_last_counters(dg_ctx *, uint64_t *out, int cap);
 
 /* ---- stage probes (parity tests of single kernels; mirror oracle/dart_oracle.h) ----
@@ -115,6 +143,12 @@ int dg_probe_seeds(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16_
  * NUL-free gapped strings of equal length out_len[i] at out_a/out_b + out_off[i] (cap each = sum of lengths) */
 int dg_probe_nw(dg_ctx *, int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b,
                 uint32_t *out_off, uint32_t *out_len, char *out_a, char *out_b, size_t cap);
+/* the same through each form of nw_alignment the kernels run: mode 0 = serial strips (what dg_probe_nw runs), 1 = register
+ * strips (pairs up to 24 x 24), 2 = the wave-wide service (8-lane groups up to 64 columns, the whole wave beyond) with the
+ * owner's traceback, 3 = the whole-wave form for every pair.  Modes 2 and 3 take the b side from a 2-bit text, as the
+ * kernels do (RefSequence, bwt_index.cpp:193-212): b must be ACGT, else DG_ERR_ARG.                                  */
+int dg_probe_nw_mode(dg_ctx *, int mode, int n, const uint32_t *a_off, const uint32_t *b_off, const char *a, const char *b,
+                     uint32_t *out_off, uint32_t *out_len, char *out_a, char *out_b, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -1365,6 +1365,34 @@ int orc_seeds(const orc_index *ix, const orc_params *pr, const char *seq, int rl
     return n;
 }
 
+/* stage probe for the host-compiled checks of the kernels' list helpers (tests/native/report_checks.hip): one of the list
+ * passes of GenMappingReport on a caller-supplied seed list, in place.  op 0 = RemoveTandemRepeatSeeds + RemoveTranslocatedSeeds,
+ * 1 = IdentifyNormalPairs (with CheckOverlappingSeeds), 2 = CheckSpliceJunction (returns the SJ type).  flags: bit 0 bSimple,
+ * bit 1 bAcceptorSite.  Returns the new list length through *n (cap = array capacity).                                          */
+int orc_seed_stage(const orc_index *ix, const orc_params *pr, int op, int *n, int cap, int32_t *rpos, int32_t *rlen, int32_t *glen, int64_t *gpos, uint32_t *flags)
+{
+    ctx_t cx; seedvec v; int i, ret = 0;
+    memset(&cx, 0, sizeof cx); memset(&v, 0, sizeof v);
+    cx.ix = ix; cx.pr = pr;
+    for (i = 0; i < *n; i++) {
+        seed_t s; memset(&s, 0, sizeof s);
+        s.rPos = rpos[i]; s.rLen = rlen[i]; s.gLen = glen[i]; s.gPos = gpos[i]; s.PosDiff = s.gPos - s.rPos;
+        s.simple = (uint8_t)(flags[i] & 1u); s.acceptor = (uint8_t)((flags[i] >> 1) & 1u);
+        sv_push(&v, &s);
+    }
+    if (op == 0) { remove_tandem_repeat_seeds(&v); remove_translocated_seeds(&v); }
+    else if (op == 1) identify_normal_pairs(&v);
+    else ret = check_splice_junction(&cx, &v);
+    if (v.n > cap) { sv_free(&v); return -99; }
+    for (i = 0; i < v.n; i++) {
+        rpos[i] = v.a[i].rPos; rlen[i] = v.a[i].rLen; glen[i] = v.a[i].gLen; gpos[i] = v.a[i].gPos;
+        flags[i] = (uint32_t)v.a[i].simple | ((uint32_t)v.a[i].acceptor << 1);
+    }
+    *n = v.n;
+    sv_free(&v);
+    return ret;
+}
+
 /* ------------------------------------------------------------------------------------------
  * index files  (bwt_index.cpp:15-121,229-251)
  * ---------------------------------------------------------------------------------------- */

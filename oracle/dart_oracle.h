@@ -64,6 +64,8 @@ int  orc_bwt_search(const orc_index *, const orc_params *, const uint8_t *enc, i
 /* seeds of one read after the (gPos,rPos) sort; returns count (<= cap) */
 int  orc_seeds(const orc_index *, const orc_params *, const char *seq, int rlen, int32_t *rpos, int32_t *slen, int64_t *gpos, int cap);
 char orc_refbase(const orc_index *, int64_t g);
+/* one list pass of GenMappingReport on a caller-supplied seed list (see dart_oracle.c) */
+int  orc_seed_stage(const orc_index *, const orc_params *, int op, int *n, int cap, int32_t *rpos, int32_t *rlen, int32_t *glen, int64_t *gpos, uint32_t *flags);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,30 @@ def main():
         for (a, b), line in zip(pairs, out):
             o1, o2 = line.split()
             f.write(("%s\t%s\t%s\t%s\n" % (a, b, o1, o2)).encode())
+    # larger nw_alignment answers with the genome side in ACGT only (what RefSequence holds): these reach the wave-wide forms of
+    # the kernels (8-lane groups up to 64 columns, the whole-wave anti-diagonal form beyond, several 64-column blocks, traceback
+    # words of more than 16 rows); own generator so the first file's bytes do not change
+    rng2 = np.random.default_rng(77)
+    big = []
+    for i in range(420):
+        m = int(rng2.integers(1, 260)) if i % 3 else int(rng2.integers(1, 40))
+        a = alpha[rng2.choice(5, m, p=[.245, .245, .245, .245, .02])]
+        b = a.copy(); b[b == ord("N")] = ord("A")
+        mut = rng2.random(len(b)) < 0.08
+        b[mut] = alpha[rng2.integers(0, 4, int(mut.sum()))]
+        for _ in range(int(rng2.integers(0, 3))):
+            c0 = int(rng2.integers(0, len(b) + 1))
+            if rng2.random() < 0.5: b = np.concatenate([b[:c0], b[c0 + int(rng2.integers(1, 12)):]])
+            else: b = np.concatenate([b[:c0], alpha[rng2.integers(0, 4, int(rng2.integers(1, 40)))], b[c0:]])
+        if i % 7 == 0: b = alpha[rng2.integers(0, 4, int(rng2.integers(1, 330)))]
+        if len(b) == 0: b = alpha[:1]
+        big.append((a.tobytes().decode(), b.tobytes().decode()))
+    inp = "".join("%s %s\n" % p for p in big)
+    out = subprocess.run([REF, "nw"], input=inp.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().split("\n")
+    with gzip.GzipFile(os.path.join(HERE, "nw_known_answers_large.tsv.gz"), "wb", mtime=0) as f:
+        for (a, b), line in zip(big, out):
+            o1, o2 = line.split()
+            f.write(("%s\t%s\t%s\t%s\n" % (a, b, o1, o2)).encode())
     # BWT_Search known answers on the first case's index: every start position of 60 reads
     name = "pe101_spliced"; spec = CASES[name]; g, m1, m2 = case_inputs(spec, d)
     reads = "".join(m1[i].tobytes().decode() + "\n" for i in range(0, 60))

@@ -52,3 +52,22 @@ def test_shard_bounds_cover_everything():
                 lo, hi = ddist.shard_bounds(n, w, r)
                 cover += list(range(lo, hi))
             assert cover == list(range(n))
+
+
+def test_bench_refuses_a_rank_count_that_is_not_gpus(monkeypatch):
+    """`bench.py --gpus N` must run N ranks: under a launcher with another world size it stops (before touching any GPU)"""
+    import subprocess, sys
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "3"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "--gpus 3 but WORLD_SIZE is 2" in r.stderr
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """without a launcher, `bench.py --gpus N` starts N ranks through torch.distributed.run on 127.0.0.1 and returns their code"""
+    import bench, subprocess, argparse
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 0)
+    rc = bench.self_launch(argparse.Namespace(gpus=4), ["--gpus", "4", "--steps", "3"])
+    cmd = seen["cmd"]
+    assert rc == 0 and cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")

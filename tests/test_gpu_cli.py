@@ -45,3 +45,23 @@ def test_dart_cli_error_behaviour(workdir):
     assert r.returncode == 1 and b"Please specify a valid reference index" in r.stderr
     r = subprocess.run([DART, "-v"], stdout=subprocess.PIPE)
     assert r.returncode == 0 and r.stdout.startswith(b"DART v1.4.6")
+
+
+def test_bench_two_ranks_through_the_self_launcher(workdir):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts two ranks itself (torch.distributed.run), each maps
+    its own distinct batches host to host, the per-read records are gathered to rank 0 inside the timed region, and ONE JSON line
+    comes back with n_gpus = 2.  On a one-GPU box the ranks share the card and talk over gloo (DART_BENCH_REHEARSE=1): the launch,
+    threading, ordering and gather logic of the N>1 path, not its speed."""
+    import json, subprocess, sys
+    env = dict(os.environ, DART_BENCH_REHEARSE="1", DART_BENCH_CACHE=os.path.join(workdir, "bench2_cache"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--genome", "3000000", "--pairs", "20000", "--batches", "3", "--steps", "2",
+                        "--warmup", "1", "--inflight", "2", "--cpu-sample-pairs", "4000"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "gather" in line["config"]["parallelism"] and "host-to-host" in line["config"]["workload"]
+    assert line["cpu_baseline"]["gpu_records_identical_on_sample"] is True
+    assert line["roofline"]["frac"] > 0 and line["accuracy"]["correct_frac"] > 0.9

@@ -21,14 +21,28 @@ def ctxs(workdir):
         gpu.close(); orc.close()
 
 
+def cigars_of(reports, cigar):
+    """the CIGAR ops of every report, in report order (cigar_off/n_cigar dereferenced: the ABI fixes what a report's ops are,
+    not where in the op array they lie)"""
+    off = reports["cigar_off"].astype(np.int64); k = reports["n_cigar"].astype(np.int64)
+    idx = np.repeat(off - np.concatenate([[0], np.cumsum(k)[:-1]]), k) + np.arange(int(k.sum()))
+    return cigar[idx] if len(idx) else np.zeros(0, np.uint32)
+
+
 def assert_same(res, ores):
     reads, rep, cig, sj = ores
     for f in reads.dtype.names:
-        assert np.array_equal(reads[f], res.reads[f]), "read field %s differs at %s" % (f, np.nonzero(reads[f] != res.reads[f])[0][:5])
+        if f != "sj_off":
+            assert np.array_equal(reads[f], res.reads[f]), "read field %s differs at %s" % (f, np.nonzero(reads[f] != res.reads[f])[0][:5])
+    has_sj = reads["n_sj"] > 0                            # (sj_off says where a read's tuples are; it means nothing for a read without any)
+    assert np.array_equal(reads["sj_off"][has_sj], res.reads["sj_off"][has_sj])
     assert len(rep) == len(res.reports)
     for f in rep.dtype.names:
-        assert np.array_equal(rep[f], res.reports[f]), "report field %s differs at %s" % (f, np.nonzero(rep[f] != res.reports[f])[0][:5])
-    assert np.array_equal(cig, res.cigar)
+        if f != "cigar_off":
+            assert np.array_equal(rep[f], res.reports[f]), "report field %s differs at %s" % (f, np.nonzero(rep[f] != res.reports[f])[0][:5])
+    assert len(cig) == len(res.cigar)
+    a, b = cigars_of(rep, cig), cigars_of(res.reports, res.cigar)
+    assert np.array_equal(a, b), "CIGAR ops differ, first at flattened op %s" % (np.nonzero(a != b)[0][:5] if len(a) == len(b) else "(length)")
     assert np.array_equal(sj, res.sj)
 
 
@@ -47,13 +61,34 @@ def test_gpu_matches_golden_sam(name, ctxs):
         assert_same(res, orc.map_batch(orc.params(paired=int(c["spec"]["paired"]), **p), so, rl, flat))
 
 
+def _nw_vectors():
+    out = []
+    for fn in ("nw_known_answers.tsv.gz", "nw_known_answers_large.tsv.gz"):
+        for line in gzip.open(os.path.join(common.GOLDEN, fn), "rt"):
+            a, b, o1, o2 = line.rstrip("\n").split("\t")
+            out.append(((a.encode(), b.encode()), (o1.encode(), o2.encode())))
+    return out
+
+
 def test_gpu_nw_known_answers(ctxs):
+    """every form of nw_alignment that runs in production against the reference-generated known answers (nw_alignment.cpp:18-82):
+    0 = serial strips, 1 = register strips (<= 24 x 24), 2 = the wave-wide service (8-lane groups / whole wave) + the owner's
+    traceback, 3 = the whole-wave form for every pair.  Forms 2 and 3 read the genome side from 2-bit text: ACGT vectors only."""
     c, ix, gpu, orc = ctxs["se100"]
-    pairs, want = [], []
-    for line in gzip.open(os.path.join(common.GOLDEN, "nw_known_answers.tsv.gz"), "rt"):
-        a, b, o1, o2 = line.rstrip("\n").split("\t")
-        pairs.append((a.encode(), b.encode())); want.append((o1.encode(), o2.encode()))
-    assert gpu.probe_nw(pairs) == want
+    vec = _nw_vectors()
+    acgt = set(b"ACGT")
+    sel = {0: vec,
+           1: [v for v in vec if 1 <= len(v[0][0]) <= 24 and 1 <= len(v[0][1]) <= 24],
+           2: [v for v in vec if set(v[0][1]) <= acgt],
+           3: [v for v in vec if set(v[0][1]) <= acgt]}
+    assert len(sel[0]) == 1508 + 420 and len(sel[1]) > 300 and len(sel[2]) > 1200
+    assert sum(len(v[0][1]) > 64 for v in sel[2]) > 250 and sum(len(v[0][1]) > 128 for v in sel[2]) > 100     # several 64-column blocks
+    for mode, vs in sel.items():
+        got = gpu.probe_nw([v[0] for v in vs], mode=mode)
+        bad = [i for i, (g, v) in enumerate(zip(got, vs)) if g != v[1]]
+        assert not bad, "nw form %d: %d of %d pairs differ, first %r -> %r, expected %r" % (mode, len(bad), len(vs), vs[bad[0]][0], got[bad[0]], vs[bad[0]][1])
+    with pytest.raises(RuntimeError):
+        gpu.probe_nw([(b"ACGT", b"ACNT")], mode=2)
 
 
 def test_gpu_seeds_match_oracle(ctxs):
@@ -304,8 +339,75 @@ def test_gpu_seeding_rounds_variant_matches_oracle(workdir, monkeypatch):
     assert_same(base, want)
     for rounds, steps in (("6", "4"), ("2", "1"), ("3", "16")):
         monkeypatch.setenv("DG_SEED_ROUNDS", rounds); monkeypatch.setenv("DG_SEED_ROUND_STEPS", steps)
+        gpu.set_params(gpu.params)                     # the DG_* switches are read at init and at dg_set_params, not per batch
         assert_same(gpu.map_batch(so, rl, flat), want)
         ctr = gpu.counters()
         for k in ("steps", "lf_steps", "sa_lookups", "seeds", "occ_blocks"):
             assert ctr[k] == base_ctr[k], k
+    gpu.close(); orc.close()
+
+
+def test_gpu_packed_reads_and_pinned_buffers(workdir):
+    """dg_map_batch_packed (2 bit/base + N list) gives the records of dg_map_batch on the same reads, with fixed and with
+    per-read lengths; page-locked caller buffers (dg_host_alloc) through the raw ABI; a read with a lower-case base is refused
+    by the packer (it must go through the ASCII entry)"""
+    import ctypes as C
+    g = synth.make_genome([1500000, 500000], seed=81, repeat_scale=60.0, n_introns=150)
+    prefix = os.path.join(workdir, "packed")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
+    m1, m2 = synth.make_reads(g, 25000, rlen=101, seed=82, sub_rate=0.015, indel_frac=0.04, spliced_frac=0.1, n_frac=0.01)
+    arr = host.interleave_pairs(m1, m2)
+    so, rl, flat = host.pack_reads(arr)
+    want = orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=16)
+    words, nlist = host.pack_reads_2bit(arr)
+    assert len(nlist) > 1000
+    assert_same(gpu.map_batch_packed(words, nlist, 101), want)
+    # ragged: every read cut to its own length (the tail bases stay in the words, the lengths say where the read ends)
+    rng = np.random.default_rng(5)
+    lens = rng.integers(30, 102, size=len(arr)).astype(np.uint16)
+    seqs = [arr[i, :lens[i]].tobytes() for i in range(len(arr))]
+    so2, rl2, flat2 = host.pack_reads(seqs)
+    keep = np.nonzero(arr == ord("N"))
+    inside = keep[1] < lens[keep[0]]
+    nl2 = (keep[0][inside].astype(np.uint64) * words.shape[1] * 16 + keep[1][inside].astype(np.uint64)).astype(np.uint32)
+    lens[0] = 101                                        # words_per_read is ceil(longest / 16)
+    seqs[0] = arr[0].tobytes(); so2, rl2, flat2 = host.pack_reads(seqs)
+    keep = np.nonzero(arr == ord("N")); inside = keep[1] < lens[keep[0]]
+    nl2 = (keep[0][inside].astype(np.uint64) * words.shape[1] * 16 + keep[1][inside].astype(np.uint64)).astype(np.uint32)
+    assert_same(gpu.map_batch_packed(words, nl2, 0, rlen=lens), orc.map_batch(orc.params(paired=1, max_mismatch=5), so2, rl2, flat2, threads=16))
+    low = arr[:4].copy(); low[1, 7] = ord("a")
+    with pytest.raises(ValueError):
+        host.pack_reads_2bit(low)
+    # pinned buffers through dg_map_batch itself
+    n = len(rl)
+    p_so = gpu.pinned((n,), np.uint32); p_rl = gpu.pinned((n,), np.uint16); p_seq = gpu.pinned((len(flat) + 64,), np.uint8)
+    p_so.a[:] = so; p_rl.a[:] = rl; p_seq.a[:len(flat)] = flat
+    caps = (C.c_size_t * 3)(n * 4, n * 16, n * 2); used = (C.c_size_t * 3)()
+    o_r = gpu.pinned((n,), host.READ_OUT); o_p = gpu.pinned((caps[0],), host.REPORT_OUT); o_c = gpu.pinned((caps[1],), np.uint32); o_s = gpu.pinned((caps[2],), host.SJ_OUT)
+    rc = gpu.lib.dg_map_batch(gpu.ctx, n, p_so.a.ctypes.data, p_rl.a.ctypes.data, p_seq.a.ctypes.data, o_r.a.ctypes.data, o_p.a.ctypes.data, o_c.a.ctypes.data, o_s.a.ctypes.data, caps, used)
+    assert rc == 0
+    assert_same(host.BatchResult(o_r.a.copy(), o_p.a[:used[0]].copy(), o_c.a[:used[1]].copy(), o_s.a[:used[2]].copy()), want)
+    for p in (p_so, p_rl, p_seq, o_r, o_p, o_c, o_s):
+        p.free()
+    gpu.close(); orc.close()
+
+
+def test_gpu_capacity_estimates_grow_and_results_stay(workdir):
+    """the data-dependent buffers are sized from estimates and grown on overflow (no mid-batch size read-back): a first batch
+    far denser in seeds / reports than the estimates (repeat family reads, -m, -max_dup 1000) and a sparse one afterwards both
+    equal the oracle"""
+    g = synth.make_genome([800000], seed=91, repeat_scale=400.0)
+    prefix = os.path.join(workdir, "caps")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    p, _ = common.parse_flags(["-mis", "8", "-m", "-max_dup", "1000"])
+    gpu = host.DartGPU(ix, host.default_params(paired=1, **p))
+    m1, m2 = synth.make_reads(g, 3000, rlen=151, seed=92, sub_rate=0.02, indel_frac=0.1)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    want = orc.map_batch(orc.params(paired=1, **p), so, rl, flat, threads=16)
+    assert len(want[1]) > 3 * len(rl)                    # many reports per read: the first estimate (1.25 per read) is too small
+    assert_same(gpu.map_batch(so, rl, flat), want)
+    assert_same(gpu.map_batch(so[:200], rl[:200], flat), orc.map_batch(orc.params(paired=1, **p), so[:200], rl[:200], flat, threads=4))
     gpu.close(); orc.close()

@@ -53,3 +53,78 @@ def test_chain_stage_lane_code_on_host_against_reference_dumps(workdir):
             assert got == w, (name, got, w)
         total += len(want)
     assert total > 1000
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_report_list_passes_on_host_against_oracle(workdir):
+    """dg_report.h's list passes (tandem / translocation clean-up, overlap trimming + normal pairs, splice junctions) compiled
+    for the host and run against the oracle's restatement of the same reference functions on 660 000 random seed lists"""
+    src = os.path.join(common.ROOT, "tests", "native", "report_checks.hip")
+    exe = os.path.join(workdir, "report_checks")
+    oracle_py.build()
+    odir = os.path.dirname(oracle_py.LIB)
+    subprocess.run(["hipcc", "-O2", "--offload-arch=gfx950", "-std=c++17", "-w", "-o", exe, src, "-L" + odir, "-loracle", "-Wl,-rpath," + odir], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("bad=0"), out.stdout + out.stderr
+
+
+def _pair_check_file(path, prefix, params, paired, reads_arr, orc):
+    import numpy as np
+    from dart_amd import host
+    so, rl, flat = host.pack_reads(reads_arr)
+    o_reads, o_rep, o_cig, o_sj = orc.map_batch(orc.params(paired=paired, **params), so, rl, flat, threads=8)
+    seed_off = [0]; rp, sl, gp = [], [], []
+    sp = orc.params(**{k: v for k, v in params.items() if k in ("max_dup",)})
+    for i in range(len(rl)):
+        a, b, c = orc.seeds(sp, reads_arr[i].tobytes() if hasattr(reads_arr[i], "tobytes") else reads_arr[i])
+        rp.append(a); sl.append(b); gp.append(c); seed_off.append(seed_off[-1] + len(a))
+    rp = np.concatenate(rp).astype(np.int32); sl = np.concatenate(sl).astype(np.int32); gp = np.concatenate(gp).astype(np.int64)
+    ix = host.Index(prefix)
+    p = dict(max_gaps=5, max_dup=100, max_intron=500000, min_intron=5, max_mismatch=0, multi_hit=0, all_sj=0); p.update(params)
+    hdr = np.zeros(16, np.int32)
+    hdr[:10] = [len(ix.names), paired, len(rl), p["max_gaps"], p["max_dup"], p["max_intron"], p["min_intron"], p["max_mismatch"], p["multi_hit"], p["all_sj"]]
+    hdr[10] = np.int64(ix.l_pac & 0xFFFFFFFF).astype(np.uint32).view(np.int32) if False else int(np.array([ix.l_pac & 0xFFFFFFFF], np.uint32).view(np.int32)[0])
+    hdr[11] = ix.l_pac >> 32
+    hdr[12:16] = [len(rp), len(o_rep), len(o_cig), len(flat)]
+    with open(path, "wb") as f:
+        for a in (hdr, ix.chr_off.astype(np.int64), ix.chr_len.astype(np.int64), ix.pac[: ix.l_pac // 4 + 1], so.astype(np.uint32), rl.astype(np.uint16), flat,
+                  np.asarray(seed_off, np.uint32), rp, sl, gp, o_reads, o_rep, o_cig):
+            f.write(np.ascontiguousarray(a).tobytes())
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_pair_kernel_unit_code_on_host_against_oracle(workdir):
+    """k_pair's per-unit code (dg_pair.h) compiled for the host: from the oracle's seeds of each unit to finished records,
+    compared field by field with the oracle's records for every unit the code finishes itself -- the golden cases under their
+    flag sets, and a repeat-rich genome where reads have several equally good candidates (pair settling, FLAG, MAPQ ties)"""
+    import numpy as np
+    from dart_amd import synth, index_build, host
+    src = os.path.join(common.ROOT, "tests", "native", "pair_checks.hip")
+    exe = os.path.join(workdir, "pair_checks")
+    subprocess.run(["hipcc", "-O2", "--offload-arch=gfx950", "-std=c++17", "-w", "-o", exe, src], check=True)
+    runs = []
+    for name in sorted(common.MANIFEST["cases"]):
+        c = common.build_case(name, workdir)
+        for run in c["runs"]:
+            p, _ = common.parse_flags(run["flags"])
+            runs.append((c["prefix"], p, int(c["spec"]["paired"]), c["reads"]))
+    g = synth.make_genome([600000, 400000], seed=71, repeat_scale=300.0, n_introns=50)
+    prefix = os.path.join(workdir, "pairchk")
+    index_build.build_index_from_genome(g, prefix, device="cpu")
+    m1, m2 = synth.make_reads(g, 6000, rlen=101, seed=72, sub_rate=0.01, indel_frac=0.02, n_frac=0.003, spliced_frac=0.02)
+    arr = host.interleave_pairs(m1, m2)
+    for flags in (["-mis", "5"], [], ["-mis", "5", "-m"], ["-mis", "2", "-max_dup", "1000"]):
+        p, _ = common.parse_flags(flags)
+        runs.append((prefix, p, 1, arr))
+    runs.append((prefix, common.parse_flags(["-mis", "4"])[0], 0, m1))
+    fast = total = multi = 0
+    for k, (pf, p, paired, reads_arr) in enumerate(runs):
+        path = os.path.join(workdir, "pairchk_%d.bin" % k)
+        orc = oracle_py.Oracle(pf)
+        _pair_check_file(path, pf, p, paired, reads_arr, orc)
+        orc.close()
+        out = subprocess.run([exe, path], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip().endswith("bad=0"), (k, p, out.stdout + out.stderr)
+        f = out.stdout.split()
+        total += int(f[1].rstrip(":")); fast += int(f[4].rstrip(",")); multi += int(f[f.index("reports") + 1].rstrip(";"))
+    assert total > 20000 and fast > 0.5 * total and multi > 200, (total, fast, multi)
