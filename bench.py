@@ -149,21 +149,30 @@ class Batch:
 class Worker:
     """one context = one batch in flight: its own device buffers, its own page-locked output arrays, driven by its own thread"""
 
-    def __init__(self, gpu, n, mode):
+    def __init__(self, gpu, n, mode, records):
         import ctypes as C
         import numpy as np
         from dart_amd import host
-        self.gpu, self.mode, self.C = gpu, mode, C
+        self.gpu, self.mode, self.records, self.C = gpu, mode, records, C
         self.caps = (C.c_size_t * 3)(int(n * 1.3) + 1024, 4 * n + 4096, n + 1024)
         self.used = (C.c_size_t * 3)()
-        self.o_r = gpu.pinned((n,), host.READ_OUT); self.o_p = gpu.pinned((self.caps[0],), host.REPORT_OUT)
+        self.o_r = gpu.pinned((n,), host.READ_OUT); self.o_p = gpu.pinned((self.caps[0],), host.REPORT_OUT)          # (the compact types use the front of these)
         self.o_c = gpu.pinned((self.caps[1],), np.uint32); self.o_s = gpu.pinned((self.caps[2],), host.SJ_OUT)
-        self.kern = {}; self.n_runs = 0; self.extra_runs = 0
+        self.c_r = self.o_r.a.view(np.uint8)[:n * 16].view(host.READ_C); self.c_p = self.o_p.a.view(np.uint8)[:self.caps[0] * 20].view(host.REPORT_C)
+        self.kern = {}; self.n_runs = 0; self.last_records = records
 
-    def map(self, b, mode=None):
+    def map(self, b, mode=None, records=None):
         g, lib = self.gpu, self.gpu.lib
         mode = mode or self.mode
-        if mode == "packed":
+        records = records or self.records
+        if mode != "resident":
+            self.last_records = records
+        if records == "compact" and mode in ("packed", "ascii"):
+            pk = mode == "packed"
+            rc = lib.dg_map_batch_compact(g.ctx, b.n, None if pk else b.so.a.ctypes.data, None if pk else b.rl.a.ctypes.data, None if pk else b.seq.a.ctypes.data,
+                                          b.rlen, b.W2, b.words.a.ctypes.data if pk else None, (b.nlist.a.ctypes.data if b.n_n else None) if pk else None, b.n_n if pk else 0,
+                                          self.c_r.ctypes.data, self.c_p.ctypes.data, self.o_c.a.ctypes.data, self.o_s.a.ctypes.data, self.caps, self.used)
+        elif mode == "packed":
             rc = lib.dg_map_batch_packed(g.ctx, b.n, b.rlen, None, b.W2, b.words.a.ctypes.data, b.nlist.a.ctypes.data if b.n_n else None, b.n_n,
                                          self.o_r.a.ctypes.data, self.o_p.a.ctypes.data, self.o_c.a.ctypes.data, self.o_s.a.ctypes.data, self.caps, self.used)
         elif mode == "ascii":
@@ -180,7 +189,14 @@ class Worker:
     def result(self):
         from dart_amd import host
         u = [int(x) for x in self.used]
+        if self.last_records == "compact":
+            r, p = host.expand_compact(self.c_r.copy(), self.c_p[:u[0]].copy())
+            return host.BatchResult(r, p, self.o_c.a[:u[1]].copy(), self.o_s.a[:u[2]].copy())
         return host.BatchResult(self.o_r.a.copy(), self.o_p.a[:u[0]].copy(), self.o_c.a[:u[1]].copy(), self.o_s.a[:u[2]].copy())
+
+    def out_bytes(self, n):
+        u = [int(x) for x in self.used]
+        return (16 * n + 20 * u[0] if self.last_records == "compact" else 36 * n + 40 * u[0]) + 4 * u[1] + 24 * u[2]
 
 
 def main():
@@ -195,6 +211,7 @@ def main():
     ap.add_argument("--repeat-scale", type=float, default=1.0, help="scales the planted repeat families of the synthetic genome (1.0 = SURVEY 8d's: ~18 %% of the genome)")
     ap.add_argument("--mis", type=int, default=5, help="-mis N (MaxMismatch); the reference default is 0, see DESIGN.md")
     ap.add_argument("--input", choices=["packed", "ascii"], default="packed", help="entry point that carries the reads in the timed region")
+    ap.add_argument("--records", choices=["compact", "full"], default="compact", help="record types that carry the results in the timed region (include/dartgpu.h: 16 + 20 bytes, or 36 + 40)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=150000)
     ap.add_argument("--rlen", type=int, default=101)
     ap.add_argument("--spliced", type=float, default=0.0, help="fraction of reads spanning a planted intron (BASELINE config 5 shape: --rlen 151 --spliced 0.3 --introns 20000)")
@@ -272,7 +289,7 @@ def main():
     # `inflight` contexts share the index; each is driven by its own host thread, the way the reference runs ReadMapping in -t
     # threads.  Work item i = batch i % nb on context i % inflight; a step = nb items.
     n_ctx = max(1, min(args.inflight, nb * max(1, args.steps)))
-    workers = [Worker(gpu if k == 0 else gpu.clone(), n_reads, args.input) for k in range(n_ctx)]
+    workers = [Worker(gpu if k == 0 else gpu.clone(), n_reads, args.input, args.records) for k in range(n_ctx)]
     for k, w in enumerate(workers):                # sizes every context's device buffers before any counted step (distinct batches)
         w.map(batches[k % nb])
         w.kern = {}; w.n_runs = 0
@@ -353,6 +370,12 @@ def main():
         items = min(args.steps, 3) * nb
         other = "ascii" if args.input == "packed" else "packed"
         secondary["value_%s_input" % other] = round(2 * args.pairs * world * items / timed(items, other) / 1e6, 3)
+        other_rec = "full" if args.records == "compact" else "compact"
+        for w in workers:
+            w.records = other_rec
+        secondary["value_%s_records" % other_rec] = round(2 * args.pairs * world * items / timed(items, args.input) / 1e6, 3)
+        for w in workers:
+            w.records = args.records
         gsave, do_gather = do_gather, False
         run_items(len(workers), "resident")                # (every context holds the batch it mapped last)
         secondary["value_device_resident"] = round(2 * args.pairs * world * items / timed(items, "resident") / 1e6, 3)
@@ -379,7 +402,11 @@ def main():
         "k_seed": 64 * counters["occ_blocks"] + batches[0].bases + 16 * n_reads,
         "k_locate": 64 * counters["lf_steps"] + 8 * counters["sa_lookups"] + 8 * counters["seeds"],
     }
-    stage_kernels = [k for k in ("k_seed", "k_locate", "k_pair", "k_report", "k_chain_heavy") if k in kern]
+    for d_ in (kern, iso):                                   # (the re-seeding kernels run on the second stream, beside k_report)
+        if "k_reseed(overlapped)" in d_:
+            d_["k_reseed"] = d_.pop("k_reseed(overlapped)")
+    alg["k_reseed"] = counters["reseed_window"] // 4 + 64 * counters["reseed_calls"]      # window bases at 2 bit/base, streamed once (B_ref)
+    stage_kernels = [k for k in ("k_seed", "k_locate", "k_pair", "k_report", "k_chain_heavy", "k_reseed") if k in kern]
     dom = max(stage_kernels, key=lambda k: iso.get(k, kern.get(k, 0.0)))
     per_read_B = (alg["k_seed"] + alg["k_locate"]) / n_reads
     dom_bytes = alg.get(dom)
@@ -474,8 +501,9 @@ def main():
                                % (args.repeat_scale, round(nb * args.pairs / 1e6), args.rlen, nb, args.pairs,
                                   ("%.0f %% of the reads spliced over %d planted introns, -max_intron %d, " % (100 * args.spliced, args.introns, args.max_intron)) if args.spliced else "", args.mis),
                    "input": ("packed reads (2 bit/base + N list, dg_map_batch_packed): %.1f MB per batch" if args.input == "packed" else "ASCII reads (dg_map_batch): %.1f MB per batch") % (in_bytes / 1e6),
-                   "output": "dg_read_out + dg_report_out + CIGAR ops + junction tuples into page-locked host arrays: %.1f MB per batch" %
-                             ((36 * n_reads + 40 * workers[0].used[0] + 4 * workers[0].used[1] + 24 * workers[0].used[2]) / 1e6),
+                   "output": ("%s + CIGAR ops + junction tuples into page-locked host arrays: %%.1f MB per batch" %
+                              ("compact records (dg_read_c 16 B + dg_report_c 20 B, lossless)" if args.records == "compact" else "dg_read_out 36 B + dg_report_out 40 B")) % (workers[0].out_bytes(n_reads) / 1e6),
+                   "host_link": "57 GB/s in total, both directions together (profiles/probes/pcie_probe.py): bytes in + bytes out per read bound this rate",
                    "timed_region": "first batch handed over in host memory -> last record back in host memory (H2D + all kernels + D2H, %d batches in flight)" % len(workers),
                    "pairs_per_gpu_per_step": nb * args.pairs, "read_len": args.rlen, "spliced_fraction": args.spliced, "batches_in_flight_per_gpu": len(workers),
                    "synthetic_genome_repeat_content": "planted repeat families cover ~18 %% of the genome at --repeat-scale 1 (real human DNA: ~50 %%, which would move work "

@@ -59,6 +59,7 @@ struct dg_ctx {
     DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> done; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy, seed_left; DBuf<uint32_t> seed_list; DBuf<RState> seed_state;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
+    DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c;
     DBuf<unsigned char> ws;
     DBuf<unsigned long long> scan_state;
     size_t cap_seeds = 0, cap_rep = 0, cap_work = 0, cap_cig = 0;
@@ -445,7 +446,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
     c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_left.release(); c->seed_list.release(); c->seed_state.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
-    c->ws.release(); c->scan_state.release();
+    c->ws.release(); c->scan_state.release(); c->reads_c.release(); c->reports_c.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     if (c->ev_reseed0) (void)hipEventDestroy(c->ev_reseed0);
@@ -988,12 +989,79 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
 
 static int enqueue_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3])
 {
-    if (caps[0] < c->used[0] || caps[1] < c->used[1] || caps[2] < c->used[2]) { snprintf(c->err, 512, "output capacity too small"); return DG_ERR_CAPACITY; }
+    if (caps[0] < c->used[0] || caps[1] < c->used[1] || caps[2] < c->used[2]) {
+        snprintf(c->err, 512, "output capacity too small: reports %zu of %zu, cigar ops %zu of %zu, junction tuples %zu of %zu", c->used[0], caps[0], c->used[1], caps[1], c->used[2], caps[2]);
+        return DG_ERR_CAPACITY;
+    }
     if (c->n_reads && ro) HIPCHK(hipMemcpyAsync(ro, c->reads_out.p, (size_t)c->n_reads * sizeof(dg_read_out), hipMemcpyDeviceToHost, c->stream));
     if (c->used[0] && po) HIPCHK(hipMemcpyAsync(po, c->reports.p, c->used[0] * sizeof(dg_report_out), hipMemcpyDeviceToHost, c->stream));
     if (c->used[1] && cig) HIPCHK(hipMemcpyAsync(cig, c->cigfinal.p, c->used[1] * 4, hipMemcpyDeviceToHost, c->stream));
     if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, c->stream));
     return DG_OK;
+}
+
+// full records -> compact records (include/dartgpu.h); *bad is raised when a field does not fit
+__global__ void __launch_bounds__(256)
+k_pack_records(uint32_t n_reads, uint32_t n_rep, const dg_read_out *__restrict__ ro, const dg_report_out *__restrict__ po,
+               dg_read_c *__restrict__ rc, dg_report_c *__restrict__ pc, int *bad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool over = false;
+    if (i < n_reads) {
+        const dg_read_out r = ro[i];
+        dg_read_c o;
+        o.score = (uint16_t)r.score; o.sub_score = (uint16_t)r.sub_score; o.mis_num = (uint16_t)r.mis_num; o.mapq = (uint8_t)r.mapq; o.n_sj = (uint8_t)r.n_sj;
+        o.n_rep = (uint16_t)r.n_rep; o.best = (uint16_t)r.best; o.rep_off = (uint32_t)r.rep_off;
+        over = (uint32_t)r.score > 0xFFFFu || (uint32_t)r.sub_score > 0xFFFFu || (uint32_t)r.mis_num > 0xFFFFu || (uint32_t)r.mapq > 0xFFu || (uint32_t)r.n_sj > 0xFFu ||
+               (uint32_t)r.n_rep > 0xFFFFu || (uint32_t)r.best > 0xFFFFu;
+        rc[i] = o;
+    }
+    if (i < n_rep) {
+        const dg_report_out p = po[i];
+        dg_report_c o;
+        o.pos = (int32_t)p.pos; o.cigar_off = p.cigar_off; o.aln_score = (uint16_t)p.aln_score; o.flag = (uint16_t)p.flag; o.paired_idx = (int16_t)p.paired_idx;
+        o.chr = p.chr < 0 ? (uint16_t)0xFFFFu : (uint16_t)p.chr; o.n_cigar = (uint8_t)p.n_cigar; o.sj_type = (int8_t)p.sj_type; o.bdir = (uint8_t)p.bdir; o.pad = 0;
+        over = over || p.pos != (int64_t)(int32_t)p.pos || (uint32_t)p.aln_score > 0xFFFFu || (uint32_t)p.flag > 0xFFFFu || p.paired_idx > 32767 || p.paired_idx < -1 ||
+               p.chr >= 0xFFFF || p.n_cigar > 255u || p.sj_type < -128 || p.sj_type > 127 || (uint32_t)p.bdir > 1u;
+        pc[i] = o;
+    }
+    if (over) atomicMax(bad, 1);
+}
+
+extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3])
+{
+    if (!c || !caps) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (caps[0] < c->used[0] || caps[1] < c->used[1] || caps[2] < c->used[2]) {
+        snprintf(c->err, 512, "output capacity too small: reports %zu of %zu, cigar ops %zu of %zu, junction tuples %zu of %zu", c->used[0], caps[0], c->used[1], caps[1], c->used[2], caps[2]);
+        return DG_ERR_CAPACITY;
+    }
+    const size_t n = (size_t)c->n_reads, nr = c->used[0];
+    if (n == 0) return DG_OK;
+    HIPCHK(c->reads_c.ensure(n + 1)); HIPCHK(c->reports_c.ensure(nr + 1));
+    HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
+    const size_t m = n > nr ? n : nr;
+    k_pack_records<<<(unsigned)((m + 255) / 256), 256, 0, c->stream>>>((uint32_t)n, (uint32_t)nr, c->reads_out.p, c->reports.p, c->reads_c.p, c->reports_c.p, c->d_err);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&c->h_tail->err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    if (ro) HIPCHK(hipMemcpyAsync(ro, c->reads_c.p, n * sizeof(dg_read_c), hipMemcpyDeviceToHost, c->stream));
+    if (nr && po) HIPCHK(hipMemcpyAsync(po, c->reports_c.p, nr * sizeof(dg_report_c), hipMemcpyDeviceToHost, c->stream));
+    if (c->used[1] && cig) HIPCHK(hipMemcpyAsync(cig, c->cigfinal.p, c->used[1] * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->h_tail->err) { snprintf(c->err, 512, "a record field does not fit the compact types: use dg_batch_download"); return DG_ERR_RANGE; }
+    return DG_OK;
+}
+
+extern "C" int dg_map_batch_compact(dg_ctx *c, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
+                                    int rlen_all, int words_per_read, const uint32_t *words, const uint32_t *nlist, size_t n_n,
+                                    dg_read_c *ro, dg_report_c *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3], size_t used[3])
+{
+    if (!c || !caps) return DG_ERR_ARG;
+    int rc = words ? enqueue_upload_packed(c, n_reads, rlen_all, rlen, words_per_read, words, nlist, n_n) : enqueue_upload(c, n_reads, seq_off, rlen, seq);
+    if (rc) return rc;
+    if ((rc = dg_batch_run(c, used))) return rc;
+    return dg_batch_download_compact(c, ro, po, cig, so, caps);
 }
 
 extern "C" int dg_batch_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3])

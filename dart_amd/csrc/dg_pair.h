@@ -174,7 +174,7 @@ struct UnitState {
     int flag0[2];
     bool fast;            // records complete in LDS; else: candidates go to the general path
     uint32_t n_cig;       // CIGAR ops of its reports (fast only)
-    uint32_t n_one;       // 1 x 1 segment pairs met (each is an nw_alignment call of one cell in the reference: counters)
+    uint32_t n_nw, n_cells;   // nw_alignment calls / cells the reference spends on this unit's segment pairs (counters)
 };
 
 // insertion sort of a lane's seed segment in its LDS slice
@@ -189,6 +189,42 @@ __host__ __device__ __forceinline__ void d_unit_sort(SKey *key, int n)
     }
 }
 
+// nw_alignment (nw_alignment.cpp:18-82, integers x2 as d_nw in dg_report.h) of two strings of the same length g <= 8, asked one
+// question: is the traceback the plain diagonal (g columns of M, no gap)?  The DP runs row by row with the previous row in
+// registers (one strip of 8 columns, as d_nw's strips); only the cells (i,i) decide: the walk from (g,g) stays on the diagonal
+// exactly when none of them equals its r or t value.  a = read bases, b8 = genome bases (byte k = base k).
+#define SMALL_NW 8
+__host__ __device__ inline bool d_small_nw_is_diagonal(const unsigned char *a, uint64_t b8, int g)
+{
+    int sp[SMALL_NW], tp[SMALL_NW];
+    uint8_t cb[SMALL_NW];
+#pragma unroll
+    for (int q = 0; q < SMALL_NW; q++) { sp[q] = -2 - (q + 1); tp[q] = -131072; cb[q] = q < g ? d_nt4((unsigned char)(b8 >> (8 * q))) : (uint8_t)7; }
+    int diag0 = 0;
+    bool leaves = false;
+    for (int i = 1; i <= g; i++) {
+        int left_s = -2 - i, left_r = -131072;
+        const uint8_t ca = d_nt4(a[i - 1]);
+        int diag = diag0;
+        diag0 = left_s;
+#pragma unroll
+        for (int q = 0; q < SMALL_NW; q++) {
+            int x = left_r - 1, y = left_s - 3;
+            const int r = x > y ? x : y;
+            x = tp[q] - 1; y = sp[q] - 3;
+            const int t = x > y ? x : y;
+            const int d = d_tr2(diag + (ca == cb[q] ? 3 : -3));
+            const int rr = d_tr2(r), tt = d_tr2(t);
+            const int sv = d > rr ? (d > tt ? d : tt) : (rr > tt ? rr : tt);
+            leaves = leaves || (q == i - 1 && (sv == r || sv == t));
+            diag = sp[q];
+            sp[q] = sv; tp[q] = t;
+            left_s = sv; left_r = r;
+        }
+    }
+    return !leaves;
+}
+
 // GenMappingReport for the live candidates of one mate, where it reduces to "[S] M [S]": every seed of the candidate exact and on
 // one diagonal, at least one read base between neighbours, and the bases between them either equal-length with <= 2 and <= 20 %
 // mismatches (ProcessNormalSequencePair's M shortcut, tools.cpp:137-141) or a single substituted base (a 1 x 1 nw_alignment).
@@ -197,7 +233,7 @@ __host__ __device__ __forceinline__ void d_unit_sort(SKey *key, int n)
 // the pattern (nothing of this unit is then kept: the general path redoes it).
 template <int S>
 __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &pr, bool first, const unsigned char *seq, int len,
-                                               const SKey *key, uint32_t *cw, int nc, uint64_t *rw, int &n_slot, DRead &rd, uint32_t &n_cig, uint32_t &n_one)
+                                               const SKey *key, uint32_t *cw, int nc, uint64_t *rw, int &n_slot, DRead &rd, uint32_t &n_cig, uint32_t &n_nw, uint32_t &n_cells)
 {
     const int64_t L = ix.l_pac;
     rd.score = rd.sub_score = rd.mis_num = rd.mapq = rd.iBest = 0;
@@ -211,7 +247,7 @@ __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &
         if (n > 1 && diag == -1) return false;
         SKey prev = k0;
         int aln = sk_rlen(k0), mis = 0;
-        uint32_t ones = 0;
+        uint32_t calls = 0, cells = 0;
         for (int k = 1; k < n; k++) {
             const SKey cur = key[(f + k) * S];
             const int from = sk_rpos(prev) + sk_rlen(prev), g = sk_rpos(cur) - from;
@@ -225,7 +261,12 @@ __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &
                 for (int t = 0; t < e; t++) { const unsigned char ch = seq[from + q + t]; dash = dash || ch == '-'; nm += ch != (unsigned char)(ref >> (8 * t)); }
             }
             if (nm <= 2 && nm <= (int)(g * 0.2)) { aln += g - nm; mis += nm; }
-            else if (g == 1 && !dash) { ones++; mis += 1; }
+            else if (g == 1 && !dash) { calls++; cells++; mis += 1; }
+            else if (g <= SMALL_NW && !dash && d_small_nw_is_diagonal(seq + from, d_ref8(ix, gp), g)) {
+                // two substitutions a few bases apart: ProcessNormalSequencePair calls nw_alignment (tools.cpp:142-163), the
+                // alignment is g columns of M, AddNewCigarElements scores the identical characters
+                calls++; cells += (uint32_t)(g * g); aln += g - nm; mis += nm;
+            }
             else return false;
             aln += sk_rlen(cur);
             prev = cur;
@@ -252,7 +293,7 @@ __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &
         rw[(2 * slot) * S] = w0;
         rw[(2 * slot + 1) * S] = (uint64_t)head | ((uint64_t)span << 12) | ((uint64_t)tail << 24) | ((uint64_t)mis << 48);
         cw[i * S] = (w & ~(15u << 27)) | ((uint32_t)slot << 27);
-        n_one += ones;
+        n_nw += calls; n_cells += cells;
     }
     return true;
 }
@@ -276,12 +317,12 @@ __host__ __device__ inline void d_unit_process(const DIndex &ix, const DParams &
                                            [&](int first, int count, int score, int64_t) { cw[(k++) * S] = cw_make(first, count, score); });
     }
     d_candidate_rules(paired, a, b);
-    st.fast = false; st.n_cig = 0; st.n_one = 0; st.flag0[0] = st.flag0[1] = 0;
+    st.fast = false; st.n_cig = 0; st.n_nw = st.n_cells = 0; st.flag0[0] = st.flag0[1] = 0;
     if (!try_fast) return;
     int n_slot = 0;
-    uint32_t n_cig = 0, n_one = 0;
-    if (!d_unit_reports<S>(ix, pr, true, seq1, len1, key, cw, st.nc[0], rw, n_slot, st.rd[0], n_cig, n_one)) return;
-    if (paired && !d_unit_reports<S>(ix, pr, false, seq2, len2, key + n1 * S, cw + st.nc[0] * S, st.nc[1], rw, n_slot, st.rd[1], n_cig, n_one)) return;
+    uint32_t n_cig = 0, n_nw = 0, n_cells = 0;
+    if (!d_unit_reports<S>(ix, pr, true, seq1, len1, key, cw, st.nc[0], rw, n_slot, st.rd[0], n_cig, n_nw, n_cells)) return;
+    if (paired && !d_unit_reports<S>(ix, pr, false, seq2, len2, key + n1 * S, cw + st.nc[0] * S, st.nc[1], rw, n_slot, st.rd[1], n_cig, n_nw, n_cells)) return;
     RepLds<S> p1{cw, rw, st.nc[0], 0}, p2{cw + st.nc[0] * S, rw, st.nc[1], 0};
     if (paired) {
         d_settle_pair(pr, st.rd[0], p1, st.rd[1], p2);
@@ -290,7 +331,7 @@ __host__ __device__ inline void d_unit_process(const DIndex &ix, const DParams &
     } else d_flag_single(st.rd[0], p1);
     d_mapq(st.rd[0], p1);
     st.flag0[0] = p1.flag0; st.flag0[1] = p2.flag0;
-    st.fast = true; st.n_cig = n_cig; st.n_one = n_one;
+    st.fast = true; st.n_cig = n_cig; st.n_nw = n_nw; st.n_cells = n_cells;
 }
 
 // the records of one read of a fast unit, written at their final places; returns the CIGAR ops written
@@ -363,7 +404,7 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
     uint32_t *cw = s_cw + threadIdx.x;
     uint64_t *rw = s_rw + threadIdx.x;
     UnitState st;
-    st.fast = false; st.n_cig = 0; st.n_one = 0; st.nc[0] = st.nc[1] = 0; st.flag0[0] = st.flag0[1] = 0;
+    st.fast = false; st.n_cig = 0; st.n_nw = st.n_cells = 0; st.nc[0] = st.nc[1] = 0; st.flag0[0] = st.flag0[1] = 0;
     int r1 = 0, n1 = 0, n2 = 0, len1 = 0, len2 = 0;
     uint32_t b1 = 0;
     bool heavy = false;
@@ -394,7 +435,7 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
     const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 12, err);
     const uint32_t rep0 = base.x + inb.x, slow_at = base.y + inb.y;
     const uint64_t cig0 = base.z + inb.z;
-    unsigned long long n_cands = 0, n_one = 0;
+    unsigned long long n_cands = 0, n_nw = 0, n_cells = 0;
     if (valid) {
         rep_off[r1] = rep0;
         if (paired) rep_off[r1 + 1] = rep0 + nrep1;
@@ -407,7 +448,7 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
                 RepLds<PU_THREADS> p1{cw, rw, st.nc[0], st.flag0[0]}, p2{cw + st.nc[0] * PU_THREADS, rw, st.nc[1], st.flag0[1]};
                 const uint32_t c1 = d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar);
                 if (paired) d_unit_emit_read<PU_THREADS>(false, st.rd[1], p2, rep0 + nrep1, (uint32_t)cig0 + c1, rout + r1 + 1, reports, cigar);
-                n_one = st.n_one;
+                n_nw = st.n_nw; n_cells = st.n_cells;
             }
         } else {
             done[r1] = 0xFF; if (paired) done[r1 + 1] = 0xFF;
@@ -417,18 +458,18 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
         if (!heavy && (!st.fast || write_all_sorted)) {
             const int nt = n1 + n2;
             for (int i = 0; i < nt; i++) seeds[b1 + i] = key[i * PU_THREADS];
-            const uint32_t bm[2] = {b1, b1 + (uint32_t)n1};
-            int q = 0;
-            for (int m = 0; m < (paired ? 2 : 1); m++) {
-                for (int i = 0; i < st.nc[m]; i++, q++) {
-                    const uint32_t w = cw[q * PU_THREADS];
-                    const int64_t d = sk_diag(key[((m ? n1 : 0) + cw_first(w)) * PU_THREADS]);
-                    DCand c = d_new_cand(bm[m] + (uint32_t)cw_first(w), cw_count(w), cw_score(w), d < 0 ? 0 : d);
+            auto put_cands = [&](int first_cw, int first_key, uint32_t seg, int count, int r) {     // (called with constants: st stays in registers)
+                for (int i = 0; i < count; i++) {
+                    const uint32_t w = cw[(first_cw + i) * PU_THREADS];
+                    const int64_t d = sk_diag(key[(first_key + cw_first(w)) * PU_THREADS]);
+                    DCand c = d_new_cand(seg + (uint32_t)cw_first(w), cw_count(w), cw_score(w), d < 0 ? 0 : d);
                     c.PairedIdx = cw_mate(w);
-                    cands[bm[m] + i] = c;
+                    cands[seg + i] = c;
                 }
-                ncand[r1 + m] = (uint32_t)st.nc[m];
-            }
+                ncand[r] = (uint32_t)count;
+            };
+            put_cands(0, 0, b1, st.nc[0], r1);
+            if (paired) put_cands(st.nc[0], n1, b1 + (uint32_t)n1, st.nc[1], r1 + 1);
         } else if (!heavy) { ncand[r1] = (uint32_t)st.nc[0]; if (paired) ncand[r1 + 1] = (uint32_t)st.nc[1]; }
     }
     if (tile == gridDim.x - 1 && threadIdx.x == 0) {
@@ -437,6 +478,6 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
         *pool_top = (base.x + tot.x) * CIG_SLOT;                     // the report kernel's CIGAR pool: one slot group per report, overflow area behind
     }
     d_wave_add(ctr + CTR_CANDS, n_cands);
-    d_wave_add(ctr + CTR_NW, n_one);
-    d_wave_add(ctr + CTR_NWCELLS, n_one);
+    d_wave_add(ctr + CTR_NW, n_nw);
+    d_wave_add(ctr + CTR_NWCELLS, n_cells);
 }

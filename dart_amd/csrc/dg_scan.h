@@ -21,8 +21,12 @@
 struct TileScan { unsigned long long *a, *b; unsigned int *ticket; };
 struct Triple { uint32_t x, y; uint64_t z; };
 
-__device__ __forceinline__ unsigned long long ts_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ts_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// RELAXED on purpose: a state word carries its whole message (status + payload in one 64-bit atomic access that goes to the
+// device-coherent level, `sc1`), nothing else is published through it.  Acquire / release at agent scope cost a `buffer_inv sc1`
+// per poll and a `buffer_wbl2 sc1` -- a write-back of the XCD's whole L2 -- per store on gfx950: with those the scan was 90 % of
+// k_pair's time.
+__device__ __forceinline__ unsigned long long ts_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ts_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ts_pack_a(int st, uint32_t x, uint32_t y) { return ((unsigned long long)st << 62) | ((unsigned long long)(y & 0x7FFFFFFFu) << 31) | (unsigned long long)(x & 0x7FFFFFFFu); }
 __device__ __forceinline__ unsigned long long ts_pack_b(int st, uint64_t z) { return ((unsigned long long)st << 62) | (z & 0x3FFFFFFFFFFFFFFFull); }
 

@@ -32,7 +32,25 @@ READ_OUT = np.dtype([("score", "<i4"), ("sub_score", "<i4"), ("mis_num", "<i4"),
 REPORT_OUT = np.dtype([("aln_score", "<i4"), ("sj_type", "<i4"), ("flag", "<i4"), ("paired_idx", "<i4"), ("chr", "<i4"),
                        ("bdir", "<i4"), ("pos", "<i8"), ("cigar_off", "<u4"), ("n_cigar", "<u4")])
 SJ_OUT = np.dtype([("g1", "<i8"), ("g2", "<i8"), ("type", "<i4"), ("read_idx", "<i4")])
-assert READ_OUT.itemsize == 36 and REPORT_OUT.itemsize == 40 and SJ_OUT.itemsize == 24
+READ_C = np.dtype([("score", "<u2"), ("sub_score", "<u2"), ("mis_num", "<u2"), ("mapq", "u1"), ("n_sj", "u1"), ("n_rep", "<u2"), ("best", "<u2"), ("rep_off", "<u4")])
+REPORT_C = np.dtype([("pos", "<i4"), ("cigar_off", "<u4"), ("aln_score", "<u2"), ("flag", "<u2"), ("paired_idx", "<i2"), ("chr", "<u2"), ("n_cigar", "u1"),
+                     ("sj_type", "i1"), ("bdir", "u1"), ("pad", "u1")])
+assert READ_OUT.itemsize == 36 and REPORT_OUT.itemsize == 40 and SJ_OUT.itemsize == 24 and READ_C.itemsize == 16 and REPORT_C.itemsize == 20
+
+
+def expand_compact(reads_c, reports_c):
+    """dg_read_c / dg_report_c arrays -> the full record dtypes (sj_off rebuilt as the running sum of n_sj)"""
+    r = np.zeros(len(reads_c), READ_OUT)
+    for f in ("score", "sub_score", "mis_num", "mapq", "n_rep", "best", "n_sj"):
+        r[f] = reads_c[f]
+    r["rep_off"] = reads_c["rep_off"].astype(np.int64)
+    nsj = reads_c["n_sj"].astype(np.int64)
+    r["sj_off"] = np.cumsum(nsj) - nsj
+    p = np.zeros(len(reports_c), REPORT_OUT)
+    for f in ("aln_score", "sj_type", "flag", "paired_idx", "bdir", "pos", "cigar_off", "n_cigar"):
+        p[f] = reports_c[f]
+    p["chr"] = np.where(reports_c["chr"] == 0xFFFF, -1, reports_c["chr"].astype(np.int32))
+    return r, p
 
 
 class Index:
@@ -117,6 +135,8 @@ def _load_lib():
     lib.dg_batch_upload.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.dg_batch_upload_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_size_t]
     lib.dg_map_batch_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
+    lib.dg_batch_download_compact.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dg_map_batch_compact.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
     lib.dg_host_alloc.restype = C.c_void_p
     lib.dg_host_alloc.argtypes = [C.c_size_t]
     lib.dg_host_free.argtypes = [vp]
@@ -260,6 +280,16 @@ class DartGPU:
         self.upload(seq_off, rlen, flat)
         self.run()
         return self.download()
+
+    def download_compact(self) -> BatchResult:
+        """the records through the compact types (dg_batch_download_compact), expanded to the full dtypes"""
+        u = self._used
+        reads = np.zeros(self._n, dtype=READ_C); reports = np.zeros(max(u[0], 1), dtype=REPORT_C)
+        cigar = np.zeros(max(u[1], 1), dtype=np.uint32); sj = np.zeros(max(u[2], 1), dtype=SJ_OUT)
+        caps = (C.c_size_t * 3)(len(reports), len(cigar), len(sj))
+        self._chk(self.lib.dg_batch_download_compact(self.ctx, reads.ctypes.data, reports.ctypes.data, cigar.ctypes.data, sj.ctypes.data, caps), "dg_batch_download_compact")
+        r, p = expand_compact(reads, reports[:u[0]])
+        return BatchResult(r, p, cigar[:u[1]], sj[:u[2]])
 
     def upload_packed(self, words, nlist, rlen_all, rlen=None):
         self._n = int(words.shape[0])

@@ -28,7 +28,8 @@ enum dg_status {
     DG_ERR_HIP = -2,         /* a HIP call failed; text in dg_last_error                  */
     DG_ERR_ARG = -3,         /* bad argument (NULL, read longer than DG_MAX_RLEN, ...)    */
     DG_ERR_CAPACITY = -4,    /* caller's output arrays too small; `used` holds the need   */
-    DG_ERR_INTERNAL = -5
+    DG_ERR_INTERNAL = -5,
+    DG_ERR_RANGE = -6        /* a field does not fit the compact record types: use the full ones  */
 };
 
 #define DG_MAX_RLEN 1000     /* the reference's gz reader caps lines at 1024 bytes (GetData.cpp:186) */
@@ -107,6 +108,21 @@ void  dg_host_free(void *);
 int dg_map_batch_packed(dg_ctx *, int n_reads, int rlen_all, const uint16_t *rlen, int words_per_read, const uint32_t *words,
                         const uint32_t *nlist, size_t n_n, dg_read_out *, dg_report_out *, uint32_t *cigar_ops, dg_sj_out *,
                         const size_t caps[3], size_t used[3]);
+
+/* ---- compact records: the same information in 16 + 20 bytes instead of 36 + 40 ----
+ * The host link carries ~57 GB/s in total on an MI355X box (both directions together), so at several hundred million reads
+ * per second the bytes of the records ARE the throughput: 85 -> 42 bytes per read.  Lossless while the fields fit (scores and
+ * mismatches < 65536, at most 65535 reports per read / chromosomes, at most 255 CIGAR ops per report, |POS| < 2^31); when one
+ * does not, dg_batch_download_compact returns DG_ERR_RANGE and the caller takes the full records with dg_batch_download.
+ * sj_off is not carried: the tuples lie in read order, a read's tuples start at the sum of n_sj of the reads before it.     */
+typedef struct { uint16_t score, sub_score, mis_num; uint8_t mapq, n_sj; uint16_t n_rep, best; uint32_t rep_off; } dg_read_c;           /* 16 bytes */
+typedef struct { int32_t pos; uint32_t cigar_off; uint16_t aln_score, flag; int16_t paired_idx; uint16_t chr /* 0xFFFF = none */;
+                 uint8_t n_cigar; int8_t sj_type; uint8_t bdir, pad; } dg_report_c;                                                         /* 20 bytes */
+int dg_batch_download_compact(dg_ctx *, dg_read_c *, dg_report_c *, uint32_t *cigar_ops, dg_sj_out *, const size_t caps[3]);
+/* upload (ASCII when words == NULL, else packed as dg_map_batch_packed) + run + compact download in one call */
+int dg_map_batch_compact(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
+                         int rlen_all, int words_per_read, const uint32_t *words, const uint32_t *nlist, size_t n_n,
+                         dg_read_c *, dg_report_c *, uint32_t *cigar_ops, dg_sj_out *, const size_t caps[3], size_t used[3]);
 
 /* ---- the same path split so a caller can keep the batch resident in HBM (bench.py) ----
  * dg_batch_upload copies reads to the device; dg_batch_run runs the whole path on the device

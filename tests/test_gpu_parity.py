@@ -191,7 +191,7 @@ def test_gpu_size_independent_properties(workdir):
     a = gpu.map_batch(*host.pack_reads(arr[:h])); b = gpu.map_batch(*host.pack_reads(arr[h:]))
     for f in ("score", "sub_score", "mis_num", "mapq", "n_rep", "best", "n_sj"):
         assert np.array_equal(np.concatenate([a.reads[f], b.reads[f]]), whole.reads[f])
-    assert np.array_equal(np.concatenate([a.cigar, b.cigar]), whole.cigar)
+    assert np.array_equal(np.concatenate([cigars_of(a.reports, a.cigar), cigars_of(b.reports, b.cigar)]), cigars_of(whole.reports, whole.cigar))
     # permuting the pairs permutes the records
     perm = np.random.default_rng(1).permutation(30000)
     idx = np.stack([2 * perm, 2 * perm + 1], 1).reshape(-1)
@@ -362,8 +362,9 @@ def test_gpu_packed_reads_and_pinned_buffers(workdir):
     so, rl, flat = host.pack_reads(arr)
     want = orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=16)
     words, nlist = host.pack_reads_2bit(arr)
-    assert len(nlist) > 1000
+    assert len(nlist) > 300
     assert_same(gpu.map_batch_packed(words, nlist, 101), want)
+    assert_same(gpu.download_compact(), want)            # the same records through the 16 + 20 byte types
     # ragged: every read cut to its own length (the tail bases stay in the words, the lengths say where the read ends)
     rng = np.random.default_rng(5)
     lens = rng.integers(30, 102, size=len(arr)).astype(np.uint16)
@@ -384,10 +385,10 @@ def test_gpu_packed_reads_and_pinned_buffers(workdir):
     n = len(rl)
     p_so = gpu.pinned((n,), np.uint32); p_rl = gpu.pinned((n,), np.uint16); p_seq = gpu.pinned((len(flat) + 64,), np.uint8)
     p_so.a[:] = so; p_rl.a[:] = rl; p_seq.a[:len(flat)] = flat
-    caps = (C.c_size_t * 3)(n * 4, n * 16, n * 2); used = (C.c_size_t * 3)()
+    caps = (C.c_size_t * 3)(n * 8, n * 16, n * 2); used = (C.c_size_t * 3)()     # (a repeat-rich genome: ~5 reports per read)
     o_r = gpu.pinned((n,), host.READ_OUT); o_p = gpu.pinned((caps[0],), host.REPORT_OUT); o_c = gpu.pinned((caps[1],), np.uint32); o_s = gpu.pinned((caps[2],), host.SJ_OUT)
     rc = gpu.lib.dg_map_batch(gpu.ctx, n, p_so.a.ctypes.data, p_rl.a.ctypes.data, p_seq.a.ctypes.data, o_r.a.ctypes.data, o_p.a.ctypes.data, o_c.a.ctypes.data, o_s.a.ctypes.data, caps, used)
-    assert rc == 0
+    assert rc == 0, (rc, gpu.lib.dg_last_error(gpu.ctx), list(used), list(caps))
     assert_same(host.BatchResult(o_r.a.copy(), o_p.a[:used[0]].copy(), o_c.a[:used[1]].copy(), o_s.a[:used[2]].copy()), want)
     for p in (p_so, p_rl, p_seq, o_r, o_p, o_c, o_s):
         p.free()
@@ -410,4 +411,26 @@ def test_gpu_capacity_estimates_grow_and_results_stay(workdir):
     assert len(want[1]) > 3 * len(rl)                    # many reports per read: the first estimate (1.25 per read) is too small
     assert_same(gpu.map_batch(so, rl, flat), want)
     assert_same(gpu.map_batch(so[:200], rl[:200], flat), orc.map_batch(orc.params(paired=1, **p), so[:200], rl[:200], flat, threads=4))
+    gpu.close(); orc.close()
+
+
+def test_gpu_compact_records_range_and_wide_chromosome_table(workdir):
+    """66 000 chromosomes: the chromosome index does not fit k_pair's report slots (every unit takes the general path) nor the
+    compact record types (dg_batch_download_compact answers DG_ERR_RANGE, the full records are right)"""
+    g = synth.make_genome([120] * 66000, seed=5, repeat_scale=0.0)
+    prefix = os.path.join(workdir, "manychr")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    gpu = host.DartGPU(ix, host.default_params(paired=0, max_mismatch=3))
+    s1, _ = synth.make_reads(g, 6000, rlen=60, seed=6, paired=False, indel_frac=0.0, n_frac=0.0)
+    so, rl, flat = host.pack_reads(s1)
+    want = orc.map_batch(orc.params(paired=0, max_mismatch=3), so, rl, flat, threads=8)
+    assert int(want[1]["chr"].max()) > 0xFFFF
+    res = gpu.map_batch(so, rl, flat)
+    assert_same(res, want)
+    assert gpu.counters()["general_path_units"] == len(rl)
+    with pytest.raises(RuntimeError) as e:
+        gpu.download_compact()
+    assert "(-6)" in str(e.value)
+    assert_same(gpu.map_batch(so[:2000], rl[:2000], flat), orc.map_batch(orc.params(paired=0, max_mismatch=3), so[:2000], rl[:2000], flat, threads=8))
     gpu.close(); orc.close()
