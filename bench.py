@@ -298,12 +298,15 @@ def main():
 
     def gather(w):
         nonlocal gather_buf
-        local_t = w.gpu.device_reads_tensor()
+        local_t = w.gpu.device_reads_tensor(compact=(w.last_records == "compact"))      # 16 (or 36) bytes per read, straight from HBM
         if rehearse:
             local_t = local_t.cpu()
-        if rank == 0 and gather_buf is None:
-            gather_buf = [torch.empty_like(local_t) for _ in range(world)]
-        dist.gather(local_t, gather_buf if rank == 0 else None, dst=0)
+        if gather_buf is None:
+            gather_buf = {}
+        key = tuple(local_t.shape)
+        if rank == 0 and key not in gather_buf:
+            gather_buf[key] = [torch.empty_like(local_t) for _ in range(world)]
+        dist.gather(local_t, gather_buf[key] if rank == 0 else None, dst=0)
         if not rehearse:
             torch.cuda.current_stream().synchronize()       # the context's next run overwrites these records
 
@@ -508,7 +511,7 @@ def main():
                    "pairs_per_gpu_per_step": nb * args.pairs, "read_len": args.rlen, "spliced_fraction": args.spliced, "batches_in_flight_per_gpu": len(workers),
                    "synthetic_genome_repeat_content": "planted repeat families cover ~18 %% of the genome at --repeat-scale 1 (real human DNA: ~50 %%, which would move work "
                                                       "from k_pair to the wave-per-unit kernels and the general report path)",
-                   "parallelism": ("reads sharded x%d, index replicated" % world) + (", RCCL gather of the per-read records to rank 0 inside the timed region" if do_gather else ", no data-path collective")},
+                   "parallelism": ("reads sharded x%d, index replicated" % world) + (", RCCL gather of the per-read records (%d B per read) to rank 0 inside the timed region" % (16 if args.records == "compact" else 36) if do_gather else ", no data-path collective")},
         "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
         "kernels_ms_one_batch_in_flight": {k: round(v, 4) for k, v in iso.items()},
         "counters_per_launch": counters,

@@ -1104,6 +1104,13 @@ extern "C" int dg_batch_device_ptrs(dg_ctx *c, void *ptrs[4])
     return DG_OK;
 }
 
+extern "C" int dg_batch_device_ptrs_compact(dg_ctx *c, void *ptrs[2])
+{
+    if (!c || !ptrs) return DG_ERR_ARG;
+    ptrs[0] = c->reads_c.p; ptrs[1] = c->reports_c.p;
+    return DG_OK;
+}
+
 // ---- roofline calibration (not in the public header): random 64-byte block reads over the resident
 // Occ array, the access pattern of k_seed / k_locate without any of their arithmetic.
 // dependent = 1: the next block index depends on the loaded data (a chain per lane, like an FM walk);

@@ -143,6 +143,7 @@ def _load_lib():
     lib.dg_batch_run.argtypes = [vp, vp]
     lib.dg_batch_download.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.dg_batch_device_ptrs.argtypes = [vp, vp]
+    lib.dg_batch_device_ptrs_compact.argtypes = [vp, vp]
     lib.dg_last_timings.argtypes = [vp, vp, vp, C.c_int]
     lib.dg_last_counters.argtypes = [vp, vp, C.c_int]
     lib.dg_probe_seeds.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
@@ -307,16 +308,19 @@ class DartGPU:
     def pinned(self, shape, dtype) -> "PinnedArray":
         return PinnedArray(self.lib, shape, dtype)
 
-    def device_reads_tensor(self):
-        """torch uint8 view [n_reads, 36] of the per-read records in HBM (for RCCL collectives)."""
+    def device_reads_tensor(self, compact: bool = False):
+        """torch uint8 view [n_reads, 36] (or [n_reads, 16] of the compact type) of the per-read records in HBM (for RCCL collectives)."""
         import torch
         ptrs = (C.c_void_p * 4)()
-        self._chk(self.lib.dg_batch_device_ptrs(self.ctx, ptrs), "dg_batch_device_ptrs")
+        if compact:
+            self._chk(self.lib.dg_batch_device_ptrs_compact(self.ctx, ptrs), "dg_batch_device_ptrs_compact")
+        else:
+            self._chk(self.lib.dg_batch_device_ptrs(self.ctx, ptrs), "dg_batch_device_ptrs")
 
         class _View:
             pass
         v = _View()
-        v.__cuda_array_interface__ = {"shape": (self._n, READ_OUT.itemsize), "typestr": "|u1", "data": (int(ptrs[0]), False), "version": 2}
+        v.__cuda_array_interface__ = {"shape": (self._n, READ_C.itemsize if compact else READ_OUT.itemsize), "typestr": "|u1", "data": (int(ptrs[0]), False), "version": 2}
         return torch.as_tensor(v, device="cuda")
 
     def timings(self):

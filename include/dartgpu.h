@@ -137,6 +137,8 @@ int dg_batch_download(dg_ctx *, dg_read_out *, dg_report_out *, uint32_t *cigar_
  * ptrs[0] dg_read_out[n_reads], [1] dg_report_out[used0], [2] cigar u32[used1], [3] dg_sj_out[used2].
  * Lets a caller hand the records to RCCL (torch.distributed) without a host round trip.       */
 int dg_batch_device_ptrs(dg_ctx *, void *ptrs[4]);
+/* the compact records of the last dg_batch_download_compact / dg_map_batch_compact in HBM: [0] dg_read_c[n_reads], [1] dg_report_c[used0] */
+int dg_batch_device_ptrs_compact(dg_ctx *, void *ptrs[2]);
 
 /* per-kernel device time of the last dg_batch_run, measured with HIP events on the library's
  * stream: names[i] -> ms[i]; returns the number of entries written (<= cap)                   */
