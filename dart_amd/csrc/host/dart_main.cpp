@@ -31,6 +31,8 @@
 #include <thread>
 #include <vector>
 
+#include "fast_fastq.h"
+
 static const char *VersionStr = "1.4.6";
 
 struct Options {
@@ -334,7 +336,6 @@ static bool check_read_format(const char *fn)   // CheckReadFormat, Mapping.cpp:
 // ---------------------------------------------------------------------------------------------
 // SAM text
 // ---------------------------------------------------------------------------------------------
-struct Counters { long long total = 0, unique = 0, unmapped = 0, paired = 0; };
 static const char *XS_A[3] = { "", " XS:A:+", " XS:A:-" };
 
 // decimal text without snprintf (the formatter was spending most of its time there)
@@ -457,6 +458,16 @@ int main(int argc, char *argv[])
         }
         if (!ok) return 0;
     }
+    // page-locked batch slots for the parallel FASTQ pipeline: allocated in the background while the index loads
+    int n_gpu = getenv("DART_GPUS") ? atoi(getenv("DART_GPUS")) : 1; if (n_gpu < 1) n_gpu = 1;
+    size_t batch_reads = getenv("DART_BATCH") ? (size_t)atoll(getenv("DART_BATCH")) : 1000000; batch_reads = std::max<size_t>(4000, batch_reads & ~(size_t)1);
+    const int inflight_cfg = std::max(1, getenv("DART_INFLIGHT") ? atoi(getenv("DART_INFLIGHT")) : 2);
+    SlotPool pool;
+    {
+        const std::string &fn0 = o.f1[0];
+        if (!getenv("DART_STREAMING") && fn0.substr(fn0.find_last_of('.') + 1) != "gz" && check_read_format(fn0.c_str()))
+            pool.start((size_t)n_gpu * inflight_cfg + 2, batch_reads, 160);
+    }
     HostIndex ix;
     if (!o.index || !file_exists(std::string(o.index) + ".ann") || !file_exists(std::string(o.index) + ".amb") || !file_exists(std::string(o.index) + ".pac")) {
         fprintf(stderr, "Error! Please specify a valid reference index!\n"); usage(argv[0], o); return 1;
@@ -465,12 +476,10 @@ int main(int argc, char *argv[])
     if (!load_index(o.index, ix)) { fprintf(stderr, "\n\nError! Index files are corrupt!\n"); return 0; }
     fprintf(stdout, "\nLoad the reference sequences...\n");
 
-    int n_gpu = getenv("DART_GPUS") ? atoi(getenv("DART_GPUS")) : 1; if (n_gpu < 1) n_gpu = 1;
-    size_t batch_reads = getenv("DART_BATCH") ? (size_t)atoll(getenv("DART_BATCH")) : 1000000; batch_reads = std::max<size_t>(4000, batch_reads & ~(size_t)1);
     std::vector<dg_ctx *> ctx, roots, clones;
     dg_index_view view = ix.view();
 
-    FILE *sam = fopen(o.out, "w");
+    FILE *sam = fopen(o.out, "w+");     // (read access too: the parallel pipeline maps the file to write it)
     if (!sam) { fprintf(stderr, "Cannot write %s\n", o.out); return 1; }
     fprintf(sam, "@PG\tID:Dart\tPN:Dart\tVN:%s\n", VersionStr);
     for (size_t i = 0; i < ix.names.size(); i++) fprintf(sam, "@SQ\tSN:%s\tLN:%lld\n", ix.names[i].c_str(), (long long)ix.len[i]);
@@ -494,12 +503,14 @@ int main(int argc, char *argv[])
         }
         if (!s1.fp && !s1.gz) continue;
         if (sep && !s2.fp && !s2.gz) continue;
+        // plain FASTQ goes through the parallel host pipeline (fast_fastq.h); FASTA, .gz and DART_STREAMING=1 through the streaming one below
+        const bool fast_host = fastq && !gz && !getenv("DART_STREAMING") && (!sep || o.f2[lib].substr(o.f2[lib].find_last_of('.') + 1) != "gz");
         // the mate files start being parsed now, i.e. also while dg_init uploads the index and builds its tables
         Prefetch pf1, pf2;
-        if (sep) { pf1.start(&s1, false); pf2.start(&s2, pair_end); }
+        if (sep && !fast_host) { pf1.start(&s1, false); pf2.start(&s2, pair_end); }
         if (ctx.empty()) {   // contexts are created once the first library opens (so flag errors never touch the GPU)
             o.p.paired = pair_end ? 1 : 0;
-            const int inflight = std::max(1, getenv("DART_INFLIGHT") ? atoi(getenv("DART_INFLIGHT")) : 1);
+            const int inflight = inflight_cfg;
             for (int d = 0; d < n_gpu; d++) {
                 int st = 0; dg_ctx *c = dg_init(&view, &o.p, d, &st);
                 if (!c) { fprintf(stderr, "Error! GPU %d: %s\n", d, dg_last_error(nullptr)); return 1; }
@@ -510,6 +521,19 @@ int main(int argc, char *argv[])
                     ctx.push_back(cl); clones.push_back(cl);
                 }
             }
+        }
+        if (fast_host) {
+            fflush(sam);
+            uint64_t off = (uint64_t)ftello(sam);
+            std::string ferr; FastStats fst;
+            const int frc = run_fast_library(fn.c_str(), sep ? o.f2[lib].c_str() : nullptr, pair_end, o.threads, batch_reads, ctx, o.p, ix.names, o.unique, o.multi, o.silent,
+                                             fileno(sam), &off, total, sjmap, t0, ferr, fst, pool);
+            fseeko(sam, (off_t)off, SEEK_SET);
+            if (frc) { fprintf(stderr, "\nError! GPU mapping failed (%d): %s\n", frc, ferr.c_str()); return 1; }
+            if (getenv("DART_TIMING")) fprintf(stderr, "[dart timing] index %.3f s, assemble %.3f s (of which page-locked allocation %.3f s), map (sum over workers) %.3f s, format %.3f s, write %.3f s\n", fst.t_index, fst.t_asm, fst.t_alloc, fst.t_map, fst.t_fmt, fst.t_write);
+            if (s1.fp) fclose(s1.fp);
+            if (s2.fp) fclose(s2.fp);
+            continue;
         }
         // ---- three-stage pipeline: reader thread -> mapping workers (one per context) -> ordered writer ----
         // Contexts = devices x DART_INFLIGHT (dg_clone: contexts of a device share its index), so the next batch is

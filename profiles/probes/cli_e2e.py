@@ -12,10 +12,14 @@ label, gnames, glens = bench.genome_spec(sys.argv[2] if len(sys.argv) > 2 else "
 print(label + ")")
 prefix, g = bench.prepare_index("/tmp/dart_bench_cache", (gnames, glens), 0, lambda: None)
 m1, m2 = synth.make_reads(g, pairs, rlen=101, seed=1000, sub_rate=0.01, indel_frac=0.02, n_frac=0.002)
-d = "/tmp/cli_e2e"; os.makedirs(d, exist_ok=True)
+import shutil
+need = pairs * 2 * 560                     # FASTQ in + SAM out
+d = "/dev/shm/cli_e2e" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need * 1.2 else "/tmp/cli_e2e"
+os.makedirs(d, exist_ok=True)
+print("files under", d)
 synth.write_fastq(os.path.join(d, "1.fq"), m1, 1); synth.write_fastq(os.path.join(d, "2.fq"), m2, 2)
 dart = os.path.join(ROOT, "dart_amd", "dart")
-for env_extra in ({"DART_INFLIGHT": "1"}, {"DART_INFLIGHT": "2"}):
+for env_extra in ({"DART_INFLIGHT": "2", "DART_STREAMING": "1"}, {"DART_INFLIGHT": "2"}, {"DART_INFLIGHT": "2", "DART_WRITE": "mmap"}, {"DART_INFLIGHT": "2", "DART_PINNED": "1"}, {"DART_INFLIGHT": "2", "DART_BATCH": "500000"}):
     env = dict(os.environ, DART_TIMING="1", **env_extra)
     t = time.time()
     r = subprocess.run([dart, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-o", "gpu.sam", "-j", "gpu.j", "-t", "16", "-mis", "5"], cwd=d, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)

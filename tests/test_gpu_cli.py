@@ -26,16 +26,61 @@ def test_dart_cli_reproduces_golden_sam(workdir):
             assert open(os.path.join(d, "o.j")).read() == common.golden_junctions(run["base"])
 
 
+@pytest.mark.parametrize("host_path", ["parallel", "streaming"])
 @pytest.mark.parametrize("flags,label", cli_inputs.VARIANTS, ids=[v[1] for v in cli_inputs.VARIANTS])
-def test_dart_cli_matches_oracle_cli_on_input_variants(flags, label, workdir):
+def test_dart_cli_matches_oracle_cli_on_input_variants(flags, label, host_path, workdir):
+    """both host pipelines of `dart` (the parallel one takes plain FASTQ: fast_fastq.h; the streaming one everything, and all of it
+    with DART_STREAMING=1) against the oracle's command line, byte for byte"""
     oracle_py.build()
     c, d = cli_inputs.make(workdir)
     env = dict(os.environ, DART_BATCH="5000")      # several batches, so batch seams are exercised too
-    subprocess.run([DART, "-i", c["prefix"]] + flags + ["-o", "gpu.sam", "-j", "gpu.j"], cwd=d, stdout=subprocess.DEVNULL, check=True, env=env)
+    if host_path == "streaming":
+        env["DART_STREAMING"] = "1"
+    subprocess.run([DART, "-i", c["prefix"]] + flags + ["-o", "gpu.sam", "-j", "gpu.j", "-t", "3"], cwd=d, stdout=subprocess.DEVNULL, check=True, env=env)
     subprocess.run([oracle_py.ORACLE_CLI, "-i", c["prefix"]] + flags + ["-o", "orc.sam", "-j", "orc.j"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
     a, b = open(os.path.join(d, "orc.sam")).read(), open(os.path.join(d, "gpu.sam")).read()
     assert a == b, common.first_diff(b, a)
     assert open(os.path.join(d, "orc.j")).read() == open(os.path.join(d, "gpu.j")).read()
+
+
+@pytest.mark.parametrize("host_path", ["parallel", "streaming"])
+def test_dart_cli_awkward_fastq(host_path, workdir):
+    """FASTQ the readers must agree on with the reference's GetNextEntry (GetData.cpp:77-132): headers with blanks / slashes / tabs and
+    repeated '@', quality lines that start with '@' or '+', qualities longer than the read (shorter ones are undefined behaviour in
+    the reference: GetData.cpp:158-159 copies rlen bytes out of a shorter string), lower-case and IUPAC bases, a last
+    line without newline, 4001+ reads so the 4000-read chunk rule decides the unpaired tail of an odd -p file, and -- second file --
+    a record without bases in the middle (the stream ends there)"""
+    oracle_py.build()
+    c, d0 = cli_inputs.make(workdir)
+    d = os.path.join(workdir, "awkward"); os.makedirs(d, exist_ok=True)
+    m1, m2 = synth.make_reads(c["genome"], 4603, rlen=101, seed=78, spliced_frac=0.2)
+    def rec(i, seq, tag):
+        s = seq.tobytes().decode()
+        if i % 7 == 1: s = s[:40].lower() + s[40:]
+        if i % 11 == 2: s = s[:10] + "R" + s[11:]
+        q = "".join(chr(33 + (i * 7 + k * 3) % 41) for k in range(len(s)))
+        if i % 5 == 0: q = "@" + q[1:]
+        if i % 13 == 3: q = "+" + q[1:]
+        if i % 19 == 5: q = q + "IIII"
+        h = ["@r%d/%s" % (i, tag), "@@r%d extra words" % i, "@r%d\tx" % i, "@r%d" % i][i % 4]
+        return "%s\n%s\n+%s\n%s\n" % (h, s, "" if i % 3 else h[1:], q)
+    with open(os.path.join(d, "a1.fq"), "w") as f:
+        f.write("".join(rec(i, m1[i], "1") for i in range(4603))[:-1])            # no newline at the end
+    with open(os.path.join(d, "a2.fq"), "w") as f:
+        f.write("".join(rec(i, m2[i], "2") for i in range(4603)))
+    with open(os.path.join(d, "inter_odd.fq"), "w") as f:
+        f.write("".join(rec(i, m1[i], "1") + (rec(i, m2[i], "2") if i < 4302 else "") for i in range(4303)))
+    with open(os.path.join(d, "stop.fq"), "w") as f:
+        f.write("".join(rec(i, m1[i], "1") for i in range(700)) + "@empty\n\n+\n\n" + "".join(rec(i, m1[i], "1") for i in range(700, 900)))
+    env = dict(os.environ, DART_BATCH="4000")
+    if host_path == "streaming":
+        env["DART_STREAMING"] = "1"
+    for flags in (["-f", "a1.fq", "-f2", "a2.fq", "-mis", "5"], ["-f", "inter_odd.fq", "-p", "-mis", "5"], ["-f", "stop.fq", "-mis", "3"], ["-f", "a1.fq", "a2.fq", "-mis", "2", "-m"]):
+        subprocess.run([DART, "-i", c["prefix"]] + flags + ["-o", "gpu.sam", "-j", "gpu.j", "-t", "5"], cwd=d, stdout=subprocess.DEVNULL, check=True, env=env)
+        subprocess.run([oracle_py.ORACLE_CLI, "-i", c["prefix"]] + flags + ["-o", "orc.sam", "-j", "orc.j"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        a, b = open(os.path.join(d, "orc.sam"), "rb").read(), open(os.path.join(d, "gpu.sam"), "rb").read()
+        assert a == b, (flags, common.first_diff(b.decode("latin1"), a.decode("latin1")))
+        assert open(os.path.join(d, "orc.j")).read() == open(os.path.join(d, "gpu.j")).read()
 
 
 def test_dart_cli_error_behaviour(workdir):
