@@ -7,6 +7,7 @@
 #include "dg_report.h"
 #include "dg_pair.h"
 #include "dg_reseed.h"
+#include "dg_sort.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1198,6 +1199,41 @@ extern "C" int dg_last_counters(dg_ctx *c, uint64_t *out, int cap)
     const uint64_t extra[3] = { c->h_tail ? c->h_tail->sizes.n_slow_units : 0u, c->h_tail ? c->h_tail->tops[TOP_HEAVY_UNITS] : 0u, (uint64_t)c->runs_of_last_batch };
     for (int i = 0; i < 3 && k < cap; i++) out[k++] = extra[i];
     return k;
+}
+
+// ---- the index builder's sorter (dg_sort.h): stable radix sort of n (key, value) pairs in device memory, ascending by the low
+// key_bits bits of the key.  keys/vals hold the input and the result; *_tmp are scratch of the same size.  Runs on the NULL
+// stream of `device` (so it is ordered with a caller that uses the default stream, e.g. torch) and returns when it is done.
+extern "C" int dg_sort_pairs(int device, uint64_t *keys, int64_t *vals, uint64_t *keys_tmp, int64_t *vals_tmp, size_t n, int key_bits)
+{
+    dg_ctx *c = nullptr;                                   // (HIPCHK reports through the init error string)
+    if (!keys || !vals || !keys_tmp || !vals_tmp || key_bits < 1 || key_bits > 64 || n >= 0xFFFFF000ull) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(device));
+    if (n < 2) return DG_OK;
+    const uint32_t tiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE), m = 16u * tiles;
+    const uint32_t scan_tiles = (m + SCAN_TILE - 1) / SCAN_TILE;
+    uint32_t *hist = nullptr, *sums = nullptr;
+    HIPCHK(hipMalloc((void **)&hist, ((size_t)m + 1) * 4));
+    if (hipMalloc((void **)&sums, ((size_t)scan_tiles + 1) * 4) != hipSuccess) { (void)hipFree(hist); return DG_ERR_HIP; }
+    uint64_t *ka = keys, *kb = keys_tmp; int64_t *va = vals, *vb = vals_tmp;
+    hipError_t e = hipSuccess;
+    for (int shift = 0; shift < key_bits && e == hipSuccess; shift += 4) {
+        k_rs_hist<<<tiles, 256, 0, 0>>>(ka, (uint32_t)n, shift, tiles, hist);
+        k_scan_tiles<<<scan_tiles, 256, 0, 0>>>(hist, hist, sums, m);
+        k_scan_top<<<1, 256, 0, 0>>>(sums, scan_tiles, hist + m, nullptr, 0, nullptr, 0);
+        k_scan_add<<<(m + 255) / 256, 256, 0, 0>>>(hist, sums, m);
+        k_rs_scatter<<<tiles, 256, 0, 0>>>(ka, va, kb, vb, (uint32_t)n, shift, tiles, hist);
+        e = hipGetLastError();
+        std::swap(ka, kb); std::swap(va, vb);
+    }
+    if (e == hipSuccess && ka != keys) {
+        e = hipMemcpyAsync(keys, ka, n * 8, hipMemcpyDeviceToDevice, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(vals, va, n * 8, hipMemcpyDeviceToDevice, 0);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(0);
+    (void)hipFree(hist); (void)hipFree(sums);
+    if (e != hipSuccess) return fail(nullptr, DG_ERR_HIP, "dg_sort_pairs", e);
+    return DG_OK;
 }
 
 // ---- stage probes ----

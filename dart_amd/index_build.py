@@ -6,9 +6,10 @@ The index files are a pure function of the text, so any correct suffix sorter re
 reference's files byte for byte (SURVEY.md 8a, "Format validated here");
 tests/test_oracle_golden.py::test_index_builder_matches_reference_indexer checks that against the digests of
 oracle/_ref/bwt_index's files (CPU path) and tests/test_gpu_index.py does the same for the GPU path.  The suffix array comes from prefix doubling with
-torch.sort, which runs on the MI355X when one is present (chr20-sized text: seconds) and on the
-CPU otherwise (fine for the <= few-Mbp test genomes).  This is scope row 8f#1 ("next"), kept in
-Python on purpose: it is plumbing around the hot path, not the hot path.
+one sort of (rank pair, suffix) per round: on the MI355X that sort is the library's own radix sort (dg_sort_pairs,
+dart_amd/csrc/dg_sort.h -- hand-written HIP, 4 bits per pass, LDS-staged tiles), on the CPU (the <= few-Mbp genomes of the CPU
+suite) torch.sort.  The orchestration around the sort (rank updates, bucketing, BWT/Occ packing) is element-wise torch: plumbing.
+Scope row 8f#1 ("next").
 
 Layout facts restated from the reference:
   .pac  forward strand, 2 bit/base MSB first; +1 zero byte when l_pac%4==0; last byte = l_pac%4
@@ -91,6 +92,34 @@ def pack_sequences(seqs):
     return (np.concatenate(out) if out else np.zeros(0, np.uint8)), holes, n_ambs
 
 
+_lib = None
+
+
+def sort_pairs(key: torch.Tensor, key_bits: int):
+    """(sorted keys, order) of a non-negative int64 key tensor.  On the GPU this is the library's own radix sort (dg_sort_pairs,
+    dart_amd/csrc/dg_sort.h: stable, 4 bits per pass, key_bits says how many low bits matter); on the CPU (the small test genomes of
+    the CPU suite) torch.sort.  No silent fallback on the GPU: without libdartgpu.so the build fails."""
+    if key.device.type != "cuda":
+        return torch.sort(key)
+    global _lib
+    if _lib is None:
+        import ctypes as C
+        from . import host
+        _lib = host._load_lib()
+        _lib.dg_sort_pairs.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    m = int(key.numel())
+    vals = torch.arange(m, dtype=torch.int64, device=key.device)
+    if m < 2:
+        return key, vals
+    key = key.contiguous()
+    tk, tv = torch.empty_like(key), torch.empty_like(vals)
+    torch.cuda.current_stream(key.device).synchronize()          # (the sorter runs on the NULL stream)
+    rc = _lib.dg_sort_pairs(key.device.index or 0, key.data_ptr(), vals.data_ptr(), tk.data_ptr(), tv.data_ptr(), m, int(key_bits))
+    if rc != 0:
+        raise RuntimeError("dg_sort_pairs failed (%d)" % rc)
+    return key, vals
+
+
 def suffix_array(codes: torch.Tensor) -> torch.Tensor:
     """Suffix array of codes+'$' ('$' smallest) by prefix doubling. Returns int64 [n+1]."""
     dev = codes.device
@@ -103,7 +132,7 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
     for j in range(k0):
         key = key * 5 + t[j:j + N]
     del t
-    sk, sa = torch.sort(key)
+    sk, sa = sort_pairs(key, 38)                       # 16 symbols base 5 < 2^38
     del key
     flag = torch.ones(N, dtype=torch.int64, device=dev)
     flag[1:] = (sk[1:] != sk[:-1]).to(torch.int64)
@@ -119,7 +148,7 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
             r2[:N - k] = rank[k:] + 1
         key = rank * (N + 1) + r2
         del r2
-        sk, sa = torch.sort(key)
+        sk, sa = sort_pairs(key, max(1, (N * (N + 1) + N).bit_length()))
         del key
         flag = torch.ones(N, dtype=torch.int64, device=dev)
         flag[1:] = (sk[1:] != sk[:-1]).to(torch.int64)
@@ -181,7 +210,7 @@ def suffix_array_bucketed(codes: torch.Tensor, log=None) -> torch.Tensor:
         key = torch.zeros(m, dtype=torch.int64, device=dev)
         for j in range(k0):
             key = key * 5 + t[idx + j].to(torch.int64)
-        sk, order = torch.sort(key)
+        sk, order = sort_pairs(key, 38)
         del key
         members = idx[order]
         del idx, order
@@ -205,7 +234,7 @@ def suffix_array_bucketed(codes: torch.Tensor, log=None) -> torch.Tensor:
             r2 = torch.where(nxt < N, rank[nxt.clamp(max=N - 1)] + 1, torch.zeros_like(nxt))
             key = (r1 << 34) | r2                                 # r2 <= N < 2^34
             del r1, r2, nxt
-            sk, order = torch.sort(key)
+            sk, order = sort_pairs(key, 63)
             del key
             members = members[order]
             del order

@@ -152,6 +152,12 @@ int dg_last_timings(dg_ctx *, const char **names, float *ms, int cap);
  * [20] how many times the batch was enqueued (> 1: a capacity estimate was too small and the batch ran again)          */
 int dg_last_counters(dg_ctx *, uint64_t *out, int cap);
 
+/* ---- the index builder's sorter (replaces the suffix sorting inside BWT_Index/bwtindex.c:77-148) ----
+ * Stable radix sort of n < 2^32 (key, value) pairs in DEVICE memory, ascending by the low key_bits bits of the key; keys/vals hold the
+ * input and the result, *_tmp are scratch of the same size.  Runs on the device's NULL stream and returns when done.
+ * dart_amd/index_build.py drives it (prefix doubling: one sort of (rank pair, suffix) per round).                              */
+int dg_sort_pairs(int device, uint64_t *keys, int64_t *vals, uint64_t *keys_tmp, int64_t *vals_tmp, size_t n, int key_bits);
+
 /* ---- stage probes (parity tests of single kernels; mirror oracle/dart_oracle.h) ----
  * seeds of every read after the (gPos,rPos) sort (IdentifySeedPairs, AlignmentCandidates.cpp:181-215):
  * read i owns [seed_off[i], seed_off[i+1]) of rpos/slen/gpos; seed_off has n_reads+1 entries. */

@@ -26,3 +26,19 @@ def test_gpu_index_builder_matches_reference_indexer(name, sorter, workdir, monk
     index_build.build_index_from_genome(g, prefix, device="cuda")
     for ext, want in common.MANIFEST["manifest"][name]["index_sha256"].items():
         assert common.sha(prefix + "." + ext) == want, "GPU-built .%s differs from the reference bwt_index output (%s sorter)" % (ext, sorter)
+
+
+def test_gpu_radix_sort_matches_stable_sort():
+    """dg_sort_pairs (dart_amd/csrc/dg_sort.h), the index builder's sorter: random keys of several widths and counts (not multiples of
+    the 4096-pair tile, heavy duplicates, a single distinct key) against torch's stable sort -- keys AND the order of equal keys"""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    for n, bits, distinct in ((1, 8, None), (2, 1, None), (4095, 13, None), (4097, 38, None), (300001, 63, None), (1000003, 20, 37), (2500000, 38, 1), (777777, 4, None)):
+        hi = (1 << bits) if distinct is None else distinct
+        key = torch.randint(0, min(hi, (1 << 62)), (n,), dtype=torch.int64, device="cuda", generator=g)
+        if bits == 63:
+            key = key | (torch.randint(0, 2, (n,), dtype=torch.int64, device="cuda", generator=g) << 62)
+        want_k, want_o = torch.sort(key, stable=True)
+        got_k, got_o = index_build.sort_pairs(key.clone(), bits)
+        assert torch.equal(got_k, want_k), (n, bits)
+        assert torch.equal(got_o, want_o), (n, bits, "order of equal keys")
