@@ -34,7 +34,7 @@ template <typename T> struct DBuf {
 #define N_TIMERS 20
 #define N_TOPS 32               // small device counters of a batch (bump tops, tickets, list sizes), zeroed per run
 enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAVY_UNITS, TOP_SEED_NEXT, TOP_SEED_HEAVY, TOP_ROUNDS /* 8..14 */,
-       TOP_WORK = 16, TOP_TICKET_PAIR, TOP_TICKET_EMIT };
+       TOP_WORK = 16, TOP_TICKET_PAIR, TOP_TICKET_EMIT, TOP_RESEED_COUNT /* 19..21 */, TOP_RESEED_TICKET = 22 /* 22..24 */ };
 
 struct dg_ctx {
     int device = 0;
@@ -57,7 +57,7 @@ struct dg_ctx {
     // them without asking the device for a size first, the device reports what it needed (DSizes) and flags an overflow
     // (d_err >= DG_ABORT), in which case the host grows the buffer and runs the batch again
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, rep_off, tile_sums, tile_read, slow_units;
-    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint8_t> done; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy, seed_left; DBuf<uint32_t> seed_list; DBuf<RState> seed_state;
+    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint32_t> job_lists; DBuf<uint8_t> done; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy, seed_left; DBuf<uint32_t> seed_list; DBuf<RState> seed_state;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c;
@@ -445,7 +445,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     if (c->h_tail) (void)hipHostFree(c->h_tail);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->packed_in.release(); c->nlist_in.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
-    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_left.release(); c->seed_list.release(); c->seed_state.release();
+    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_lists.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_left.release(); c->seed_list.release(); c->seed_state.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release(); c->scan_state.release(); c->reads_c.release(); c->reports_c.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -512,7 +512,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     }
     if ((e = hipMalloc(&c->d_sa, sa_bytes)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc sa", e);
     if ((e = hipMemcpy(c->d_sa, v->sa, sa_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload sa", e);
-    if ((e = hipMalloc(&c->d_pac, pac_bytes + 1024)) != hipSuccess || (e = hipMemset(c->d_pac, 0, pac_bytes + 1024)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc pac", e);
+    if ((e = hipMalloc(&c->d_pac, pac_bytes + 4096)) != hipSuccess || (e = hipMemset(c->d_pac, 0, pac_bytes + 4096)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc pac", e);
     if ((e = hipMemcpy(c->d_pac, v->pac, pac_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload pac", e);
     {
         const int n = v->n_chr;
@@ -823,7 +823,7 @@ static int enqueue_run(dg_ctx *c)
     const size_t cigcap = (size_t)n * 48 + c->cap_rep * (16 + CIG_SLOT) + 4096, sjcap = (size_t)n * 4 + 1024;
     HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n)); HIPCHK(c->done.ensure((size_t)n + 16));
     HIPCHK(c->heavy.ensure((size_t)n_units + 16)); HIPCHK(c->slow_units.ensure((size_t)n_units + 16));
-    HIPCHK(c->reports.ensure(c->cap_rep + 1)); HIPCHK(c->work.ensure(c->cap_work + 16)); HIPCHK(c->jobs.ensure(c->cap_seeds + 16));
+    HIPCHK(c->reports.ensure(c->cap_rep + 1)); HIPCHK(c->work.ensure(c->cap_work + 16)); HIPCHK(c->jobs.ensure(c->cap_seeds + 16)); HIPCHK(c->job_lists.ensure(3 * c->jobs.cap + 16));
     HIPCHK(c->cigpool.ensure(cigcap)); HIPCHK(c->cigfinal.ensure(c->cap_cig + 16)); HIPCHK(c->sjpool.ensure(sjcap)); HIPCHK(c->sjfinal.ensure(sjcap));
     HIPCHK(c->perm.ensure((size_t)n + 16)); HIPCHK(c->hist.ensure((size_t)COST_CLASSES * nb * 2 + 16));
     unsigned int *tops = c->d_tops;
@@ -874,9 +874,11 @@ static int enqueue_run(dg_ctx *c)
     HIPCHK(hipEventRecord(c->ev_prep, c->stream));
     HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_prep, 0));
     HIPCHK(hipEventRecord(c->ev_reseed0, c->stream2));
-    k_reseed<1><<<c->n_cu * 8, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_ctr, c->d_err);
-    k_reseed<2><<<c->n_cu * 5, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_ctr, c->d_err);
-    k_reseed<4><<<c->n_cu * 3, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_ctr, c->d_err);
+    const uint32_t jobcap = (uint32_t)c->jobs.cap;
+    k_order_jobs<<<1, 1024, 0, c->stream2>>>(c->jobs.p, tops + TOP_JOBS, jobcap, c->job_lists.p, tops + TOP_RESEED_COUNT, c->d_err);
+    k_reseed<1><<<c->n_cu * 10, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p, tops + TOP_RESEED_COUNT, tops + TOP_RESEED_TICKET, c->d_ctr, c->d_err);
+    k_reseed<2><<<c->n_cu * 6, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + jobcap, tops + TOP_RESEED_COUNT + 1, tops + TOP_RESEED_TICKET + 1, c->d_ctr, c->d_err);
+    k_reseed<4><<<c->n_cu * 4, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + 2 * (size_t)jobcap, tops + TOP_RESEED_COUNT + 2, tops + TOP_RESEED_TICKET + 2, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_reseed1, c->stream2));
     k_cost<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->seed_off.p, c->cands.p, c->ncand.p, c->done.p, c->hist.p, c->d_err);
@@ -914,7 +916,8 @@ static int enqueue_run(dg_ctx *c)
 #endif
     TICK("k_report");
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_reseed1, 0));
-    k_report<2><<<blocks_main < c->n_cu ? blocks_main : c->n_cu, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
+    // (the reads that waited for k_reseed: a handful on DNA, a third of a spliced batch -- the full persistent grid; waves without work leave at once)
+    k_report<2><<<blocks_main, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
                                                c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, heavy_end_p, single_first_p, 1, c->reads_out.p, c->reports.p, c->cigpool.p,
                                                (uint32_t)cigcap, tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
@@ -1195,7 +1198,7 @@ extern "C" int dg_last_counters(dg_ctx *c, uint64_t *out, int cap)
     if (!c) return 0;
     int k = CTR_N < cap ? CTR_N : cap;
     for (int i = 0; i < k; i++) out[i] = c->counters[i];
-    // [18] units that took the general path, [19] units chained by a wave each, [20] times the batch was enqueued (> 1: a buffer grew)
+    // [20] units that took the general path, [21] units chained by a wave each, [22] times the batch was enqueued (> 1: a buffer grew)
     const uint64_t extra[3] = { c->h_tail ? c->h_tail->sizes.n_slow_units : 0u, c->h_tail ? c->h_tail->tops[TOP_HEAVY_UNITS] : 0u, (uint64_t)c->runs_of_last_batch };
     for (int i = 0; i < 3 && k < cap; i++) out[k++] = extra[i];
     return k;

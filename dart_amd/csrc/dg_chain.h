@@ -229,6 +229,7 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
     __shared__ SKey ls[2][CH_MAXS];
     __shared__ DCand lc[2][CH_MAXC];
     __shared__ int s_n[2], s_pairing;
+    __shared__ int16_t s_pick[CH_MAXC];
     if (*abort_p >= DG_ABORT) return;
     const int lane = threadIdx.x;
     const unsigned int n_heavy = *n_heavy_p;
@@ -272,29 +273,35 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
                 if (n1 * n2 > 1000) { if (lane == 0) { d_keep_top(a1); d_keep_top(a2); } __syncthreads(); }
                 if (lane == 0) s_pairing = 0;
                 __syncthreads();
-                for (int i = 0; i < n1; i++) {                       // d_pair_mates with the inner search spread over the wave
-                    if (a1.score(i) == 0) continue;                  // uniform: read from LDS by every lane
-                    const int64_t here = a1.diag(i);
-                    int64_t reach = 2000000; int pick = 0x7FFFFFFF;
-                    for (int j = lane; j < n2; j += 64) {
-                        if (a2.score(j) == 0) continue;
-                        const int64_t ahead = a2.diag(j) - here;
-                        if (ahead >= 0 && ahead < reach) { reach = ahead; pick = j; }     // per lane: first minimum in increasing j
+                // d_pair_mates in two steps: which partner a candidate would pick depends only on scores and PosDiffs, which the
+                // pairing does not change -- so all picks are made first, 64 candidates of mate 1 at a time (every lane scans mate 2's
+                // list: broadcast LDS reads), and lane 0 then replays the take / change-hands decisions in candidate order
+                for (int i = lane; i < n1; i += 64) {
+                    int pick = -1;
+                    if (a1.score(i) != 0) {
+                        const int64_t here = a1.diag(i);
+                        int64_t reach = 2000000;
+                        for (int j = 0; j < n2; j++) {
+                            if (a2.score(j) == 0) continue;
+                            const int64_t ahead = a2.diag(j) - here;
+                            if (ahead >= 0 && ahead < reach) { reach = ahead; pick = j; }
+                        }
                     }
-                    for (int o = 32; o > 0; o >>= 1) {               // wave minimum of (distance, j): first minimum overall
-                        const int64_t od = __shfl_xor(reach, o, 64); const int oj = __shfl_xor(pick, o, 64);
-                        if (od < reach || (od == reach && oj < pick)) { reach = od; pick = oj; }
-                    }
-                    if (lane == 0 && reach < 2000000) {
+                    s_pick[i] = (int16_t)pick;
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    for (int i = 0; i < n1; i++) {
+                        const int pick = s_pick[i];
+                        if (pick < 0) continue;
                         const int holder = a2.mate(pick);
-                        bool take = true;
                         if (holder < 0) s_pairing = 1;
                         else if (a1.score(i) > a1.score(holder)) a1.set_mate(holder, -1);
-                        else take = false;
-                        if (take) { a1.set_mate(i, pick); a2.set_mate(pick, i); }
+                        else continue;
+                        a1.set_mate(i, pick); a2.set_mate(pick, i);
                     }
-                    __syncthreads();
                 }
+                __syncthreads();
                 if (lane == 0) {
                     if (s_pairing) d_settle_mates(a1, a2);
                     d_keep_top(a1); d_keep_top(a2);

@@ -135,39 +135,54 @@ struct RsFold { int s, max_len, best_r; int64_t best_g, next_fin; };
 // LDS ring of diagonals, word-major (ring[w * RS_RING + slot]) so that 64 consecutive diagonals are
 // read conflict-free; `dirty` has one bit per group of 64 diagonals that received a hit.
 // Folds the complete diagonal groups below `lim` (all remaining ones when `final`) into st, in
-// increasing diagonal order; every lane of the wave calls it with the same arguments.
+// increasing diagonal order; every lane of the wave calls it with the same arguments.  Only the groups
+// whose dirty bit is set cost anything: the mask is read once and walked in a scalar register.
 template <int WORDS>
 __device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, uint32_t *dirty, RsFold &st, const int64_t lim, const bool final, const int lane)
 {
-    while (st.next_fin + 64 <= lim || (final && st.next_fin < lim)) {
-        const int64_t b0 = st.next_fin;
-        const uint32_t gbit = 1u << ((uint32_t)((uint64_t)b0 >> 6) & (RS_RING / 64 - 1));
-        if (*dirty & gbit) {
+    static_assert(RS_RING / 64 == 16, "the dirty mask is walked as a 16-bit rotation");
+    const int64_t room = lim - st.next_fin;
+    const int ng = final ? (room > 0 ? (int)((room + 63) >> 6) : 0) : (room >= 64 ? (int)(room >> 6) : 0);   // (at most 16: the ring never holds more)
+    if (ng == 0) return;
+    const uint32_t dm = __builtin_amdgcn_readfirstlane(*dirty);
+    if (dm) {
+        const uint32_t gi = (uint32_t)((uint64_t)st.next_fin >> 6) & 15u;
+        uint32_t m = ((dm | (dm << 16)) >> gi) & (ng >= 16 ? 0xFFFFu : ((1u << ng) - 1u));        // bit k: group next_fin + 64 k has hits
+        uint32_t cleared = 0;
+        while (m) {
+            const int k = __ffs((int)m) - 1;
+            m &= m - 1;
+            const int64_t b0 = st.next_fin + 64 * k;
+            cleared |= 1u << ((gi + (uint32_t)k) & 15u);
             const int slot = (int)((uint64_t)(b0 + lane) & (RS_RING - 1));
-            int cnt = 0, first = -1, last = -1;
+            int cnt = 0, first = 0, last = 0;
+            bool any = false;
 #pragma unroll
             for (int w = 0; w < WORDS; w++) {
                 const unsigned long long v = ring[w * RS_RING + slot];
                 if (v) {
                     cnt += __popcll(v);
-                    if (first < 0) first = w * 64 + (__ffsll((long long)v) - 1);
+                    if (!any) first = w * 64 + (__ffsll((long long)v) - 1);
+                    any = true;
                     last = w * 64 + 63 - __clzll((long long)v);
                     ring[w * RS_RING + slot] = 0;
                 }
             }
-            if (lane == 0) *dirty &= ~gbit;
-            unsigned long long mask = __ballot(cnt > 0);
+            const uint32_t pk = (uint32_t)cnt | ((uint32_t)first << 9) | ((uint32_t)last << 17);      // cnt <= 256, first / last < 256
+            unsigned long long mask = __ballot(any);
             while (mask) {
                 const int l = __ffsll((long long)mask) - 1;
-                const int c = __shfl(cnt, l, 64), f = __shfl(first, l, 64), la = __shfl(last, l, 64);
+                const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)pk, l);
+                const int c = (int)(q & 511u), f = (int)((q >> 9) & 255u), la = (int)(q >> 17);
                 st.s += c - 1;
                 const int len = 8 + (la - f);
                 if (len > st.max_len && st.s > (len - 8) / 2) { st.best_r = f; st.best_g = b0 + l + f; st.max_len = len; st.s = 1; }
                 mask &= mask - 1;
             }
         }
-        st.next_fin = b0 + 64;
+        if (lane == 0) *dirty = dm & ~cleared;
     }
+    st.next_fin += 64 * (int64_t)ng;
 }
 
 // the block is ONE wave: LDS operations of a wave complete in order, so ordering needs only a
@@ -177,62 +192,126 @@ __device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, uint32_t
 #define RS_CHUNK 512             // window positions per trip: one coalesced pac load, RS_PPL consecutive positions per lane;
                                  // live diagonals: span + 63 + RS_CHUNK <= RS_RING
 #define RS_PPL (RS_CHUNK / 64)
+#define RS_SUPER (8 * RS_CHUNK)  // window positions per pac fetch: one uint4 per lane covers eight chunks, so a wave waits for memory once
+                                 // per 4096 positions instead of once per 512 (the fetch of chunk g+1 issued during chunk g did not
+                                 // hide a miss: 4.6 us per chunk was the latency, not the work)
+
+// Work order of the re-seeding jobs: per ring size (1, 2, 4 bitmap words per diagonal) the jobs of that size, longest window first
+// (32 length classes by the position of the top bit): windows are log-uniform up to MaxIntronSize, a wave takes one window at a
+// time, so with the static job -> wave assignment of round 1 the kernel's time was the unluckiest wave's (one 500 kb window = 1000
+// chunks after the others had finished).  lists[w] (w = 0, 1, 2) holds the job indices, counts[w] their number.  One workgroup.
+__global__ void __launch_bounds__(1024)
+k_order_jobs(const DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, uint32_t jobcap, uint32_t *__restrict__ lists, unsigned int *__restrict__ counts,
+             const int *__restrict__ abort_p)
+{
+    __shared__ unsigned int hist[3 * 32], start[3 * 32];
+    if (*abort_p >= DG_ABORT) return;
+    const unsigned int njobs = *jobtop < jobcap ? *jobtop : jobcap;
+    if (threadIdx.x < 96) hist[threadIdx.x] = 0;
+    __syncthreads();
+    auto cls = [](const DJob &j, int &w, int &b) -> bool {
+        if (j.found < 0) return false;                                    // too long for the LDS ring: serial path in k_report
+        const int need = j.rl >= 8 ? (j.rl - 8) / 64 + 1 : 1;
+        w = need <= 1 ? 0 : (need <= 2 ? 1 : 2);
+        b = 31 - (j.glen > 0 ? 31 - __clz(j.glen) : 0);                    // longest windows -> class 0
+        return true;
+    };
+    for (unsigned int i = threadIdx.x; i < njobs; i += blockDim.x) { int w, b; if (cls(jobs[i], w, b)) atomicAdd(&hist[w * 32 + b], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 3) { unsigned int run = 0; for (int b = 0; b < 32; b++) { start[threadIdx.x * 32 + b] = run; run += hist[threadIdx.x * 32 + b]; } counts[threadIdx.x] = run; }
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < njobs; i += blockDim.x) { int w, b; if (cls(jobs[i], w, b)) lists[(size_t)w * jobcap + atomicAdd(&start[w * 32 + b], 1u)] = i; }
+}
+
+#define RS_TAB      512          // open-addressing table: 8-mer id -> first entry of km[] with that id (at most 256 ids: half full)
+#define RS_FLT_BITS 14           // the bitmap filter looks at the low 14 bits of an id (2 KB); the table decides
+#define RS_EMPTY    0xFFFFFFFFu
+__device__ __forceinline__ uint32_t d_rs_hash(uint32_t w) { return (w ^ (w >> 7)) & (RS_TAB - 1); }
 
 // WORDS = 64-bit bitmap words per diagonal: a job with read gap rl needs (rl - 8) / 64 + 1 of them; the kernel is
-// instantiated for 1, 2 and 4 (8 / 16 / 32 KB of ring, so 8 / 5 / 3 waves per CU) and each instance takes the jobs of its size
+// instantiated for 1, 2 and 4 (8 / 16 / 32 KB of ring + 6.5 KB of tables: 10 / 6 / 4 waves per CU) and each instance takes the
+// jobs of its size.  Keys of the read gap's 8-mers are (id << 9 | position): ids stay below 2^17 (CreateKmerID adds
+// nst_nt4_table values up to 5 without masking), positions below 512.
+// Per trip a wave looks at RS_CHUNK window positions, RS_PPL consecutive ones per lane: the lane's 15 bases come from two
+// dwords of the staged pac bytes (reverse half: bit-reversed and complemented once, not per 8-mer), every 8-mer is one
+// bit-field extract, the bitmap says which of them can be in the read gap at all (0.3 % are), and those go through the
+// table -- one or two LDS reads -- to their entries of km[].
 template <int WORDS>
 __global__ void __launch_bounds__(64)
 k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off,
-         DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, uint32_t jobcap, unsigned long long *ctr, const int *__restrict__ abort_p)
+         DJob *__restrict__ jobs, const uint32_t *__restrict__ list, const unsigned int *__restrict__ count_p, unsigned int *ticket, unsigned long long *ctr, const int *__restrict__ abort_p)
 {
     __shared__ unsigned char rs[RS_MAX_RL + 9];
-    __shared__ uint64_t tmpk[RS_MAX_RL + 1], km[RS_MAX_RL + 1];
-    __shared__ uint32_t flt[2048];
+    __shared__ uint32_t km[RS_MAX_RL + 1];
+    __shared__ uint32_t flt[(1 << RS_FLT_BITS) / 32];
+    __shared__ uint32_t tab[RS_TAB];
     __shared__ unsigned long long ring[RS_RING * WORDS];
-    __shared__ uint32_t pacbuf[68];
+    __shared__ uint32_t pacbuf[RS_SUPER / 16 + 16];         // one super-chunk of pac: RS_SUPER / 4 bytes + alignment slack
     __shared__ uint32_t s_dirty;
     __shared__ int s_nk;
+    __shared__ unsigned int s_next;
+    uint32_t *tmpk = (uint32_t *)ring;                       // the unsorted keys live in the ring's space until the ring is cleared
     const int lane = threadIdx.x;
     if (*abort_p >= DG_ABORT) return;
-    const unsigned int njobs = *jobtop < jobcap ? *jobtop : jobcap;
+    const unsigned int njobs = *count_p;               // this ring size's jobs, longest window first (k_order_jobs)
     const int64_t L = ix.l_pac;
-    unsigned long long n_done = 0, w_done = 0;
-    for (unsigned int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
+    const uint64_t t_start = wall_clock64();
+    unsigned long long n_done = 0, w_done = 0, n_trips = 0;
+    while (true) {
+        __syncthreads();
+        if (lane == 0) s_next = atomicAdd(ticket, 1u);
+        __syncthreads();
+        if (s_next >= njobs) break;
+        const unsigned int jb = list[s_next];
         const DJob job = jobs[jb];
-        if (job.found < 0) continue;                    // too long for the LDS ring: serial path in k_report
         const int rl = job.rl, glen = job.glen;
-        {
-            const int need = rl >= 8 ? (rl - 8) / 64 + 1 : 1;
-            if ((need <= 1 ? 1 : (need <= 2 ? 2 : 4)) != WORDS) continue;
-        }
         int thr = (int)(rl * 0.85); if (thr < 8) thr = 8;
         n_done += 1; w_done += (unsigned long long)(glen > 0 ? glen : 0);
         const unsigned char *rd = seq + seq_off[job.read] + job.rBegin;
-        __syncthreads();
-        for (int i = lane; i < rl; i += 64) rs[i] = rd[i];
-        for (int i = lane; i < 2048; i += 64) flt[i] = 0;
-        for (int i = lane; i < RS_RING * WORDS; i += 64) ring[i] = 0;
+        bool plain = true;                                   // only A, C, G, T, N in the gap (any case for the four): the 8-mer ids need no carries
+        for (int i = lane; i < rl + 8; i += 64) {
+            const unsigned char ch = i < rl ? rd[i] : (unsigned char)'N';
+            rs[i] = ch;
+            if (i < rl && ch != 'N' && d_nt4(ch) > 3) plain = false;
+        }
+        for (int i = lane; i < (1 << RS_FLT_BITS) / 32; i += 64) flt[i] = 0;
+        for (int i = lane; i < RS_TAB; i += 64) tab[i] = RS_EMPTY;
         if (lane == 0) s_dirty = 0;
+        plain = __ballot(!plain) == 0;
         __syncthreads();
-        if (lane == 0) {   // CreateKmerVecFromReadSeq :34-80 on the read gap, position order
+        // CreateKmerVecFromReadSeq :34-80 on the read gap: one key per position whose 8 bases hold no 'N'
+        if (plain) {
+            int nk = 0;
+            for (int base = 0; base + 8 <= rl; base += 64) {
+                const int head = base + lane;
+                bool ok = head + 8 <= rl;
+                uint32_t wid = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const unsigned char ch = rs[head + i]; ok = ok && ch != 'N'; wid = (wid << 2) + (d_nt4(ch) & 3u); }
+                const unsigned long long mk = __ballot(ok);
+                if (ok) tmpk[nk + __popcll(mk & ((1ull << lane) - 1ull))] = (wid << 9) | (uint32_t)head;
+                nk += __popcll(mk);
+            }
+            if (lane == 0) s_nk = nk;
+        } else if (lane == 0) {   // the reference's rolling form, literally: a letter outside ACGTN carries into the id
             int nk = 0, count = 0, head, tail = 0;
             uint32_t wid = 0;
             while (count < 8 && tail < rl) { if (rs[tail++] != 'N') count++; else count = 0; }
             if (count == 8) {
                 head = tail - 8; wid = 0;
                 for (int i = head; i < head + 8; i++) wid = (wid << 2) + d_nt4(rs[i]);
-                tmpk[nk++] = ((uint64_t)wid << 32) | (uint32_t)head;
+                tmpk[nk++] = (wid << 9) | (uint32_t)head;
                 for (head += 1; tail < rl; head++, tail++) {
                     if (rs[tail] != 'N') {
                         wid = ((wid & 0x3FFF) << 2) + d_nt4(rs[tail]);
-                        tmpk[nk++] = ((uint64_t)wid << 32) | (uint32_t)head;
+                        tmpk[nk++] = (wid << 9) | (uint32_t)head;
                     } else {
                         count = 0; tail++;
                         while (count < 8 && tail < rl) { if (rs[tail++] != 'N') count++; else count = 0; }
                         if (count == 8) {
                             head = tail - 8; wid = 0;
                             for (int i = head; i < head + 8; i++) wid = (wid << 2) + d_nt4(rs[i]);
-                            tmpk[nk++] = ((uint64_t)wid << 32) | (uint32_t)head;
+                            tmpk[nk++] = (wid << 9) | (uint32_t)head;
                         } else break;
                     }
                 }
@@ -244,13 +323,22 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
         int found = 0, best_r = 0, max_len = 0;
         int64_t best_g = 0;
         if (nk > 0 && glen >= 8) {
-            for (int e = lane; e < nk; e += 64) {       // rank sort by (wid,pos); keys are distinct
-                const uint64_t key = tmpk[e];
+            for (int e = lane; e < nk; e += 64) {           // rank sort by (id, position); keys are distinct
+                const uint32_t key = tmpk[e];
                 int rank = 0;
                 for (int j = 0; j < nk; j++) rank += tmpk[j] < key ? 1 : 0;
                 km[rank] = key;
-                const uint32_t w16 = (uint32_t)(key >> 32) & 0xFFFFu;
-                atomicOr(&flt[w16 >> 5], 1u << (w16 & 31));
+                const uint32_t fw = (key >> 9) & ((1u << RS_FLT_BITS) - 1u);
+                atomicOr(&flt[fw >> 5], 1u << (fw & 31));
+            }
+            __syncthreads();
+            for (int i = lane; i < RS_RING * WORDS; i += 64) ring[i] = 0;       // (tmpk is dead from here)
+            for (int e = lane; e < nk; e += 64) {            // the first entry of every id goes into the table
+                const uint32_t id = km[e] >> 9;
+                if (e == 0 || (km[e - 1] >> 9) != id) {
+                    uint32_t slot = d_rs_hash(id);
+                    while (atomicCAS(&tab[slot], RS_EMPTY, (id << 9) | (uint32_t)e) != RS_EMPTY) slot = (slot + 1) & (RS_TAB - 1);
+                }
             }
             __syncthreads();
             const int span = rl - 8;
@@ -259,73 +347,73 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
             // window entirely inside one strand half -> k-mers come from coalesced pac dwords staged in LDS
             const bool fwd = job.Lb >= 0 && job.Lb + glen <= L;
             const bool rev = job.Lb >= L && job.Lb + glen <= 2 * L;
-            auto chunk_base = [&](int g0) -> int64_t {                  // first pac byte (4-aligned) of chunk g0
-                if (fwd) return (int64_t)(((job.Lb + g0) >> 2) & ~(int64_t)3);
-                int64_t ulo = 2 * L - 1 - (job.Lb + g0 + RS_CHUNK - 1) - 7;
+            auto super_base = [&](int gs) -> int64_t {                  // first pac byte (16-aligned) of the super-chunk that starts at window position gs
+                if (fwd) return (int64_t)(((job.Lb + gs) >> 2) & ~(int64_t)15);
+                int64_t ulo = 2 * L - 1 - (job.Lb + gs + RS_SUPER - 1) - 7;
                 if (ulo < 0) ulo = 0;
-                return (int64_t)((ulo >> 2) & ~(int64_t)3);
+                return (int64_t)((ulo >> 2) & ~(int64_t)15);
             };
-            uint32_t pre0 = 0, pre1 = 0;
+            uint4 pre = make_uint4(0, 0, 0, 0), pre_t = make_uint4(0, 0, 0, 0);
             if (fwd || rev) {
-                const uint32_t *src = (const uint32_t *)(ix.pac + chunk_base(0));
-                pre0 = src[lane]; if (lane < 4) pre1 = src[64 + lane];
+                const uint4 *src = (const uint4 *)(ix.pac + super_base(0));
+                pre = src[lane]; if (lane < 4) pre_t = src[64 + lane];
             }
+            int64_t B0 = 0;
             for (int g0 = 0; g0 + 8 <= glen; g0 += RS_CHUNK) {
+                n_trips++;
                 d_rs_finalize<WORDS>(ring, &s_dirty, st, (int64_t)g0 - span, false, lane);
-                uint64_t x = 0;                 // the lane's RS_PPL + 7 bases, first base in the top bits
-                int o_rev = 0;
+                const int p0 = g0 + RS_PPL * lane;
+                uint32_t y = 0;                 // the lane's RS_PPL + 7 window bases (and one more), first base in the top bits
                 if (fwd || rev) {
-                    const int64_t B0 = chunk_base(g0);
-                    RS_WAVE_SYNC();
-                    pacbuf[lane] = pre0; if (lane < 4) pacbuf[64 + lane] = pre1;
-                    if (g0 + RS_CHUNK + 8 <= glen) {                    // prefetch the next chunk while this one is processed
-                        const uint32_t *src = (const uint32_t *)(ix.pac + chunk_base(g0 + RS_CHUNK));
-                        pre0 = src[lane]; if (lane < 4) pre1 = src[64 + lane];
+                    if (g0 % RS_SUPER == 0) {                              // (uniform) a new super-chunk: the fetch issued one super-chunk ago has arrived
+                        B0 = super_base(g0);
+                        RS_WAVE_SYNC();
+                        ((uint4 *)pacbuf)[lane] = pre; if (lane < 4) ((uint4 *)pacbuf)[64 + lane] = pre_t;
+                        if (g0 + RS_SUPER + 8 <= glen) {
+                            const uint4 *src = (const uint4 *)(ix.pac + super_base(g0 + RS_SUPER));
+                            pre = src[lane]; if (lane < 4) pre_t = src[64 + lane];
+                        }
+                        RS_WAVE_SYNC();
                     }
-                    RS_WAVE_SYNC();
                     // first forward base this lane needs, relative to base 4*B0 of the staged bytes
-                    int64_t fb;
-                    if (fwd) fb = job.Lb + g0 + RS_PPL * lane - 4 * B0;
-                    else { fb = 2 * L - 1 - (job.Lb + g0 + RS_PPL * lane + RS_PPL - 1) - 7 - 4 * B0; if (fb < 0) { o_rev = (int)-fb; fb = 0; } }
-                    const int m = (int)(fb >> 4), o = (int)(fb & 15);                 // dword index, base offset inside it
-                    const uint32_t w0 = __builtin_bswap32(pacbuf[m]), w1 = __builtin_bswap32(pacbuf[m + 1]), w2 = __builtin_bswap32(pacbuf[m + 2]);
-                    const uint64_t hi = ((uint64_t)w0 << 32) | w1;
-                    x = o ? ((hi << (2 * o)) | ((uint64_t)w2 >> (32 - 2 * o))) : hi;
-                    if (o_rev) x = o_rev > 23 ? 0 : x >> (2 * o_rev);     // window start of the reverse half clipped at forward base 0 (never a valid position)
+                    int fb, o_rev = 0;
+                    if (fwd) fb = (int)(job.Lb + p0 - 4 * B0);
+                    else { const int64_t f64 = 2 * L - 1 - (job.Lb + p0 + RS_PPL - 1) - 7 - 4 * B0; fb = (int)f64; if (f64 < 0) { o_rev = f64 < -64 ? 64 : (int)-f64; fb = 0; } }
+                    const int m = fb >> 4, o = fb & 15;                                   // dword index, base offset inside it
+                    const uint32_t w0 = __builtin_bswap32(pacbuf[m]), w1 = __builtin_bswap32(pacbuf[m + 1]);
+                    uint32_t f = o ? ((w0 << (2 * o)) | (w1 >> (32 - 2 * o))) : w0;       // 16 forward bases from fb on
+                    if (fwd) y = f;
+                    else {
+                        // window base k is the complement of forward base 14 - k: the 2-bit groups reversed, one group up, complemented
+                        if (o_rev) f = o_rev > 15 ? 0u : f >> (2 * o_rev);   // window start clipped at forward base 0 (never a valid position)
+                        uint32_t r = __builtin_bitreverse32(f);
+                        r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+                        y = ~r << 2;
+                    }
+                } else {                                                    // straddles the strand boundary or the end of the text
+                    for (int i = 0; i < RS_PPL + 7; i++)
+                        if (p0 + i < glen) y |= (uint32_t)(d_nt4((unsigned char)d_refchar(ix, job.Lb + p0 + i)) & 3u) << (30 - 2 * i);
                 }
-                uint32_t wid[RS_PPL];
+                const int n_valid = glen - 7 - p0;                          // positions p0 + j with j < n_valid have their 8 bases inside the window
                 uint32_t pass = 0;
 #pragma unroll
                 for (int j = 0; j < RS_PPL; j++) {
-                    const int p = g0 + RS_PPL * lane + j;
-                    uint32_t w;
-                    if (fwd) w = (uint32_t)(x >> (48 - 2 * j)) & 0xFFFFu;
-                    else if (rev) {
-                        uint32_t f = (uint32_t)(x >> (48 - 2 * (RS_PPL - 1 - j))) & 0xFFFFu;      // forward 8-mer, mirrored position
-                        f = ((f & 0x3333u) << 2) | ((f >> 2) & 0x3333u);
-                        f = ((f & 0x0F0Fu) << 4) | ((f >> 4) & 0x0F0Fu);
-                        f = ((f << 8) | (f >> 8)) & 0xFFFFu;
-                        w = f ^ 0xFFFFu;
-                    } else w = p + 8 <= glen ? d_window_kmer(ix, job.Lb + p) : 0u;
-                    wid[j] = w;
+                    const uint32_t fw = (y >> (16 - 2 * j)) & ((1u << RS_FLT_BITS) - 1u);
+                    pass |= ((flt[fw >> 5] >> (fw & 31)) & 1u) << j;
                 }
-#pragma unroll
-                for (int j = 0; j < RS_PPL; j++) {
-                    const uint32_t w16 = wid[j] & 0xFFFFu;
-                    const bool ok = g0 + RS_PPL * lane + j + 8 <= glen;
-                    pass |= (ok ? ((flt[w16 >> 5] >> (w16 & 31)) & 1u) : 0u) << j;
-                }
+                pass &= n_valid >= RS_PPL ? (1u << RS_PPL) - 1u : (n_valid > 0 ? (1u << n_valid) - 1u : 0u);
                 while (pass) {
                     const int j = __ffs((int)pass) - 1;
                     pass &= pass - 1;
-                    const int p = g0 + RS_PPL * lane + j;
-                    uint32_t w = wid[0];
-#pragma unroll
-                    for (int q = 1; q < RS_PPL; q++) w = j == q ? wid[q] : w;
-                    int lo = 0, hi2 = nk;
-                    while (lo < hi2) { const int mid = (lo + hi2) >> 1; if ((uint32_t)(km[mid] >> 32) < w) lo = mid + 1; else hi2 = mid; }
-                    for (; lo < nk && (uint32_t)(km[lo] >> 32) == w; lo++) {
-                        const int rp = (int)(uint32_t)km[lo];
+                    const uint32_t w = (y >> (16 - 2 * j)) & 0xFFFFu;
+                    uint32_t slot = d_rs_hash(w), e = tab[slot];
+                    for (int t = 0; e != RS_EMPTY && (e >> 9) != w && t < RS_TAB; t++) { slot = (slot + 1) & (RS_TAB - 1); e = tab[slot]; }
+                    if (e == RS_EMPTY || (e >> 9) != w) continue;                          // only the low bits of the id were in the read gap
+                    const int p = p0 + j;
+                    for (int lo = (int)(e & 511u); lo < nk; lo++) {
+                        const uint32_t key = km[lo];
+                        if ((key >> 9) != w) break;
+                        const int rp = (int)(key & 511u);
                         const int64_t d = (int64_t)p - rp;
                         atomicOr(&ring[(rp >> 6) * RS_RING + (int)((uint64_t)d & (RS_RING - 1))], 1ull << (rp & 63));
                         atomicOr(&s_dirty, 1u << ((uint32_t)((uint64_t)d >> 6) & (RS_RING / 64 - 1)));
@@ -342,5 +430,10 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
             o.found = found; o.len = max_len; o.rPos = best_r + job.rBegin; o.gPos = best_g + job.Lb;
         }
     }
-    if (lane == 0) { if (n_done) atomicAdd(d_ctr_stripe(ctr) + CTR_RESEED, n_done); if (w_done) atomicAdd(d_ctr_stripe(ctr) + CTR_RESEEDW, w_done); }
+    if (lane == 0) {
+        if (n_done) atomicAdd(d_ctr_stripe(ctr) + CTR_RESEED, n_done);
+        if (w_done) atomicAdd(d_ctr_stripe(ctr) + CTR_RESEEDW, w_done);
+        if (n_trips) atomicAdd(d_ctr_stripe(ctr) + CTR_RESEED_TRIPS, n_trips);
+        atomicAdd(d_ctr_stripe(ctr) + CTR_RESEED_TICKS, (unsigned long long)(wall_clock64() - t_start));
+    }
 }
