@@ -3,6 +3,7 @@
 #include "../../include/dartgpu.h"
 #include "dg_common.h"
 #include "dg_fm.h"
+#include "dg_seedq.h"
 #include "dg_chain.h"
 #include "dg_report.h"
 #include "dg_pair.h"
@@ -39,6 +40,7 @@ enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAV
 struct dg_ctx {
     int device = 0;
     bool owns_index = true;       // false for dg_clone()d contexts: the index arrays belong to the parent
+    size_t seedq_lds_set = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr;
     float reseed_ms = 0;
@@ -73,13 +75,14 @@ struct dg_ctx {
     uint64_t counters[CTR_N];
     int n_cu = 256, runs_of_last_batch = 0;
     // environment switches, read once per context (not per batch)
-    int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_rounds = 0, env_round_steps = 4, env_round_bpc = 16, env_report_bpc = 8, env_no_fast = 0;
+    int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_rounds = 0, env_round_steps = 4, env_round_bpc = 16, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0;
 };
 
 static void read_env(dg_ctx *c)
 {
     auto geti = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
     c->env_seed_waves = geti("DG_SEED_WAVES", 4); c->env_bail_trips = geti("DG_SEED_BAIL_TRIPS", 128); c->env_both = geti("DG_SEED_BOTH", 0);
+    c->env_seed_legacy = geti("DG_SEED_LEGACY", 0); c->env_seed_slots_lg = geti("DG_SEED_SLOTS_LG", 0); c->env_seed_wgs = geti("DG_SEED_WGS", 0);
     c->env_rounds = geti("DG_SEED_ROUNDS", 0); c->env_round_steps = geti("DG_SEED_ROUND_STEPS", 4); c->env_round_bpc = geti("DG_SEED_ROUND_BPC", 16);
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
 }
@@ -763,6 +766,24 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
         }
         items = c->seed_left.p; n_items_p = tops + TOP_ROUNDS + 6;
     }
+    // default: the queue kernel (dg_seedq.h).  DG_SEED_LEGACY=1, the lock-step rounds or reads too long for its LDS slots: the lane-per-read kernel
+    if (!c->env_seed_legacy && rounds == 0 && W <= 62) {
+        int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 10 ? c->env_seed_slots_lg : 9;
+        while (lg > 6 && sq_lds_bytes(lg, W) > (size_t)80 * 1024) lg--;
+        const size_t lds = sq_lds_bytes(lg, W);
+        if (lds > c->seedq_lds_set) {
+            if ((e = hipFuncSetAttribute((const void *)k_seed_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+            c->seedq_lds_set = lds;
+        }
+        unsigned per_cu = (unsigned)(((size_t)160 * 1024) / lds);
+        if (per_cu > 4u) per_cu = 4u;
+        if (c->env_seed_wgs > 0) per_cu = (unsigned)c->env_seed_wgs;
+        unsigned wgs = (unsigned)c->n_cu * per_cu;
+        const unsigned need = (unsigned)(((size_t)n + ((size_t)1 << lg) - 1) >> lg);
+        if (wgs > need) wgs = need;
+        k_seed_q<<<wgs, SQ_THREADS, lds, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, lg, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT,
+                                                      c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, c->d_err);
+    } else
     if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr, items, n_items_p);
     else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr, items, n_items_p);
     k_seed_heavy<<<(unsigned)c->n_cu * 8u, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr);
@@ -876,6 +897,8 @@ static int enqueue_run(dg_ctx *c)
     HIPCHK(hipEventRecord(c->ev_reseed0, c->stream2));
     const uint32_t jobcap = (uint32_t)c->jobs.cap;
     k_order_jobs<<<1, 1024, 0, c->stream2>>>(c->jobs.p, tops + TOP_JOBS, jobcap, c->job_lists.p, tops + TOP_RESEED_COUNT, c->d_err);
+    // (one stream for the three ring sizes: side by side on streams of their own they finish sooner alone -- the wide ones have few jobs, but a
+    //  single 500 kb window keeps one wave busy for ~1 ms -- and cost the step 8 % with eight batches in flight: streams share 4 hardware queues)
     k_reseed<1><<<c->n_cu * 10, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p, tops + TOP_RESEED_COUNT, tops + TOP_RESEED_TICKET, c->d_ctr, c->d_err);
     k_reseed<2><<<c->n_cu * 6, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + jobcap, tops + TOP_RESEED_COUNT + 1, tops + TOP_RESEED_TICKET + 1, c->d_ctr, c->d_err);
     k_reseed<4><<<c->n_cu * 4, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + 2 * (size_t)jobcap, tops + TOP_RESEED_COUNT + 2, tops + TOP_RESEED_TICKET + 2, c->d_ctr, c->d_err);

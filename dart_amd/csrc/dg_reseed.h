@@ -268,32 +268,33 @@ k_reseed(const DIndex ix, const unsigned char *__restrict__ seq, const uint32_t 
         int thr = (int)(rl * 0.85); if (thr < 8) thr = 8;
         n_done += 1; w_done += (unsigned long long)(glen > 0 ? glen : 0);
         const unsigned char *rd = seq + seq_off[job.read] + job.rBegin;
-        bool plain = true;                                   // only A, C, G, T, N in the gap (any case for the four): the 8-mer ids need no carries
+        bool plain = true;                                   // only A, C, G, T in the gap (either case): the ids need no carries, and the reference's restart
+                                                             // after an 'N' (which leaves its window one base behind its label from there on) does not happen
         for (int i = lane; i < rl + 8; i += 64) {
             const unsigned char ch = i < rl ? rd[i] : (unsigned char)'N';
             rs[i] = ch;
-            if (i < rl && ch != 'N' && d_nt4(ch) > 3) plain = false;
+            if (i < rl && d_nt4(ch) > 3) plain = false;
         }
         for (int i = lane; i < (1 << RS_FLT_BITS) / 32; i += 64) flt[i] = 0;
         for (int i = lane; i < RS_TAB; i += 64) tab[i] = RS_EMPTY;
         if (lane == 0) s_dirty = 0;
         plain = __ballot(!plain) == 0;
         __syncthreads();
-        // CreateKmerVecFromReadSeq :34-80 on the read gap: one key per position whose 8 bases hold no 'N'
+        // CreateKmerVecFromReadSeq :34-80 on the read gap: one key per position
         if (plain) {
             int nk = 0;
             for (int base = 0; base + 8 <= rl; base += 64) {
                 const int head = base + lane;
-                bool ok = head + 8 <= rl;
+                const bool ok = head + 8 <= rl;
                 uint32_t wid = 0;
 #pragma unroll
-                for (int i = 0; i < 8; i++) { const unsigned char ch = rs[head + i]; ok = ok && ch != 'N'; wid = (wid << 2) + (d_nt4(ch) & 3u); }
+                for (int i = 0; i < 8; i++) wid = (wid << 2) + (d_nt4(rs[head + i]) & 3u);
                 const unsigned long long mk = __ballot(ok);
                 if (ok) tmpk[nk + __popcll(mk & ((1ull << lane) - 1ull))] = (wid << 9) | (uint32_t)head;
                 nk += __popcll(mk);
             }
             if (lane == 0) s_nk = nk;
-        } else if (lane == 0) {   // the reference's rolling form, literally: a letter outside ACGTN carries into the id
+        } else if (lane == 0) {   // the reference's rolling form, literally
             int nk = 0, count = 0, head, tail = 0;
             uint32_t wid = 0;
             while (count < 8 && tail < rl) { if (rs[tail++] != 'N') count++; else count = 0; }

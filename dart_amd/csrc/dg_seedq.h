@@ -1,0 +1,208 @@
+// dart_amd/csrc/dg_seedq.h -- k_seed_q: the seeding stage as a workgroup of waves around LDS work queues.
+//
+// Same work as k_seed (dg_fm.h: IdentifySeedPairs, AlignmentCandidates.cpp:181-215, around BWT_Search, bwt_search.cpp:139-182)
+// and the same per-trip functions (d_begin_issue/finish, d_trip_issue/load/finish), so hits, their order and the
+// reference-equivalent counters are the same by construction.  What differs is who runs which trip:
+//
+//   k_seed     lane = read.  The 64 reads of a wave are wherever their greedy walks happen to be, so every trip runs the code
+//              of every mode with 10-25 of 64 lanes active: 785 wave-instructions per trip, 522 M per 2 M reads.
+//   k_seed_q   a workgroup keeps NSLOT reads (slots) in LDS: their words and the 48-byte state of their current search.  A slot
+//              sits in exactly one of five queues -- begin a search, Occ step, text comparison, locate, free -- and every
+//              wave-trip takes up to 64 slots from ONE queue: all its lanes run the same code with the same kind of load.
+//              A phase = [barrier] every wave reads the same queue counts and derives the same assignment (fullest queue
+//              first, 64 slots per wave) [barrier] pop, load the slot's state, issue, wait, finish, store, push to the queue
+//              of the slot's new mode.  A free slot is refilled with the next read of the batch (one wave per phase).
+//
+// LDS per workgroup: NSLOT x (48 B state + 4 W B read words + 20 B queue entries); 512 slots of 101-base reads = 63 KB.
+// Bound: HBM / Infinity-Cache random 64-byte reads (one Occ block, one SA entry, one table entry or 20 B of text per lane-trip).
+#pragma once
+#include "dg_fm.h"
+
+#define SQ_WAVES   4
+#define SQ_THREADS (SQ_WAVES * 64)
+enum { SQ_BEGIN = 0, SQ_STEP = 1, SQ_CMP = 2, SQ_LOC = 3, SQ_FREE = 4, SQ_NQ = 5 };     // 0..3 = Search::mode
+#define SQ_MAX_PHASES (1u << 22)     // no batch comes near (a phase retires >= 1 lane-trip): a safety net, not a limit
+
+__device__ __forceinline__ uint32_t sq_rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// bytes of dynamic LDS for 2^nslot_lg slots of W-word reads
+__host__ __device__ inline size_t sq_lds_bytes(int nslot_lg, int W)
+{
+    const size_t n = (size_t)1 << nslot_lg;
+    return n * 48 + n * 4 * (size_t)W + 2 * n * 2 * SQ_NQ + SQ_WAVES * 64 * 2 + 16 * 4;
+}
+
+__global__ void __launch_bounds__(SQ_THREADS)
+k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H, int nslot_lg,
+         DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
+         DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int *err)
+{
+    extern __shared__ uint4 sq_sh[];
+    const int NSLOT = 1 << nslot_lg;
+    const int QCAP = 2 * NSLOT;                                  // ring entries per queue: the slots a phase puts back must not land on entries
+    const uint32_t SM = (uint32_t)QCAP - 1u;                      // another wave of the same phase is still taking (a queue can hold almost all slots)
+    uint4 *st = sq_sh;                                           // [slot][3]
+    uint32_t *rd = (uint32_t *)(st + 3 * (size_t)NSLOT);         // [word][slot]
+    uint16_t *q = (uint16_t *)(rd + (size_t)W * NSLOT);          // [queue][ring of QCAP slot numbers]
+    uint16_t *tab = q + (size_t)SQ_NQ * QCAP;                   // [wave][64]: slots of the reads a refill is fetching
+    uint32_t *ctl = (uint32_t *)(tab + SQ_WAVES * 64);           // head[5] (entries taken), tail[5] (entries put), [10] = the batch has no more reads
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)sq_rfl((uint32_t)(tid >> 6));
+    const int W2 = W >> 1;
+    const int K = ix.ktab ? ix.ktab_k : 0;
+    const bool direct = ix.sa_dense != nullptr;
+    const uint32_t w_magic = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;       // i / W == (i * w_magic) >> 20 for i < 64 W <= 2^12
+    SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t max_trips = 0, wtrips = 0;
+
+    for (int i = tid; i < NSLOT; i += SQ_THREADS) q[(size_t)SQ_FREE * QCAP + i] = (uint16_t)i;
+    if (tid < 16) ctl[tid] = tid == 5 + SQ_FREE ? (uint32_t)NSLOT : 0u;
+
+    for (uint32_t phase = 0; ; phase++) {
+        __syncthreads();                                          // every push of the previous phase has landed
+        uint32_t hd[SQ_NQ], cn[SQ_NQ];
+#pragma unroll
+        for (int k = 0; k < SQ_NQ; k++) { hd[k] = sq_rfl(ctl[k]); cn[k] = sq_rfl(ctl[5 + k]) - hd[k]; }
+        const bool ex = sq_rfl(ctl[10]) != 0u;
+        __syncthreads();                                          // every wave holds the same snapshot before anybody changes it
+        if (cn[SQ_FREE] == (uint32_t)NSLOT && ex) break;          // all slots free, nothing left to claim
+        if (phase >= SQ_MAX_PHASES) { if (tid == 0) atomicMax(err, DG_E_SCAN); break; }
+        if (ex) cn[SQ_FREE] = 0;
+        // the same greedy assignment in every wave: wave w takes up to 64 slots of the queue that is fullest after waves 0..w-1
+        int my_q = SQ_BEGIN;
+        uint32_t my_n = 0, my_first = 0;
+#pragma unroll
+        for (int w = 0; w < SQ_WAVES; w++) {
+            int best = 0;
+            uint32_t bc = cn[0];
+#pragma unroll
+            for (int k = 1; k < SQ_NQ; k++) if (cn[k] > bc) { bc = cn[k]; best = k; }
+            const uint32_t n = bc < 64u ? bc : 64u;
+#pragma unroll
+            for (int k = 0; k < SQ_NQ; k++) if (k == best) {
+                if (w == wave) { my_q = k; my_n = n; my_first = hd[k]; }
+                hd[k] += n; cn[k] -= n;
+                if (k == SQ_FREE) cn[k] = 0;                      // one refill per phase
+            }
+        }
+        if (my_n == 0) continue;                                  // (uniform per wave; the barriers are at the top)
+        wtrips++;
+        const bool act = (uint32_t)lane < my_n;
+        uint32_t slot = 0;
+        if (act) slot = q[(size_t)my_q * QCAP + ((my_first + (uint32_t)lane) & SM)];
+        if (lane == 0) atomicAdd(&ctl[my_q], my_n);
+        int nq = SQ_FREE;                                         // the queue this lane's slot goes to
+
+        if (my_q == SQ_FREE) {
+            // ---- refill: the next my_n reads of the batch move into the free slots ----
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(next_read, my_n);
+            base = sq_rfl(base);
+            const uint32_t avail = base < (unsigned int)n_reads ? (unsigned int)n_reads - base : 0u;
+            const uint32_t take = avail < my_n ? avail : my_n;
+            if (take < my_n && lane == 0) ctl[10] = 1u;
+            if (act && (uint32_t)lane < take) {
+                const uint32_t r = base + (uint32_t)lane;
+                tab[wave * 64 + lane] = (uint16_t)slot;
+                st[slot * 3] = make_uint4(r, (uint32_t)rlen[r], 0u, 0u);       // r | len, pos = 0 | nh, searches, trips = 0 | ns = 0
+                nq = SQ_BEGIN;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tab is read by the other lanes of this wave
+            const uint32_t total = take * (uint32_t)W;            // the reads are consecutive: one contiguous run of enc
+            const uint32_t *src = enc + (size_t)base * W;
+            for (uint32_t i0 = 0; i0 < total; i0 += 256u) {
+                uint32_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < total ? src[i] : 0u; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = i0 + (uint32_t)(k * 64 + lane);
+                    if (i < total) { const uint32_t rk = (i * w_magic) >> 20; rd[(size_t)(i - rk * (uint32_t)W) * NSLOT + tab[wave * 64 + rk]] = v[k]; }
+                }
+            }
+        } else {
+            // ---- one trip of up to 64 searches that are all in mode my_q ----
+            uint4 A = make_uint4(0, 0, 0, 0), B = A, C = A;
+            if (act) { A = st[slot * 3]; if (my_q != SQ_BEGIN) { B = st[slot * 3 + 1]; C = st[slot * 3 + 2]; } }
+            const int r = (int)A.x, len = (int)(A.y & 0xFFFFu), end_pos = len - 13;
+            int pos = (int)(A.y >> 16), nh = (int)(A.z & 0xFFFu);
+            uint32_t nsearch = (A.z >> 12) & 0xFFu, trips = A.z >> 20, ns = A.w;
+            Search s;
+            s.mode = my_q; s.hit_len = 0; s.located = false;
+            s.start = (int)(B.x & 0xFFFFu); s.p = (int)(B.x >> 16); s.ref_steps = B.y & 0xFFFFu; s.ref_blocks = B.y >> 16;
+            s.x0 = s.x1 = s.lk = 0; s.x2 = 1; s.tpos = 0; s.lsteps = 0;
+            if (my_q == SQ_STEP) { s.x0 = d_u64(B.z, B.w); s.x1 = d_u64(C.x, C.y); s.x2 = d_u64(C.z, C.w); }
+            else if (my_q == SQ_LOC) { s.lk = d_u64(B.z, B.w); s.lsteps = C.x; }
+            else if (my_q == SQ_CMP) { s.tpos = (int64_t)d_u64(B.z, B.w); s.lk = d_u64(C.x, C.y); s.lsteps = C.z; }
+            auto rb = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)wc * NSLOT + slot]; return w < W2 ? v : 0u; };
+            auto rm = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)(W2 + wc) * NSLOT + slot]; return w < W2 ? v : 0xFFFFFFFFu; };
+            bool live = act, finished = false, beginning = false;
+            TripData t; t.aux = T_NONE;
+            TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
+            if (act) {
+                trips = trips < 4095u ? trips + 1u : trips;
+                if (my_q == SQ_BEGIN) {                        // IdentifySeedPairs :191-211: next start
+                    while (pos < end_pos && d_at(rm, pos)) pos++;
+                    if (pos >= end_pos) finished = true;
+                    else if (nsearch >= SEED_BAIL || trips >= (uint32_t)bail_trips) {     // a long walk: let a whole wave finish this read
+                        DHeavy hv; hv.read = (uint32_t)r; hv.pos = pos; hv.nh = nh; hv.ns = ns;
+                        heavy[atomicAdd(n_heavy, 1u)] = hv;
+                        max_trips = trips > max_trips ? trips : max_trips;
+                        live = false;
+                    } else { nsearch++; beginning = true; d_begin_issue(ix, K, rb, rm, pos, s, c, ta, t); }
+                } else d_trip_issue(ix, rm, len, direct, s, c, ta, t);
+            }
+            d_trip_load(ta, t);
+            if (live) {
+                if (beginning) d_begin_finish(ix, K, rb, s, c, t);
+                else if (t.aux != T_NONE) d_trip_finish(ix, pr, rb, rm, len, s, c, t);
+                if (direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
+                if (!finished && s.mode == 0) {          // a search just ended (or the table said "absent")
+                    c.steps += s.ref_steps; c.blocks += s.ref_blocks;
+                    if (s.hit_len) {
+                        if (nh < H) {
+                            DHit h; h.rPos = (uint16_t)s.start; h.len = (uint16_t)s.hit_len;
+                            if (s.located) { h.x0 = (uint64_t)s.tpos; h.freq = 1u | 0x80000000u; c.lf_ref += s.lsteps + (uint32_t)(s.lk >> 40); }
+                            else { h.x0 = s.x0; h.freq = (uint32_t)s.x2; }
+                            hits[(size_t)r * H + nh] = h;
+                        }
+                        nh++; ns += (uint32_t)s.x2;
+                        pos = s.start + s.hit_len;
+                    } else pos = s.start + 1;
+                }
+                if (finished) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; max_trips = trips > max_trips ? trips : max_trips; }
+                else {
+                    nq = s.mode;
+                    A.y = (uint32_t)len | ((uint32_t)pos << 16); A.z = (uint32_t)nh | (nsearch << 12) | (trips << 20); A.w = ns;
+                    B.x = (uint32_t)s.start | ((uint32_t)s.p << 16); B.y = (s.ref_steps & 0xFFFFu) | (s.ref_blocks << 16);
+                    if (s.mode == 1) { B.z = (uint32_t)s.x0; B.w = (uint32_t)(s.x0 >> 32); C = make_uint4((uint32_t)s.x1, (uint32_t)(s.x1 >> 32), (uint32_t)s.x2, (uint32_t)(s.x2 >> 32)); }
+                    else if (s.mode == 3) { B.z = (uint32_t)s.lk; B.w = (uint32_t)(s.lk >> 32); C.x = s.lsteps; }
+                    else if (s.mode == 2) { B.z = (uint32_t)s.tpos; B.w = (uint32_t)((uint64_t)s.tpos >> 32); C.x = (uint32_t)s.lk; C.y = (uint32_t)(s.lk >> 32); C.z = s.lsteps; }
+                    st[slot * 3] = A;
+                    if (s.mode != 0) { st[slot * 3 + 1] = B; st[slot * 3 + 2] = C; }
+                }
+            }
+        }
+        // ---- every slot of this trip goes to the queue of its new state ----
+#pragma unroll
+        for (int k = 0; k < SQ_NQ; k++) {
+            const unsigned long long m = __ballot(act && nq == k);
+            if (m) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(&ctl[5 + k], (unsigned int)__popcll(m));
+                base = sq_rfl(base);
+                if (act && nq == k) q[(size_t)k * QCAP + ((base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))) & SM)] = (uint16_t)slot;
+            }
+        }
+    }
+    atomicMax(d_ctr_stripe(ctr) + CTR_MAXTRIPS, (unsigned long long)max_trips);
+    if (lane == 0) { atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips); }
+    d_wave_add(ctr + CTR_STEPS, c.steps);
+    d_wave_add(ctr + CTR_BLOCKS, c.blocks);
+    d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
+    d_wave_add(ctr + CTR_BLOCKS_ACT, c.blocks_act);
+    d_wave_add(ctr + CTR_KTAB, c.ktab);
+    d_wave_add(ctr + CTR_LF, c.lf_ref);
+    d_wave_add(ctr + CTR_LF_ACT, c.lf_act);
+    d_wave_add(ctr + CTR_DIRECT, c.n_direct);
+}
