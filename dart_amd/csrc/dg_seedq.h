@@ -54,6 +54,7 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
     const uint32_t w_magic = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;       // i / W == (i * w_magic) >> 20 for i < 64 W <= 2^12
     SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_trips = 0, wtrips = 0;
+    uint32_t q_trips[SQ_NQ] = {0, 0, 0, 0, 0}, q_lanes[SQ_NQ] = {0, 0, 0, 0, 0};
 
     for (int i = tid; i < NSLOT; i += SQ_THREADS) q[(size_t)SQ_FREE * QCAP + i] = (uint16_t)i;
     if (tid < 16) ctl[tid] = tid == 5 + SQ_FREE ? (uint32_t)NSLOT : 0u;
@@ -67,26 +68,37 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
         __syncthreads();                                          // every wave holds the same snapshot before anybody changes it
         if (cn[SQ_FREE] == (uint32_t)NSLOT && ex) break;          // all slots free, nothing left to claim
         if (phase >= SQ_MAX_PHASES) { if (tid == 0) atomicMax(err, DG_E_SCAN); break; }
-        if (ex) cn[SQ_FREE] = 0;
-        // the same greedy assignment in every wave: wave w takes up to 64 slots of the queue that is fullest after waves 0..w-1
+        // Which 64 slots this wave takes -- every wave derives the same plan from the same snapshot.  Full chunks of 64 first:
+        // a refill whenever 64 slots are free (keeps the slots busy), then the queues deepest stage first (text comparison,
+        // locate, Occ step, begin), chunk number = wave number.  Only when fewer than SQ_WAVES full chunks exist are the
+        // remainders (< 64 slots of a queue) handed out, in the same order.
+        const uint32_t f_free = (ex || cn[SQ_FREE] < 64u) ? 0u : 1u;                      // one refill per phase
+        const uint32_t r_free = (ex || cn[SQ_FREE] >= 64u) ? 0u : cn[SQ_FREE];
+        const uint32_t p0 = f_free, p1 = p0 + (cn[SQ_CMP] >> 6), p2 = p1 + (cn[SQ_LOC] >> 6), p3 = p2 + (cn[SQ_STEP] >> 6), p4 = p3 + (cn[SQ_BEGIN] >> 6);
         int my_q = SQ_BEGIN;
         uint32_t my_n = 0, my_first = 0;
-#pragma unroll
-        for (int w = 0; w < SQ_WAVES; w++) {
-            int best = 0;
-            uint32_t bc = cn[0];
-#pragma unroll
-            for (int k = 1; k < SQ_NQ; k++) if (cn[k] > bc) { bc = cn[k]; best = k; }
-            const uint32_t n = bc < 64u ? bc : 64u;
-#pragma unroll
-            for (int k = 0; k < SQ_NQ; k++) if (k == best) {
-                if (w == wave) { my_q = k; my_n = n; my_first = hd[k]; }
-                hd[k] += n; cn[k] -= n;
-                if (k == SQ_FREE) cn[k] = 0;                      // one refill per phase
-            }
+        const uint32_t wv = (uint32_t)wave;
+        if (wv < p4) {
+            my_n = 64u;
+            if (wv < p0) { my_q = SQ_FREE; my_first = hd[SQ_FREE]; }
+            else if (wv < p1) { my_q = SQ_CMP; my_first = hd[SQ_CMP] + ((wv - p0) << 6); }
+            else if (wv < p2) { my_q = SQ_LOC; my_first = hd[SQ_LOC] + ((wv - p1) << 6); }
+            else if (wv < p3) { my_q = SQ_STEP; my_first = hd[SQ_STEP] + ((wv - p2) << 6); }
+            else { my_q = SQ_BEGIN; my_first = hd[SQ_BEGIN] + ((wv - p3) << 6); }
+        } else {
+            uint32_t j = wv - p4;                                                       // the j-th non-empty remainder
+            const uint32_t r_cmp = cn[SQ_CMP] & 63u, r_loc = cn[SQ_LOC] & 63u, r_step = cn[SQ_STEP] & 63u, r_beg = cn[SQ_BEGIN] & 63u;
+            bool got = false;
+            if (r_free) { if (j == 0) { my_q = SQ_FREE; my_n = r_free; my_first = hd[SQ_FREE]; got = true; } else j--; }
+            if (!got && r_cmp) { if (j == 0) { my_q = SQ_CMP; my_n = r_cmp; my_first = hd[SQ_CMP] + (cn[SQ_CMP] & ~63u); got = true; } else j--; }
+            if (!got && r_loc) { if (j == 0) { my_q = SQ_LOC; my_n = r_loc; my_first = hd[SQ_LOC] + (cn[SQ_LOC] & ~63u); got = true; } else j--; }
+            if (!got && r_step) { if (j == 0) { my_q = SQ_STEP; my_n = r_step; my_first = hd[SQ_STEP] + (cn[SQ_STEP] & ~63u); got = true; } else j--; }
+            if (!got && r_beg) { if (j == 0) { my_q = SQ_BEGIN; my_n = r_beg; my_first = hd[SQ_BEGIN] + (cn[SQ_BEGIN] & ~63u); got = true; } else j--; }
         }
         if (my_n == 0) continue;                                  // (uniform per wave; the barriers are at the top)
         wtrips++;
+#pragma unroll
+        for (int k = 0; k < SQ_NQ; k++) if (k == my_q) { q_trips[k]++; q_lanes[k] += my_n; }
         const bool act = (uint32_t)lane < my_n;
         uint32_t slot = 0;
         if (act) slot = q[(size_t)my_q * QCAP + ((my_first + (uint32_t)lane) & SM)];
@@ -157,6 +169,7 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
                 if (beginning) d_begin_finish(ix, K, rb, s, c, t);
                 else if (t.aux != T_NONE) d_trip_finish(ix, pr, rb, rm, len, s, c, t);
                 if (direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
+                if (s.mode == 1 && (s.p >= len || d_at(rm, s.p))) d_search_end(pr, s);              // what its next trip would find (T_STOP), without the trip
                 if (!finished && s.mode == 0) {          // a search just ended (or the table said "absent")
                     c.steps += s.ref_steps; c.blocks += s.ref_blocks;
                     if (s.hit_len) {
@@ -169,6 +182,8 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
                         nh++; ns += (uint32_t)s.x2;
                         pos = s.start + s.hit_len;
                     } else pos = s.start + 1;
+                    while (pos < end_pos && d_at(rm, pos)) pos++;                                   // the next start, or the end of the read:
+                    if (pos >= end_pos) finished = true;                                            // no begin-trip just to find out
                 }
                 if (finished) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; max_trips = trips > max_trips ? trips : max_trips; }
                 else {
@@ -183,20 +198,27 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
                 }
             }
         }
-        // ---- every slot of this trip goes to the queue of its new state ----
+        // ---- every slot of this trip goes to the queue of its new state: lane k reserves queue k's entries, one round trip for all five ----
+        {
+            unsigned long long m[SQ_NQ];
 #pragma unroll
-        for (int k = 0; k < SQ_NQ; k++) {
-            const unsigned long long m = __ballot(act && nq == k);
-            if (m) {
-                unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(&ctl[5 + k], (unsigned int)__popcll(m));
-                base = sq_rfl(base);
-                if (act && nq == k) q[(size_t)k * QCAP + ((base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))) & SM)] = (uint16_t)slot;
-            }
+            for (int k = 0; k < SQ_NQ; k++) m[k] = __ballot(act && nq == k);
+            uint32_t mine = 0;
+            unsigned long long mq = 0;
+#pragma unroll
+            for (int k = 0; k < SQ_NQ; k++) { if (lane == k) mine = (uint32_t)__popcll(m[k]); if (nq == k) mq = m[k]; }
+            uint32_t base = 0;
+            if (lane < SQ_NQ && mine) base = atomicAdd(&ctl[5 + lane], mine);
+            base = (uint32_t)__shfl((int)base, nq, 64);
+            if (act) q[(size_t)nq * QCAP + ((base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))) & SM)] = (uint16_t)slot;
         }
     }
     atomicMax(d_ctr_stripe(ctr) + CTR_MAXTRIPS, (unsigned long long)max_trips);
-    if (lane == 0) { atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips); }
+    if (lane == 0) {
+        atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips);
+#pragma unroll
+        for (int k = 0; k < SQ_NQ; k++) if (q_trips[k]) { atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_TRIPS + k, (unsigned long long)q_trips[k]); atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_LANES + k, (unsigned long long)q_lanes[k]); }
+    }
     d_wave_add(ctr + CTR_STEPS, c.steps);
     d_wave_add(ctr + CTR_BLOCKS, c.blocks);
     d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
