@@ -222,7 +222,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1 only: do not gather the per-read records to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (other entry point, device-resident)")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "8")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "12")),
                     help="batches in flight per GPU: contexts sharing one index, one host thread each (dg_clone)")
     ap.add_argument("--cache", default=os.environ.get("DART_BENCH_CACHE", "/tmp/dart_bench_cache"))
     args = ap.parse_args()

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $ROOT
 python3 bench.py --steps 1 --warmup 0 --batches 1 --inflight 1 --no-cpu-baseline --no-secondary $EXTRA > /dev/null 2> $OUT/prep.err || true   # builds and caches the index outside the profiler
-# the default command (ten distinct batches per step, eight in flight), fewer steps, minus the CPU leg
+# the default command (ten distinct batches per step, the default number in flight), fewer steps, minus the CPU leg
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary $EXTRA > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 echo "trace done"
 # counters: one batch in flight (the profiler serialises dispatches anyway), separate passes

@@ -21,29 +21,7 @@ def ctxs(workdir):
         gpu.close(); orc.close()
 
 
-def cigars_of(reports, cigar):
-    """the CIGAR ops of every report, in report order (cigar_off/n_cigar dereferenced: the ABI fixes what a report's ops are,
-    not where in the op array they lie)"""
-    off = reports["cigar_off"].astype(np.int64); k = reports["n_cigar"].astype(np.int64)
-    idx = np.repeat(off - np.concatenate([[0], np.cumsum(k)[:-1]]), k) + np.arange(int(k.sum()))
-    return cigar[idx] if len(idx) else np.zeros(0, np.uint32)
-
-
-def assert_same(res, ores):
-    reads, rep, cig, sj = ores
-    for f in reads.dtype.names:
-        if f != "sj_off":
-            assert np.array_equal(reads[f], res.reads[f]), "read field %s differs at %s" % (f, np.nonzero(reads[f] != res.reads[f])[0][:5])
-    has_sj = reads["n_sj"] > 0                            # (sj_off says where a read's tuples are; it means nothing for a read without any)
-    assert np.array_equal(reads["sj_off"][has_sj], res.reads["sj_off"][has_sj])
-    assert len(rep) == len(res.reports)
-    for f in rep.dtype.names:
-        if f != "cigar_off":
-            assert np.array_equal(rep[f], res.reports[f]), "report field %s differs at %s" % (f, np.nonzero(rep[f] != res.reports[f])[0][:5])
-    assert len(cig) == len(res.cigar)
-    a, b = cigars_of(rep, cig), cigars_of(res.reports, res.cigar)
-    assert np.array_equal(a, b), "CIGAR ops differ, first at flattened op %s" % (np.nonzero(a != b)[0][:5] if len(a) == len(b) else "(length)")
-    assert np.array_equal(sj, res.sj)
+cigars_of, assert_same = common.cigars_of, common.assert_same
 
 
 @pytest.mark.parametrize("name", CASES)
