@@ -436,6 +436,12 @@ def main():
                 "kernel_ms_one_batch_in_flight": round(iso.get(dom, 0.0), 4),
                 "achieved_one_batch_in_flight": round(dom_bytes / (iso[dom] * 1e-3) / 1e9, 2) if iso.get(dom) else None,
                 "own_requested_bytes_per_launch": int(own.get(dom, dom_bytes)),
+                # what the memory system allows for THIS access pattern: random 64-byte lines over 8 ... 119 GB run at 48 G lines/s = 3.1 TB/s from
+                # 4 waves per CU on, ~1 us per dependent line (profiles/r02/tlb_probe_big_footprints.txt); the PMC traffic of one launch over
+                # its duration alone on the GPU, against that
+                "random_64B_line_ceiling_GBps": 3100.0,
+                "traffic_GBps_one_batch_in_flight": round(traffic / (iso[dom] * 1e-3) / 1e9, 1) if traffic and iso.get(dom) else None,
+                "frac_of_random_line_ceiling_one_batch_in_flight": round(traffic / (iso[dom] * 1e-3) / 1e9 / 3100.0, 4) if traffic and iso.get(dom) else None,
                 "fm_bytes_per_read": round(per_read_B, 1),
                 # SURVEY 8d's whole-job form: reads/s x algorithmic bytes per read (this GPU's share of `value`), against the same 8 TB/s
                 "whole_job_algorithmic_GBps_per_gpu": round(value / world * 1e6 * per_read_B / 1e9, 1),

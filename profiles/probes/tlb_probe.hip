@@ -23,13 +23,17 @@ int main(int argc, char **argv)
     int n_cu = 256;
     hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0); n_cu = pr.multiProcessorCount;
     uint32_t *sink; hipMalloc(&sink, 4);
-    const double sizes_gb[] = {0.0625, 0.25, 1, 2, 4, 8, 16, 32};
-    for (double gb : sizes_gb) {
+    // default: the round-1 sweep; with arguments: the footprints in GB given on the command line (e.g. 69 119: the K=16 prefix table, table + full SA)
+    double sizes_gb[16] = {0.0625, 0.25, 1, 2, 4, 8, 16, 32};
+    int n_sizes = 8;
+    if (argc > 1) { n_sizes = 0; for (int i = 1; i < argc && n_sizes < 16; i++) sizes_gb[n_sizes++] = atof(argv[i]); }
+    for (int si = 0; si < n_sizes; si++) {
+        const double gb = sizes_gb[si];
         const uint64_t bytes = (uint64_t)(gb * (1ull << 30));
         void *buf;
         if (hipMalloc(&buf, bytes) != hipSuccess) { printf("%.2f GB: alloc failed\n", gb); continue; }
         hipMemset(buf, 1, bytes);
-        for (int dep = 0; dep < 2; dep++) for (int wpc : {4, 8, 16}) {
+        for (int dep = 0; dep < 2; dep++) for (int wpc : {1, 2, 4, 8, 16}) {
             const int blocks = n_cu * wpc, iters = 400;
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             k_probe<<<blocks, 64>>>((const uint4 *)buf, bytes / 64, 8, dep, sink);
