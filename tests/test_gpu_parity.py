@@ -81,6 +81,41 @@ def test_gpu_seeds_match_oracle(ctxs):
             assert np.array_equal(rp, grp[a:b]) and np.array_equal(sl, gsl[a:b]) and np.array_equal(gp, ggp[a:b]), (name, i)
 
 
+def test_gpu_seed_queue_configurations(ctxs, monkeypatch):
+    """k_seed_q (dg_seedq.h) against the lane-per-read kernel k_seed: the same hits whatever the number of read slots per workgroup
+    (64 ... 512: the queue rings wrap thousands of times, most chunks are partial), the workgroups per CU, and the bail-out threshold
+    that moves reads to k_seed_heavy; ragged reads, N runs, reads shorter than a seed; then whole records against the oracle"""
+    c, ix, gpu, orc = ctxs["pe101_spliced"]
+    rng = np.random.default_rng(11)
+    asc = c["genome"].ascii()
+    seqs = []
+    for i in range(5000):
+        L = int(rng.choice([8, 15, 16, 31, 64, 101, 101, 101, 150, 333, 480]))
+        p = int(rng.integers(0, c["genome"].total - 600))
+        s = bytearray(asc[p:p + L].tobytes())
+        for k in rng.integers(0, L, size=L // 50): s[int(k)] = int(rng.choice(list(b"ACGT")))
+        if i % 9 == 0 and L > 40: s[L // 3:L // 3 + 5] = b"NNNNN"
+        if i % 13 == 0: s = bytearray(bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8)))            # maps nowhere: every start fails
+        seqs.append(bytes(s))
+    so, rl, flat = host.pack_reads(seqs)
+    monkeypatch.setenv("DG_SEED_LEGACY", "1")
+    gpu.set_params(host.default_params())                    # (the switches are read by dg_set_params)
+    want = gpu.probe_seeds(so, rl, flat)
+    monkeypatch.setenv("DG_SEED_LEGACY", "0")
+    for lg, wgs, bail in ((9, 0, 128), (6, 1, 128), (7, 3, 128), (8, 2, 6), (9, 2, 1000)):
+        monkeypatch.setenv("DG_SEED_SLOTS_LG", str(lg)); monkeypatch.setenv("DG_SEED_WGS", str(wgs)); monkeypatch.setenv("DG_SEED_BAIL_TRIPS", str(bail))
+        gpu.set_params(host.default_params())
+        got = gpu.probe_seeds(so, rl, flat)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), (lg, wgs, bail)
+    monkeypatch.setenv("DG_SEED_SLOTS_LG", "6"); monkeypatch.setenv("DG_SEED_WGS", "2"); monkeypatch.delenv("DG_SEED_BAIL_TRIPS")
+    gpu.set_params(host.default_params(paired=0, max_mismatch=4))
+    assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=0, max_mismatch=4), so, rl, flat))
+    for k in ("DG_SEED_SLOTS_LG", "DG_SEED_WGS", "DG_SEED_LEGACY"):
+        monkeypatch.delenv(k)
+    gpu.set_params(host.default_params())
+
+
 def test_gpu_edge_cases(ctxs):
     """empty batch, ragged lengths, reads shorter than a seed, all-N reads, lower case, odd paired batch"""
     c, ix, gpu, orc = ctxs["pe101_spliced"]
