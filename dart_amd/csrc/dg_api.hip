@@ -34,7 +34,7 @@ template <typename T> struct DBuf {
 
 #define N_TIMERS 20
 #define N_TOPS 32               // small device counters of a batch (bump tops, tickets, list sizes), zeroed per run
-enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAVY_UNITS, TOP_SEED_NEXT, TOP_SEED_HEAVY, TOP_ROUNDS /* 8..14 */,
+enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAVY_UNITS, TOP_SEED_NEXT, TOP_SEED_HEAVY,
        TOP_WORK = 16, TOP_TICKET_PAIR, TOP_TICKET_EMIT, TOP_RESEED_COUNT /* 19..21 */, TOP_RESEED_TICKET = 22 /* 22..24 */ };
 
 struct dg_ctx {
@@ -59,7 +59,7 @@ struct dg_ctx {
     // them without asking the device for a size first, the device reports what it needed (DSizes) and flags an overflow
     // (d_err >= DG_ABORT), in which case the host grows the buffer and runs the batch again
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, rep_off, tile_sums, tile_read, slow_units;
-    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint32_t> job_lists; DBuf<uint8_t> done; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy, seed_left; DBuf<uint32_t> seed_list; DBuf<RState> seed_state;
+    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint32_t> job_lists; DBuf<uint8_t> done; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c;
@@ -75,7 +75,7 @@ struct dg_ctx {
     uint64_t counters[CTR_N];
     int n_cu = 256, runs_of_last_batch = 0;
     // environment switches, read once per context (not per batch)
-    int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_rounds = 0, env_round_steps = 4, env_round_bpc = 16, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0;
+    int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0;
 };
 
 static void read_env(dg_ctx *c)
@@ -83,7 +83,6 @@ static void read_env(dg_ctx *c)
     auto geti = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
     c->env_seed_waves = geti("DG_SEED_WAVES", 4); c->env_bail_trips = geti("DG_SEED_BAIL_TRIPS", 128); c->env_both = geti("DG_SEED_BOTH", 0);
     c->env_seed_legacy = geti("DG_SEED_LEGACY", 0); c->env_seed_slots_lg = geti("DG_SEED_SLOTS_LG", 0); c->env_seed_wgs = geti("DG_SEED_WGS", 0);
-    c->env_rounds = geti("DG_SEED_ROUNDS", 0); c->env_round_steps = geti("DG_SEED_ROUND_STEPS", 4); c->env_round_bpc = geti("DG_SEED_ROUND_BPC", 16);
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
 }
 
@@ -448,7 +447,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     if (c->h_tail) (void)hipHostFree(c->h_tail);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->packed_in.release(); c->nlist_in.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
-    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_lists.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_left.release(); c->seed_list.release(); c->seed_state.release();
+    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_lists.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release(); c->scan_state.release(); c->reads_c.release(); c->reports_c.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -742,32 +741,9 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
                                                                          // that to the other batches in flight (measured 5.4 vs 6.0 ms per step with four batches)
     if ((size_t)blocks * 64 > (size_t)n) blocks = (unsigned)((n + 63) / 64);
     const int bail_trips = c->env_bail_trips, both_thr = c->env_both;
-    // Rounds (k_seed_round, DG_SEED_ROUNDS=1..6; default 0 = the general kernel does everything): search number r of every read
-    // that has one, lanes in lock step; what does not fit the common case is left to the general kernel.  Needs the prefix table
-    // and the dense SA.  Measured (GRCh38-sized): 426 M instead of 518 M wave-instructions per 2 M reads, but the
-    // rounds wait for memory 85 % of their cycles and the step as a whole is slower (467 against 504 M reads/s), so it is off.
-    int rounds = c->env_rounds;
-    if (rounds > 6) rounds = 6;
-    if (!c->ix.ktab || !c->ix.sa_dense || W > 40) rounds = 0;                 // (W x 1 KB of LDS per block)
-    const DHeavy *items = nullptr;
-    const unsigned int *n_items_p = nullptr;
     unsigned int *tops = c->d_tops;
-    if (rounds > 0) {
-        const int max_steps = c->env_round_steps;
-        if ((e = c->seed_left.ensure((size_t)n + 16)) != hipSuccess || (e = c->seed_list.ensure((size_t)2 * n + 16)) != hipSuccess ||
-            (e = c->seed_state.ensure((size_t)n + 16)) != hipSuccess) return e;
-        unsigned rb = (unsigned)c->n_cu * (unsigned)c->env_round_bpc;
-        if ((size_t)rb * 256 > (size_t)n) rb = (unsigned)((n + 255) / 256);
-        for (int r = 1; r <= rounds; r++) {
-            const uint32_t *lin = r == 1 ? nullptr : c->seed_list.p + (size_t)((r - 1) & 1) * n;
-            uint32_t *lout = c->seed_list.p + (size_t)(r & 1) * n;
-            k_seed_round<<<rb, 256, (size_t)W * 256 * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, lin, r == 1 ? nullptr : tops + TOP_ROUNDS + (r - 2), W, H, max_steps, r == rounds ? 1 : 0,
-                                                    c->hits.p, c->nhits.p, c->nseeds.p, c->seed_state.p, lout, tops + TOP_ROUNDS + (r - 1), c->seed_left.p, tops + TOP_ROUNDS + 6, c->d_ctr);
-        }
-        items = c->seed_left.p; n_items_p = tops + TOP_ROUNDS + 6;
-    }
-    // default: the queue kernel (dg_seedq.h).  DG_SEED_LEGACY=1, the lock-step rounds or reads too long for its LDS slots: the lane-per-read kernel
-    if (!c->env_seed_legacy && rounds == 0 && W <= 62) {
+    // default: the queue kernel (dg_seedq.h).  DG_SEED_LEGACY=1 or reads too long for its LDS slots (> 496 bases): the lane-per-read kernel
+    if (!c->env_seed_legacy && W <= 62) {
         int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 10 ? c->env_seed_slots_lg : 9;
         while (lg > 6 && sq_lds_bytes(lg, W) > (size_t)80 * 1024) lg--;
         const size_t lds = sq_lds_bytes(lg, W);
@@ -784,8 +760,8 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
         k_seed_q<<<wgs, SQ_THREADS, lds, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, lg, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT,
                                                       c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, c->d_err);
     } else
-    if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr, items, n_items_p);
-    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr, items, n_items_p);
+    if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr);
+    else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr);
     k_seed_heavy<<<(unsigned)c->n_cu * 8u, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr);
     return hipGetLastError();
 }

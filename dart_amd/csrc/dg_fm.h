@@ -474,12 +474,8 @@ template <bool USE_LDS>
 __global__ void __launch_bounds__(64)
 k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H,
        DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
-       DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int both_thr,
-       const DHeavy *__restrict__ items, const unsigned int *__restrict__ n_items_p)
+       DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int both_thr)
 {
-    // items != nullptr: the work is not reads 0..n_reads-1 from their first base but the list the round kernels left over
-    // (k_seed_round): read, position of the next search, hits and seeds so far
-    if (items) n_reads = (int)*n_items_p;
     extern __shared__ uint32_t sh[];
     const int lane = threadIdx.x;
     SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -605,19 +601,13 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
                     take = take < avail ? take : avail; take = take < cap ? take : cap;
                     const unsigned int rank = (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
                     if (r_nxt < 0 && rank < take) {
-                        if (items) { const DHeavy hv = items[pool_next + rank]; r_nxt = (int)hv.read; pos_nxt = hv.pos; nh_nxt = hv.nh; ns_nxt = hv.ns; }
-                        else { r_nxt = (int)(pool_next + rank); pos_nxt = 0; nh_nxt = 0; ns_nxt = 0; }
+                        r_nxt = (int)(pool_next + rank); pos_nxt = 0; nh_nxt = 0; ns_nxt = 0;
                         tab[rank] = (uint32_t)lane | ((uint32_t)(cur ^ 1) << 8);
                         len_nxt = rlen[r_nxt];
                     }
                     const uint32_t *src = enc + (size_t)pool_next * W;
                     pend_total = take * (unsigned int)W;
-                    // word i of the batch: consecutive reads are one contiguous run of enc; listed reads are gathered word by word
-                    auto fetch = [&](unsigned int i) -> uint32_t {
-                        if (!items) return src[i];
-                        const unsigned int rk = (i * w_magic) >> 16;
-                        return enc[(size_t)items[pool_next + rk].read * W + (i - rk * (unsigned int)W)];
-                    };
+                    auto fetch = [&](unsigned int i) -> uint32_t { return src[i]; };   // word i of the batch: consecutive reads are one contiguous run of enc
                     if ((unsigned int)lane < pend_total) pv0 = fetch((unsigned int)lane);
                     if ((unsigned int)lane + 64 < pend_total) pv1 = fetch((unsigned int)lane + 64);
                     if ((unsigned int)lane + 128 < pend_total) pv2 = fetch((unsigned int)lane + 128);
@@ -632,8 +622,7 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
                 const unsigned int rank = (unsigned int)__popcll(idl & ((1ull << lane) - 1ull));
                 if (r < 0 && rank < avail) {
                     pos = 0; nh = 0; ns = 0;
-                    if (items) { const DHeavy hv = items[pool_next + rank]; r = (int)hv.read; pos = hv.pos; nh = hv.nh; ns = hv.ns; }
-                    else r = (int)(pool_next + rank);
+                    r = (int)(pool_next + rank);
                     len = rlen[r]; end_pos = len - 13; s.mode = 0; trips = 0; nsearch = 0;
                 }
                 pool_next += n_idl < avail ? n_idl : avail;
@@ -662,141 +651,6 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
     }
     atomicMax(d_ctr_stripe(ctr) + CTR_MAXTRIPS, (unsigned long long)max_trips);
     if (lane == 0) { atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips); }
-    d_wave_add(ctr + CTR_STEPS, c.steps);
-    d_wave_add(ctr + CTR_BLOCKS, c.blocks);
-    d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
-    d_wave_add(ctr + CTR_BLOCKS_ACT, c.blocks_act);
-    d_wave_add(ctr + CTR_KTAB, c.ktab);
-    d_wave_add(ctr + CTR_LF, c.lf_ref);
-    d_wave_add(ctr + CTR_LF_ACT, c.lf_act);
-    d_wave_add(ctr + CTR_DIRECT, c.n_direct);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_seed_round: ONE search of every still-unfinished read per launch, the lanes of a wave in the same phase at the
-// same time.  k_seed above keeps 64 reads per wave in flight, each wherever its own greedy walk happens to be, so a
-// mode's code runs for ~25 (heavy modes) or ~10 (begin) of 64 lanes and the kernel spends ~110 wave-instructions per
-// search; here lane = read, and a search is the straight sequence  table entry -> up to max_steps Occ steps ->
-// SA entry -> text comparison  with every lane of the wave in the same stage (~30 wave-instructions per search).
-// Round r handles the r-th search of the reads that have one: the reads that need another search are compacted into
-// the next round's list, so every wave of every round is full.  What does not fit the common case goes to the
-// general kernel as a leftover (read, start of the unfinished search, hits and seeds so far): an N inside the first
-// K bases, an overflow table entry, more than max_steps steps (repeat families), anything still unfinished after
-// the last round.  Same hits, same order, same reference-equivalent counters (they are added when a search ends,
-// and an abandoned search is restarted from its start by the general kernel).
-// Requires the prefix table and the SA of every row or every few rows (both built by dg_init whenever they fit).
-// ---------------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) RState { int32_t pos, nh; uint32_t ns, pad; };
-
-__global__ void __launch_bounds__(256)
-k_seed_round(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_first,
-             const uint32_t *__restrict__ list_in, const unsigned int *__restrict__ n_active_p, int W, int H, int max_steps, int last,
-             DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, RState *__restrict__ state,
-             uint32_t *__restrict__ list_out, unsigned int *n_out, DHeavy *__restrict__ left, unsigned int *n_left, unsigned long long *ctr)
-{
-    extern __shared__ uint32_t rsh[];                      // W words x 256 lanes, word-major
-    const int lane = threadIdx.x & 63;
-    const unsigned int n_active = list_in ? *n_active_p : (unsigned int)n_first;
-    const int W2 = W >> 1, K = ix.ktab_k;
-    SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x - (unsigned int)lane; i0 < n_active; i0 += gridDim.x * blockDim.x) {   // whole waves
-        const unsigned int i = i0 + (unsigned int)lane;
-        const bool have = i < n_active;
-        const int r = have ? (list_in ? (int)list_in[i] : (int)i) : 0;
-        int len = 0, end_pos = 0, pos = 0, nh = 0;
-        uint32_t ns = 0;
-        if (have) {
-            len = rlen[r]; end_pos = len - 13;
-            if (list_in) { const RState st = state[r]; pos = st.pos; nh = st.nh; ns = st.ns; }
-        }
-        // the read's words go to this lane's LDS column once (independent loads: one round trip); every later access is a ds_read
-        // (straight from global memory each of the ~8 accesses of a search was a dependent round trip of its own)
-        const uint32_t *er = enc + (size_t)r * W;
-        uint32_t *col = rsh + threadIdx.x;
-        for (int w = 0; w < W; w++) col[w * 256] = er[w];
-        auto rb = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = col[wc * 256]; return w < W2 ? v : 0u; };
-        auto rm = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = col[(W2 + wc) * 256]; return w < W2 ? v : 0xFFFFFFFFu; };
-        bool act = have, bail = false;
-        if (act && !list_in) {                               // first round: find the first start (IdentifySeedPairs :191-211)
-            while (pos < end_pos && d_at(rm, pos)) pos++;
-            if (pos >= end_pos) { nhits[r] = 0; nseeds[r] = 0; act = false; }
-        }
-        Search s; s.mode = 0; s.hit_len = 0; s.located = false; s.x0 = s.x1 = s.x2 = s.lk = 0; s.tpos = 0; s.lsteps = 0; s.start = pos; s.p = pos; s.ref_steps = s.ref_blocks = 0;
-        {   // ---- table entry ----
-            TripData t; t.aux = T_NONE;
-            TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
-            if (act) d_begin_issue(ix, K, rb, rm, pos, s, c, ta, t);
-            d_trip_load(ta, t);
-            if (act) {
-                if (t.aux != T_TABLE || (t.s16.w >> 31)) bail = true;
-                else {
-                    d_begin_finish(ix, K, rb, s, c, t);
-                    if (s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
-                }
-            }
-        }
-        // ---- stages: Occ steps (mode 1), SA entry (mode 3; a few LF steps first if the SA is not of every row), text (mode 2) ----
-        for (int stage = 0; stage < 3; stage++) {
-            const int mode = stage == 0 ? 1 : (stage == 1 ? 3 : 2);
-            const int cap = stage == 0 ? max_steps : (stage == 1 ? 4 : 16);
-            for (int it = 0; it < cap; it++) {
-                const bool on = act && !bail && s.mode == mode;
-                if (!__ballot(on)) break;
-                TripData t; t.aux = T_NONE;
-                TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
-                if (on) d_trip_issue(ix, rm, len, true, s, c, ta, t);
-                d_trip_load(ta, t);
-                if (on) {
-                    d_trip_finish(ix, pr, rb, rm, len, s, c, t);
-                    if (s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
-                }
-            }
-            if (act && !bail && s.mode == mode) bail = true;   // not done within the cap: a long walk
-        }
-        // ---- the search has ended (s.mode == 0) or was abandoned (bail) ----
-        bool more = false;
-        if (act && !bail) {
-            c.steps += s.ref_steps; c.blocks += s.ref_blocks;
-            if (s.hit_len) {
-                if (nh < H) {
-                    DHit h; h.rPos = (uint16_t)s.start; h.len = (uint16_t)s.hit_len;
-                    if (s.located) { h.x0 = (uint64_t)s.tpos; h.freq = 1u | 0x80000000u; c.lf_ref += s.lsteps + (uint32_t)(s.lk >> 40); }
-                    else { h.x0 = s.x0; h.freq = (uint32_t)s.x2; }
-                    hits[(size_t)r * H + nh] = h;
-                }
-                nh++; ns += (uint32_t)s.x2;
-                pos = s.start + s.hit_len;
-            } else pos = s.start + 1;
-            while (pos < end_pos && d_at(rm, pos)) pos++;
-            if (pos >= end_pos) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; }
-            else more = true;
-        }
-        const bool to_next = more && !last, to_left = (act && bail) || (more && last);
-        {
-            const unsigned long long m = __ballot(to_next);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                unsigned int base = 0;
-                if (lane == leader) base = atomicAdd(n_out, (unsigned int)__popcll(m));
-                base = (unsigned int)__shfl((int)base, leader, 64);
-                if (to_next) {
-                    list_out[base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
-                    RState st; st.pos = pos; st.nh = nh; st.ns = ns; st.pad = 0;
-                    state[r] = st;
-                }
-            }
-        }
-        {
-            const unsigned long long m = __ballot(to_left);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                unsigned int base = 0;
-                if (lane == leader) base = atomicAdd(n_left, (unsigned int)__popcll(m));
-                base = (unsigned int)__shfl((int)base, leader, 64);
-                if (to_left) { DHeavy hv; hv.read = (uint32_t)r; hv.pos = pos; hv.nh = nh; hv.ns = ns; left[base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = hv; }
-            }
-        }
-    }
     d_wave_add(ctr + CTR_STEPS, c.steps);
     d_wave_add(ctr + CTR_BLOCKS, c.blocks);
     d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);

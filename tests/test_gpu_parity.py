@@ -337,11 +337,12 @@ def test_gpu_noisy_long_reads_wave_nw_paths(workdir):
     gpu.close(); orc.close()
 
 
-def test_gpu_seeding_rounds_variant_matches_oracle(workdir, monkeypatch):
-    """DG_SEED_ROUNDS (k_seed_round: one lock-step search per read and launch, leftovers to the general kernel; off by default):
-    same records and same reference-equivalent counters as the oracle, on plain, spliced and N-rich reads."""
+def test_gpu_both_seeding_kernels_match_oracle(workdir, monkeypatch):
+    """the queue kernel k_seed_q (default) and the lane-per-read kernel k_seed (DG_SEED_LEGACY=1; also what reads longer than 496 bases
+    take): same records as the oracle and the same reference-equivalent counters, on plain, spliced and N-rich reads of a
+    repeat-rich genome (many reads end in k_seed_heavy)."""
     g = synth.make_genome([2000000, 1000000], seed=61, repeat_scale=100.0, n_introns=300)
-    prefix = os.path.join(workdir, "rounds")
+    prefix = os.path.join(workdir, "twoseed")
     index_build.build_index_from_genome(g, prefix)
     ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
     gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
@@ -350,16 +351,16 @@ def test_gpu_seeding_rounds_variant_matches_oracle(workdir, monkeypatch):
     want = orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=16)
     base = gpu.map_batch(so, rl, flat); base_ctr = gpu.counters()
     assert_same(base, want)
-    for rounds, steps in (("6", "4"), ("2", "1"), ("3", "16")):
-        monkeypatch.setenv("DG_SEED_ROUNDS", rounds); monkeypatch.setenv("DG_SEED_ROUND_STEPS", steps)
-        gpu.set_params(gpu.params)                     # the DG_* switches are read at init and at dg_set_params, not per batch
-        assert_same(gpu.map_batch(so, rl, flat), want)
-        ctr = gpu.counters()
-        for k in ("steps", "lf_steps", "sa_lookups", "seeds", "occ_blocks"):
-            assert ctr[k] == base_ctr[k], k
+    assert base_ctr["seedq_trips_step"] > 0                # the queue kernel really ran
+    monkeypatch.setenv("DG_SEED_LEGACY", "1")
+    gpu.set_params(gpu.params)                             # the DG_* switches are read at init and at dg_set_params, not per batch
+    assert_same(gpu.map_batch(so, rl, flat), want)
+    ctr = gpu.counters()
+    assert ctr["seedq_trips_step"] == 0
+    for k in ("steps", "lf_steps", "sa_lookups", "seeds", "occ_blocks"):
+        assert ctr[k] == base_ctr[k], k
+    monkeypatch.delenv("DG_SEED_LEGACY")
     gpu.close(); orc.close()
-
-
 def test_gpu_packed_reads_and_pinned_buffers(workdir):
     """dg_map_batch_packed (2 bit/base + N list) gives the records of dg_map_batch on the same reads, with fixed and with
     per-read lengths; page-locked caller buffers (dg_host_alloc) through the raw ABI; a read with a lower-case base is refused
