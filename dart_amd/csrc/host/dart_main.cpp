@@ -6,7 +6,7 @@
 //   FASTA/FASTQ(.gz) readers, chunking, mate-2 reverse complement   GetData.cpp:44-247
 //   SAM header/records, statistics, junctions.tab   Mapping.cpp:208-369,567-577,683-716,741-751,806-822
 // Everything between "chunk read" and "records formatted" (Mapping.cpp:598-639) is dg_map_batch.
-// Out of scope and refused with a message: -bo (BAM via htslib), `index`, `update`.
+// -bo: BAM through bam_writer.h (the reference hands its SAM lines to htslib).  Out of scope and refused with a message: `index`, `update`.
 //
 // Batches are much larger than the reference's 4000-read chunks (a GPU launch needs >= 10^5 reads);
 // output order is input order, which equals the reference at -t 1.  -t keeps its
@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "fast_fastq.h"
+#include "bam_writer.h"
 
 static const char *VersionStr = "1.4.6";
 
@@ -40,7 +41,7 @@ struct Options {
     char sj[256] = "junctions.tab";
     std::vector<std::string> f1, f2;
     int threads = 4;
-    bool pair_end = false, multi = false, unique = false, silent = false, all_sj = false;
+    bool pair_end = false, multi = false, unique = false, silent = false, all_sj = false, bam = false;
     dg_params p;
 };
 
@@ -424,8 +425,8 @@ int main(int argc, char *argv[])
         else if (p == "-f") { while (++i < argc && argv[i][0] != '-') o.f1.push_back(argv[i]); i--; }
         else if (p == "-f2") { while (++i < argc && argv[i][0] != '-') o.f2.push_back(argv[i]); i--; }
         else if (p == "-t") { if ((o.threads = atoi(argv[++i])) <= 0) { fprintf(stdout, "Warning! Thread number should be a positive number!\n"); o.threads = 4; } }
-        else if (p == "-o") o.out = argv[++i];
-        else if (p == "-bo") { fprintf(stderr, "Error! BAM output (-bo) is outside this build's scope; use -o\n"); return 1; }
+        else if (p == "-o") { o.out = argv[++i]; o.bam = false; }                      // main.cpp:158-168
+        else if (p == "-bo") { o.out = argv[++i]; o.bam = true; }
         else if (p == "-mis" && i + 1 < argc) o.p.max_mismatch = atoi(argv[++i]);
         else if (p == "-max_dup" && i + 1 < argc) { o.p.max_dup = atoi(argv[++i]); if (o.p.max_dup < 100) o.p.max_dup = 100; else if (o.p.max_dup >= 10000) o.p.max_dup = 10000; }
         else if (p == "-silent") o.silent = true;
@@ -465,7 +466,7 @@ int main(int argc, char *argv[])
     SlotPool pool;
     {
         const std::string &fn0 = o.f1[0];
-        if (!getenv("DART_STREAMING") && fn0.substr(fn0.find_last_of('.') + 1) != "gz" && check_read_format(fn0.c_str()))
+        if (!o.bam && !getenv("DART_STREAMING") && fn0.substr(fn0.find_last_of('.') + 1) != "gz" && check_read_format(fn0.c_str()))
             pool.start((size_t)n_gpu * inflight_cfg + 2, batch_reads, 160);
     }
     HostIndex ix;
@@ -479,10 +480,17 @@ int main(int argc, char *argv[])
     std::vector<dg_ctx *> ctx, roots, clones;
     dg_index_view view = ix.view();
 
-    FILE *sam = fopen(o.out, "w+");     // (read access too: the parallel pipeline maps the file to write it)
-    if (!sam) { fprintf(stderr, "Cannot write %s\n", o.out); return 1; }
-    fprintf(sam, "@PG\tID:Dart\tPN:Dart\tVN:%s\n", VersionStr);
-    for (size_t i = 0; i < ix.names.size(); i++) fprintf(sam, "@SQ\tSN:%s\tLN:%lld\n", ix.names[i].c_str(), (long long)ix.len[i]);
+    std::string hdr_text = std::string("@PG\tID:Dart\tPN:Dart\tVN:") + VersionStr + "\n";      // Mapping.cpp:741-751
+    for (size_t i = 0; i < ix.names.size(); i++) hdr_text += "@SQ\tSN:" + ix.names[i] + "\tLN:" + std::to_string((long long)ix.len[i]) + "\n";
+    FILE *sam = nullptr;
+    BamWriter bam;
+    if (o.bam) {
+        if (!bam.open(o.out, hdr_text, ix.names, std::vector<int64_t>(ix.len.begin(), ix.len.end()), o.threads)) { fprintf(stderr, "Cannot write %s\n", o.out); return 1; }
+    } else {
+        sam = fopen(o.out, "w+");     // (read access too: the parallel pipeline maps the file to write it)
+        if (!sam) { fprintf(stderr, "Cannot write %s\n", o.out); return 1; }
+        fwrite(hdr_text.data(), 1, hdr_text.size(), sam);
+    }
 
     Counters total;
     std::map<std::pair<int64_t, int64_t>, int> sjmap;
@@ -503,8 +511,8 @@ int main(int argc, char *argv[])
         }
         if (!s1.fp && !s1.gz) continue;
         if (sep && !s2.fp && !s2.gz) continue;
-        // plain FASTQ goes through the parallel host pipeline (fast_fastq.h); FASTA, .gz and DART_STREAMING=1 through the streaming one below
-        const bool fast_host = fastq && !gz && !getenv("DART_STREAMING") && (!sep || o.f2[lib].substr(o.f2[lib].find_last_of('.') + 1) != "gz");
+        // plain FASTQ goes through the parallel host pipeline (fast_fastq.h); FASTA, .gz, -bo and DART_STREAMING=1 through the streaming one below
+        const bool fast_host = fastq && !gz && !o.bam && !getenv("DART_STREAMING") && (!sep || o.f2[lib].substr(o.f2[lib].find_last_of('.') + 1) != "gz");
         // the mate files start being parsed now, i.e. also while dg_init uploads the index and builds its tables
         Prefetch pf1, pf2;
         if (sep && !fast_host) { pf1.start(&s1, false); pf2.start(&s2, pair_end); }
@@ -660,7 +668,8 @@ int main(int argc, char *argv[])
             const double t = now();
             const size_t n = b->n_reads;
             for (size_t t2 = 0; t2 < b->outs.size(); t2++) {
-                fwrite(b->outs[t2].data(), 1, b->outs[t2].size(), sam);
+                if (o.bam) bam.add_sam_text(b->outs[t2].data(), b->outs[t2].size());      // Mapping.cpp:655-662: every SAM line -> one BAM record
+                else fwrite(b->outs[t2].data(), 1, b->outs[t2].size(), sam);
                 total.unique += b->cts[t2].unique; total.unmapped += b->cts[t2].unmapped; total.paired += b->cts[t2].paired;
             }
             total.total += (long long)n;
@@ -682,7 +691,8 @@ int main(int argc, char *argv[])
         if (s2.gz) gzclose(s2.gz);
     }
     if (!o.silent) fprintf(stdout, "\rAll the %lld %s reads have been processed in %lld seconds.\n", total.total, pair_end ? "paired-end" : "single-end", (long long)(time(NULL) - t0));
-    fclose(sam);
+    if (o.bam) { if (!bam.close()) { fprintf(stderr, "Error while writing %s\n", o.out); return 1; } }
+    else fclose(sam);
     for (auto c : clones) dg_destroy(c);
     for (auto c : roots) dg_destroy(c);
 
