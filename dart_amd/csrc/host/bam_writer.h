@@ -71,6 +71,34 @@ public:
         f_ = nullptr;
         return !bad_;
     }
+    // several pieces of SAM text (each whole lines) that follow one another in the output: converted side by side, appended in order
+    void add_sam_chunks(const std::vector<std::pair<const char *, size_t>> &chunks)
+    {
+        const size_t n = chunks.size();
+        std::vector<std::vector<uint8_t>> recs(n);
+        std::vector<long long> good(n, 0), refused(n, 0);
+        const int T = (int)std::min<size_t>((size_t)threads_, n);
+        auto work = [&](int t) {
+            std::vector<uint8_t> one;
+            for (size_t c = (size_t)t; c < n; c += (size_t)T) {
+                const char *p = chunks[c].first, *end = p + chunks[c].second;
+                recs[c].reserve(chunks[c].second);
+                while (p < end) {
+                    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                    const char *le = nl ? nl : end;
+                    if (le > p && *p != '@') {
+                        one.clear();
+                        if (sam_line_to_bam(p, (size_t)(le - p), one)) { recs[c].insert(recs[c].end(), one.begin(), one.end()); good[c]++; } else refused[c]++;
+                    }
+                    p = nl ? nl + 1 : end;
+                }
+            }
+        };
+        if (T <= 1) work(0);
+        else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
+        for (size_t c = 0; c < n; c++) { append(recs[c].data(), recs[c].size()); n_records_ += good[c]; n_refused_ += refused[c]; }
+        compress_full_blocks();
+    }
     long long records() const { return n_records_; }
     long long refused() const { return n_refused_; }
 

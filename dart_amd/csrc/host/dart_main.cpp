@@ -667,9 +667,13 @@ int main(int argc, char *argv[])
             if (b->rc) { bad = true; bad_rc = b->rc; bad_msg = b->err; std::lock_guard<std::mutex> lk(mu); failed = true; cv_in.notify_all(); cv_space.notify_all(); break; }
             const double t = now();
             const size_t n = b->n_reads;
+            if (o.bam) {                                     // Mapping.cpp:655-662: every SAM line -> one BAM record
+                std::vector<std::pair<const char *, size_t>> chunks;
+                for (size_t t2 = 0; t2 < b->outs.size(); t2++) chunks.emplace_back(b->outs[t2].data(), b->outs[t2].size());
+                bam.add_sam_chunks(chunks);
+            }
             for (size_t t2 = 0; t2 < b->outs.size(); t2++) {
-                if (o.bam) bam.add_sam_text(b->outs[t2].data(), b->outs[t2].size());      // Mapping.cpp:655-662: every SAM line -> one BAM record
-                else fwrite(b->outs[t2].data(), 1, b->outs[t2].size(), sam);
+                if (!o.bam) fwrite(b->outs[t2].data(), 1, b->outs[t2].size(), sam);
                 total.unique += b->cts[t2].unique; total.unmapped += b->cts[t2].unmapped; total.paired += b->cts[t2].paired;
             }
             total.total += (long long)n;

@@ -25,14 +25,19 @@ int main(int argc, char **argv)
     BamWriter w;
     if (!w.open(argv[2], header, names, lens, atoi(argv[3]))) return 1;
     // in pieces of awkward sizes that end on line boundaries, as the host program's formatter threads deliver them
-    size_t chunk = 7;
+    // alternately one piece (add_sam_text) and a group of pieces converted side by side (add_sam_chunks)
+    size_t chunk = 7; int turn = 0;
+    std::vector<std::pair<const char *, size_t>> group;
     while (p < text.size()) {
         size_t e = std::min(text.size(), p + chunk);
         e = text.find('\n', e - 1);
         e = e == std::string::npos ? text.size() : e + 1;
-        w.add_sam_text(text.data() + p, e - p);
+        if (turn % 5 == 0) w.add_sam_text(text.data() + p, e - p);
+        else { group.emplace_back(text.data() + p, e - p); if (turn % 5 == 4) { w.add_sam_chunks(group); group.clear(); } }
         p = e; chunk = chunk * 3 + 11; if (chunk > (1u << 22)) chunk = 7;
+        turn++;
     }
+    if (!group.empty()) w.add_sam_chunks(group);
     if (!w.close()) return 1;
     printf("records=%lld refused=%lld\n", w.records(), w.refused());
     return 0;

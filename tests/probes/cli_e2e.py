@@ -25,6 +25,10 @@ for env_extra in ({"DART_INFLIGHT": "2", "DART_STREAMING": "1"}, {"DART_INFLIGHT
     r = subprocess.run([dart, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-o", "gpu.sam", "-j", "gpu.j", "-t", "16", "-mis", "5"], cwd=d, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     dt = time.time() - t
     print(env_extra, "dart wall %.2f s = %.2f M reads/s (incl. index load + dg_init)" % (dt, 2 * pairs / dt / 1e6), r.stderr.decode().strip().splitlines()[-1:])
+t = time.time()
+r = subprocess.run([dart, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-bo", "gpu.bam", "-j", "gpu.j", "-t", "16", "-mis", "5"], cwd=d, env=dict(os.environ, DART_TIMING="1", DART_INFLIGHT="2"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+dt = time.time() - t
+print("-bo (BAM, 16 compression threads): dart wall %.2f s = %.2f M reads/s, %d bytes" % (dt, 2 * pairs / dt / 1e6, os.path.getsize(os.path.join(d, "gpu.bam"))), r.stderr.decode().strip().splitlines()[-1:])
 if os.environ.get("CLI_E2E_COMPARE", "1") == "1":
     oracle_py.build()
     t = time.time()
