@@ -158,7 +158,7 @@ class Worker:
         self.used = (C.c_size_t * 3)()
         self.o_r = gpu.pinned((n,), host.READ_OUT); self.o_p = gpu.pinned((self.caps[0],), host.REPORT_OUT)          # (the compact types use the front of these)
         self.o_c = gpu.pinned((self.caps[1],), np.uint32); self.o_s = gpu.pinned((self.caps[2],), host.SJ_OUT)
-        self.c_r = self.o_r.a.view(np.uint8)[:n * 16].view(host.READ_C); self.c_p = self.o_p.a.view(np.uint8)[:self.caps[0] * 20].view(host.REPORT_C)
+        self.c_r = self.o_r.a.view(np.uint8)[:n * host.READ_C.itemsize].view(host.READ_C); self.c_p = self.o_p.a.view(np.uint8)[:self.caps[0] * host.REPORT_C.itemsize].view(host.REPORT_C)
         self.kern = {}; self.n_runs = 0; self.last_records = records
 
     def map(self, b, mode=None, records=None):
@@ -182,21 +182,23 @@ class Worker:
             rc = lib.dg_batch_run(g.ctx, self.used)
         g._chk(rc, "dg_map_batch(%s)" % mode)
         g._n = b.n; g._used = [int(x) for x in self.used]
+        self.last_rlen = b.rlen
         for name, ms in g.timings():
             self.kern[name] = self.kern.get(name, 0.0) + ms
         self.n_runs += 1
 
     def result(self):
+        import numpy as np
         from dart_amd import host
         u = [int(x) for x in self.used]
         if self.last_records == "compact":
-            r, p = host.expand_compact(self.c_r.copy(), self.c_p[:u[0]].copy())
-            return host.BatchResult(r, p, self.o_c.a[:u[1]].copy(), self.o_s.a[:u[2]].copy())
+            r, p, cg = host.expand_compact(self.c_r.copy(), self.c_p[:u[0]].copy(), self.o_c.a[:u[1]].copy(), np.full(len(self.c_r), self.last_rlen, np.uint16))
+            return host.BatchResult(r, p, cg, self.o_s.a[:u[2]].copy())
         return host.BatchResult(self.o_r.a.copy(), self.o_p.a[:u[0]].copy(), self.o_c.a[:u[1]].copy(), self.o_s.a[:u[2]].copy())
 
     def out_bytes(self, n):
         u = [int(x) for x in self.used]
-        return (16 * n + 20 * u[0] if self.last_records == "compact" else 36 * n + 40 * u[0]) + 4 * u[1] + 24 * u[2]
+        return (12 * n + 16 * u[0] if self.last_records == "compact" else 36 * n + 40 * u[0]) + 4 * u[1] + 24 * u[2]
 
 
 def main():
@@ -298,7 +300,7 @@ def main():
 
     def gather(w):
         nonlocal gather_buf
-        local_t = w.gpu.device_reads_tensor(compact=(w.last_records == "compact"))      # 16 (or 36) bytes per read, straight from HBM
+        local_t = w.gpu.device_reads_tensor(compact=(w.last_records == "compact"))      # 12 (or 36) bytes per read, straight from HBM
         if rehearse:
             local_t = local_t.cpu()
         if gather_buf is None:
@@ -513,13 +515,13 @@ def main():
                                   ("%.0f %% of the reads spliced over %d planted introns, -max_intron %d, " % (100 * args.spliced, args.introns, args.max_intron)) if args.spliced else "", args.mis),
                    "input": ("packed reads (2 bit/base + N list, dg_map_batch_packed): %.1f MB per batch" if args.input == "packed" else "ASCII reads (dg_map_batch): %.1f MB per batch") % (in_bytes / 1e6),
                    "output": ("%s + CIGAR ops + junction tuples into page-locked host arrays: %%.1f MB per batch" %
-                              ("compact records (dg_read_c 16 B + dg_report_c 20 B, lossless)" if args.records == "compact" else "dg_read_out 36 B + dg_report_out 40 B")) % (workers[0].out_bytes(n_reads) / 1e6),
+                              ("compact records (dg_read_c 12 B + dg_report_c 16 B, no CIGAR for plain full-length matches, lossless)" if args.records == "compact" else "dg_read_out 36 B + dg_report_out 40 B")) % (workers[0].out_bytes(n_reads) / 1e6),
                    "host_link": "57 GB/s in total, both directions together (profiles/probes/pcie_probe.py): bytes in + bytes out per read bound this rate",
                    "timed_region": "first batch handed over in host memory -> last record back in host memory (H2D + all kernels + D2H, %d batches in flight)" % len(workers),
                    "pairs_per_gpu_per_step": nb * args.pairs, "read_len": args.rlen, "spliced_fraction": args.spliced, "batches_in_flight_per_gpu": len(workers),
                    "synthetic_genome_repeat_content": "planted repeat families cover ~18 %% of the genome at --repeat-scale 1 (real human DNA: ~50 %%, which would move work "
                                                       "from k_pair to the wave-per-unit kernels and the general report path)",
-                   "parallelism": ("reads sharded x%d, index replicated" % world) + (", RCCL gather of the per-read records (%d B per read) to rank 0 inside the timed region" % (16 if args.records == "compact" else 36) if do_gather else ", no data-path collective")},
+                   "parallelism": ("reads sharded x%d, index replicated" % world) + (", RCCL gather of the per-read records (%d B per read) to rank 0 inside the timed region" % (12 if args.records == "compact" else 36) if do_gather else ", no data-path collective")},
         "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
         "kernels_ms_one_batch_in_flight": {k: round(v, 4) for k, v in iso.items()},
         "counters_per_launch": counters,

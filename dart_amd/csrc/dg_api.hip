@@ -42,7 +42,7 @@ struct dg_ctx {
     bool owns_index = true;       // false for dg_clone()d contexts: the index arrays belong to the parent
     size_t seedq_lds_set = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr, ev_wait = nullptr;
     float reseed_ms = 0;
     char err[512] = "";
     DIndex ix{};
@@ -62,7 +62,7 @@ struct dg_ctx {
     DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint32_t> job_lists; DBuf<uint8_t> done; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
-    DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c;
+    DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c; DBuf<uint32_t> cig_cnt, cig_off, cig_c;     // compact download: records, stored-op counts / offsets / ops
     DBuf<unsigned char> ws;
     DBuf<unsigned long long> scan_state;
     size_t cap_seeds = 0, cap_rep = 0, cap_work = 0, cap_cig = 0;
@@ -75,14 +75,14 @@ struct dg_ctx {
     uint64_t counters[CTR_N];
     int n_cu = 256, runs_of_last_batch = 0;
     // environment switches, read once per context (not per batch)
-    int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0;
+    int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
 };
 
 static void read_env(dg_ctx *c)
 {
     auto geti = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
     c->env_seed_waves = geti("DG_SEED_WAVES", 4); c->env_bail_trips = geti("DG_SEED_BAIL_TRIPS", 128); c->env_both = geti("DG_SEED_BOTH", 0);
-    c->env_seed_legacy = geti("DG_SEED_LEGACY", 0); c->env_seed_slots_lg = geti("DG_SEED_SLOTS_LG", 0); c->env_seed_wgs = geti("DG_SEED_WGS", 0);
+    c->env_seed_legacy = geti("DG_SEED_LEGACY", 0); c->env_seed_slots_lg = geti("DG_SEED_SLOTS_LG", 0); c->env_seed_wgs = geti("DG_SEED_WGS", 0); c->env_blocking_sync = geti("DG_BLOCKING_SYNC", 0);
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
 }
 
@@ -147,6 +147,15 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t *out, const uint32_t 
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] += tile_sums[i / SCAN_TILE];
+}
+
+// waiting for a context's stream on the per-batch path.  DG_BLOCKING_SYNC=1: through an event created with hipEventBlockingSync, so the
+// host thread sleeps instead of spinning (one thread per context: a dozen spinning threads per GPU is a dozen busy cores)
+static hipError_t wait_stream(dg_ctx *c)
+{
+    if (!c->env_blocking_sync || !c->ev_wait) return hipStreamSynchronize(c->stream);
+    const hipError_t e = hipEventRecord(c->ev_wait, c->stream);
+    return e != hipSuccess ? e : hipEventSynchronize(c->ev_wait);
 }
 
 // out[0..n) = exclusive scan of in, out[n] = total (also stored at total_copy; flagged in *err when it exceeds cap)
@@ -449,9 +458,10 @@ extern "C" void dg_destroy(dg_ctx *c)
     c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
     c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_lists.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
-    c->ws.release(); c->scan_state.release(); c->reads_c.release(); c->reports_c.release();
+    c->ws.release(); c->scan_state.release(); c->reads_c.release(); c->reports_c.release(); c->cig_cnt.release(); c->cig_off.release(); c->cig_c.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+    if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     if (c->ev_reseed0) (void)hipEventDestroy(c->ev_reseed0);
     if (c->ev_reseed1) (void)hipEventDestroy(c->ev_reseed1);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -465,7 +475,8 @@ static hipError_t make_ctx_objects(dg_ctx *c)
     hipError_t e;
     for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) return e;
-    if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess) return e;
+    if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return e;
     for (int i = 0; i <= N_TIMERS; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, N_TOPS * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess || (e = hipMalloc((void **)&c->d_sizes, sizeof(DSizes))) != hipSuccess) return e;
@@ -943,7 +954,7 @@ static int finish_run(dg_ctx *c, size_t used[3])
     c->runs_of_last_batch = 0;
     for (int attempt = 0; attempt < 6; attempt++) {
         c->runs_of_last_batch++;
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(wait_stream(c));
         HIPCHK(hipStreamSynchronize(c->stream2));
         const DSizes &sz = c->h_tail->sizes;
         const int derr = c->h_tail->err;
@@ -1003,56 +1014,80 @@ static int enqueue_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint3
     return DG_OK;
 }
 
-// full records -> compact records (include/dartgpu.h); *bad is raised when a field does not fit
+// full records -> compact records (include/dartgpu.h); *bad is raised when a field does not fit.  One thread per read: the read's record,
+// the records of its reports, and per report how many CIGAR ops will be stored (0 for the plain full-length match "<rlen>M")
 __global__ void __launch_bounds__(256)
-k_pack_records(uint32_t n_reads, uint32_t n_rep, const dg_read_out *__restrict__ ro, const dg_report_out *__restrict__ po,
-               dg_read_c *__restrict__ rc, dg_report_c *__restrict__ pc, int *bad)
+k_pack_records(uint32_t n_reads, const dg_read_out *__restrict__ ro, const dg_report_out *__restrict__ po, const uint32_t *__restrict__ cig,
+               const uint16_t *__restrict__ rlen, dg_read_c *__restrict__ rc, dg_report_c *__restrict__ pc, uint32_t *__restrict__ n_ops, int *bad)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool over = false;
-    if (i < n_reads) {
-        const dg_read_out r = ro[i];
-        dg_read_c o;
-        o.score = (uint16_t)r.score; o.sub_score = (uint16_t)r.sub_score; o.mis_num = (uint16_t)r.mis_num; o.mapq = (uint8_t)r.mapq; o.n_sj = (uint8_t)r.n_sj;
-        o.n_rep = (uint16_t)r.n_rep; o.best = (uint16_t)r.best; o.rep_off = (uint32_t)r.rep_off;
-        over = (uint32_t)r.score > 0xFFFFu || (uint32_t)r.sub_score > 0xFFFFu || (uint32_t)r.mis_num > 0xFFFFu || (uint32_t)r.mapq > 0xFFu || (uint32_t)r.n_sj > 0xFFu ||
-               (uint32_t)r.n_rep > 0xFFFFu || (uint32_t)r.best > 0xFFFFu;
-        rc[i] = o;
-    }
-    if (i < n_rep) {
-        const dg_report_out p = po[i];
-        dg_report_c o;
-        o.pos = (int32_t)p.pos; o.cigar_off = p.cigar_off; o.aln_score = (uint16_t)p.aln_score; o.flag = (uint16_t)p.flag; o.paired_idx = (int16_t)p.paired_idx;
-        o.chr = p.chr < 0 ? (uint16_t)0xFFFFu : (uint16_t)p.chr; o.n_cigar = (uint8_t)p.n_cigar; o.sj_type = (int8_t)p.sj_type; o.bdir = (uint8_t)p.bdir; o.pad = 0;
+    if (i >= n_reads) return;
+    const dg_read_out r = ro[i];
+    dg_read_c o;
+    o.score = (uint16_t)r.score; o.sub_score = (uint16_t)r.sub_score; o.mis_num = (uint16_t)r.mis_num; o.mapq = (uint8_t)r.mapq; o.n_sj = (uint8_t)r.n_sj;
+    o.n_rep = (uint16_t)r.n_rep; o.best = (uint16_t)r.best;
+    bool over = (uint32_t)r.score > 0xFFFFu || (uint32_t)r.sub_score > 0xFFFFu || (uint32_t)r.mis_num > 0xFFFFu || (uint32_t)r.mapq > 0xFFu || (uint32_t)r.n_sj > 0xFFu ||
+                (uint32_t)r.n_rep > 0xFFFFu || (uint32_t)r.best > 0xFFFFu;
+    rc[i] = o;
+    const uint32_t full_match = (uint32_t)rlen[i] << 4;                       // "<rlen>M"
+    for (int32_t k = 0; k < r.n_rep; k++) {
+        const uint32_t j = (uint32_t)r.rep_off + (uint32_t)k;
+        const dg_report_out p = po[j];
+        dg_report_c q;
+        q.pos = (int32_t)p.pos; q.aln_score = (uint16_t)p.aln_score; q.flag = (uint16_t)p.flag; q.paired_idx = (int16_t)p.paired_idx;
+        q.chr = p.chr < 0 ? (uint16_t)0xFFFFu : (uint16_t)p.chr; q.sj_type = (int8_t)p.sj_type; q.bdir = (uint8_t)p.bdir; q.pad = 0;
+        const bool plain = p.n_cigar == 1u && cig[p.cigar_off] == full_match;
+        q.n_cigar = plain ? (uint8_t)DG_CIGAR_FULL_MATCH : (uint8_t)p.n_cigar;
+        n_ops[j] = plain ? 0u : p.n_cigar;
         over = over || p.pos != (int64_t)(int32_t)p.pos || (uint32_t)p.aln_score > 0xFFFFu || (uint32_t)p.flag > 0xFFFFu || p.paired_idx > 32767 || p.paired_idx < -1 ||
-               p.chr >= 0xFFFF || p.n_cigar > 255u || p.sj_type < -128 || p.sj_type > 127 || (uint32_t)p.bdir > 1u;
-        pc[i] = o;
+               p.chr >= 0xFFFF || p.n_cigar > 254u || p.sj_type < -128 || p.sj_type > 127 || (uint32_t)p.bdir > 1u;
+        pc[j] = q;
     }
     if (over) atomicMax(bad, 1);
 }
 
-extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3])
+// the stored CIGAR ops, report by report (op_off = exclusive scan of n_ops)
+__global__ void __launch_bounds__(256)
+k_pack_cigar(uint32_t n_rep, const dg_report_out *__restrict__ po, const uint32_t *__restrict__ cig, const uint32_t *__restrict__ op_off, uint32_t *__restrict__ out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rep) return;
+    const uint32_t a = op_off[j], n = op_off[j + 1] - a, src = po[j].cigar_off;
+    for (uint32_t t = 0; t < n; t++) out[a + t] = cig[src + t];
+}
+
+extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3], size_t *n_ops_out)
 {
     if (!c || !caps) return DG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    if (caps[0] < c->used[0] || caps[1] < c->used[1] || caps[2] < c->used[2]) {
-        snprintf(c->err, 512, "output capacity too small: reports %zu of %zu, cigar ops %zu of %zu, junction tuples %zu of %zu", c->used[0], caps[0], c->used[1], caps[1], c->used[2], caps[2]);
+    if (n_ops_out) *n_ops_out = 0;
+    if (caps[0] < c->used[0] || caps[2] < c->used[2]) {
+        snprintf(c->err, 512, "output capacity too small: reports %zu of %zu, junction tuples %zu of %zu", c->used[0], caps[0], c->used[2], caps[2]);
         return DG_ERR_CAPACITY;
     }
     const size_t n = (size_t)c->n_reads, nr = c->used[0];
     if (n == 0) return DG_OK;
-    HIPCHK(c->reads_c.ensure(n + 1)); HIPCHK(c->reports_c.ensure(nr + 1));
+    HIPCHK(c->reads_c.ensure(n + 1)); HIPCHK(c->reports_c.ensure(nr + 1)); HIPCHK(c->cig_cnt.ensure(nr + 1)); HIPCHK(c->cig_off.ensure(nr + 2)); HIPCHK(c->cig_c.ensure(c->used[1] + 1));
     HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
-    const size_t m = n > nr ? n : nr;
-    k_pack_records<<<(unsigned)((m + 255) / 256), 256, 0, c->stream>>>((uint32_t)n, (uint32_t)nr, c->reads_out.p, c->reports.p, c->reads_c.p, c->reports_c.p, c->d_err);
+    k_pack_records<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((uint32_t)n, c->reads_out.p, c->reports.p, c->cigfinal.p, c->rlen.p, c->reads_c.p, c->reports_c.p, c->cig_cnt.p, c->d_err);
+    HIPCHK(scan_u32(c, c->cig_cnt.p, c->cig_off.p, (uint32_t)nr, &c->d_sizes->pad[0]));
+    if (nr) k_pack_cigar<<<(unsigned)((nr + 255) / 256), 256, 0, c->stream>>>((uint32_t)nr, c->reports.p, c->cigfinal.p, c->cig_off.p, c->cig_c.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&c->h_tail->err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h_tail->sizes.pad[0], &c->d_sizes->pad[0], 4, hipMemcpyDeviceToHost, c->stream));
+    // the records (their sizes are known) travel while the host waits for the op count
     if (ro) HIPCHK(hipMemcpyAsync(ro, c->reads_c.p, n * sizeof(dg_read_c), hipMemcpyDeviceToHost, c->stream));
     if (nr && po) HIPCHK(hipMemcpyAsync(po, c->reports_c.p, nr * sizeof(dg_report_c), hipMemcpyDeviceToHost, c->stream));
-    if (c->used[1] && cig) HIPCHK(hipMemcpyAsync(cig, c->cigfinal.p, c->used[1] * 4, hipMemcpyDeviceToHost, c->stream));
     if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(wait_stream(c));
     if (c->h_tail->err) { snprintf(c->err, 512, "a record field does not fit the compact types: use dg_batch_download"); return DG_ERR_RANGE; }
+    const size_t n_ops = nr ? (size_t)c->h_tail->sizes.pad[0] : 0;
+    if (n_ops_out) *n_ops_out = n_ops;
+    if (caps[1] < n_ops) { snprintf(c->err, 512, "output capacity too small: cigar ops %zu of %zu", n_ops, caps[1]); return DG_ERR_CAPACITY; }
+    if (n_ops && cig) {
+        HIPCHK(hipMemcpyAsync(cig, c->cig_c.p, n_ops * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(wait_stream(c));
+    }
     return DG_OK;
 }
 
@@ -1064,7 +1099,10 @@ extern "C" int dg_map_batch_compact(dg_ctx *c, int n_reads, const uint32_t *seq_
     int rc = words ? enqueue_upload_packed(c, n_reads, rlen_all, rlen, words_per_read, words, nlist, n_n) : enqueue_upload(c, n_reads, seq_off, rlen, seq);
     if (rc) return rc;
     if ((rc = dg_batch_run(c, used))) return rc;
-    return dg_batch_download_compact(c, ro, po, cig, so, caps);
+    size_t n_ops = 0;
+    rc = dg_batch_download_compact(c, ro, po, cig, so, caps, &n_ops);
+    if (used && (rc == DG_OK || rc == DG_ERR_CAPACITY)) used[1] = n_ops ? n_ops : (rc == DG_OK ? 0 : used[1]);
+    return rc;
 }
 
 extern "C" int dg_batch_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3])
@@ -1073,7 +1111,7 @@ extern "C" int dg_batch_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, 
     HIPCHK(hipSetDevice(c->device));
     const int rc = enqueue_download(c, ro, po, cig, so, caps);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(wait_stream(c));
     return DG_OK;
 }
 

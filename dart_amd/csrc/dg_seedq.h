@@ -32,6 +32,90 @@ __host__ __device__ inline size_t sq_lds_bytes(int nslot_lg, int W)
     return n * 48 + n * 4 * (size_t)W + 2 * n * 2 * SQ_NQ + SQ_WAVES * 64 * 2 + 16 * 4;
 }
 
+// what a trip needs besides its slot (kernel-wide, uniform)
+struct SqEnv {
+    const DIndex &ix; const DParams &pr;
+    uint4 *st; uint32_t *rd;
+    int NSLOT, W2, K, H, bail_trips; bool direct;
+    DHit *hits; uint32_t *nhits, *nseeds; DHeavy *heavy; unsigned int *n_heavy;
+};
+
+// One trip of up to 64 searches that are all in mode MODE (a compile-time constant: every instance holds only its mode's code, and the
+// four instances share no registers across a merge -- as ONE body switched by a uniform mode the compiler kept all modes' state alive
+// and moved it around: 448 v_mov and 126 SGPR reloads in a 2500-instruction loop).  Returns the queue the slot goes to.
+template <int MODE>
+__device__ __forceinline__ int sq_trip(const SqEnv &e, const bool act, const uint32_t slot, SeedCtr &c, uint32_t &max_trips)
+{
+    const DIndex &ix = e.ix;
+    const int NSLOT = e.NSLOT, W2 = e.W2;
+    uint32_t *rd = e.rd; uint4 *st = e.st;
+    int nq = SQ_FREE;
+    uint4 A = make_uint4(0, 0, 0, 0), B = A, C = A;
+    if (act) { A = st[slot * 3]; if (MODE != SQ_BEGIN) { B = st[slot * 3 + 1]; C = st[slot * 3 + 2]; } }
+    const int r = (int)A.x, len = (int)(A.y & 0xFFFFu), end_pos = len - 13;
+    int pos = (int)(A.y >> 16), nh = (int)(A.z & 0xFFFu);
+    uint32_t nsearch = (A.z >> 12) & 0xFFu, trips = A.z >> 20, ns = A.w;
+    Search s;
+    s.mode = MODE; s.hit_len = 0; s.located = false;
+    s.start = (int)(B.x & 0xFFFFu); s.p = (int)(B.x >> 16); s.ref_steps = B.y & 0xFFFFu; s.ref_blocks = B.y >> 16;
+    s.x0 = s.x1 = s.lk = 0; s.x2 = 1; s.tpos = 0; s.lsteps = 0;
+    if (MODE == SQ_STEP) { s.x0 = d_u64(B.z, B.w); s.x1 = d_u64(C.x, C.y); s.x2 = d_u64(C.z, C.w); }
+    else if (MODE == SQ_LOC) { s.lk = d_u64(B.z, B.w); s.lsteps = C.x; }
+    else if (MODE == SQ_CMP) { s.tpos = (int64_t)d_u64(B.z, B.w); s.lk = d_u64(C.x, C.y); s.lsteps = C.z; }
+    auto rb = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)wc * NSLOT + slot]; return w < W2 ? v : 0u; };
+    auto rm = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)(W2 + wc) * NSLOT + slot]; return w < W2 ? v : 0xFFFFFFFFu; };
+    bool live = act, finished = false, beginning = false;
+    TripData t; t.aux = T_NONE;
+    TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
+    if (act) {
+        trips = trips < 4095u ? trips + 1u : trips;
+        if (MODE == SQ_BEGIN) {                        // IdentifySeedPairs :191-211: next start
+            while (pos < end_pos && d_at(rm, pos)) pos++;
+            if (pos >= end_pos) finished = true;
+            else if (nsearch >= SEED_BAIL || trips >= (uint32_t)e.bail_trips) {     // a long walk: let a whole wave finish this read
+                DHeavy hv; hv.read = (uint32_t)r; hv.pos = pos; hv.nh = nh; hv.ns = ns;
+                e.heavy[atomicAdd(e.n_heavy, 1u)] = hv;
+                max_trips = trips > max_trips ? trips : max_trips;
+                live = false;
+            } else { nsearch++; beginning = true; d_begin_issue(ix, e.K, rb, rm, pos, s, c, ta, t); }
+        } else d_trip_issue(ix, rm, len, e.direct, s, c, ta, t);
+    }
+    d_trip_load(ta, t);
+    if (live) {
+        if (MODE == SQ_BEGIN) { if (beginning) d_begin_finish(ix, e.K, rb, s, c, t); }
+        else if (t.aux != T_NONE) d_trip_finish(ix, e.pr, rb, rm, len, s, c, t);
+        if (e.direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
+        if (s.mode == 1 && (s.p >= len || d_at(rm, s.p))) d_search_end(e.pr, s);              // what its next trip would find (T_STOP), without the trip
+        if (!finished && s.mode == 0) {          // a search just ended (or the table said "absent")
+            c.steps += s.ref_steps; c.blocks += s.ref_blocks;
+            if (s.hit_len) {
+                if (nh < e.H) {
+                    DHit h; h.rPos = (uint16_t)s.start; h.len = (uint16_t)s.hit_len;
+                    if (s.located) { h.x0 = (uint64_t)s.tpos; h.freq = 1u | 0x80000000u; c.lf_ref += s.lsteps + (uint32_t)(s.lk >> 40); }
+                    else { h.x0 = s.x0; h.freq = (uint32_t)s.x2; }
+                    e.hits[(size_t)r * e.H + nh] = h;
+                }
+                nh++; ns += (uint32_t)s.x2;
+                pos = s.start + s.hit_len;
+            } else pos = s.start + 1;
+            while (pos < end_pos && d_at(rm, pos)) pos++;                                   // the next start, or the end of the read:
+            if (pos >= end_pos) finished = true;                                            // no begin-trip just to find out
+        }
+        if (finished) { e.nhits[r] = (uint32_t)nh; e.nseeds[r] = ns; max_trips = trips > max_trips ? trips : max_trips; }
+        else {
+            nq = s.mode;
+            A.y = (uint32_t)len | ((uint32_t)pos << 16); A.z = (uint32_t)nh | (nsearch << 12) | (trips << 20); A.w = ns;
+            B.x = (uint32_t)s.start | ((uint32_t)s.p << 16); B.y = (s.ref_steps & 0xFFFFu) | (s.ref_blocks << 16);
+            if (s.mode == 1) { B.z = (uint32_t)s.x0; B.w = (uint32_t)(s.x0 >> 32); C = make_uint4((uint32_t)s.x1, (uint32_t)(s.x1 >> 32), (uint32_t)s.x2, (uint32_t)(s.x2 >> 32)); }
+            else if (s.mode == 3) { B.z = (uint32_t)s.lk; B.w = (uint32_t)(s.lk >> 32); C.x = s.lsteps; }
+            else if (s.mode == 2) { B.z = (uint32_t)s.tpos; B.w = (uint32_t)((uint64_t)s.tpos >> 32); C.x = (uint32_t)s.lk; C.y = (uint32_t)(s.lk >> 32); C.z = s.lsteps; }
+            st[slot * 3] = A;
+            if (s.mode != 0) { st[slot * 3 + 1] = B; st[slot * 3 + 2] = C; }
+        }
+    }
+    return nq;
+}
+
 __global__ void __launch_bounds__(SQ_THREADS)
 k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H, int nslot_lg,
          DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
@@ -54,6 +138,7 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
     const uint32_t w_magic = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;       // i / W == (i * w_magic) >> 20 for i < 64 W <= 2^12
     SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_trips = 0, wtrips = 0;
+    const SqEnv env = { ix, pr, st, rd, NSLOT, W2, K, H, bail_trips, direct, hits, nhits, nseeds, heavy, n_heavy };
     uint32_t q_trips[SQ_NQ] = {0, 0, 0, 0, 0}, q_lanes[SQ_NQ] = {0, 0, 0, 0, 0};
 
     for (int i = tid; i < NSLOT; i += SQ_THREADS) q[(size_t)SQ_FREE * QCAP + i] = (uint16_t)i;
@@ -132,72 +217,10 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
                     if (i < total) { const uint32_t rk = (i * w_magic) >> 20; rd[(size_t)(i - rk * (uint32_t)W) * NSLOT + tab[wave * 64 + rk]] = v[k]; }
                 }
             }
-        } else {
-            // ---- one trip of up to 64 searches that are all in mode my_q ----
-            uint4 A = make_uint4(0, 0, 0, 0), B = A, C = A;
-            if (act) { A = st[slot * 3]; if (my_q != SQ_BEGIN) { B = st[slot * 3 + 1]; C = st[slot * 3 + 2]; } }
-            const int r = (int)A.x, len = (int)(A.y & 0xFFFFu), end_pos = len - 13;
-            int pos = (int)(A.y >> 16), nh = (int)(A.z & 0xFFFu);
-            uint32_t nsearch = (A.z >> 12) & 0xFFu, trips = A.z >> 20, ns = A.w;
-            Search s;
-            s.mode = my_q; s.hit_len = 0; s.located = false;
-            s.start = (int)(B.x & 0xFFFFu); s.p = (int)(B.x >> 16); s.ref_steps = B.y & 0xFFFFu; s.ref_blocks = B.y >> 16;
-            s.x0 = s.x1 = s.lk = 0; s.x2 = 1; s.tpos = 0; s.lsteps = 0;
-            if (my_q == SQ_STEP) { s.x0 = d_u64(B.z, B.w); s.x1 = d_u64(C.x, C.y); s.x2 = d_u64(C.z, C.w); }
-            else if (my_q == SQ_LOC) { s.lk = d_u64(B.z, B.w); s.lsteps = C.x; }
-            else if (my_q == SQ_CMP) { s.tpos = (int64_t)d_u64(B.z, B.w); s.lk = d_u64(C.x, C.y); s.lsteps = C.z; }
-            auto rb = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)wc * NSLOT + slot]; return w < W2 ? v : 0u; };
-            auto rm = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)(W2 + wc) * NSLOT + slot]; return w < W2 ? v : 0xFFFFFFFFu; };
-            bool live = act, finished = false, beginning = false;
-            TripData t; t.aux = T_NONE;
-            TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
-            if (act) {
-                trips = trips < 4095u ? trips + 1u : trips;
-                if (my_q == SQ_BEGIN) {                        // IdentifySeedPairs :191-211: next start
-                    while (pos < end_pos && d_at(rm, pos)) pos++;
-                    if (pos >= end_pos) finished = true;
-                    else if (nsearch >= SEED_BAIL || trips >= (uint32_t)bail_trips) {     // a long walk: let a whole wave finish this read
-                        DHeavy hv; hv.read = (uint32_t)r; hv.pos = pos; hv.nh = nh; hv.ns = ns;
-                        heavy[atomicAdd(n_heavy, 1u)] = hv;
-                        max_trips = trips > max_trips ? trips : max_trips;
-                        live = false;
-                    } else { nsearch++; beginning = true; d_begin_issue(ix, K, rb, rm, pos, s, c, ta, t); }
-                } else d_trip_issue(ix, rm, len, direct, s, c, ta, t);
-            }
-            d_trip_load(ta, t);
-            if (live) {
-                if (beginning) d_begin_finish(ix, K, rb, s, c, t);
-                else if (t.aux != T_NONE) d_trip_finish(ix, pr, rb, rm, len, s, c, t);
-                if (direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
-                if (s.mode == 1 && (s.p >= len || d_at(rm, s.p))) d_search_end(pr, s);              // what its next trip would find (T_STOP), without the trip
-                if (!finished && s.mode == 0) {          // a search just ended (or the table said "absent")
-                    c.steps += s.ref_steps; c.blocks += s.ref_blocks;
-                    if (s.hit_len) {
-                        if (nh < H) {
-                            DHit h; h.rPos = (uint16_t)s.start; h.len = (uint16_t)s.hit_len;
-                            if (s.located) { h.x0 = (uint64_t)s.tpos; h.freq = 1u | 0x80000000u; c.lf_ref += s.lsteps + (uint32_t)(s.lk >> 40); }
-                            else { h.x0 = s.x0; h.freq = (uint32_t)s.x2; }
-                            hits[(size_t)r * H + nh] = h;
-                        }
-                        nh++; ns += (uint32_t)s.x2;
-                        pos = s.start + s.hit_len;
-                    } else pos = s.start + 1;
-                    while (pos < end_pos && d_at(rm, pos)) pos++;                                   // the next start, or the end of the read:
-                    if (pos >= end_pos) finished = true;                                            // no begin-trip just to find out
-                }
-                if (finished) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; max_trips = trips > max_trips ? trips : max_trips; }
-                else {
-                    nq = s.mode;
-                    A.y = (uint32_t)len | ((uint32_t)pos << 16); A.z = (uint32_t)nh | (nsearch << 12) | (trips << 20); A.w = ns;
-                    B.x = (uint32_t)s.start | ((uint32_t)s.p << 16); B.y = (s.ref_steps & 0xFFFFu) | (s.ref_blocks << 16);
-                    if (s.mode == 1) { B.z = (uint32_t)s.x0; B.w = (uint32_t)(s.x0 >> 32); C = make_uint4((uint32_t)s.x1, (uint32_t)(s.x1 >> 32), (uint32_t)s.x2, (uint32_t)(s.x2 >> 32)); }
-                    else if (s.mode == 3) { B.z = (uint32_t)s.lk; B.w = (uint32_t)(s.lk >> 32); C.x = s.lsteps; }
-                    else if (s.mode == 2) { B.z = (uint32_t)s.tpos; B.w = (uint32_t)((uint64_t)s.tpos >> 32); C.x = (uint32_t)s.lk; C.y = (uint32_t)(s.lk >> 32); C.z = s.lsteps; }
-                    st[slot * 3] = A;
-                    if (s.mode != 0) { st[slot * 3 + 1] = B; st[slot * 3 + 2] = C; }
-                }
-            }
-        }
+        } else if (my_q == SQ_BEGIN) nq = sq_trip<SQ_BEGIN>(env, act, slot, c, max_trips);
+        else if (my_q == SQ_STEP) nq = sq_trip<SQ_STEP>(env, act, slot, c, max_trips);
+        else if (my_q == SQ_CMP) nq = sq_trip<SQ_CMP>(env, act, slot, c, max_trips);
+        else nq = sq_trip<SQ_LOC>(env, act, slot, c, max_trips);
         // ---- every slot of this trip goes to the queue of its new state: lane k reserves queue k's entries, one round trip for all five ----
         {
             unsigned long long m[SQ_NQ];

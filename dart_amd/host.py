@@ -32,25 +32,45 @@ READ_OUT = np.dtype([("score", "<i4"), ("sub_score", "<i4"), ("mis_num", "<i4"),
 REPORT_OUT = np.dtype([("aln_score", "<i4"), ("sj_type", "<i4"), ("flag", "<i4"), ("paired_idx", "<i4"), ("chr", "<i4"),
                        ("bdir", "<i4"), ("pos", "<i8"), ("cigar_off", "<u4"), ("n_cigar", "<u4")])
 SJ_OUT = np.dtype([("g1", "<i8"), ("g2", "<i8"), ("type", "<i4"), ("read_idx", "<i4")])
-READ_C = np.dtype([("score", "<u2"), ("sub_score", "<u2"), ("mis_num", "<u2"), ("mapq", "u1"), ("n_sj", "u1"), ("n_rep", "<u2"), ("best", "<u2"), ("rep_off", "<u4")])
-REPORT_C = np.dtype([("pos", "<i4"), ("cigar_off", "<u4"), ("aln_score", "<u2"), ("flag", "<u2"), ("paired_idx", "<i2"), ("chr", "<u2"), ("n_cigar", "u1"),
+READ_C = np.dtype([("score", "<u2"), ("sub_score", "<u2"), ("mis_num", "<u2"), ("mapq", "u1"), ("n_sj", "u1"), ("n_rep", "<u2"), ("best", "<u2")])
+REPORT_C = np.dtype([("pos", "<i4"), ("aln_score", "<u2"), ("flag", "<u2"), ("paired_idx", "<i2"), ("chr", "<u2"), ("n_cigar", "u1"),
                      ("sj_type", "i1"), ("bdir", "u1"), ("pad", "u1")])
-assert READ_OUT.itemsize == 36 and REPORT_OUT.itemsize == 40 and SJ_OUT.itemsize == 24 and READ_C.itemsize == 16 and REPORT_C.itemsize == 20
+CIGAR_FULL_MATCH = 255
+assert READ_OUT.itemsize == 36 and REPORT_OUT.itemsize == 40 and SJ_OUT.itemsize == 24 and READ_C.itemsize == 12 and REPORT_C.itemsize == 16
 
 
-def expand_compact(reads_c, reports_c):
-    """dg_read_c / dg_report_c arrays -> the full record dtypes (sj_off rebuilt as the running sum of n_sj)"""
-    r = np.zeros(len(reads_c), READ_OUT)
+def expand_compact(reads_c, reports_c, cigar_c, rlen):
+    """dg_read_c / dg_report_c arrays + the stored CIGAR ops + the read lengths -> (reads, reports, cigar ops) in the full record
+    dtypes: rep_off / sj_off as running sums, cigar_off as the running sum of the op counts, a report marked DG_CIGAR_FULL_MATCH
+    gets its "<length of its read>M" back.  The reference expansion of include/dartgpu.h's compact layout."""
+    n = len(reads_c)
+    r = np.zeros(n, READ_OUT)
     for f in ("score", "sub_score", "mis_num", "mapq", "n_rep", "best", "n_sj"):
         r[f] = reads_c[f]
-    r["rep_off"] = reads_c["rep_off"].astype(np.int64)
+    nrep = reads_c["n_rep"].astype(np.int64)
+    r["rep_off"] = np.cumsum(nrep) - nrep
     nsj = reads_c["n_sj"].astype(np.int64)
     r["sj_off"] = np.cumsum(nsj) - nsj
-    p = np.zeros(len(reports_c), REPORT_OUT)
-    for f in ("aln_score", "sj_type", "flag", "paired_idx", "bdir", "pos", "cigar_off", "n_cigar"):
+    m = len(reports_c)
+    assert m == int(nrep.sum()), "the reports do not add up to the reads' n_rep"
+    p = np.zeros(m, REPORT_OUT)
+    for f in ("aln_score", "sj_type", "flag", "paired_idx", "bdir", "pos"):
         p[f] = reports_c[f]
     p["chr"] = np.where(reports_c["chr"] == 0xFFFF, -1, reports_c["chr"].astype(np.int32))
-    return r, p
+    plain = reports_c["n_cigar"] == CIGAR_FULL_MATCH
+    stored = np.where(plain, 0, reports_c["n_cigar"]).astype(np.int64)
+    full = np.where(plain, 1, reports_c["n_cigar"]).astype(np.int64)
+    p["n_cigar"] = full
+    off_full = np.cumsum(full) - full
+    p["cigar_off"] = off_full
+    cig = np.zeros(int(full.sum()), np.uint32)
+    owner = np.repeat(np.arange(n), nrep)                         # the read of every report
+    cig[off_full[plain]] = np.asarray(rlen, np.uint32)[owner[plain]] << 4
+    st = stored[~plain]                                           # the stored ops lie one report after the other
+    if st.sum():
+        dst = np.repeat(off_full[~plain] - (np.cumsum(st) - st), st) + np.arange(int(st.sum()))
+        cig[dst] = np.asarray(cigar_c[:int(st.sum())], np.uint32)
+    return r, p, cig
 
 
 class Index:
@@ -135,7 +155,7 @@ def _load_lib():
     lib.dg_batch_upload.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.dg_batch_upload_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_size_t]
     lib.dg_map_batch_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
-    lib.dg_batch_download_compact.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dg_batch_download_compact.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.dg_map_batch_compact.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
     lib.dg_host_alloc.restype = C.c_void_p
     lib.dg_host_alloc.argtypes = [C.c_size_t]
@@ -257,6 +277,7 @@ class DartGPU:
 
     def upload(self, seq_off, rlen, flat):
         self._n = len(rlen)
+        self._rlen_of_batch = np.asarray(rlen, np.uint16).copy()
         self._keep = (np.ascontiguousarray(seq_off, np.uint32), np.ascontiguousarray(rlen, np.uint16), np.ascontiguousarray(flat, np.uint8))
         a, b, c = self._keep
         self._chk(self.lib.dg_batch_upload(self.ctx, self._n, a.ctypes.data, b.ctypes.data, c.ctypes.data), "dg_batch_upload")
@@ -288,12 +309,15 @@ class DartGPU:
         reads = np.zeros(self._n, dtype=READ_C); reports = np.zeros(max(u[0], 1), dtype=REPORT_C)
         cigar = np.zeros(max(u[1], 1), dtype=np.uint32); sj = np.zeros(max(u[2], 1), dtype=SJ_OUT)
         caps = (C.c_size_t * 3)(len(reports), len(cigar), len(sj))
-        self._chk(self.lib.dg_batch_download_compact(self.ctx, reads.ctypes.data, reports.ctypes.data, cigar.ctypes.data, sj.ctypes.data, caps), "dg_batch_download_compact")
-        r, p = expand_compact(reads, reports[:u[0]])
-        return BatchResult(r, p, cigar[:u[1]], sj[:u[2]])
+        n_ops = C.c_size_t(0)
+        self._chk(self.lib.dg_batch_download_compact(self.ctx, reads.ctypes.data, reports.ctypes.data, cigar.ctypes.data, sj.ctypes.data, caps, C.byref(n_ops)), "dg_batch_download_compact")
+        self.last_compact_ops = int(n_ops.value)
+        r, p, cg = expand_compact(reads, reports[:u[0]], cigar[:int(n_ops.value)], self._rlen_of_batch)
+        return BatchResult(r, p, cg, sj[:u[2]])
 
     def upload_packed(self, words, nlist, rlen_all, rlen=None):
         self._n = int(words.shape[0])
+        self._rlen_of_batch = np.full(self._n, rlen_all, np.uint16) if rlen is None else np.asarray(rlen, np.uint16).copy()
         w = np.ascontiguousarray(words, np.uint32); nl = np.ascontiguousarray(nlist, np.uint32)
         rl = None if rlen is None else np.ascontiguousarray(rlen, np.uint16)
         self._keep = (w, nl, rl)

@@ -109,17 +109,26 @@ int dg_map_batch_packed(dg_ctx *, int n_reads, int rlen_all, const uint16_t *rle
                         const uint32_t *nlist, size_t n_n, dg_read_out *, dg_report_out *, uint32_t *cigar_ops, dg_sj_out *,
                         const size_t caps[3], size_t used[3]);
 
-/* ---- compact records: the same information in 16 + 20 bytes instead of 36 + 40 ----
+/* ---- compact records: the same information in 12 + 16 bytes instead of 36 + 40, and no CIGAR for a plain full-length match ----
  * The host link carries ~57 GB/s in total on an MI355X box (both directions together), so at several hundred million reads
- * per second the bytes of the records ARE the throughput: 85 -> 42 bytes per read.  Lossless while the fields fit (scores and
- * mismatches < 65536, at most 65535 reports per read / chromosomes, at most 255 CIGAR ops per report, |POS| < 2^31); when one
- * does not, dg_batch_download_compact returns DG_ERR_RANGE and the caller takes the full records with dg_batch_download.
- * sj_off is not carried: the tuples lie in read order, a read's tuples start at the sum of n_sj of the reads before it.     */
-typedef struct { uint16_t score, sub_score, mis_num; uint8_t mapq, n_sj; uint16_t n_rep, best; uint32_t rep_off; } dg_read_c;           /* 16 bytes */
-typedef struct { int32_t pos; uint32_t cigar_off; uint16_t aln_score, flag; int16_t paired_idx; uint16_t chr /* 0xFFFF = none */;
-                 uint8_t n_cigar; int8_t sj_type; uint8_t bdir, pad; } dg_report_c;                                                         /* 20 bytes */
-int dg_batch_download_compact(dg_ctx *, dg_read_c *, dg_report_c *, uint32_t *cigar_ops, dg_sj_out *, const size_t caps[3]);
-/* upload (ASCII when words == NULL, else packed as dg_map_batch_packed) + run + compact download in one call */
+ * per second the bytes of the records ARE the throughput: 85 -> 30 bytes per read.  Nothing is lost; what the layout already
+ * says is not sent:
+ *   rep_off    reports lie in read order: a read's reports start at the sum of n_rep of the reads before it
+ *   sj_off     likewise the junction tuples: the sum of n_sj of the reads before it
+ *   cigar_off  the CIGAR ops lie in REPORT order here (unlike the full records): a report's ops start at the sum of the stored
+ *              op counts of the reports before it
+ *   n_cigar    DG_CIGAR_FULL_MATCH (255): the CIGAR is the single op "<length of the report's read>M" and is not stored
+ *              (19 of 20 reports of a DNA run); otherwise the number of stored ops (at most 254)
+ * Lossless while the fields fit (scores and mismatches < 65536, at most 65535 reports per read / chromosomes, at most 254 CIGAR
+ * ops per report, |POS| < 2^31); when one does not, dg_batch_download_compact returns DG_ERR_RANGE and the caller takes the
+ * full records with dg_batch_download.  dart_amd/host.py::expand_compact is the reference expansion.                        */
+#define DG_CIGAR_FULL_MATCH 255
+typedef struct { uint16_t score, sub_score, mis_num; uint8_t mapq, n_sj; uint16_t n_rep, best; } dg_read_c;                             /* 12 bytes */
+typedef struct { int32_t pos; uint16_t aln_score, flag; int16_t paired_idx; uint16_t chr /* 0xFFFF = none */;
+                 uint8_t n_cigar; int8_t sj_type; uint8_t bdir, pad; } dg_report_c;                                                         /* 16 bytes */
+/* caps[1] counts stored ops (never more than the full records' op count, `used[1]` of dg_batch_run); *n_ops (may be NULL) = how many were written */
+int dg_batch_download_compact(dg_ctx *, dg_read_c *, dg_report_c *, uint32_t *cigar_ops, dg_sj_out *, const size_t caps[3], size_t *n_ops);
+/* upload (ASCII when words == NULL, else packed as dg_map_batch_packed) + run + compact download in one call; used[1] = stored ops */
 int dg_map_batch_compact(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
                          int rlen_all, int words_per_read, const uint32_t *words, const uint32_t *nlist, size_t n_n,
                          dg_read_c *, dg_report_c *, uint32_t *cigar_ops, dg_sj_out *, const size_t caps[3], size_t used[3]);

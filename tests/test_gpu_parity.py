@@ -378,7 +378,9 @@ def test_gpu_packed_reads_and_pinned_buffers(workdir):
     words, nlist = host.pack_reads_2bit(arr)
     assert len(nlist) > 300
     assert_same(gpu.map_batch_packed(words, nlist, 101), want)
-    assert_same(gpu.download_compact(), want)            # the same records through the 16 + 20 byte types
+    res_c = gpu.download_compact()                       # the same records through the 12 + 16 byte types
+    assert_same(res_c, want)
+    assert 0 < gpu.last_compact_ops < len(want[2])      # plain "101M" reports travel without their CIGAR op
     # ragged: every read cut to its own length (the tail bases stay in the words, the lengths say where the read ends)
     rng = np.random.default_rng(5)
     lens = rng.integers(30, 102, size=len(arr)).astype(np.uint16)
@@ -391,7 +393,9 @@ def test_gpu_packed_reads_and_pinned_buffers(workdir):
     seqs[0] = arr[0].tobytes(); so2, rl2, flat2 = host.pack_reads(seqs)
     keep = np.nonzero(arr == ord("N")); inside = keep[1] < lens[keep[0]]
     nl2 = (keep[0][inside].astype(np.uint64) * words.shape[1] * 16 + keep[1][inside].astype(np.uint64)).astype(np.uint32)
-    assert_same(gpu.map_batch_packed(words, nl2, 0, rlen=lens), orc.map_batch(orc.params(paired=1, max_mismatch=5), so2, rl2, flat2, threads=16))
+    want2 = orc.map_batch(orc.params(paired=1, max_mismatch=5), so2, rl2, flat2, threads=16)
+    assert_same(gpu.map_batch_packed(words, nl2, 0, rlen=lens), want2)
+    assert_same(gpu.download_compact(), want2)           # "<length of the read>M" comes back per read
     low = arr[:4].copy(); low[1, 7] = ord("a")
     with pytest.raises(ValueError):
         host.pack_reads_2bit(low)
