@@ -964,6 +964,7 @@ static int finish_run(dg_ctx *c, size_t used[3])
         else if (derr == DG_E_REPORTS) { c->cap_rep = grow(sz.total_rep); if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep; }
         else if (derr == DG_E_WORK) c->cap_work = grow(c->h_tail->tops[TOP_WORK]);
         else if (derr == DG_E_CIGFINAL) c->cap_cig = grow(sz.total_cig > 2 * c->cap_cig ? sz.total_cig : 2 * c->cap_cig);
+        else if (derr == DG_E_SCAN && attempt < 2) { /* a look-back that did not complete (dg_scan.h): nothing to grow, the batch simply runs again */ }
         else { snprintf(c->err, 512, "device-side scan did not complete (status %d)", derr); return DG_ERR_INTERNAL; }
         if (attempt == 5) { snprintf(c->err, 512, "buffer capacities did not converge (status %d)", derr); return DG_ERR_INTERNAL; }
         const int rc = enqueue_run(c);

@@ -14,7 +14,8 @@
 // A reader accepts a tile when both words carry the same non-zero status (the writer updates A then B, so a torn pair shows
 // different statuses and is polled again).  The first wave of the workgroup looks back 64 tiles at a time: it adds totals
 // until it meets an inclusive prefix.  The arrays must be zero before the launch (status 0 = nothing yet).
-// A poll budget turns a protocol failure into an error code instead of a hung GPU.
+// A poll budget turns a protocol failure into an error code instead of a hung GPU; the host then runs the batch again (seen once in ~10^5
+// batches with a dozen contexts in flight, cause not found: finish_run in dg_api.hip).
 #pragma once
 #include "dg_common.h"
 
@@ -68,8 +69,18 @@ __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile,
                     sx += x; sy += y; sz += z;
                     if (done) break;
                     base -= 64;
-                } else if (++polls > (1u << 22)) { if (lane == 0) atomicMax(err, DG_E_SCAN); break; }
-                else __builtin_amdgcn_s_sleep(2);
+                } else {
+                    polls++;
+                    if ((polls & 1023u) == 0u) {
+                        // another kernel stage gave the batch up (the host will run it again): nobody needs this prefix any more
+                        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= DG_ABORT) break;
+                        // belt and braces: a state word is read with a device-coherent load, but should a stale copy ever sit in a cache
+                        // of this XCD, this drops it (one invalidate per thousand polls costs nothing; one per poll tripled k_pair's time)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    if (polls > (1u << 20)) { if (lane == 0) atomicMax(err, DG_E_SCAN); break; }       // ~2 s: the host runs the batch again
+                    __builtin_amdgcn_s_sleep(2);
+                }
             }
         }
         if (lane == 0) {
