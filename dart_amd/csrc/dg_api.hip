@@ -15,6 +15,8 @@
 #include <string>
 #include <algorithm>
 #include <vector>
+#include <atomic>
+#include <chrono>
 
 static char g_init_error[512] = "";
 
@@ -149,6 +151,7 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t *out, const uint32_t 
     if (i < n) out[i] += tile_sums[i / SCAN_TILE];
 }
 
+static std::atomic<uint64_t> g_phase_ns[4];
 // waiting for a context's stream on the per-batch path.  DG_BLOCKING_SYNC=1: through an event created with hipEventBlockingSync, so the
 // host thread sleeps instead of spinning (one thread per context: a dozen spinning threads per GPU is a dozen busy cores)
 static hipError_t wait_stream(dg_ctx *c)
@@ -1097,11 +1100,22 @@ extern "C" int dg_map_batch_compact(dg_ctx *c, int n_reads, const uint32_t *seq_
                                     dg_read_c *ro, dg_report_c *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3], size_t used[3])
 {
     if (!c || !caps) return DG_ERR_ARG;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = words ? enqueue_upload_packed(c, n_reads, rlen_all, rlen, words_per_read, words, nlist, n_n) : enqueue_upload(c, n_reads, seq_off, rlen, seq);
     if (rc) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     if ((rc = dg_batch_run(c, used))) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
     size_t n_ops = 0;
     rc = dg_batch_download_compact(c, ro, po, cig, so, caps, &n_ops);
+    const auto t3 = std::chrono::steady_clock::now();
+    g_phase_ns[0] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    g_phase_ns[1] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+    g_phase_ns[2] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t3 - t2).count();
+    g_phase_ns[3] += 1;
+    if (getenv("DG_HOST_PHASES") && (g_phase_ns[3] % 100) == 0)
+        fprintf(stderr, "[dg host phases] batches %llu: upload enqueue %.3f ms, run (enqueue + wait) %.3f ms, download %.3f ms per batch\n", (unsigned long long)g_phase_ns[3],
+                g_phase_ns[0] / 1e6 / g_phase_ns[3], g_phase_ns[1] / 1e6 / g_phase_ns[3], g_phase_ns[2] / 1e6 / g_phase_ns[3]);
     if (used && (rc == DG_OK || rc == DG_ERR_CAPACITY)) used[1] = n_ops ? n_ops : (rc == DG_OK ? 0 : used[1]);
     return rc;
 }
