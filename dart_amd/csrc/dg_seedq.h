@@ -21,7 +21,7 @@
 #define SQ_WAVES   4
 #define SQ_THREADS (SQ_WAVES * 64)
 enum { SQ_BEGIN = 0, SQ_STEP = 1, SQ_CMP = 2, SQ_LOC = 3, SQ_FREE = 4, SQ_NQ = 5 };     // 0..3 = Search::mode
-#define SQ_MAX_PHASES (1u << 22)     // no batch comes near (a phase retires >= 1 lane-trip): a safety net, not a limit
+#define SQ_MAX_PHASES (1u << 20)     // no batch comes near (a workgroup of a 2 M-read batch runs ~300 phases): a safety net -- the host runs the batch again
 
 __device__ __forceinline__ uint32_t sq_rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
