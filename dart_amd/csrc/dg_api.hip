@@ -648,27 +648,30 @@ extern "C" int dg_batch_upload(dg_ctx *c, int n_reads, const uint32_t *seq_off, 
 // packed reads -> the ASCII buffer the report stage reads (A/C/G/T, then 'N' at the listed positions) and the 2-bit + mask
 // words the seeding stage reads (k_encode's format).  One thread = 16 bases = one input word.
 __global__ void __launch_bounds__(256)
-k_unpack(const uint32_t *__restrict__ words, int n_reads, int W2, int rlen_all, const uint16_t *rlen_in, unsigned char *__restrict__ seq,
+k_unpack(const uint32_t *__restrict__ words, uint32_t n_words, int W2, double inv_w2, int rlen_all, const uint16_t *rlen_in, unsigned char *__restrict__ seq,
          uint32_t *__restrict__ seq_off, uint16_t *rlen_out, uint32_t *__restrict__ enc)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n_reads * W2) return;
-    const int r = (int)(t / W2), ww = (int)(t - (size_t)r * W2);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_words) return;
+    uint32_t r = (uint32_t)((double)t * inv_w2);                        // t / W2 without an integer division: the product is within one of it
+    if (r * (uint32_t)W2 > t) r--; else if ((r + 1u) * (uint32_t)W2 <= t) r++;
+    const int ww = (int)(t - r * (uint32_t)W2);
     const int len = rlen_in ? rlen_in[r] : rlen_all, left = len - 16 * ww;
     const uint32_t w = words[t];
     uint32_t out[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        uint32_t x = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) x |= ((0x54474341u >> (8u * ((w >> (30 - 2 * (4 * q + k))) & 3u))) & 0xFFu) << (8 * k);     // "ACGT"[code]
-        out[q] = x;
+        // four codes (one byte of w, first base on top) -> one selector byte each (copies of the byte at shifts 0, 10, 20, 30 put the
+        // k-th pair at bit 8 k + 6), then "ACGT"[code] for all four with one byte permute
+        const uint32_t a = (w >> (24 - 8 * q)) & 0xFFu;
+        const uint32_t sel = ((a * 0x40100401u) >> 6) & 0x03030303u;
+        out[q] = __builtin_amdgcn_perm(0u, 0x54474341u, sel);
     }
     *(uint4 *)(seq + (size_t)r * 16 * W2 + 16 * ww) = make_uint4(out[0], out[1], out[2], out[3]);       // (bases past the end: never read)
     const uint32_t past = left >= 16 ? 0u : (left <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu >> (2 * left));          // mask 0b11 past the end, as k_encode
     enc[(size_t)r * 2 * W2 + ww] = w & ~past;
     enc[(size_t)r * 2 * W2 + W2 + ww] = past;
-    if (ww == 0) { seq_off[r] = (uint32_t)((size_t)r * 16 * W2); if (!rlen_in) rlen_out[r] = (uint16_t)len; }      // (given lengths are already in place)
+    if (ww == 0) { seq_off[r] = r * 16u * (uint32_t)W2; if (!rlen_in) rlen_out[r] = (uint16_t)len; }      // (given lengths are already in place)
 }
 __global__ void __launch_bounds__(256)
 k_unpack_n(const uint32_t *__restrict__ nlist, uint32_t n_n, int W2, unsigned char *__restrict__ seq, uint32_t *__restrict__ enc)
@@ -700,7 +703,7 @@ static int enqueue_upload_packed(dg_ctx *c, int n_reads, int rlen_all, const uin
     HIPCHK(hipMemcpyAsync(c->packed_in.p, words, nw * 4, hipMemcpyHostToDevice, c->stream));
     if (rlen) HIPCHK(hipMemcpyAsync(c->rlen.p, rlen, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->stream));
     if (n_n) HIPCHK(hipMemcpyAsync(c->nlist_in.p, nlist, n_n * 4, hipMemcpyHostToDevice, c->stream));
-    k_unpack<<<(unsigned)((nw + 255) / 256), 256, 0, c->stream>>>(c->packed_in.p, n_reads, W2, rlen_all, rlen ? c->rlen.p : nullptr, c->seq.p, c->seq_off.p, c->rlen.p, c->enc.p);
+    k_unpack<<<(unsigned)((nw + 255) / 256), 256, 0, c->stream>>>(c->packed_in.p, (uint32_t)nw, W2, 1.0 / (double)W2, rlen_all, rlen ? c->rlen.p : nullptr, c->seq.p, c->seq_off.p, c->rlen.p, c->enc.p);
     if (n_n) k_unpack_n<<<(unsigned)((n_n + 255) / 256), 256, 0, c->stream>>>(c->nlist_in.p, (uint32_t)n_n, W2, c->seq.p, c->enc.p);
     HIPCHK(hipGetLastError());
     return DG_OK;
