@@ -215,9 +215,12 @@ k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const D
         k = done ? (uint32_t)DIAG_DONE : 2 * k + ((nw || k == 15) ? 0u : 1u);    // (class 15 not done cannot occur; its key 30 keeps 31 for the done reads)
         key[r] = (uint8_t)k;
     }
-    for (uint32_t c = 0; c < COST_CLASSES; c++) {
+    // only the classes that occur in the wave (two to four of the 32: most reads are "done")
+    for (unsigned long long rem = __ballot(k < COST_CLASSES); rem; ) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)k, __ffsll((long long)rem) - 1);
         const unsigned long long m = __ballot(k == c);
-        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&sh[c], (uint32_t)__popcll(m));
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sh[c], (uint32_t)__popcll(m));
+        rem &= ~m;
     }
     __syncthreads();
     if (threadIdx.x < COST_CLASSES) counts[(size_t)threadIdx.x * n_blocks + blockIdx.x] = sh[threadIdx.x];
@@ -232,10 +235,13 @@ k_cost_scatter(int n_reads, int n_blocks, const uint8_t *__restrict__ key, const
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
     const uint32_t k = r < n_reads ? key[r] : COST_CLASSES;
     uint32_t my_rank = 0;
-    for (uint32_t c = 0; c < COST_CLASSES; c++) {
+    if (ln < COST_CLASSES) wave_cnt[wv][ln] = 0;
+    for (unsigned long long rem = __ballot(k < COST_CLASSES); rem; ) {          // only the classes that occur in the wave
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)k, __ffsll((long long)rem) - 1);
         const unsigned long long m = __ballot(k == c);
         if (k == c) my_rank = (uint32_t)__popcll(m & ((1ull << ln) - 1ull));
         if (ln == 0) wave_cnt[wv][c] = (uint32_t)__popcll(m);
+        rem &= ~m;
     }
     __syncthreads();
     if (r < n_reads) {
