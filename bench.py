@@ -204,8 +204,8 @@ class Worker:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30, help="timed steps (one step = --batches distinct batches); 30 steps = about one second: filling and draining the\n                    pipeline of batches in flight costs a fixed ~20 ms, which a 6-step run (0.2 s) shows as -8 %%")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1000000, help="pairs per batch")
     ap.add_argument("--batches", type=int, default=10, help="distinct batches per step and GPU (10 x 1 M pairs = BASELINE configs[2])")
     ap.add_argument("--genome", default=os.environ.get("DART_BENCH_GENOME", "grch38"),
@@ -368,6 +368,10 @@ def main():
             kern[k] = kern.get(k, 0.0) + v
     kern = {k: v / max(runs, 1) for k, v in kern.items()}
     counters = workers[0].gpu.counters()
+    # batches a context had to run again since it was created, over all contexts: capacities that grew (expected while the first batches
+    # size the buffers), scans that did not complete (dg_scan.h: should be 0)
+    for key in ("reruns_capacity_total", "reruns_scan_total"):
+        counters[key] = sum(w.gpu.counters().get(key, 0) for w in workers)
 
     # ---- secondary rates, outside the timed region (fewer items) ----
     secondary = {}

@@ -75,6 +75,7 @@ struct dg_ctx {
     // timings
     hipEvent_t ev[N_TIMERS + 1]; const char *tname[N_TIMERS]; int n_t = 0; float tms[N_TIMERS];
     uint64_t counters[CTR_N];
+    uint64_t reruns_capacity = 0, reruns_scan = 0;      // since dg_init / dg_clone
     int n_cu = 256, runs_of_last_batch = 0;
     // environment switches, read once per context (not per batch)
     int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
@@ -976,9 +977,10 @@ static int finish_run(dg_ctx *c, size_t used[3])
         else if (derr == DG_E_REPORTS) { c->cap_rep = grow(sz.total_rep); if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep; }
         else if (derr == DG_E_WORK) c->cap_work = grow(c->h_tail->tops[TOP_WORK]);
         else if (derr == DG_E_CIGFINAL) c->cap_cig = grow(sz.total_cig > 2 * c->cap_cig ? sz.total_cig : 2 * c->cap_cig);
-        else if (derr == DG_E_SCAN && attempt < 2) { /* a look-back that did not complete (dg_scan.h): nothing to grow, the batch simply runs again */ }
+        else if (derr == DG_E_SCAN && attempt < 2) { c->reruns_scan++; /* a look-back that did not complete (dg_scan.h): nothing to grow, the batch simply runs again */ }
         else { snprintf(c->err, 512, "device-side scan did not complete (status %d)", derr); return DG_ERR_INTERNAL; }
         if (attempt == 5) { snprintf(c->err, 512, "buffer capacities did not converge (status %d)", derr); return DG_ERR_INTERNAL; }
+        if (derr != DG_E_SCAN) c->reruns_capacity++;
         const int rc = enqueue_run(c);
         if (rc) return rc;
     }
@@ -1259,9 +1261,10 @@ extern "C" int dg_last_counters(dg_ctx *c, uint64_t *out, int cap)
     if (!c) return 0;
     int k = CTR_N < cap ? CTR_N : cap;
     for (int i = 0; i < k; i++) out[i] = c->counters[i];
-    // [30] units that took the general path, [31] units chained by a wave each, [32] times the batch was enqueued (> 1: a buffer grew)
-    const uint64_t extra[3] = { c->h_tail ? c->h_tail->sizes.n_slow_units : 0u, c->h_tail ? c->h_tail->tops[TOP_HEAVY_UNITS] : 0u, (uint64_t)c->runs_of_last_batch };
-    for (int i = 0; i < 3 && k < cap; i++) out[k++] = extra[i];
+    // [30] units that took the general path, [31] units chained by a wave each, [32] times the batch was enqueued, [33] / [34] re-runs of this context so far: capacity grown / scan not completed (> 1: a buffer grew)
+    const uint64_t extra[5] = { c->h_tail ? c->h_tail->sizes.n_slow_units : 0u, c->h_tail ? c->h_tail->tops[TOP_HEAVY_UNITS] : 0u, (uint64_t)c->runs_of_last_batch,
+                                c->reruns_capacity, c->reruns_scan };
+    for (int i = 0; i < 5 && k < cap; i++) out[k++] = extra[i];
     return k;
 }
 
