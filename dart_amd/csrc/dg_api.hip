@@ -1261,7 +1261,7 @@ extern "C" int dg_last_counters(dg_ctx *c, uint64_t *out, int cap)
     if (!c) return 0;
     int k = CTR_N < cap ? CTR_N : cap;
     for (int i = 0; i < k; i++) out[i] = c->counters[i];
-    // [30] units that took the general path, [31] units chained by a wave each, [32] times the batch was enqueued, [33] / [34] re-runs of this context so far: capacity grown / scan not completed (> 1: a buffer grew)
+    // [31] units that took the general path, [32] units chained by a wave each, [33] times the batch was enqueued, [34] / [35] re-runs of this context so far: capacity grown / scan not completed (> 1: a buffer grew)
     const uint64_t extra[5] = { c->h_tail ? c->h_tail->sizes.n_slow_units : 0u, c->h_tail ? c->h_tail->tops[TOP_HEAVY_UNITS] : 0u, (uint64_t)c->runs_of_last_batch,
                                 c->reruns_capacity, c->reruns_scan };
     for (int i = 0; i < 5 && k < cap; i++) out[k++] = extra[i];

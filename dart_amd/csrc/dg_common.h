@@ -107,7 +107,7 @@ struct DSizes { uint32_t total_seeds, total_rep, total_work, total_cig, total_sj
 enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, CTR_NWCELLS, CTR_RESEED, CTR_RESEEDW,
        CTR_STEPS_ACT, CTR_BLOCKS_ACT, CTR_KTAB, CTR_LF_ACT, CTR_DIRECT, CTR_MAXTRIPS, CTR_WTRIPS_MAX, CTR_WTRIPS_SUM,
        CTR_RESEED_TRIPS, CTR_RESEED_TICKS,
-       CTR_SQ_TRIPS, CTR_SQ_LANES = CTR_SQ_TRIPS + 5, CTR_N = CTR_SQ_LANES + 5 };   // k_seed_q: wave-trips and slots served per queue (begin, step, compare, locate, refill)   // *_ACT: steps/blocks this implementation really executed
+       CTR_SQ_TRIPS, CTR_SQ_LANES = CTR_SQ_TRIPS + 5, CTR_SQ_PHASES = CTR_SQ_LANES + 5, CTR_N };   // k_seed_q: wave-trips and slots served per queue (begin, step, compare, locate, refill)   // *_ACT: steps/blocks this implementation really executed
 
 __host__ __device__ __forceinline__ uint8_t d_nt4(unsigned char c)   // nst_nt4_table, BWT_Index/bntseq.c:40: ACGT/acgt -> 0..3, '-' -> 5, else 4
 {

@@ -144,7 +144,9 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
     for (int i = tid; i < NSLOT; i += SQ_THREADS) q[(size_t)SQ_FREE * QCAP + i] = (uint16_t)i;
     if (tid < 16) ctl[tid] = tid == 5 + SQ_FREE ? (uint32_t)NSLOT : 0u;
 
+    uint32_t n_phases = 0;
     for (uint32_t phase = 0; ; phase++) {
+        n_phases = phase;
         __syncthreads();                                          // every push of the previous phase has landed
         uint32_t hd[SQ_NQ], cn[SQ_NQ];
 #pragma unroll
@@ -237,6 +239,7 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
         }
     }
     atomicMax(d_ctr_stripe(ctr) + CTR_MAXTRIPS, (unsigned long long)max_trips);
+    if (tid == 0) atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_PHASES, (unsigned long long)n_phases);
     if (lane == 0) {
         atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips);
 #pragma unroll

@@ -159,9 +159,10 @@ int dg_last_timings(dg_ctx *, const char **names, float *ms, int cap);
  * implementation really executed, [12] k-mer prefix-table look-ups, [13] LF steps really executed, [14..17] seeding statistics,
  * [18] 512-position trips of k_reseed's waves, [19] the time its waves were resident, summed, in 10 ns ticks,
  * [20..24] wave-trips of the seeding kernel per queue (begin, Occ step, text comparison, locate, refill), [25..29] the slots they served,
- * [30] units (pairs / single reads) that took the general report path, [31] units chained by a wave each (> 16 seeds),
- * [32] how many times the batch was enqueued (> 1: a capacity estimate was too small and the batch ran again),
- * [33] / [34] how often this context has run a batch again since it was created: capacity grown / a scan that did not complete   */
+ * [30] its phases, summed over the workgroups (a phase can serve four wave-trips),
+ * [31] units (pairs / single reads) that took the general report path, [32] units chained by a wave each (> 16 seeds),
+ * [33] how many times the batch was enqueued (> 1: a capacity estimate was too small and the batch ran again),
+ * [34] / [35] how often this context has run a batch again since it was created: capacity grown / a scan that did not complete   */
 int dg_last_counters(dg_ctx *, uint64_t *out, int cap);
 
 /* ---- the index builder's sorter (replaces the suffix sorting inside BWT_Index/bwtindex.c:77-148) ----
