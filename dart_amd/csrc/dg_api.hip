@@ -76,6 +76,7 @@ struct dg_ctx {
     hipEvent_t ev[N_TIMERS + 1]; const char *tname[N_TIMERS]; int n_t = 0; float tms[N_TIMERS];
     uint64_t counters[CTR_N];
     uint64_t reruns_capacity = 0, reruns_scan = 0;      // since dg_init / dg_clone
+    bool pack_in_run = false, packed_valid = false;     // compact records: built inside the run / present for the batch that ran last
     int n_cu = 256, runs_of_last_batch = 0;
     // environment switches, read once per context (not per batch)
     int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
@@ -823,6 +824,8 @@ static int zero_batch_state(dg_ctx *c, int n_units)
     return DG_OK;
 }
 
+static int enqueue_pack(dg_ctx *c);      // (compact records, below)
+
 // Enqueues the whole path of the uploaded batch on the context's stream and returns without waiting: no size is read back
 // in between.  finish_run() waits, learns the sizes, and runs the batch again if a capacity was too small.
 static int enqueue_run(dg_ctx *c)
@@ -951,6 +954,7 @@ static int enqueue_run(dg_ctx *c)
                                                                     (uint32_t)c->cap_cig, c->sjpool.p, c->sjfinal.p, ts_emit, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_finalize");
+    if (c->pack_in_run) { const int prc = enqueue_pack(c); if (prc) return prc; }
     // the tail: sizes, status, counters -> pinned host memory, one copy each
     HIPCHK(hipMemcpyAsync(&c->h_tail->sizes, c->d_sizes, sizeof(DSizes), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&c->h_tail->err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
@@ -998,6 +1002,7 @@ static int finish_run(dg_ctx *c, size_t used[3])
     const int derr = c->h_tail->err;
     if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == DG_E_CIGAR ? "cigar" : (derr == DG_E_SJ ? "splice junction" : "reseed jobs")); return DG_ERR_INTERNAL; }
     c->used[0] = sz.total_rep; c->used[1] = sz.total_cig; c->used[2] = sz.total_sj;
+    c->packed_valid = c->pack_in_run;
     if (used) { used[0] = c->used[0]; used[1] = c->used[1]; used[2] = c->used[2]; }
     return DG_OK;
 }
@@ -1010,6 +1015,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     memset(c->counters, 0, sizeof c->counters);
     if (used) used[0] = used[1] = used[2] = 0;
     c->n_t = 0;
+    c->packed_valid = false;
     if (c->n_reads == 0) return DG_OK;
     const int rc = enqueue_run(c);
     if (rc) return rc;
@@ -1033,10 +1039,11 @@ static int enqueue_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint3
 // the records of its reports, and per report how many CIGAR ops will be stored (0 for the plain full-length match "<rlen>M")
 __global__ void __launch_bounds__(256)
 k_pack_records(uint32_t n_reads, const dg_read_out *__restrict__ ro, const dg_report_out *__restrict__ po, const uint32_t *__restrict__ cig,
-               const uint16_t *__restrict__ rlen, dg_read_c *__restrict__ rc, dg_report_c *__restrict__ pc, uint32_t *__restrict__ n_ops, int *bad)
+               const uint16_t *__restrict__ rlen, dg_read_c *__restrict__ rc, dg_report_c *__restrict__ pc, uint32_t *__restrict__ n_ops, uint32_t *bad,
+               const int *__restrict__ abort_p)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_reads) return;
+    if (i >= n_reads || *abort_p >= DG_ABORT) return;
     const dg_read_out r = ro[i];
     dg_read_c o;
     o.score = (uint16_t)r.score; o.sub_score = (uint16_t)r.sub_score; o.mis_num = (uint16_t)r.mis_num; o.mapq = (uint8_t)r.mapq; o.n_sj = (uint8_t)r.n_sj;
@@ -1058,17 +1065,36 @@ k_pack_records(uint32_t n_reads, const dg_read_out *__restrict__ ro, const dg_re
                p.chr >= 0xFFFF || p.n_cigar > 254u || p.sj_type < -128 || p.sj_type > 127 || (uint32_t)p.bdir > 1u;
         pc[j] = q;
     }
-    if (over) atomicMax(bad, 1);
+    if (over) atomicMax(bad, 1u);
 }
 
-// the stored CIGAR ops, report by report (op_off = exclusive scan of n_ops)
+// the stored CIGAR ops, report by report (op_off = exclusive scan of n_ops; the grid covers the report CAPACITY: slots behind the
+// last report hold a count of zero)
 __global__ void __launch_bounds__(256)
 k_pack_cigar(uint32_t n_rep, const dg_report_out *__restrict__ po, const uint32_t *__restrict__ cig, const uint32_t *__restrict__ op_off, uint32_t *__restrict__ out)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_rep) return;
-    const uint32_t a = op_off[j], n = op_off[j + 1] - a, src = po[j].cigar_off;
+    const uint32_t a = op_off[j], n = op_off[j + 1] - a;
+    if (n == 0) return;
+    const uint32_t src = po[j].cigar_off;
     for (uint32_t t = 0; t < n; t++) out[a + t] = cig[src + t];
+}
+
+// records -> compact records, on the context's stream, without knowing a size on the host: thread per read, the scan and the gather
+// run over the report CAPACITY (counts behind the last report are zero).  d_sizes->pad[0] = stored ops, pad[1] = a field did not fit.
+static int enqueue_pack(dg_ctx *c)
+{
+    const size_t n = (size_t)c->n_reads, cap = c->cap_rep;
+    HIPCHK(c->reads_c.ensure(n + 1)); HIPCHK(c->reports_c.ensure(cap + 1)); HIPCHK(c->cig_cnt.ensure(cap + 1)); HIPCHK(c->cig_off.ensure(cap + 2)); HIPCHK(c->cig_c.ensure(c->cap_cig + 1));
+    HIPCHK(hipMemsetAsync(c->cig_cnt.p, 0, (cap + 1) * 4, c->stream));
+    HIPCHK(hipMemsetAsync(&c->d_sizes->pad[0], 0, 8, c->stream));
+    k_pack_records<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((uint32_t)n, c->reads_out.p, c->reports.p, c->cigfinal.p, c->rlen.p, c->reads_c.p, c->reports_c.p, c->cig_cnt.p,
+                                                                      &c->d_sizes->pad[1], c->d_err);
+    HIPCHK(scan_u32(c, c->cig_cnt.p, c->cig_off.p, (uint32_t)cap, &c->d_sizes->pad[0]));
+    k_pack_cigar<<<(unsigned)((cap + 255) / 256), 256, 0, c->stream>>>((uint32_t)cap, c->reports.p, c->cigfinal.p, c->cig_off.p, c->cig_c.p);
+    HIPCHK(hipGetLastError());
+    return DG_OK;
 }
 
 extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3], size_t *n_ops_out)
@@ -1082,27 +1108,22 @@ extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *
     }
     const size_t n = (size_t)c->n_reads, nr = c->used[0];
     if (n == 0) return DG_OK;
-    HIPCHK(c->reads_c.ensure(n + 1)); HIPCHK(c->reports_c.ensure(nr + 1)); HIPCHK(c->cig_cnt.ensure(nr + 1)); HIPCHK(c->cig_off.ensure(nr + 2)); HIPCHK(c->cig_c.ensure(c->used[1] + 1));
-    HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
-    k_pack_records<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((uint32_t)n, c->reads_out.p, c->reports.p, c->cigfinal.p, c->rlen.p, c->reads_c.p, c->reports_c.p, c->cig_cnt.p, c->d_err);
-    HIPCHK(scan_u32(c, c->cig_cnt.p, c->cig_off.p, (uint32_t)nr, &c->d_sizes->pad[0]));
-    if (nr) k_pack_cigar<<<(unsigned)((nr + 255) / 256), 256, 0, c->stream>>>((uint32_t)nr, c->reports.p, c->cigfinal.p, c->cig_off.p, c->cig_c.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&c->h_tail->err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&c->h_tail->sizes.pad[0], &c->d_sizes->pad[0], 4, hipMemcpyDeviceToHost, c->stream));
-    // the records (their sizes are known) travel while the host waits for the op count
-    if (ro) HIPCHK(hipMemcpyAsync(ro, c->reads_c.p, n * sizeof(dg_read_c), hipMemcpyDeviceToHost, c->stream));
-    if (nr && po) HIPCHK(hipMemcpyAsync(po, c->reports_c.p, nr * sizeof(dg_report_c), hipMemcpyDeviceToHost, c->stream));
-    if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(wait_stream(c));
-    if (c->h_tail->err) { snprintf(c->err, 512, "a record field does not fit the compact types: use dg_batch_download"); return DG_ERR_RANGE; }
-    const size_t n_ops = nr ? (size_t)c->h_tail->sizes.pad[0] : 0;
+    if (!c->packed_valid) {                       // (dg_map_batch_compact packs inside the run: its counts arrive with the batch's sizes)
+        const int rc = enqueue_pack(c);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(&c->h_tail->sizes.pad[0], &c->d_sizes->pad[0], 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(wait_stream(c));
+        c->packed_valid = true;
+    }
+    if (c->h_tail->sizes.pad[1]) { snprintf(c->err, 512, "a record field does not fit the compact types: use dg_batch_download"); return DG_ERR_RANGE; }
+    const size_t n_ops = (size_t)c->h_tail->sizes.pad[0];
     if (n_ops_out) *n_ops_out = n_ops;
     if (caps[1] < n_ops) { snprintf(c->err, 512, "output capacity too small: cigar ops %zu of %zu", n_ops, caps[1]); return DG_ERR_CAPACITY; }
-    if (n_ops && cig) {
-        HIPCHK(hipMemcpyAsync(cig, c->cig_c.p, n_ops * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(wait_stream(c));
-    }
+    if (ro) HIPCHK(hipMemcpyAsync(ro, c->reads_c.p, n * sizeof(dg_read_c), hipMemcpyDeviceToHost, c->stream));
+    if (nr && po) HIPCHK(hipMemcpyAsync(po, c->reports_c.p, nr * sizeof(dg_report_c), hipMemcpyDeviceToHost, c->stream));
+    if (n_ops && cig) HIPCHK(hipMemcpyAsync(cig, c->cig_c.p, n_ops * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(wait_stream(c));
     return DG_OK;
 }
 
@@ -1115,7 +1136,10 @@ extern "C" int dg_map_batch_compact(dg_ctx *c, int n_reads, const uint32_t *seq_
     int rc = words ? enqueue_upload_packed(c, n_reads, rlen_all, rlen, words_per_read, words, nlist, n_n) : enqueue_upload(c, n_reads, seq_off, rlen, seq);
     if (rc) return rc;
     const auto t1 = std::chrono::steady_clock::now();
-    if ((rc = dg_batch_run(c, used))) return rc;
+    c->pack_in_run = true;                                  // the compact records are built at the end of the run: one host round trip less
+    rc = dg_batch_run(c, used);
+    c->pack_in_run = false;
+    if (rc) return rc;
     const auto t2 = std::chrono::steady_clock::now();
     size_t n_ops = 0;
     rc = dg_batch_download_compact(c, ro, po, cig, so, caps, &n_ops);
