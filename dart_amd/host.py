@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdartgpu.so")
+LIB_PATH = os.environ.get("DARTGPU_LIB") or os.path.join(_HERE, "libdartgpu.so")      # (DARTGPU_LIB: another build of the library, for A/B runs)
 
 
 class IndexView(C.Structure):
