@@ -68,6 +68,10 @@ struct dg_ctx {
     DBuf<unsigned char> ws;
     DBuf<unsigned long long> scan_state;
     size_t cap_seeds = 0, cap_rep = 0, cap_work = 0, cap_cig = 0;
+    // what any context of this index has learned about capacities (the root owns it, clones point to it): a clone does not have to overflow
+    // and run its first batch again to find out what its siblings already know
+    struct SharedCaps { std::atomic<size_t> seeds{0}, rep{0}, work{0}, cig{0}; } *shared_caps = nullptr;
+    bool owns_shared_caps = false;
     unsigned long long *d_ctr = nullptr; unsigned int *d_tops = nullptr; int *d_err = nullptr; DSizes *d_sizes = nullptr;
     struct HostTail { DSizes sizes; int err; unsigned int tops[N_TOPS]; uint64_t ctr_stripes[CTR_STRIPES * CTR_STRIDE]; } *h_tail = nullptr;   // pinned
     size_t used[3] = {0, 0, 0};
@@ -154,6 +158,8 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t *out, const uint32_t 
 }
 
 static std::atomic<uint64_t> g_phase_ns[4];
+static void caps_publish(std::atomic<size_t> &a, size_t v) { size_t cur = a.load(); while (cur < v && !a.compare_exchange_weak(cur, v)) { } }
+static void caps_adopt(size_t &mine, const std::atomic<size_t> &a) { const size_t v = a.load(); if (v > mine) mine = v; }
 // waiting for a context's stream on the per-batch path.  DG_BLOCKING_SYNC=1: through an event created with hipEventBlockingSync, so the
 // host thread sleeps instead of spinning (one thread per context: a dozen spinning threads per GPU is a dozen busy cores)
 static hipError_t wait_stream(dg_ctx *c)
@@ -477,6 +483,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     if (c->ev_reseed1) (void)hipEventDestroy(c->ev_reseed1);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->owns_shared_caps) delete c->shared_caps;
     delete c;
 }
 
@@ -514,6 +521,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(DG_ERR_HIP, "hipSetDevice", e);
     c = new dg_ctx();
     c->device = device;
+    c->shared_caps = new dg_ctx::SharedCaps(); c->owns_shared_caps = true;
     if ((e = make_ctx_objects(c)) != hipSuccess) return bail(DG_ERR_HIP, "stream / event / counter allocation", e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -613,6 +621,7 @@ extern "C" dg_ctx *dg_clone(dg_ctx *parent, int *status)
     dg_ctx *c = new dg_ctx();
     c->device = parent->device; c->owns_index = false; c->n_cu = parent->n_cu;
     c->ix = parent->ix; c->pr = parent->pr;
+    c->shared_caps = parent->shared_caps;
     if ((e = make_ctx_objects(c)) != hipSuccess) {
         snprintf(g_init_error, sizeof g_init_error, "dg_clone: %s", hipGetErrorString(e)); dg_destroy(c); if (status) *status = DG_ERR_HIP; return nullptr;
     }
@@ -798,6 +807,7 @@ static int enqueue_seeding(dg_ctx *c, int n, int H, bool timed)
 {
     const uint32_t nb = (uint32_t)((n + 255) / 256);
     HIPCHK(c->hits.ensure((size_t)n * H)); HIPCHK(c->nhits.ensure(n)); HIPCHK(c->nseeds.ensure(n)); HIPCHK(c->seed_off.ensure((size_t)n + 1));
+    if (c->shared_caps) caps_adopt(c->cap_seeds, c->shared_caps->seeds);
     if (c->cap_seeds < (size_t)n * 3 + 1024) c->cap_seeds = (size_t)n * 3 + 1024;              // first guess: ~2.5 seeds per read; grows by itself
     HIPCHK(c->seeds.ensure(c->cap_seeds + 1)); HIPCHK(c->cands.ensure(c->cap_seeds + 1)); HIPCHK(c->tile_read.ensure(c->cap_seeds / 64 + 16));
     if (timed) c->tname[c->n_t] = "k_encode";
@@ -841,6 +851,7 @@ static int enqueue_run(dg_ctx *c)
     { const int rc = enqueue_seeding(c, n, H, true); if (rc) return rc; }
 
     // capacities of the data-dependent buffers (sticky; see dg_ctx)
+    if (c->shared_caps) { caps_adopt(c->cap_rep, c->shared_caps->rep); caps_adopt(c->cap_cig, c->shared_caps->cig); caps_adopt(c->cap_work, c->shared_caps->work); }
     if (c->cap_rep < (size_t)n + (size_t)n / 4 + 1024) c->cap_rep = (size_t)n + (size_t)n / 4 + 1024;
     if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep;
     if (c->cap_work < (size_t)n * 8 + 65536) c->cap_work = (size_t)n * 8 + 65536;
@@ -981,6 +992,8 @@ static int finish_run(dg_ctx *c, size_t used[3])
         else if (derr == DG_E_REPORTS) { c->cap_rep = grow(sz.total_rep); if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep; }
         else if (derr == DG_E_WORK) c->cap_work = grow(c->h_tail->tops[TOP_WORK]);
         else if (derr == DG_E_CIGFINAL) c->cap_cig = grow(sz.total_cig > 2 * c->cap_cig ? sz.total_cig : 2 * c->cap_cig);
+        if (c->shared_caps) { caps_publish(c->shared_caps->seeds, c->cap_seeds); caps_publish(c->shared_caps->rep, c->cap_rep); caps_publish(c->shared_caps->work, c->cap_work); caps_publish(c->shared_caps->cig, c->cap_cig); }
+        if (derr == DG_E_SEEDS || derr == DG_E_REPORTS || derr == DG_E_WORK || derr == DG_E_CIGFINAL) { /* grown above */ }
         else if (derr == DG_E_SCAN && attempt < 2) { c->reruns_scan++; /* a look-back that did not complete (dg_scan.h): nothing to grow, the batch simply runs again */ }
         else { snprintf(c->err, 512, "device-side scan did not complete (status %d)", derr); return DG_ERR_INTERNAL; }
         if (attempt == 5) { snprintf(c->err, 512, "buffer capacities did not converge (status %d)", derr); return DG_ERR_INTERNAL; }
