@@ -329,6 +329,31 @@ class DartGPU:
         self.run()
         return self.download()
 
+    def map_batch_compact(self, words, nlist, rlen_all, rlen=None) -> BatchResult:
+        """dg_map_batch_compact in one call: packed reads in, compact records out (built inside the run), expanded to the full dtypes;
+        arrays sized by a guess and grown on DG_ERR_CAPACITY the way a C caller would"""
+        n = int(words.shape[0])
+        w = np.ascontiguousarray(words, np.uint32); nl = np.ascontiguousarray(nlist, np.uint32)
+        rl = None if rlen is None else np.ascontiguousarray(rlen, np.uint16)
+        self._n = n
+        self._rlen_of_batch = np.full(n, rlen_all, np.uint16) if rl is None else rl.copy()
+        cap = [n + n // 8 + 64, n // 4 + 64, 64]
+        while True:
+            reads = np.zeros(max(n, 1), dtype=READ_C); reports = np.zeros(cap[0], dtype=REPORT_C)
+            cigar = np.zeros(cap[1], dtype=np.uint32); sj = np.zeros(cap[2], dtype=SJ_OUT)
+            caps = (C.c_size_t * 3)(*cap); used = (C.c_size_t * 3)()
+            rc = self.lib.dg_map_batch_compact(self.ctx, n, None, None if rl is None else rl.ctypes.data, None, int(rlen_all), int(w.shape[1]) if w.ndim == 2 else 1,
+                                               w.ctypes.data, nl.ctypes.data if len(nl) else None, len(nl),
+                                               reads.ctypes.data, reports.ctypes.data, cigar.ctypes.data, sj.ctypes.data, caps, used)
+            u = [int(x) for x in used]
+            if rc == -4:                                   # DG_ERR_CAPACITY: `used` holds the need (of what is known so far)
+                cap = [max(cap[0], u[0] + 16), max(2 * cap[1], u[1] + 16), max(cap[2], u[2] + 16)]
+                continue
+            self._chk(rc, "dg_map_batch_compact")
+            self._used = u
+            r, p, cg = expand_compact(reads[:n], reports[:u[0]], cigar[:u[1]], self._rlen_of_batch)
+            return BatchResult(r, p, cg, sj[:u[2]])
+
     def pinned(self, shape, dtype) -> "PinnedArray":
         return PinnedArray(self.lib, shape, dtype)
 

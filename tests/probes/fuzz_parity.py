@@ -40,6 +40,7 @@ def run(rounds, seed0, workdir="/tmp/fuzz", log=print):
                 words, nlist = host.pack_reads_2bit(arr)
                 common.assert_same(gpu.map_batch_packed(words, nlist, rlen), want)
                 common.assert_same(gpu.download_compact(), want)
+                common.assert_same(gpu.map_batch_compact(words, nlist, rlen), want)      # one call: compact records built inside the run
                 words_ok = " + packed/compact"
             log("round %d ok%s: genome %s rscale, %d x %s%d, %s, %s  (%.1f s)" % (k, words_ok, lens, n, "2x" if paired else "", rlen, kw, flags, time.time() - t))
         except AssertionError as e:
