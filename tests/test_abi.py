@@ -38,3 +38,38 @@ def test_record_layouts_match_header():
     # sizes the C structs must have (include/dartgpu.h): 9 x i32, 6 x i32 + i64 + 2 x u32, 2 x i64 + 2 x i32
     assert host.READ_OUT.itemsize == 36 and host.REPORT_OUT.itemsize == 40 and host.SJ_OUT.itemsize == 24
     assert C.sizeof(host.Params) == 32
+
+
+def test_compact_record_layout_round_trip(workdir):
+    """include/dartgpu.h's compact layout (12 + 16 bytes, offsets as running sums, CIGAR ops in report order, none stored for a plain
+    full-length match) against its reference expansion host.expand_compact: the oracle's records of a golden case are packed here
+    by the header's rules -- independently of the kernels that do it on the GPU -- and must come back unchanged"""
+    import numpy as np
+    import oracle_py
+    assert host.READ_C.itemsize == 12 and host.REPORT_C.itemsize == 16 and host.CIGAR_FULL_MATCH == 255
+    c = common.build_case("pe101_spliced", workdir)
+    orc = oracle_py.Oracle(c["prefix"])
+    so, rl, flat = host.pack_reads(c["reads"])
+    reads, rep, cig, sj = orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat)
+    orc.close()
+    rc = np.zeros(len(reads), host.READ_C)
+    for f in ("score", "sub_score", "mis_num", "mapq", "n_sj", "n_rep", "best"):
+        rc[f] = reads[f]
+    pc = np.zeros(len(rep), host.REPORT_C)
+    for f in ("pos", "aln_score", "flag", "paired_idx", "sj_type", "bdir"):
+        pc[f] = rep[f]
+    pc["chr"] = np.where(rep["chr"] < 0, 0xFFFF, rep["chr"])
+    owner = np.repeat(np.arange(len(reads)), reads["n_rep"])
+    first_op = cig[np.minimum(rep["cigar_off"], max(len(cig) - 1, 0))] if len(cig) else np.zeros(len(rep), np.uint32)
+    plain = (rep["n_cigar"] == 1) & (first_op == (rl[owner].astype(np.uint32) << 4))
+    pc["n_cigar"] = np.where(plain, host.CIGAR_FULL_MATCH, rep["n_cigar"])
+    stored = [cig[int(o):int(o) + int(k)] for o, k, p in zip(rep["cigar_off"], rep["n_cigar"], plain) if not p and k]
+    cc = np.concatenate(stored) if stored else np.zeros(0, np.uint32)
+    assert 0 < plain.sum() < len(rep) and len(cc) < len(cig)
+    r2, p2, c2 = host.expand_compact(rc, pc, cc, rl)
+
+    class R:
+        pass
+    res = R(); res.reads, res.reports, res.cigar, res.sj = r2, p2, c2, sj
+    common.assert_same(res, (reads, rep, cig, sj))
+
