@@ -192,12 +192,79 @@ __device__ __forceinline__ bool d_unit_is_heavy(const uint32_t *seed_off, int pa
 
 // ---------------------------------------------------------------------------------------------
 // k_chain_heavy: one wave = one heavy unit.  Seeds of both mates are staged in LDS and sorted with a wave-wide bitonic
-// network; candidates are built by lane 0 from LDS; the O(n1*n2) mate search runs 64 candidates at a time with a wave
+// network; candidates are built by the whole wave from LDS (d_gen_candidates_wave); the O(n1*n2) mate search runs 64 candidates at a time with a wave
 // min-reduction that keeps the first-minimum rule.  Anything larger than the LDS staging (> CH_MAXS seeds or > CH_MAXC
 // candidates per mate) takes the serial route through global memory (same functions).
 // ---------------------------------------------------------------------------------------------
 #define CH_MAXS 1024
 #define CH_MAXC 192
+
+// d_gen_candidates by one wave over sorted keys in LDS (num <= CH_MAXS).  Whether seed i starts a new candidate depends on its
+// predecessor only (the clustering walk compares every seed with the one it has just taken), so the starts, the covered-bases prefix
+// and every candidate's end come from ballots and one running sum; candidates are numbered in seed order as the serial walk does.
+// scratch: pref[CH_MAXS + 1] u32 and starts[CH_MAXS / 64] u64 (LDS).  Every lane returns the count.
+__device__ inline int d_gen_candidates_wave(const DIndex &ix, const DParams &pr, int rlen, const SKey *s, int num, uint32_t base, DCand *out,
+                                            uint32_t *pref, unsigned long long *starts, int lane)
+{
+    const int need = (int)(rlen * 0.3), rounds = (num + 63) >> 6;
+    // the walk skips the leading seeds on negative diagonals
+    int head0 = num;
+    for (int r = 0; r < rounds && head0 == num; r++) {
+        const int i = r * 64 + lane;
+        const unsigned long long m = __ballot(i < num && sk_diag(s[i]) >= 0);
+        if (m) head0 = r * 64 + __ffsll((long long)m) - 1;
+    }
+    uint32_t run = 0;
+    if (lane == 0) pref[0] = 0;
+    for (int r = 0; r < rounds; r++) {
+        const int i = r * 64 + lane;
+        bool start = false;
+        uint32_t len = 0;
+        if (i < num && i >= head0) {
+            const SKey cand = s[i];
+            len = (uint32_t)sk_rlen(cand);
+            if (i == head0) start = true;
+            else {
+                const SKey tail = s[i - 1];
+                int64_t jump = sk_diag(cand) - sk_diag(tail);
+                if (jump < 0) jump = -jump;
+                bool joins = jump < pr.max_gaps;
+                if (!joins && jump < pr.max_intron)
+                    joins = sk_gpos(cand) < ix.loc_key[d_loc_lower_bound(ix, sk_gpos(tail))] && sk_rpos(cand) > sk_rpos(tail);
+                start = !joins;
+            }
+        }
+        const unsigned long long m = __ballot(start);
+        if (lane == 0) starts[r] = m;
+        uint32_t incl = len;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += v; }
+        if (i < num) pref[i + 1] = run + incl;
+        run += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+    __syncthreads();
+    int made = 0;
+    for (int r = 0; r < rounds; r++) {
+        const int i = r * 64 + lane;
+        const unsigned long long sm = starts[r];
+        const bool start = (sm >> lane) & 1ull;
+        int end = num;
+        if (start) {
+            const unsigned long long later = lane == 63 ? 0ull : sm >> (lane + 1);
+            if (later) end = i + 1 + (__ffsll((long long)later) - 1);
+            else for (int q = r + 1; q < rounds; q++) if (starts[q]) { end = q * 64 + __ffsll((long long)starts[q]) - 1; break; }
+        }
+        const int covered = start ? (int)(pref[end] - pref[i]) : 0;
+        const bool emit = start && covered > need;
+        const unsigned long long em = __ballot(emit);
+        if (emit) {
+            const int64_t d = sk_diag(s[i]);
+            out[made + __popcll(em & ((1ull << lane) - 1ull))] = d_new_cand(base + (uint32_t)i, end - i, covered, d < 0 ? (int64_t)0 : d);
+        }
+        made += __popcll(em);
+    }
+    __syncthreads();
+    return made;
+}
 
 __device__ inline void d_bitonic_sort_keys(SKey *a, int n, int lane)   // n <= CH_MAXS, one wave
 {
@@ -230,6 +297,8 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
     __shared__ DCand lc[2][CH_MAXC];
     __shared__ int s_n[2], s_pairing;
     __shared__ int16_t s_pick[CH_MAXC];
+    __shared__ uint32_t s_pref[CH_MAXS + 1];
+    __shared__ unsigned long long s_starts[CH_MAXS / 64];
     if (*abort_p >= DG_ABORT) return;
     const int lane = threadIdx.x;
     const unsigned int n_heavy = *n_heavy_p;
@@ -254,10 +323,15 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
             }
             __syncthreads();
         }
-        if (lane == 0) {
+        if (fits) {
             for (int m = 0; m < nm; m++) {
-                if (!fits) d_sort_keys(seeds + b[m], (int)n[m]);
-                s_n[m] = d_gen_candidates(ix, pr, rlen[r1 + m], fits ? ls[m] : seeds + b[m], (int)n[m], b[m], cands + b[m]);
+                const int made = d_gen_candidates_wave(ix, pr, rlen[r1 + m], ls[m], (int)n[m], b[m], cands + b[m], s_pref, s_starts, lane);
+                if (lane == 0) s_n[m] = made;
+            }
+        } else if (lane == 0) {
+            for (int m = 0; m < nm; m++) {
+                d_sort_keys(seeds + b[m], (int)n[m]);
+                s_n[m] = d_gen_candidates(ix, pr, rlen[r1 + m], seeds + b[m], (int)n[m], b[m], cands + b[m]);
             }
         }
         __syncthreads();
