@@ -312,6 +312,8 @@ def main():
         if not rehearse:
             torch.cuda.current_stream().synchronize()       # the context's next run overwrites these records
 
+    stagger_s = float(os.environ.get("DART_BENCH_STAGGER_MS", "1.0")) * 1e-3
+
     def run_items(n_items, mode, ws=workers, first_item=0):
         done = [threading.Semaphore(0) for _ in ws]        # an item of this context has finished
         free = [threading.Semaphore(0) for _ in ws]        # its records have been gathered, the next item may start
@@ -319,6 +321,10 @@ def main():
 
         def work(k):
             try:
+                # the contexts do not all upload at once: the link serves one 56 MB upload in ~1 ms, twelve together in ~12 ms during which
+                # the GPU would have nothing to do; context k hands its first batch over k x stagger later (a streaming host is in this state anyway)
+                if stagger_s > 0 and k:
+                    time.sleep(k * stagger_s)
                 for i in range(k, n_items, len(ws)):
                     ws[k].map(batches[(first_item + i) % nb], mode)
                     done[k].release()
