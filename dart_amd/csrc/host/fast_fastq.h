@@ -511,7 +511,8 @@ static int run_fast_library(const char *f1, const char *f2, bool pair_end, int t
     while (true) {
         FastSlot *s = nullptr;
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fmt_q.count(next_out) || failed || (mappers_left == 0 && fmt_q.empty()); });
-          if (failed) break; if (fmt_q.count(next_out)) { s = fmt_q[next_out]; fmt_q.erase(next_out); } else break; }
+          if (failed) break;
+          if (fmt_q.count(next_out)) { s = fmt_q[next_out]; fmt_q.erase(next_out); } else break; }
         TextSet &ts = sets[fill];
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return !ts.full || failed; }); if (failed) break; }
         const double tf = now();
