@@ -67,13 +67,14 @@ struct dg_ctx {
     DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c; DBuf<uint32_t> cig_cnt, cig_off, cig_c;     // compact download: records, stored-op counts / offsets / ops
     DBuf<unsigned char> ws;
     DBuf<unsigned long long> scan_state;
+    uint32_t scan_epoch = 0;      // number of the enqueued run, carried by every state word of its single-pass scans (dg_scan.h); never 0
     size_t cap_seeds = 0, cap_rep = 0, cap_work = 0, cap_cig = 0;
     // what any context of this index has learned about capacities (the root owns it, clones point to it): a clone does not have to overflow
     // and run its first batch again to find out what its siblings already know
     struct SharedCaps { std::atomic<size_t> seeds{0}, rep{0}, work{0}, cig{0}; } *shared_caps = nullptr;
     bool owns_shared_caps = false;
-    unsigned long long *d_ctr = nullptr; unsigned int *d_tops = nullptr; int *d_err = nullptr; DSizes *d_sizes = nullptr;
-    struct HostTail { DSizes sizes; int err; unsigned int tops[N_TOPS]; uint64_t ctr_stripes[CTR_STRIPES * CTR_STRIDE]; } *h_tail = nullptr;   // pinned
+    unsigned long long *d_ctr = nullptr; unsigned int *d_tops = nullptr; int *d_err = nullptr; DSizes *d_sizes = nullptr; unsigned int *d_input_bad = nullptr;
+    struct HostTail { DSizes sizes; int err; unsigned int input_bad; unsigned int tops[N_TOPS]; uint64_t ctr_stripes[CTR_STRIPES * CTR_STRIDE]; } *h_tail = nullptr;   // pinned
     size_t used[3] = {0, 0, 0};
     bool enqueued = false;
     // timings
@@ -81,9 +82,12 @@ struct dg_ctx {
     uint64_t counters[CTR_N];
     uint64_t reruns_capacity = 0, reruns_scan = 0;      // since dg_init / dg_clone
     bool pack_in_run = false, packed_valid = false;     // compact records: built inside the run / present for the batch that ran last
-    int n_cu = 256, runs_of_last_batch = 0;
+    int n_cu = 256, runs_of_last_batch = 0, attempt_no = 0;
     // environment switches, read once per context (not per batch)
     int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
+    int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
+    size_t seedqf_lds_set = 0;
+    int env_scan_budget = 0;      // DG_SCAN_POLL_BUDGET: poll budget of a look-back on the FIRST attempt of a batch (test hook: forces the DG_E_SCAN re-run path)
 };
 
 static void read_env(dg_ctx *c)
@@ -92,6 +96,8 @@ static void read_env(dg_ctx *c)
     c->env_seed_waves = geti("DG_SEED_WAVES", 4); c->env_bail_trips = geti("DG_SEED_BAIL_TRIPS", 128); c->env_both = geti("DG_SEED_BOTH", 0);
     c->env_seed_legacy = geti("DG_SEED_LEGACY", 0); c->env_seed_slots_lg = geti("DG_SEED_SLOTS_LG", 0); c->env_seed_wgs = geti("DG_SEED_WGS", 0); c->env_blocking_sync = geti("DG_BLOCKING_SYNC", 0);
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
+    c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0);
+    c->env_seed_phases = geti("DG_SEED_PHASES", 0); c->env_seed_wg_waves = geti("DG_SEED_WG_WAVES", 4); c->env_seed_partial = geti("DG_SEED_PARTIAL_MIN", 32);
 }
 
 static int fail(dg_ctx *c, int code, const char *what, hipError_t e)
@@ -468,7 +474,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     void *ptrs[] = { c->d_ktab, c->d_sa_dense, c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff };
     if (c->owns_index) for (void *p : ptrs) if (p) (void)hipFree(p);
-    void *own[] = { c->d_ctr, c->d_tops, c->d_err, c->d_sizes };
+    void *own[] = { c->d_ctr, c->d_tops, c->d_err, c->d_sizes, c->d_input_bad };
     for (void *p : own) if (p) (void)hipFree(p);
     if (c->h_tail) (void)hipHostFree(c->h_tail);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->packed_in.release(); c->nlist_in.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
@@ -497,7 +503,8 @@ static hipError_t make_ctx_objects(dg_ctx *c)
         (e = hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return e;
     for (int i = 0; i <= N_TIMERS; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, N_TOPS * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess || (e = hipMalloc((void **)&c->d_sizes, sizeof(DSizes))) != hipSuccess) return e;
+        (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess || (e = hipMalloc((void **)&c->d_sizes, sizeof(DSizes))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_input_bad, 4)) != hipSuccess) return e;
     if ((e = hipHostMalloc((void **)&c->h_tail, sizeof(dg_ctx::HostTail), hipHostMallocDefault)) != hipSuccess) return e;
     memset(c->h_tail, 0, sizeof(dg_ctx::HostTail));
     read_env(c);
@@ -666,10 +673,11 @@ extern "C" int dg_batch_upload(dg_ctx *c, int n_reads, const uint32_t *seq_off, 
 // words the seeding stage reads (k_encode's format).  One thread = 16 bases = one input word.
 __global__ void __launch_bounds__(256)
 k_unpack(const uint32_t *__restrict__ words, uint32_t n_words, int W2, double inv_w2, int rlen_all, const uint16_t *rlen_in, unsigned char *__restrict__ seq,
-         uint32_t *__restrict__ seq_off, uint16_t *rlen_out, uint32_t *__restrict__ enc)
+         uint32_t *__restrict__ seq_off, uint16_t *rlen_out, uint32_t *__restrict__ enc, unsigned int *bad)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_words) return;
+    if (t == 0) *bad = 0u;                                              // (k_unpack_n, the next launch, raises it)
     uint32_t r = (uint32_t)((double)t * inv_w2);                        // t / W2 without an integer division: the product is within one of it
     if (r * (uint32_t)W2 > t) r--; else if ((r + 1u) * (uint32_t)W2 <= t) r++;
     const int ww = (int)(t - r * (uint32_t)W2);
@@ -691,11 +699,12 @@ k_unpack(const uint32_t *__restrict__ words, uint32_t n_words, int W2, double in
     if (ww == 0) { seq_off[r] = r * 16u * (uint32_t)W2; if (!rlen_in) rlen_out[r] = (uint16_t)len; }      // (given lengths are already in place)
 }
 __global__ void __launch_bounds__(256)
-k_unpack_n(const uint32_t *__restrict__ nlist, uint32_t n_n, int W2, unsigned char *__restrict__ seq, uint32_t *__restrict__ enc)
+k_unpack_n(const uint32_t *__restrict__ nlist, uint32_t n_n, int W2, uint32_t n_bases, unsigned char *__restrict__ seq, uint32_t *__restrict__ enc, unsigned int *bad)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_n) return;
     const uint32_t flat = nlist[i], per = 16u * (uint32_t)W2, r = flat / per, pos = flat - r * per;
+    if (flat >= n_bases) { atomicMax(bad, 1u); return; }       // a list entry outside the batch (a buggy packer) must not write outside it: dg_batch_run reports DG_ERR_ARG
     seq[flat] = 'N';
     const uint32_t bit = 3u << (30 - 2 * (pos & 15u));
     atomicAnd(&enc[(size_t)r * 2 * W2 + (pos >> 4)], ~bit);
@@ -720,8 +729,11 @@ static int enqueue_upload_packed(dg_ctx *c, int n_reads, int rlen_all, const uin
     HIPCHK(hipMemcpyAsync(c->packed_in.p, words, nw * 4, hipMemcpyHostToDevice, c->stream));
     if (rlen) HIPCHK(hipMemcpyAsync(c->rlen.p, rlen, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->stream));
     if (n_n) HIPCHK(hipMemcpyAsync(c->nlist_in.p, nlist, n_n * 4, hipMemcpyHostToDevice, c->stream));
-    k_unpack<<<(unsigned)((nw + 255) / 256), 256, 0, c->stream>>>(c->packed_in.p, (uint32_t)nw, W2, 1.0 / (double)W2, rlen_all, rlen ? c->rlen.p : nullptr, c->seq.p, c->seq_off.p, c->rlen.p, c->enc.p);
-    if (n_n) k_unpack_n<<<(unsigned)((n_n + 255) / 256), 256, 0, c->stream>>>(c->nlist_in.p, (uint32_t)n_n, W2, c->seq.p, c->enc.p);
+    k_unpack<<<(unsigned)((nw + 255) / 256), 256, 0, c->stream>>>(c->packed_in.p, (uint32_t)nw, W2, 1.0 / (double)W2, rlen_all, rlen ? c->rlen.p : nullptr, c->seq.p, c->seq_off.p, c->rlen.p, c->enc.p, c->d_input_bad);
+    if (n_n) {
+        k_unpack_n<<<(unsigned)((n_n + 255) / 256), 256, 0, c->stream>>>(c->nlist_in.p, (uint32_t)n_n, W2, (uint32_t)(nw * 16), c->seq.p, c->enc.p, c->d_input_bad);
+        HIPCHK(hipMemcpyAsync(&c->h_tail->input_bad, c->d_input_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    } else c->h_tail->input_bad = 0;
     HIPCHK(hipGetLastError());
     return DG_OK;
 }
@@ -777,6 +789,27 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     const int bail_trips = c->env_bail_trips, both_thr = c->env_both;
     unsigned int *tops = c->d_tops;
     // default: the queue kernel (dg_seedq.h).  DG_SEED_LEGACY=1 or reads too long for its LDS slots (> 496 bases): the lane-per-read kernel
+    if (!c->env_seed_legacy && !c->env_seed_phases && W <= 62) {
+        // the free-running queue kernel (dg_seedq.h, k_seed_qf): workgroups of `nw` waves around 2^lg read slots
+        int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 11 ? c->env_seed_slots_lg : 9;
+        int nw = c->env_seed_wg_waves >= 1 && c->env_seed_wg_waves <= 8 ? c->env_seed_wg_waves : 4;
+        while (lg > 6 && sqf_lds_bytes(lg, W, nw) > (size_t)156 * 1024) lg--;
+        if (c->env_seed_slots_lg == 0) while (lg > 6 && sqf_lds_bytes(lg, W, nw) > (size_t)80 * 1024) lg--;      // default: two workgroups per CU
+        const size_t lds = sqf_lds_bytes(lg, W, nw);
+        if (lds > c->seedqf_lds_set) {
+            if ((e = hipFuncSetAttribute((const void *)k_seed_qf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+            c->seedqf_lds_set = lds;
+        }
+        unsigned per_cu = (unsigned)(((size_t)160 * 1024) / lds);
+        if (per_cu * (unsigned)nw > 16u) per_cu = 16u / (unsigned)nw;
+        if (per_cu < 1u) per_cu = 1u;
+        if (c->env_seed_wgs > 0) per_cu = (unsigned)c->env_seed_wgs;
+        unsigned wgs = (unsigned)c->n_cu * per_cu;
+        const unsigned need = (unsigned)(((size_t)n + ((size_t)1 << lg) - 1) >> lg);
+        if (wgs > need) wgs = need;
+        k_seed_qf<<<wgs, nw * 64, lds, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, lg, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT,
+                                                    c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, c->env_seed_partial, c->d_err);
+    } else
     if (!c->env_seed_legacy && W <= 62) {
         int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 10 ? c->env_seed_slots_lg : 9;
         while (lg > 6 && sq_lds_bytes(lg, W) > (size_t)80 * 1024) lg--;
@@ -822,15 +855,31 @@ static int enqueue_seeding(dg_ctx *c, int n, int H, bool timed)
     return DG_OK;
 }
 
+// the small per-batch state -- work counters, bump tops and tickets, status word, sizes -- zeroed by ONE launch (round 2: five fills;
+// the four blocks stay separate allocations: the status word every workgroup reads must not share lines with the tops every workgroup bumps)
+__global__ void __launch_bounds__(256)
+k_batch_begin(unsigned long long *ctr, unsigned int *tops, int *err, DSizes *sizes)
+{
+    for (int i = threadIdx.x; i < CTR_STRIPES * CTR_STRIDE; i += 256) ctr[i] = 0ull;
+    if (threadIdx.x < N_TOPS) tops[threadIdx.x] = 0u;
+    if (threadIdx.x < (int)(sizeof(DSizes) / 4)) ((uint32_t *)sizes)[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) *err = 0;
+}
+
 static int zero_batch_state(dg_ctx *c, int n_units)
 {
-    HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_STRIPES * CTR_STRIDE * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_tops, 0, N_TOPS * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_err, 0, 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_sizes, 0, sizeof(DSizes), c->stream));
+    k_batch_begin<<<1, 256, 0, c->stream>>>(c->d_ctr, c->d_tops, c->d_err, c->d_sizes);
+    HIPCHK(hipGetLastError());
+    // the look-back state of the two single-pass scans is NOT zeroed per batch: its words carry the run's epoch (dg_scan.h).
+    // Zeroed once, when (re)allocated: epoch 0 is never used.
     const size_t tiles = (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1, tiles2 = (size_t)(2 * n_units + 255) / 256 + 1;
-    HIPCHK(c->scan_state.ensure(2 * tiles + 2 * tiles2));
-    HIPCHK(hipMemsetAsync(c->scan_state.p, 0, (2 * tiles + 2 * tiles2) * 8, c->stream));
+    const size_t words = SCAN_WORDS * (tiles + tiles2);
+    if (words > c->scan_state.cap) {
+        HIPCHK(c->scan_state.ensure(words));
+        HIPCHK(hipMemsetAsync(c->scan_state.p, 0, c->scan_state.cap * 8, c->stream));
+    }
+    c->scan_epoch = (c->scan_epoch + 1u) & 0x3FFFFFFFu;
+    if (c->scan_epoch == 0) c->scan_epoch = 1;
     return DG_OK;
 }
 
@@ -879,9 +928,10 @@ static int enqueue_run(dg_ctx *c)
     }
 #endif
     TICK("k_chain_heavy");
-    const size_t tiles = (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1, tiles2 = (size_t)(2 * n_units + 255) / 256 + 1;
-    TileScan ts_pair{c->scan_state.p, c->scan_state.p + tiles, tops + TOP_TICKET_PAIR};
-    TileScan ts_emit{c->scan_state.p + 2 * tiles, c->scan_state.p + 2 * tiles + tiles2, tops + TOP_TICKET_EMIT};
+    const size_t tiles = (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1;
+    const uint32_t budget = (c->env_scan_budget > 0 && c->attempt_no == 0) ? (uint32_t)c->env_scan_budget : (1u << 20);   // ~2 s of polling
+    TileScan ts_pair{c->scan_state.p, tops + TOP_TICKET_PAIR, c->scan_epoch, budget, c->d_sizes->scan_dbg};
+    TileScan ts_emit{c->scan_state.p + SCAN_WORDS * tiles, tops + TOP_TICKET_EMIT, c->scan_epoch, budget, c->d_sizes->scan_dbg};
     const int try_fast = (c->env_no_fast || c->ix.n_chr > 0xFFFF) ? 0 : 1;
     k_pair<<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
         c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p, c->done.p,
@@ -984,20 +1034,33 @@ static int finish_run(dg_ctx *c, size_t used[3])
         c->runs_of_last_batch++;
         HIPCHK(wait_stream(c));
         HIPCHK(hipStreamSynchronize(c->stream2));
+        if (c->enc_ready && c->h_tail->input_bad) { snprintf(c->err, 512, "packed batch: the N list holds a position outside the batch"); c->enqueued = false; return DG_ERR_ARG; }
         const DSizes &sz = c->h_tail->sizes;
         const int derr = c->h_tail->err;
         if (derr < DG_ABORT) break;
         auto grow = [](size_t need) { return need + need / 4 + 1024; };
         if (derr == DG_E_SEEDS) c->cap_seeds = grow(sz.total_seeds);
-        else if (derr == DG_E_REPORTS) { c->cap_rep = grow(sz.total_rep); if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep; }
+        else if (derr == DG_E_REPORTS) {        // (never shrinks: should the reported total ever be short, doubling still converges)
+            c->cap_rep = std::max(grow(sz.total_rep), 2 * c->cap_rep);
+            if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep;
+        }
         else if (derr == DG_E_WORK) c->cap_work = grow(c->h_tail->tops[TOP_WORK]);
         else if (derr == DG_E_CIGFINAL) c->cap_cig = grow(sz.total_cig > 2 * c->cap_cig ? sz.total_cig : 2 * c->cap_cig);
         if (c->shared_caps) { caps_publish(c->shared_caps->seeds, c->cap_seeds); caps_publish(c->shared_caps->rep, c->cap_rep); caps_publish(c->shared_caps->work, c->cap_work); caps_publish(c->shared_caps->cig, c->cap_cig); }
         if (derr == DG_E_SEEDS || derr == DG_E_REPORTS || derr == DG_E_WORK || derr == DG_E_CIGFINAL) { /* grown above */ }
-        else if (derr == DG_E_SCAN && attempt < 2) { c->reruns_scan++; /* a look-back that did not complete (dg_scan.h): nothing to grow, the batch simply runs again */ }
+        else if ((derr == DG_E_SCAN || derr == DG_E_SEEDQ) && attempt < 2) {
+            // a look-back that ran out of its poll budget (dg_scan.h) or the seeding kernel's safety net: nothing to grow, the batch runs again --
+            // but never silently: what the poller saw goes to stderr and into the context's error text, the count into dg_last_counters [35]
+            c->reruns_scan++;
+            const unsigned long long *d = sz.scan_dbg;
+            snprintf(c->err, 512, "batch run again (device status %d): look-back of tile %llu gave up on tile %lld after %llu polls (lane %llu, epoch %llu): words %016llx %016llx %016llx",
+                     derr, d[0] ? d[0] - 1 : 0ull, (long long)d[1], d[6], d[7], d[5], d[2], d[3], d[4]);
+            if (!c->env_scan_budget) fprintf(stderr, "[libdartgpu] %s\n", c->err);
+        }
         else { snprintf(c->err, 512, "device-side scan did not complete (status %d)", derr); return DG_ERR_INTERNAL; }
         if (attempt == 5) { snprintf(c->err, 512, "buffer capacities did not converge (status %d)", derr); return DG_ERR_INTERNAL; }
-        if (derr != DG_E_SCAN) c->reruns_capacity++;
+        if (derr != DG_E_SCAN && derr != DG_E_SEEDQ) c->reruns_capacity++;
+        c->attempt_no = attempt + 1;
         const int rc = enqueue_run(c);
         if (rc) return rc;
     }
@@ -1030,6 +1093,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     c->n_t = 0;
     c->packed_valid = false;
     if (c->n_reads == 0) return DG_OK;
+    c->attempt_no = 0;
     const int rc = enqueue_run(c);
     if (rc) return rc;
     return finish_run(c, used);
@@ -1361,8 +1425,7 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
         HIPCHK(c->heavy.ensure((size_t)n + 16)); HIPCHK(c->slow_units.ensure((size_t)n + 16)); HIPCHK(c->reports.ensure(16)); HIPCHK(c->cigfinal.ensure(16));
         k_heavy_list<<<(n + 255) / 256, 256, 0, c->stream>>>(n, 0, c->seed_off.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_err);
         k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
-        const size_t tiles = (size_t)(n + PU_THREADS - 1) / PU_THREADS + 1;
-        TileScan ts{c->scan_state.p, c->scan_state.p + tiles, c->d_tops + TOP_TICKET_PAIR};
+        TileScan ts{c->scan_state.p, c->d_tops + TOP_TICKET_PAIR, c->scan_epoch, 1u << 20, c->d_sizes->scan_dbg};
         k_pair<<<(unsigned)((n + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
             c->ix, c->pr, n, 0, 0, 1, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p, c->done.p,
             c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, 0xFFFFFFFFu, 0xFFFFFFFFu, ts, c->d_sizes, c->d_tops + TOP_CIG, c->d_ctr, c->d_err);

@@ -395,8 +395,9 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
     __shared__ uint64_t s_rw[2 * PU_SLOTS * PU_THREADS];
     __shared__ unsigned long long s_scan[16];
     __shared__ unsigned int s_tile;
-    if (*err == DG_E_SEEDS) return;                    // set before this launch (the only earlier abort); errors raised INSIDE this
-                                                       // launch never make a workgroup leave: its successors wait for its totals
+    { const int e0 = *err; if (e0 == DG_E_SEEDS || e0 == DG_E_SEEDQ) return; }   // both are raised before this launch (the only earlier aborts: seeds that
+                                                       // do not fit, the seeding kernel's safety net: seed_off / nseeds cannot be trusted); errors
+                                                       // raised INSIDE this launch never make a workgroup leave: its successors wait for its totals
     const unsigned int tile = d_tile_ticket(ts, &s_tile);
     const int u = (int)(tile * PU_THREADS + threadIdx.x);
     const bool valid = u < n_units;

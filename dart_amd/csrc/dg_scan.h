@@ -8,28 +8,38 @@
 //
 // Protocol (per scanned launch): workgroups take a ticket (tile number = order of arrival, so every predecessor of a tile has
 // started and never waits for a later one -- no deadlock whatever order the hardware starts workgroups in).  A tile's state is
-// two 64-bit words, each (status << 62) | payload, written with one atomic store each:
-//   word A: two 31-bit counters x | y << 31      word B: one 62-bit counter z
-//   status 1 = payload is the tile's own total, 2 = payload is the inclusive prefix up to and including the tile.
-// A reader accepts a tile when both words carry the same non-zero status (the writer updates A then B, so a torn pair shows
-// different statuses and is polled again).  The first wave of the workgroup looks back 64 tiles at a time: it adds totals
-// until it meets an inclusive prefix.  The arrays must be zero before the launch (status 0 = nothing yet).
-// A poll budget turns a protocol failure into an error code instead of a hung GPU; the host then runs the batch again (seen once in ~10^5
-// batches with a dozen contexts in flight, cause not found: finish_run in dg_api.hip).
+// three 64-bit words, one per counter, each self-describing and written with one store:
+//   word k = tag << 32 | value_k          tag = epoch << 2 | status
+//   status 1 = the values are the tile's own totals, 2 = the inclusive prefix up to and including the tile
+//   epoch    = the number of the run (dg_ctx::scan_epoch, 30 bits, never 0, different for every enqueued run of a context)
+// A reader accepts a tile when its three words carry the SAME tag and that tag's epoch is the reader's own: a word left by an
+// earlier run of the context (any status, any value) is "nothing yet", so the arrays are never zeroed between runs (they are
+// zeroed once, when allocated) and no stale word can be taken for a result -- round 2 zeroed them with a fill launch per batch and
+// trusted that no cached copy of a previous batch's word survived it.  The first wave of the workgroup looks back 64 tiles at a
+// time: it adds totals until it meets an inclusive prefix.
+// A poll budget turns a protocol failure into an error code instead of a hung GPU and records what the poller saw (ScanDebug);
+// the host logs that and runs the batch again (finish_run in dg_api.hip).
 #pragma once
 #include "dg_common.h"
 
-struct TileScan { unsigned long long *a, *b; unsigned int *ticket; };
-struct Triple { uint32_t x, y; uint64_t z; };
+struct TileScan { unsigned long long *w; unsigned int *ticket; uint32_t epoch, budget; unsigned long long *dbg; };
+struct Triple { uint32_t x, y; uint64_t z; };        // (z stays 64-bit for the callers' arithmetic; a published z is < 2^32: it counts CIGAR ops of one batch)
+#define SCAN_WORDS 3            // state words per tile
+#define SCAN_DBG_WORDS 8        // what a poller that ran out of budget saw: tile, stuck predecessor, its three words, epoch, polls, lane
 
-// RELAXED on purpose: a state word carries its whole message (status + payload in one 64-bit atomic access that goes to the
-// device-coherent level, `sc1`), nothing else is published through it.  Acquire / release at agent scope cost a `buffer_inv sc1`
-// per poll and a `buffer_wbl2 sc1` -- a write-back of the XCD's whole L2 -- per store on gfx950: with those the scan was 90 % of
-// k_pair's time.
+// RELAXED on purpose: a state word carries its whole message (tag + value in one 64-bit access that goes to the device-coherent
+// level, `sc1`), nothing else is published through it.  Acquire / release at agent scope cost a `buffer_inv sc1` per poll and a
+// `buffer_wbl2 sc1` -- a write-back of the XCD's whole L2 -- per store on gfx950: with those the scan was 90 % of k_pair's time.
 __device__ __forceinline__ unsigned long long ts_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ts_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long ts_pack_a(int st, uint32_t x, uint32_t y) { return ((unsigned long long)st << 62) | ((unsigned long long)(y & 0x7FFFFFFFu) << 31) | (unsigned long long)(x & 0x7FFFFFFFu); }
-__device__ __forceinline__ unsigned long long ts_pack_b(int st, uint64_t z) { return ((unsigned long long)st << 62) | (z & 0x3FFFFFFFFFFFFFFFull); }
+__host__ __device__ __forceinline__ uint32_t ts_tag(uint32_t epoch, int st) { return (epoch << 2) | (uint32_t)st; }
+__host__ __device__ __forceinline__ unsigned long long ts_pack(uint32_t tag, uint32_t v) { return ((unsigned long long)tag << 32) | (unsigned long long)v; }
+__device__ __forceinline__ void ts_publish(const TileScan &ts, unsigned int tile, int st, uint32_t x, uint32_t y, uint32_t z)
+{
+    const uint32_t tag = ts_tag(ts.epoch, st);
+    unsigned long long *p = ts.w + (size_t)tile * SCAN_WORDS;
+    ts_store(p, ts_pack(tag, x)); ts_store(p + 1, ts_pack(tag, y)); ts_store(p + 2, ts_pack(tag, z));
+}
 
 // ticket of this workgroup (call once, by every thread; sh = one u32 of LDS)
 __device__ __forceinline__ unsigned int d_tile_ticket(const TileScan &ts, unsigned int *sh)
@@ -41,22 +51,25 @@ __device__ __forceinline__ unsigned int d_tile_ticket(const TileScan &ts, unsign
 
 // exclusive prefix of this tile's totals over all earlier tiles; every thread of the workgroup calls it with the tile's totals
 // (only thread 0's copy is published) and gets the same result.  sh = 4 u64 of LDS.  Workgroups must have >= 64 threads.
+// Only DG_E_SCAN (another poller of this run gave up: the host runs the batch again) ends a look-back early; a capacity overflow
+// raised inside the same launch does not -- the totals the host grows its buffers from stay exact.
 __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile, Triple own, unsigned long long *sh, int *err)
 {
     if (threadIdx.x < 64) {
         const int lane = (int)threadIdx.x;
         uint64_t sx = 0, sy = 0, sz = 0;
         if (tile > 0) {
-            if (lane == 0) { ts_store(ts.a + tile, ts_pack_a(1, own.x, own.y)); ts_store(ts.b + tile, ts_pack_b(1, own.z)); }
+            if (lane == 0) ts_publish(ts, tile, 1, own.x, own.y, (uint32_t)own.z);
             long long base = (long long)tile - 1;
             unsigned int polls = 0;
+            const uint32_t want1 = ts_tag(ts.epoch, 1), want2 = ts_tag(ts.epoch, 2);
             while (true) {
                 const long long t = base - lane;
-                unsigned long long va = ts_pack_a(2, 0, 0), vb = ts_pack_b(2, 0);      // before tile 0: an inclusive prefix of nothing
-                if (t >= 0) { va = ts_load(ts.a + t); vb = ts_load(ts.b + t); }
-                const int sa = (int)(va >> 62), sb = (int)(vb >> 62);
-                const bool ready = sa != 0 && sa == sb;
-                const unsigned long long m_incl = __ballot(ready && sa == 2), m_wait = __ballot(!ready);
+                unsigned long long va = ts_pack(want2, 0), vb = va, vc = va;             // before tile 0: an inclusive prefix of nothing
+                if (t >= 0) { const unsigned long long *p = ts.w + (size_t)t * SCAN_WORDS; va = ts_load(p); vb = ts_load(p + 1); vc = ts_load(p + 2); }
+                const uint32_t ta = (uint32_t)(va >> 32), tb = (uint32_t)(vb >> 32), tc = (uint32_t)(vc >> 32);
+                const bool ready = ta == tb && tb == tc && (ta == want1 || ta == want2);   // (a torn triple shows different tags and is polled again)
+                const unsigned long long m_incl = __ballot(ready && ta == want2), m_wait = __ballot(!ready);
                 int upto = -1;                                                          // lanes 0..upto are summed; -1 = poll again
                 bool done = false;
                 if (m_incl) {
@@ -64,7 +77,7 @@ __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile,
                     if (!(m_wait & ((1ull << f) - 1ull))) { upto = f; done = true; }
                 } else if (!m_wait) upto = 63;
                 if (upto >= 0) {
-                    uint64_t x = lane <= upto ? (va & 0x7FFFFFFFull) : 0, y = lane <= upto ? ((va >> 31) & 0x7FFFFFFFull) : 0, z = lane <= upto ? (vb & 0x3FFFFFFFFFFFFFFFull) : 0;
+                    uint64_t x = lane <= upto ? (va & 0xFFFFFFFFull) : 0, y = lane <= upto ? (vb & 0xFFFFFFFFull) : 0, z = lane <= upto ? (vc & 0xFFFFFFFFull) : 0;
                     for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); z += __shfl_xor(z, o, 64); }
                     sx += x; sy += y; sz += z;
                     if (done) break;
@@ -72,19 +85,28 @@ __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile,
                 } else {
                     polls++;
                     if ((polls & 1023u) == 0u) {
-                        // another kernel stage gave the batch up (the host will run it again): nobody needs this prefix any more
-                        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= DG_ABORT) break;
-                        // belt and braces: a state word is read with a device-coherent load, but should a stale copy ever sit in a cache
-                        // of this XCD, this drops it (one invalidate per thousand polls costs nothing; one per poll tripled k_pair's time)
+                        // another poller of this run gave up (the host will run the batch again): nobody needs this prefix any more
+                        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DG_E_SCAN) break;
+                        // a state word is read with a device-coherent load; should a copy ever sit in this CU's vector cache, this drops it
+                        // (one invalidate per thousand polls costs nothing; one per poll tripled k_pair's time)
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     }
-                    if (polls > (1u << 20)) { if (lane == 0) atomicMax(err, DG_E_SCAN); break; }       // ~2 s: the host runs the batch again
+                    if (polls > ts.budget) {
+                        // the nearest predecessor this wave still waits for, and what its words look like from here
+                        const int stuck = __ffsll((long long)m_wait) - 1;
+                        if (lane == stuck && ts.dbg && atomicCAS(ts.dbg, 0ull, (unsigned long long)tile + 1ull) == 0ull) {
+                            ts.dbg[1] = (unsigned long long)t; ts.dbg[2] = va; ts.dbg[3] = vb; ts.dbg[4] = vc;
+                            ts.dbg[5] = ts.epoch; ts.dbg[6] = polls; ts.dbg[7] = (unsigned long long)lane;
+                        }
+                        if (lane == 0) atomicMax(err, DG_E_SCAN);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
         }
         if (lane == 0) {
-            ts_store(ts.a + tile, ts_pack_a(2, (uint32_t)sx + own.x, (uint32_t)sy + own.y)); ts_store(ts.b + tile, ts_pack_b(2, sz + own.z));
+            ts_publish(ts, tile, 2, (uint32_t)sx + own.x, (uint32_t)sy + own.y, (uint32_t)(sz + own.z));
             sh[0] = sx; sh[1] = sy; sh[2] = sz;
         }
     }

@@ -154,7 +154,7 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
         const bool ex = sq_rfl(ctl[10]) != 0u;
         __syncthreads();                                          // every wave holds the same snapshot before anybody changes it
         if (cn[SQ_FREE] == (uint32_t)NSLOT && ex) break;          // all slots free, nothing left to claim
-        if (phase >= SQ_MAX_PHASES) { if (tid == 0) atomicMax(err, DG_E_SCAN); break; }
+        if (phase >= SQ_MAX_PHASES) { if (tid == 0) atomicMax(err, DG_E_SEEDQ); break; }
         // Which 64 slots this wave takes -- every wave derives the same plan from the same snapshot.  Full chunks of 64 first:
         // a refill whenever 64 slots are free (keeps the slots busy), then the queues deepest stage first (text comparison,
         // locate, Occ step, begin), chunk number = wave number.  Only when fewer than SQ_WAVES full chunks exist are the
@@ -241,6 +241,199 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
     atomicMax(d_ctr_stripe(ctr) + CTR_MAXTRIPS, (unsigned long long)max_trips);
     if (tid == 0) atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_PHASES, (unsigned long long)n_phases);
     if (lane == 0) {
+        atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips);
+#pragma unroll
+        for (int k = 0; k < SQ_NQ; k++) if (q_trips[k]) { atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_TRIPS + k, (unsigned long long)q_trips[k]); atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_LANES + k, (unsigned long long)q_lanes[k]); }
+    }
+    d_wave_add(ctr + CTR_STEPS, c.steps);
+    d_wave_add(ctr + CTR_BLOCKS, c.blocks);
+    d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
+    d_wave_add(ctr + CTR_BLOCKS_ACT, c.blocks_act);
+    d_wave_add(ctr + CTR_KTAB, c.ktab);
+    d_wave_add(ctr + CTR_LF, c.lf_ref);
+    d_wave_add(ctr + CTR_LF_ACT, c.lf_act);
+    d_wave_add(ctr + CTR_DIRECT, c.n_direct);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_seed_qf: the same slots, queues and trips WITHOUT phases.  k_seed_q's waves meet at two barriers per phase, replay one plan from one
+// snapshot, and 17 % of the wave-phases find no chunk; its shell (snapshot, plan, pop, push, barriers) was 550 of the 806
+// wave-instructions of a trip.  Here every wave runs on its own: look at the queue counters, pick the queue to serve, reserve
+// entries with ONE compare-and-swap on that queue's head, pop, trip, push -- no barrier after the initial one, no wave ever waits
+// for another wave's trip.
+//
+// Queue = ring of 16-bit entries + head (entries reserved by poppers) + tail (entries reserved by pushers), all in LDS.
+//   push   a wave adds its count to `tail` (one atomic for all five queues, lane k serves queue k) and writes its entries
+//   pop    a wave reads head, then tail (in that order: tail - head never overshoots), takes n <= 64, and compare-and-swaps head -> head + n;
+//          a failed swap (another wave was faster) means: look again
+// An entry reserved through `tail` may not be written yet when a popper reserves it through `head`, and an entry reserved through
+// `head` may not be read yet when the ring comes round to it: every entry therefore carries FULL (bit 15) and the parity of its lap
+// (bit 14).  The popper of lap L waits for FULL|parity(L), takes the slot, and leaves EMPTY|parity(L); the pusher of lap L waits
+// for EMPTY|parity(L-1).  Both waits are almost never taken (the other side is a few instructions away) and neither can deadlock:
+// each waits for a wave that is past its reservation and busy storing.
+// LDS instructions of one wave execute in order, so "state stored, then entry stored" needs no wait in between -- only the
+// compiler must keep the order (workgroup-scope fences on the local address space: no vmcnt wait for the hit stores in flight).
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define SQF_FULL 0x8000u
+#define SQF_LAP  0x4000u
+#define SQF_MAX_LOOKS (1u << 24)     // looks at the counters per wave (a 2 M-read batch needs ~10^3): the safety net, as SQ_MAX_PHASES
+
+__host__ __device__ inline size_t sqf_lds_bytes(int nslot_lg, int W, int n_waves)
+{
+    const size_t n = (size_t)1 << nslot_lg;
+    return n * 48 + n * 4 * (size_t)W + 2 * n * 2 * SQ_NQ + (size_t)n_waves * 64 * 2 + 16 * 4;
+}
+
+__global__ void __launch_bounds__(512)
+k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H, int nslot_lg,
+          DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
+          DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int partial_min, int *err)
+{
+    extern __shared__ uint4 sq_sh[];
+    const int NSLOT = 1 << nslot_lg;
+    const int QCAP = 2 * NSLOT, QLG = nslot_lg + 1;
+    const uint32_t SM = (uint32_t)QCAP - 1u;
+    const int n_waves = (int)(blockDim.x >> 6);
+    uint4 *st = sq_sh;                                           // [slot][3]
+    uint32_t *rd = (uint32_t *)(st + 3 * (size_t)NSLOT);         // [word][slot]
+    uint16_t *q = (uint16_t *)(rd + (size_t)W * NSLOT);          // [queue][ring of QCAP entries]
+    uint16_t *tab = q + (size_t)SQ_NQ * QCAP;                   // [wave][64]: slots of the reads a refill is fetching
+    uint32_t *ctl = (uint32_t *)(tab + (size_t)n_waves * 64);    // head[0..4], [5] = the batch has no more reads, tail[8..12]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)sq_rfl((uint32_t)(tid >> 6));
+    const int W2 = W >> 1;
+    const int K = ix.ktab ? ix.ktab_k : 0;
+    const bool direct = ix.sa_dense != nullptr;
+    const uint32_t w_magic = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;       // i / W == (i * w_magic) >> 20 for i < 64 W <= 2^12
+    SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t max_trips = 0, wtrips = 0;
+    const SqEnv env = { ix, pr, st, rd, NSLOT, W2, K, H, bail_trips, direct, hits, nhits, nseeds, heavy, n_heavy };
+    uint32_t q_trips[SQ_NQ] = {0, 0, 0, 0, 0}, q_lanes[SQ_NQ] = {0, 0, 0, 0, 0};
+
+    // every ring starts EMPTY with the parity of "lap -1"; the free queue's first lap holds all slots
+    for (int i = tid; i < SQ_NQ * QCAP; i += (int)blockDim.x) q[i] = (uint16_t)SQF_LAP;
+    __syncthreads();
+    for (int i = tid; i < NSLOT; i += (int)blockDim.x) q[(size_t)SQ_FREE * QCAP + i] = (uint16_t)(SQF_FULL | (uint32_t)i);
+    if (tid < 16) ctl[tid] = tid == 8 + SQ_FREE ? (uint32_t)NSLOT : 0u;
+    __syncthreads();                                              // the only barrier of the kernel
+
+    volatile uint32_t *vctl = ctl;
+    volatile uint16_t *vq = q;
+    uint32_t looks = 0, idle = 0, lazy = 0;
+    while (true) {
+        if (++looks > SQF_MAX_LOOKS) { if (lane == 0) atomicMax(err, DG_E_SEEDQ); break; }
+        uint32_t hd[SQ_NQ], cn[SQ_NQ];
+#pragma unroll
+        for (int k = 0; k < SQ_NQ; k++) hd[k] = vctl[k];                           // heads first ...
+        const uint32_t exv = vctl[5];
+#pragma unroll
+        for (int k = 0; k < SQ_NQ; k++) cn[k] = vctl[8 + k];                       // ... then tails: tail - head >= 0, and <= what is there now or later
+#pragma unroll
+        for (int k = 0; k < SQ_NQ; k++) { hd[k] = sq_rfl(hd[k]); cn[k] = sq_rfl(cn[k]) - hd[k]; }
+        const bool ex = sq_rfl(exv) != 0u;
+        if (ex && cn[SQ_FREE] == (uint32_t)NSLOT) break;          // all slots free, nothing left to claim
+        // which queue: a refill whenever 64 slots are free (keeps the slots busy), then the deepest stage that has a full chunk (text
+        // comparison, locate, Occ step, begin); without a full chunk anywhere the fullest queue -- but a small remainder only after
+        // one short nap (the trips in flight are about to deliver their slots)
+        int my_q = -1;
+        uint32_t my_n = 0;
+        if (!ex && cn[SQ_FREE] >= 64u) { my_q = SQ_FREE; my_n = 64u; }
+        else if (cn[SQ_CMP] >= 64u) { my_q = SQ_CMP; my_n = 64u; }
+        else if (cn[SQ_LOC] >= 64u) { my_q = SQ_LOC; my_n = 64u; }
+        else if (cn[SQ_STEP] >= 64u) { my_q = SQ_STEP; my_n = 64u; }
+        else if (cn[SQ_BEGIN] >= 64u) { my_q = SQ_BEGIN; my_n = 64u; }
+        else {
+            uint32_t best = ex ? 0u : cn[SQ_FREE];
+            my_q = best ? SQ_FREE : -1;
+            if (cn[SQ_CMP] > best) { best = cn[SQ_CMP]; my_q = SQ_CMP; }
+            if (cn[SQ_LOC] > best) { best = cn[SQ_LOC]; my_q = SQ_LOC; }
+            if (cn[SQ_STEP] > best) { best = cn[SQ_STEP]; my_q = SQ_STEP; }
+            if (cn[SQ_BEGIN] > best) { best = cn[SQ_BEGIN]; my_q = SQ_BEGIN; }
+            my_n = best;
+            if (best == 0u || (best < (uint32_t)partial_min && lazy < 2u)) {      // nothing, or little and worth a moment's wait
+                if (best) lazy++;
+                idle++;
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+        }
+        lazy = 0;
+        uint32_t got = 0;
+        if (lane == 0) got = atomicCAS(&ctl[my_q], hd[my_q], hd[my_q] + my_n) == hd[my_q] ? 1u : 0u;
+        if (!sq_rfl(got)) continue;                               // another wave took from this queue meanwhile: look again
+        const uint32_t my_first = hd[my_q];
+        wtrips++;
+#pragma unroll
+        for (int k = 0; k < SQ_NQ; k++) if (k == my_q) { q_trips[k]++; q_lanes[k] += my_n; }
+        const bool act = (uint32_t)lane < my_n;
+        uint32_t slot = 0;
+        if (act) {
+            const uint32_t a = my_first + (uint32_t)lane, want = SQF_FULL | (((a >> QLG) & 1u) ? SQF_LAP : 0u);
+            volatile uint16_t *ep = vq + (size_t)my_q * QCAP + (a & SM);
+            uint32_t e = *ep;
+            while ((e & (SQF_FULL | SQF_LAP)) != want) { __builtin_amdgcn_s_sleep(1); e = *ep; }
+            slot = e & 0x3FFFu;
+            *ep = (uint16_t)(want & SQF_LAP);                     // EMPTY, this lap
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      // the slot's state and words were stored before its entry
+        int nq = SQ_FREE;                                         // the queue this lane's slot goes to
+
+        if (my_q == SQ_FREE) {
+            // ---- refill: the next my_n reads of the batch move into the free slots ----
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(next_read, my_n);
+            base = sq_rfl(base);
+            const uint32_t avail = base < (unsigned int)n_reads ? (unsigned int)n_reads - base : 0u;
+            const uint32_t take = avail < my_n ? avail : my_n;
+            if (take < my_n && lane == 0) vctl[5] = 1u;
+            if (act && (uint32_t)lane < take) {
+                const uint32_t r = base + (uint32_t)lane;
+                tab[wave * 64 + lane] = (uint16_t)slot;
+                st[slot * 3] = make_uint4(r, (uint32_t)rlen[r], 0u, 0u);       // r | len, pos = 0 | nh, searches, trips = 0 | ns = 0
+                nq = SQ_BEGIN;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tab is read by the other lanes of this wave
+            const uint32_t total = take * (uint32_t)W;            // the reads are consecutive: one contiguous run of enc
+            const uint32_t *src = enc + (size_t)base * W;
+            for (uint32_t i0 = 0; i0 < total; i0 += 256u) {
+                uint32_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < total ? src[i] : 0u; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = i0 + (uint32_t)(k * 64 + lane);
+                    if (i < total) { const uint32_t rk = (i * w_magic) >> 20; rd[(size_t)(i - rk * (uint32_t)W) * NSLOT + tab[wave * 64 + rk]] = v[k]; }
+                }
+            }
+        } else if (my_q == SQ_BEGIN) nq = sq_trip<SQ_BEGIN>(env, act, slot, c, max_trips);
+        else if (my_q == SQ_STEP) nq = sq_trip<SQ_STEP>(env, act, slot, c, max_trips);
+        else if (my_q == SQ_CMP) nq = sq_trip<SQ_CMP>(env, act, slot, c, max_trips);
+        else nq = sq_trip<SQ_LOC>(env, act, slot, c, max_trips);
+        // ---- every slot of this trip goes to the queue of its new state: lane k reserves queue k's entries, one round trip for all five ----
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // state and words first, entries after
+            unsigned long long m[SQ_NQ];
+#pragma unroll
+            for (int k = 0; k < SQ_NQ; k++) m[k] = __ballot(act && nq == k);
+            uint32_t mine = 0;
+            unsigned long long mq = 0;
+#pragma unroll
+            for (int k = 0; k < SQ_NQ; k++) { if (lane == k) mine = (uint32_t)__popcll(m[k]); if (nq == k) mq = m[k]; }
+            uint32_t base = 0;
+            if (lane < SQ_NQ && mine) base = atomicAdd(&ctl[8 + lane], mine);
+            base = (uint32_t)__shfl((int)base, nq, 64);
+            if (act) {
+                const uint32_t a = base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+                const uint32_t lap = ((a >> QLG) & 1u) ? SQF_LAP : 0u;
+                volatile uint16_t *ep = vq + (size_t)nq * QCAP + (a & SM);
+                while (*ep != (uint16_t)(lap ^ SQF_LAP)) __builtin_amdgcn_s_sleep(1);      // EMPTY of the previous lap (almost never waits)
+                *ep = (uint16_t)(SQF_FULL | lap | slot);
+            }
+        }
+    }
+    atomicMax(d_ctr_stripe(ctr) + CTR_MAXTRIPS, (unsigned long long)max_trips);
+    if (lane == 0) {
+        atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_PHASES, (unsigned long long)idle);                 // (here: looks that found nothing to do)
         atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips);
 #pragma unroll
         for (int k = 0; k < SQ_NQ; k++) if (q_trips[k]) { atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_TRIPS + k, (unsigned long long)q_trips[k]); atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_LANES + k, (unsigned long long)q_lanes[k]); }

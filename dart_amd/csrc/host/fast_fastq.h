@@ -15,6 +15,8 @@
 // reference's reader and of the streaming path in dart_main.cpp; tests/test_gpu_cli.py runs both paths against the oracle's
 // command line.
 #pragma once
+#include <atomic>
+#include <cerrno>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -456,8 +458,7 @@ static int run_fast_library(const char *f1, const char *f2, bool pair_end, int t
                     break;
                 }
             }
-            st.t_map += now() - tm;
-            { std::lock_guard<std::mutex> lk(mu); if (s->rc) { failed = true; fail_rc = s->rc; err = s->err; } fmt_q[s->seqno] = s; }
+            { std::lock_guard<std::mutex> lk(mu); st.t_map += now() - tm; if (s->rc) { failed = true; fail_rc = s->rc; err = s->err; } fmt_q[s->seqno] = s; }
             cv.notify_all();
         }
         { std::lock_guard<std::mutex> lk(mu); mappers_left--; }
@@ -487,14 +488,26 @@ static int run_fast_library(const char *f1, const char *f2, bool pair_end, int t
                 win = m == MAP_FAILED ? nullptr : (char *)m;
             }
             const int TW = win ? std::max(1, T / 4) : 2;     // writes to one file serialise in the kernel: more threads only burn the CPU share
-            parallel_for(TW, [&](int wt) {
+            std::atomic<int> write_errno{0};                 // a full disk must not end as a holed SAM file and exit code 0
+            if (use_mmap && offs[T] && !win) write_errno = errno ? errno : EIO;
+            else parallel_for(TW, [&](int wt) {
                 for (int tid = wt; tid < T; tid += TW) {
                     if (win) { memcpy(win + (base - a0) + offs[tid], ts.bufs[tid].b, ts.bufs[tid].n); continue; }
                     size_t done = 0;
-                    while (done < ts.bufs[tid].n) { const ssize_t w = pwrite(fd, ts.bufs[tid].b + done, ts.bufs[tid].n - done, (off_t)(base + offs[tid] + done)); if (w <= 0) break; done += (size_t)w; }
+                    while (done < ts.bufs[tid].n) {
+                        const ssize_t w = pwrite(fd, ts.bufs[tid].b + done, ts.bufs[tid].n - done, (off_t)(base + offs[tid] + done));
+                        if (w < 0 && errno == EINTR) continue;
+                        if (w <= 0) { write_errno = w < 0 ? errno : ENOSPC; break; }
+                        done += (size_t)w;
+                    }
                 }
             });
             if (win) munmap(win, win_len);
+            if (write_errno) {
+                { std::lock_guard<std::mutex> lk(mu); failed = true; fail_rc = DG_ERR_INTERNAL; err = std::string("writing the output failed: ") + strerror(write_errno); ts.full = false; }
+                cv.notify_all();
+                break;
+            }
             *file_off = base + offs[T];
             for (int k = 0; k < T; k++) { total.unique += ts.cts[k].unique; total.unmapped += ts.cts[k].unmapped; total.paired += ts.cts[k].paired; }
             total.total += s->n;

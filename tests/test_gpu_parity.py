@@ -82,9 +82,11 @@ def test_gpu_seeds_match_oracle(ctxs):
 
 
 def test_gpu_seed_queue_configurations(ctxs, monkeypatch):
-    """k_seed_q (dg_seedq.h) against the lane-per-read kernel k_seed: the same hits whatever the number of read slots per workgroup
-    (64 ... 512: the queue rings wrap thousands of times, most chunks are partial), the workgroups per CU, and the bail-out threshold
-    that moves reads to k_seed_heavy; ragged reads, N runs, reads shorter than a seed; then whole records against the oracle"""
+    """the queue kernels of dg_seedq.h -- k_seed_qf (free-running waves, the default) and k_seed_q (barrier phases, DG_SEED_PHASES=1) --
+    against the lane-per-read kernel k_seed: the same hits whatever the number of read slots per workgroup (64 ... 512: the queue rings
+    wrap thousands of times, most chunks are partial), the waves per workgroup, the workgroups per CU, the size below which a wave
+    would rather wait than take a partial chunk, and the bail-out threshold that moves reads to k_seed_heavy; ragged reads, N runs,
+    reads shorter than a seed; then whole records against the oracle"""
     c, ix, gpu, orc = ctxs["pe101_spliced"]
     rng = np.random.default_rng(11)
     asc = c["genome"].ascii()
@@ -102,16 +104,21 @@ def test_gpu_seed_queue_configurations(ctxs, monkeypatch):
     gpu.set_params(host.default_params())                    # (the switches are read by dg_set_params)
     want = gpu.probe_seeds(so, rl, flat)
     monkeypatch.setenv("DG_SEED_LEGACY", "0")
-    for lg, wgs, bail in ((9, 0, 128), (6, 1, 128), (7, 3, 128), (8, 2, 6), (9, 2, 1000)):
-        monkeypatch.setenv("DG_SEED_SLOTS_LG", str(lg)); monkeypatch.setenv("DG_SEED_WGS", str(wgs)); monkeypatch.setenv("DG_SEED_BAIL_TRIPS", str(bail))
-        gpu.set_params(host.default_params())
-        got = gpu.probe_seeds(so, rl, flat)
-        for a, b in zip(want, got):
-            assert np.array_equal(a, b), (lg, wgs, bail)
-    monkeypatch.setenv("DG_SEED_SLOTS_LG", "6"); monkeypatch.setenv("DG_SEED_WGS", "2"); monkeypatch.delenv("DG_SEED_BAIL_TRIPS")
-    gpu.set_params(host.default_params(paired=0, max_mismatch=4))
-    assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=0, max_mismatch=4), so, rl, flat))
-    for k in ("DG_SEED_SLOTS_LG", "DG_SEED_WGS", "DG_SEED_LEGACY"):
+    for phases in ("0", "1"):
+        monkeypatch.setenv("DG_SEED_PHASES", phases)
+        for lg, wgs, bail, nw, part in ((9, 0, 128, 4, 32), (6, 1, 128, 4, 1), (7, 3, 128, 2, 64), (8, 2, 6, 8, 16), (9, 2, 1000, 1, 32), (10, 1, 128, 8, 48)):
+            if phases == "1" and lg > 9:
+                continue
+            monkeypatch.setenv("DG_SEED_SLOTS_LG", str(lg)); monkeypatch.setenv("DG_SEED_WGS", str(wgs)); monkeypatch.setenv("DG_SEED_BAIL_TRIPS", str(bail))
+            monkeypatch.setenv("DG_SEED_WG_WAVES", str(nw)); monkeypatch.setenv("DG_SEED_PARTIAL_MIN", str(part))
+            gpu.set_params(host.default_params())
+            got = gpu.probe_seeds(so, rl, flat)
+            for a, b in zip(want, got):
+                assert np.array_equal(a, b), (phases, lg, wgs, bail, nw, part)
+        monkeypatch.setenv("DG_SEED_SLOTS_LG", "6"); monkeypatch.setenv("DG_SEED_WGS", "2"); monkeypatch.delenv("DG_SEED_BAIL_TRIPS")
+        gpu.set_params(host.default_params(paired=0, max_mismatch=4))
+        assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=0, max_mismatch=4), so, rl, flat))
+    for k in ("DG_SEED_SLOTS_LG", "DG_SEED_WGS", "DG_SEED_LEGACY", "DG_SEED_PHASES", "DG_SEED_WG_WAVES", "DG_SEED_PARTIAL_MIN"):
         monkeypatch.delenv(k)
     gpu.set_params(host.default_params())
 
@@ -338,9 +345,9 @@ def test_gpu_noisy_long_reads_wave_nw_paths(workdir):
 
 
 def test_gpu_both_seeding_kernels_match_oracle(workdir, monkeypatch):
-    """the queue kernel k_seed_q (default) and the lane-per-read kernel k_seed (DG_SEED_LEGACY=1; also what reads longer than 496 bases
-    take): same records as the oracle and the same reference-equivalent counters, on plain, spliced and N-rich reads of a
-    repeat-rich genome (many reads end in k_seed_heavy)."""
+    """the free-running queue kernel k_seed_qf (default), the phased one k_seed_q (DG_SEED_PHASES=1) and the lane-per-read kernel k_seed
+    (DG_SEED_LEGACY=1; also what reads longer than 496 bases take): same records as the oracle and the same reference-equivalent
+    counters, on plain, spliced and N-rich reads of a repeat-rich genome (many reads end in k_seed_heavy)."""
     g = synth.make_genome([2000000, 1000000], seed=61, repeat_scale=100.0, n_introns=300)
     prefix = os.path.join(workdir, "twoseed")
     index_build.build_index_from_genome(g, prefix)
@@ -352,8 +359,16 @@ def test_gpu_both_seeding_kernels_match_oracle(workdir, monkeypatch):
     base = gpu.map_batch(so, rl, flat); base_ctr = gpu.counters()
     assert_same(base, want)
     assert base_ctr["seedq_trips_step"] > 0                # the queue kernel really ran
-    monkeypatch.setenv("DG_SEED_LEGACY", "1")
+    monkeypatch.setenv("DG_SEED_PHASES", "1")
     gpu.set_params(gpu.params)                             # the DG_* switches are read at init and at dg_set_params, not per batch
+    assert_same(gpu.map_batch(so, rl, flat), want)
+    ctr = gpu.counters()
+    assert ctr["seedq_trips_step"] > 0 and ctr["seedq_phases"] > 0
+    for k in ("steps", "lf_steps", "sa_lookups", "seeds", "occ_blocks"):
+        assert ctr[k] == base_ctr[k], k
+    monkeypatch.delenv("DG_SEED_PHASES")
+    monkeypatch.setenv("DG_SEED_LEGACY", "1")
+    gpu.set_params(gpu.params)
     assert_same(gpu.map_batch(so, rl, flat), want)
     ctr = gpu.counters()
     assert ctr["seedq_trips_step"] == 0
@@ -466,3 +481,101 @@ def test_gpu_random_parity_sweep(workdir):
     import fuzz_parity
     assert fuzz_parity.run(10, 9000, workdir=os.path.join(workdir, "fuzz"), log=lambda m: None) == 10
 
+
+
+def test_gpu_scan_stress_many_small_batches_on_twelve_contexts(workdir):
+    """The single-pass scans (dg_scan.h) under the conditions in which round 2 once saw a look-back give up: twelve contexts in flight, every
+    one mapping small batches back to back (2 400 batches in all; batch sizes cycle so that a run's tiles meet the previous run's words at
+    every position).  No batch may have been run again because of a scan (`reruns_scan_total` == 0: the state words carry their run's
+    epoch and are never zeroed) and every context's last records equal the oracle's."""
+    import threading
+    g = synth.make_genome([600000, 400000], seed=71, repeat_scale=30.0, n_introns=100)
+    prefix = os.path.join(workdir, "stress")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
+    ctx = [gpu] + [gpu.clone() for _ in range(11)]
+    sizes = (3000, 1100, 2600, 700)
+    batches = []
+    for j, n in enumerate(sizes):
+        m1, m2 = synth.make_reads(g, n, rlen=101, seed=72 + j, spliced_frac=0.1, indel_frac=0.04, n_frac=0.01)
+        arr = host.interleave_pairs(m1, m2)
+        batches.append((host.pack_reads(arr), host.pack_reads_2bit(arr)))
+    want = [orc.map_batch(orc.params(paired=1, max_mismatch=5), *b[0], threads=16) for b in batches]
+    out, errs = [None] * len(ctx), []
+    def work(k):
+        try:
+            for i in range(200):
+                j = (i + k) % len(sizes)
+                words, nlist = batches[j][1]
+                res = ctx[k].map_batch_compact(words, nlist, 101) if i % 2 else ctx[k].map_batch(*batches[j][0])
+                out[k] = (j, res)
+        except Exception as e:
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(ctx))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for k in range(len(ctx)):
+        j, res = out[k]
+        assert_same(res, want[j])
+        assert ctx[k].counters()["reruns_scan_total"] == 0, k
+    gpu.close(); orc.close()
+
+
+def test_gpu_scan_timeout_rerun_path(workdir, monkeypatch):
+    """The path a look-back that runs out of its poll budget takes, forced: DG_SCAN_POLL_BUDGET=1 gives the first attempt of every batch
+    a budget of one poll, so some tile gives up (DG_E_SCAN), the host records what the poller saw and runs the batch again with the
+    normal budget; the records are the oracle's and the re-run is counted."""
+    g = synth.make_genome([900000], seed=81, repeat_scale=30.0)
+    prefix = os.path.join(workdir, "scanrerun")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    m1, m2 = synth.make_reads(g, 60000, rlen=101, seed=82, indel_frac=0.04, n_frac=0.01)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    want = orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=16)
+    monkeypatch.setenv("DG_SCAN_POLL_BUDGET", "1")
+    gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
+    res = gpu.map_batch(so, rl, flat)
+    c = gpu.counters()
+    monkeypatch.delenv("DG_SCAN_POLL_BUDGET")
+    assert_same(res, want)
+    assert c["reruns_scan_total"] >= 1 and c["batch_runs"] >= 2, c
+    assert b"look-back" in (gpu.lib.dg_last_error(gpu.ctx) or b"")
+    gpu.close(); orc.close()
+
+
+def test_gpu_ecoli_sized_single_end_config0(workdir):
+    """BASELINE configs[0] at its size on the HIP path: a 4 641 652 bp one-chromosome genome, 100 k single-end 100 bp reads, the reference's
+    default flags (MaxMismatch 0) and -mis 5, every record against the oracle."""
+    g = synth.make_genome([4641652], seed=20, repeat_scale=1.0, names=["ecoli"])
+    prefix = os.path.join(workdir, "ecoli")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    m1, _ = synth.make_reads(g, 100000, rlen=100, seed=21, sub_rate=0.01, indel_frac=0.02, n_frac=0.002, paired=False)
+    so, rl, flat = host.pack_reads(m1)
+    gpu = host.DartGPU(ix, host.default_params(paired=0))
+    for mis in (0, 5):
+        gpu.set_params(host.default_params(paired=0, max_mismatch=mis))
+        assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=0, max_mismatch=mis), so, rl, flat, threads=16))
+    gpu.close(); orc.close()
+
+
+def test_gpu_packed_nlist_out_of_range_is_an_argument_error(workdir):
+    """a packed batch whose N list points outside the batch (a buggy packer) is refused with DG_ERR_ARG instead of writing outside the buffers"""
+    c = common.build_case("se100", workdir)
+    ix = host.Index(c["prefix"])
+    gpu = host.DartGPU(ix, host.default_params(paired=0, max_mismatch=5))
+    arr = np.ascontiguousarray(c["reads"][:64]).copy()
+    arr[arr == ord("N")] = ord("A")
+    rl0 = arr.shape[1]
+    words, nlist = host.pack_reads_2bit(arr)
+    bad = np.array([5, 64 * 16 * words.shape[1] + 7, 0xFFFFFFF0], np.uint32)
+    gpu.upload_packed(words, bad, rl0)
+    used = (host.C.c_size_t * 3)()
+    assert gpu.lib.dg_batch_run(gpu.ctx, used) == -3
+    assert b"N list" in gpu.lib.dg_last_error(gpu.ctx)
+    good = gpu.map_batch_packed(words, np.array([5], np.uint32), rl0)       # the context is usable afterwards
+    arr[0, 5] = ord("N")
+    assert_same(good, gpu.map_batch(*host.pack_reads(arr)))
+    gpu.close()
