@@ -789,7 +789,7 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     const int bail_trips = c->env_bail_trips, both_thr = c->env_both;
     unsigned int *tops = c->d_tops;
     // default: the queue kernel (dg_seedq.h).  DG_SEED_LEGACY=1 or reads too long for its LDS slots (> 496 bases): the lane-per-read kernel
-    if (!c->env_seed_legacy && !c->env_seed_phases && W <= 62) {
+    if (!c->env_seed_legacy && !c->env_seed_phases && W <= 62 && c->pr.max_dup <= 30000) {      // (its slot state counts occurrences in 20 bits: 31 hits x max_dup)
         // the free-running queue kernel (dg_seedq.h, k_seed_qf): workgroups of `nw` waves around 2^lg read slots
         int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 11 ? c->env_seed_slots_lg : 9;
         int nw = c->env_seed_wg_waves >= 1 && c->env_seed_wg_waves <= 8 ? c->env_seed_wg_waves : 4;
@@ -1072,6 +1072,13 @@ static int finish_run(dg_ctx *c, size_t used[3])
         const bool is_max = k == CTR_MAXTRIPS || k == CTR_WTRIPS_MAX;
         for (int s = 0; s < CTR_STRIPES; s++) { const uint64_t x = c->h_tail->ctr_stripes[s * CTR_STRIDE + k]; v = is_max ? (x > v ? x : v) : v + x; }
         c->counters[k] = v;
+    }
+    if (c->counters[CTR_STEPS_ACT] == 0 && c->counters[CTR_SQ_LANES + SQ_STEP]) {
+        // k_seed_qf keeps no per-lane tallies of its own work (they cost registers and moves in its loop): what it executed follows from the
+        // slots its trips served -- one Occ step (one block; two when the interval straddles blocks, not counted) per slot of a step trip, one
+        // prefix-table entry per slot of a begin trip, one SA entry per slot of a locate trip
+        c->counters[CTR_STEPS_ACT] = c->counters[CTR_BLOCKS_ACT] = c->counters[CTR_SQ_LANES + SQ_STEP];
+        c->counters[CTR_KTAB] = c->counters[CTR_SQ_LANES + SQ_BEGIN]; c->counters[CTR_DIRECT] = c->counters[CTR_SQ_LANES + SQ_LOC];
     }
     const DSizes &sz = c->h_tail->sizes;
     c->counters[CTR_SEEDS] = sz.total_seeds;

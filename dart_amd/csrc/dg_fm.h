@@ -380,17 +380,18 @@ __device__ __forceinline__ void d_begin_finish(const DIndex &ix, int K, RB &rb, 
     s.x0 = d_L2(ix, cc) + 1; s.x1 = d_L2(ix, 3 - cc) + 1; s.x2 = d_L2(ix, cc + 1) - d_L2(ix, cc);
 }
 
-// modes 1,3,2: the addresses of this trip
-template <class RM>
+// modes 1,3,2: the addresses of this trip.  FIX >= 0: the caller knows the mode at compile time (only that mode's code is instantiated)
+template <int FIX = -1, class RM>
 __device__ __forceinline__ void d_trip_issue(const DIndex &ix, RM &rm, int len, bool direct, Search &s, SeedCtr &c, TripAddr &ta, TripData &t)
 {
-    if (s.mode == 1) {
+    const int mode = FIX >= 0 ? FIX : s.mode;
+    if (mode == 1) {
         if (s.p >= len || d_at(rm, s.p)) { t.aux = T_STOP; return; }
         d_extend_rows(ix, s.x1, s.x2, t.kk, t.ll);
         ta.pa = ix.bwt + ((t.kk >> 7) << 2);
         if ((t.ll >> 7) != (t.kk >> 7)) ta.pb = ix.bwt + ((t.ll >> 7) << 2);
         t.aux = T_STEP;
-    } else if (s.mode == 3) {                      // bwt_sa on the unique row, one LF step per trip
+    } else if (mode == 3) {                        // bwt_sa on the unique row, one LF step per trip
         if (s.lk & ((uint64_t)ix.sa_dense_intv - 1)) {
             if (s.lk == ix.primary) { t.aux = T_LF_PRIMARY; return; }
             t.kk = s.lk - (s.lk > ix.primary);
@@ -413,20 +414,21 @@ __device__ __forceinline__ void d_trip_issue(const DIndex &ix, RM &rm, int len, 
     }
 }
 
-// modes 1,3,2: consume the loads; when the search finishes, mode becomes 0 and hit_len/located hold the result
-template <class RB, class RM>
+// modes 1,3,2: consume the loads; when the search finishes, mode becomes 0 and hit_len/located hold the result.
+// FIX == 2: the caller knows this is a text comparison (T_CMP / T_CMP_SLOW)
+template <int FIX = -1, class RB, class RM>
 __device__ __forceinline__ void d_trip_finish(const DIndex &ix, const DParams &pr, RB &rb, RM &rm, int len, Search &s, SeedCtr &c, const TripData &t)
 {
-    if (t.aux == T_STOP) d_search_end(pr, s);
-    else if (t.aux == T_STEP) {
+    if (FIX != 2 && t.aux == T_STOP) d_search_end(pr, s);
+    else if (FIX != 2 && t.aux == T_STEP) {
         const int cc = (int)d_at(rb, s.p);
         const uint32_t nb = (t.ll >> 7) != (t.kk >> 7) ? 2u : 1u;
         const bool ok = d_extend_finish(ix, cc, t.a, t.b, t.kk, t.ll, s.x0, s.x1, s.x2);
         s.ref_steps++; s.ref_blocks += nb; c.steps_act++; c.blocks_act += nb;
         if (ok) s.p++; else d_search_end(pr, s);
-    } else if (t.aux == T_LF) { s.lk = d_lf_finish(ix, t.a, t.kk); s.lsteps++; c.lf_act++; }
-    else if (t.aux == T_LF_PRIMARY) { s.lk = 0; s.lsteps++; c.lf_act++; }
-    else if (t.aux == T_SA) {
+    } else if (FIX != 2 && t.aux == T_LF) { s.lk = d_lf_finish(ix, t.a, t.kk); s.lsteps++; c.lf_act++; }
+    else if (FIX != 2 && t.aux == T_LF_PRIMARY) { s.lk = 0; s.lsteps++; c.lf_act++; }
+    else if (FIX != 2 && t.aux == T_SA) {
         const uint64_t e = d_u64(t.s8.x, t.s8.y);
         s.tpos = (int64_t)(s.lsteps + (e & 0xFFFFFFFFFFull) - 1);
         s.lk = e;                                  // keeps the memoised reference LF count (bits 40..)

@@ -255,24 +255,32 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
     d_wave_add(ctr + CTR_DIRECT, c.n_direct);
 }
 
+
 // ---------------------------------------------------------------------------------------------------------------------------------
-// k_seed_qf: the same slots, queues and trips WITHOUT phases.  k_seed_q's waves meet at two barriers per phase, replay one plan from one
-// snapshot, and 17 % of the wave-phases find no chunk; its shell (snapshot, plan, pop, push, barriers) was 550 of the 806
-// wave-instructions of a trip.  Here every wave runs on its own: look at the queue counters, pick the queue to serve, reserve
-// entries with ONE compare-and-swap on that queue's head, pop, trip, push -- no barrier after the initial one, no wave ever waits
-// for another wave's trip.
+// k_seed_qf: the same slots, queues and trip functions WITHOUT phases.  k_seed_q's waves meet at two barriers per phase and replay one
+// plan from one snapshot; here every wave runs on its own: look at the queue counters (one LDS instruction: lane k reads word k), pick
+// the queue to serve, reserve entries with ONE compare-and-swap on that queue's head, pop, trip, push -- no barrier after the
+// initial one, no wave ever waits for another wave's trip.
 //
-// Queue = ring of 16-bit entries + head (entries reserved by poppers) + tail (entries reserved by pushers), all in LDS.
+// Queue = ring of NSLOT 16-bit entries + head (entries reserved by poppers) + tail (entries reserved by pushers), all in LDS.
 //   push   a wave adds its count to `tail` (one atomic for all five queues, lane k serves queue k) and writes its entries
-//   pop    a wave reads head, then tail (in that order: tail - head never overshoots), takes n <= 64, and compare-and-swaps head -> head + n;
-//          a failed swap (another wave was faster) means: look again
+//   pop    a wave takes n <= min(64, tail - head) and compare-and-swaps head -> head + n; a failed swap (another wave was faster)
+//          means: look again
 // An entry reserved through `tail` may not be written yet when a popper reserves it through `head`, and an entry reserved through
 // `head` may not be read yet when the ring comes round to it: every entry therefore carries FULL (bit 15) and the parity of its lap
 // (bit 14).  The popper of lap L waits for FULL|parity(L), takes the slot, and leaves EMPTY|parity(L); the pusher of lap L waits
 // for EMPTY|parity(L-1).  Both waits are almost never taken (the other side is a few instructions away) and neither can deadlock:
-// each waits for a wave that is past its reservation and busy storing.
+// each waits for a wave that is past its reservation and busy storing.  Because of this handshake the ring needs no slack: NSLOT
+// entries per queue (the phased kernel needs 2 NSLOT), and a slot's state is 32 bytes (below), so a workgroup of 512 slots of
+// 101-base reads takes 50 KB and three of them share a CU: 12 waves instead of 8 to cover the memory latency of a trip.
 // LDS instructions of one wave execute in order, so "state stored, then entry stored" needs no wait in between -- only the
 // compiler must keep the order (workgroup-scope fences on the local address space: no vmcnt wait for the hit stores in flight).
+//
+// Slot state, 2 x uint4 (reads up to 496 bases: 10-bit positions):
+//   A.x = read   A.y = len | pos << 10 | p << 20   (pos = start of the current search, or where the next one begins)
+//   A.z = hits (5) | searches (5) << 5 | trips (8, saturating) << 10 | ref_steps (10) << 18     A.w = occurrences (20) | ref_blocks (12) << 20
+//   B   = step: x0, x1, x2 low words, then their bits 32..39 byte-wise;  locate: row low word, row bits 32..39 | LF steps << 8;
+//         compare: text position low word, its bits 32..39 | LF steps << 8, the SA entry's memoised LF count
 // ---------------------------------------------------------------------------------------------------------------------------------
 #define SQF_FULL 0x8000u
 #define SQF_LAP  0x4000u
@@ -281,7 +289,105 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
 __host__ __device__ inline size_t sqf_lds_bytes(int nslot_lg, int W, int n_waves)
 {
     const size_t n = (size_t)1 << nslot_lg;
-    return n * 48 + n * 4 * (size_t)W + 2 * n * 2 * SQ_NQ + (size_t)n_waves * 64 * 2 + 16 * 4;
+    return n * 32 + n * 4 * (size_t)W + n * 2 * SQ_NQ + (size_t)n_waves * 64 * 2 + 32 * 4;
+}
+
+__device__ __forceinline__ uint32_t sqf_ld32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t sqf_ld16(const uint16_t *p) { return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void sqf_st16(uint16_t *p, uint32_t v) { __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// what a trip adds to the wave's work counters (added to the accumulators at ONE place in the loop: accumulators that are
+// updated inside the four trip instances get a different register in each and a block of moves at every loop edge)
+struct SqfDelta { uint32_t steps, blocks, lf_ref, max_trips; };
+
+// sq_trip with the 32-byte state.  A trip whose search reaches the text comparison (a located prefix-table entry in a begin trip,
+// the SA entry in a locate trip) makes its first comparison at once, in the same trip: a second dependent load for those lanes,
+// but no push / pop / state round trip in between (a fifth of all slot-trips were first comparisons).
+template <int MODE>
+__device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const uint32_t slot, SqfDelta &dl)
+{
+    const DIndex &ix = e.ix;
+    const int NSLOT = e.NSLOT, W2 = e.W2;
+    uint32_t *rd = e.rd; uint4 *st = e.st;
+    int nq = SQ_FREE;
+    SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};                // (only steps, blocks and lf_ref leave this function; the rest is dead code here)
+    uint4 A = make_uint4(0, 0, 0, 0), B = A;
+    if (act) { A = st[slot * 2]; if (MODE != SQ_BEGIN) B = st[slot * 2 + 1]; }
+    const int r = (int)A.x, len = (int)(A.y & 0x3FFu), end_pos = len - 13;
+    int pos = (int)((A.y >> 10) & 0x3FFu), nh = (int)(A.z & 31u);
+    uint32_t nsearch = (A.z >> 5) & 31u, trips = (A.z >> 10) & 0xFFu, ns = A.w & 0xFFFFFu;
+    Search s;
+    s.mode = MODE; s.hit_len = 0; s.located = false;
+    s.start = pos; s.p = (int)(A.y >> 20); s.ref_steps = A.z >> 18; s.ref_blocks = A.w >> 20;
+    s.x0 = s.x1 = s.lk = 0; s.x2 = 1; s.tpos = 0; s.lsteps = 0;
+    if (MODE == SQ_STEP) { s.x0 = d_u64(B.x, B.w & 0xFFu); s.x1 = d_u64(B.y, (B.w >> 8) & 0xFFu); s.x2 = d_u64(B.z, (B.w >> 16) & 0xFFu); }
+    else if (MODE == SQ_LOC) { s.lk = d_u64(B.x, B.y & 0xFFu); s.lsteps = B.y >> 8; }
+    else if (MODE == SQ_CMP) { s.tpos = (int64_t)d_u64(B.x, B.y & 0xFFu); s.lsteps = B.y >> 8; s.lk = (uint64_t)B.z << 40; }
+    auto rb = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)wc * NSLOT + slot]; return w < W2 ? v : 0u; };
+    auto rm = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)(W2 + wc) * NSLOT + slot]; return w < W2 ? v : 0xFFFFFFFFu; };
+    bool live = act, finished = false, beginning = false;
+    TripData t; t.aux = T_NONE;
+    TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t mt = 0;
+    if (act) {
+        trips = trips < 255u ? trips + 1u : trips;
+        if (MODE == SQ_BEGIN) {                        // IdentifySeedPairs :191-211: next start
+            while (pos < end_pos && d_at(rm, pos)) pos++;
+            if (pos >= end_pos) finished = true;
+            else if (nsearch >= SEED_BAIL || trips >= (uint32_t)e.bail_trips) {     // a long walk: let a whole wave finish this read
+                DHeavy hv; hv.read = (uint32_t)r; hv.pos = pos; hv.nh = nh; hv.ns = ns;
+                e.heavy[atomicAdd(e.n_heavy, 1u)] = hv;
+                mt = trips;
+                live = false;
+            } else { nsearch++; beginning = true; d_begin_issue(ix, e.K, rb, rm, pos, s, c, ta, t); }
+        } else d_trip_issue<MODE == SQ_STEP ? 1 : (MODE == SQ_CMP ? 2 : 3)>(ix, rm, len, e.direct, s, c, ta, t);
+    }
+    d_trip_load(ta, t);
+    if (live) {
+        if (MODE == SQ_BEGIN) { if (beginning) d_begin_finish(ix, e.K, rb, s, c, t); }
+        else if (MODE == SQ_CMP) d_trip_finish<2>(ix, e.pr, rb, rm, len, s, c, t);
+        else if (t.aux != T_NONE) d_trip_finish(ix, e.pr, rb, rm, len, s, c, t);
+    }
+    if (MODE == SQ_BEGIN || MODE == SQ_LOC) {              // the first comparison of a search that has just found its text position
+        const bool go = live && s.mode == 2;
+        TripData t2; t2.aux = T_NONE;
+        TripAddr ta2 = {nullptr, nullptr, nullptr, nullptr};
+        if (go) d_trip_issue<2>(ix, rm, len, e.direct, s, c, ta2, t2);
+        d_trip_load(ta2, t2);
+        if (go) d_trip_finish<2>(ix, e.pr, rb, rm, len, s, c, t2);
+    }
+    if (live) {
+        if (e.direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
+        if (s.mode == 1 && (s.p >= len || d_at(rm, s.p))) d_search_end(e.pr, s);              // what its next trip would find (T_STOP), without the trip
+        if (!finished && s.mode == 0) {          // a search just ended (or the table said "absent")
+            if (s.hit_len) {
+                if (nh < e.H) {
+                    DHit h; h.rPos = (uint16_t)s.start; h.len = (uint16_t)s.hit_len;
+                    if (s.located) { h.x0 = (uint64_t)s.tpos; h.freq = 1u | 0x80000000u; c.lf_ref += s.lsteps + (uint32_t)(s.lk >> 40); }
+                    else { h.x0 = s.x0; h.freq = (uint32_t)s.x2; }
+                    e.hits[(size_t)r * e.H + nh] = h;
+                }
+                nh++; ns += (uint32_t)s.x2;
+                pos = s.start + s.hit_len;
+            } else pos = s.start + 1;
+            dl.steps += s.ref_steps; dl.blocks += s.ref_blocks;
+            while (pos < end_pos && d_at(rm, pos)) pos++;                                   // the next start, or the end of the read:
+            if (pos >= end_pos) finished = true;                                            // no begin-trip just to find out
+            s.ref_steps = s.ref_blocks = 0;
+        }
+        if (finished) { e.nhits[r] = (uint32_t)nh; e.nseeds[r] = ns; mt = trips; }
+        else {
+            nq = s.mode;
+            A.y = (uint32_t)len | ((uint32_t)pos << 10) | ((uint32_t)(s.mode ? s.p : 0) << 20);
+            A.z = (uint32_t)nh | (nsearch << 5) | (trips << 10) | (s.ref_steps << 18); A.w = ns | (s.ref_blocks << 20);
+            st[slot * 2] = A;
+            if (s.mode == 1) st[slot * 2 + 1] = make_uint4((uint32_t)s.x0, (uint32_t)s.x1, (uint32_t)s.x2, (uint32_t)(s.x0 >> 32) | ((uint32_t)(s.x1 >> 32) << 8) | ((uint32_t)(s.x2 >> 32) << 16));
+            else if (s.mode == 3) st[slot * 2 + 1] = make_uint4((uint32_t)s.lk, (uint32_t)((s.lk >> 32) & 0xFFu) | (s.lsteps << 8), 0u, 0u);
+            else if (s.mode == 2) st[slot * 2 + 1] = make_uint4((uint32_t)s.tpos, (uint32_t)(((uint64_t)s.tpos >> 32) & 0xFFu) | (s.lsteps << 8), (uint32_t)(s.lk >> 40), 0u);
+        }
+    }
+    dl.lf_ref += (uint32_t)c.lf_ref; dl.max_trips = mt > dl.max_trips ? mt : dl.max_trips;
+    return nq;
 }
 
 __global__ void __launch_bounds__(512)
@@ -291,50 +397,44 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
 {
     extern __shared__ uint4 sq_sh[];
     const int NSLOT = 1 << nslot_lg;
-    const int QCAP = 2 * NSLOT, QLG = nslot_lg + 1;
+    const int QCAP = NSLOT, QLG = nslot_lg;
     const uint32_t SM = (uint32_t)QCAP - 1u;
     const int n_waves = (int)(blockDim.x >> 6);
-    uint4 *st = sq_sh;                                           // [slot][3]
-    uint32_t *rd = (uint32_t *)(st + 3 * (size_t)NSLOT);         // [word][slot]
+    uint4 *st = sq_sh;                                           // [slot][2]
+    uint32_t *rd = (uint32_t *)(st + 2 * (size_t)NSLOT);         // [word][slot]
     uint16_t *q = (uint16_t *)(rd + (size_t)W * NSLOT);          // [queue][ring of QCAP entries]
     uint16_t *tab = q + (size_t)SQ_NQ * QCAP;                   // [wave][64]: slots of the reads a refill is fetching
-    uint32_t *ctl = (uint32_t *)(tab + (size_t)n_waves * 64);    // head[0..4], [5] = the batch has no more reads, tail[8..12]
+    uint32_t *ctl = (uint32_t *)(tab + (size_t)n_waves * 64);    // head[0..4], [5] = the batch has no more reads, tail[8..12]; statistics [16..31]: trips [16+q], slots [24+q], [21] idle looks
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)sq_rfl((uint32_t)(tid >> 6));
     const int W2 = W >> 1;
     const int K = ix.ktab ? ix.ktab_k : 0;
     const bool direct = ix.sa_dense != nullptr;
     const uint32_t w_magic = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;       // i / W == (i * w_magic) >> 20 for i < 64 W <= 2^12
-    SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t max_trips = 0, wtrips = 0;
     const SqEnv env = { ix, pr, st, rd, NSLOT, W2, K, H, bail_trips, direct, hits, nhits, nseeds, heavy, n_heavy };
-    uint32_t q_trips[SQ_NQ] = {0, 0, 0, 0, 0}, q_lanes[SQ_NQ] = {0, 0, 0, 0, 0};
+    unsigned long long acc_steps = 0, acc_blocks = 0, acc_lf = 0;
+    uint32_t max_trips = 0, wtrips = 0;
 
     // every ring starts EMPTY with the parity of "lap -1"; the free queue's first lap holds all slots
-    for (int i = tid; i < SQ_NQ * QCAP; i += (int)blockDim.x) q[i] = (uint16_t)SQF_LAP;
-    __syncthreads();
-    for (int i = tid; i < NSLOT; i += (int)blockDim.x) q[(size_t)SQ_FREE * QCAP + i] = (uint16_t)(SQF_FULL | (uint32_t)i);
-    if (tid < 16) ctl[tid] = tid == 8 + SQ_FREE ? (uint32_t)NSLOT : 0u;
+    for (int i = tid; i < SQ_NQ * QCAP; i += (int)blockDim.x) q[i] = (uint16_t)(i >= SQ_FREE * QCAP ? (SQF_FULL | (uint32_t)(i - SQ_FREE * QCAP)) : SQF_LAP);
+    if (tid < 32) ctl[tid] = tid == 8 + SQ_FREE ? (uint32_t)NSLOT : 0u;
     __syncthreads();                                              // the only barrier of the kernel
 
-    volatile uint32_t *vctl = ctl;
-    volatile uint16_t *vq = q;
-    uint32_t looks = 0, idle = 0, lazy = 0;
-    while (true) {
-        if (++looks > SQF_MAX_LOOKS) { if (lane == 0) atomicMax(err, DG_E_SEEDQ); break; }
+    uint32_t looks = 0, lazy = 0;
+    bool running = true;
+    while (running) {
+        const uint32_t cw = sqf_ld32(&ctl[lane & 15]);            // all sixteen control words in one LDS instruction: a snapshot
         uint32_t hd[SQ_NQ], cn[SQ_NQ];
 #pragma unroll
-        for (int k = 0; k < SQ_NQ; k++) hd[k] = vctl[k];                           // heads first ...
-        const uint32_t exv = vctl[5];
-#pragma unroll
-        for (int k = 0; k < SQ_NQ; k++) cn[k] = vctl[8 + k];                       // ... then tails: tail - head >= 0, and <= what is there now or later
-#pragma unroll
-        for (int k = 0; k < SQ_NQ; k++) { hd[k] = sq_rfl(hd[k]); cn[k] = sq_rfl(cn[k]) - hd[k]; }
-        const bool ex = sq_rfl(exv) != 0u;
-        if (ex && cn[SQ_FREE] == (uint32_t)NSLOT) break;          // all slots free, nothing left to claim
+        for (int k = 0; k < SQ_NQ; k++) {
+            hd[k] = (uint32_t)__builtin_amdgcn_readlane((int)cw, k);
+            cn[k] = (uint32_t)__builtin_amdgcn_readlane((int)cw, 8 + k) - hd[k];
+            if (cn[k] > (uint32_t)NSLOT) cn[k] = 0u;              // (cannot happen while one LDS instruction is one snapshot; the swap below would catch it anyway)
+        }
+        const bool ex = __builtin_amdgcn_readlane((int)cw, 5) != 0;
         // which queue: a refill whenever 64 slots are free (keeps the slots busy), then the deepest stage that has a full chunk (text
         // comparison, locate, Occ step, begin); without a full chunk anywhere the fullest queue -- but a small remainder only after
-        // one short nap (the trips in flight are about to deliver their slots)
+        // a short nap or two (the trips in flight are about to deliver their slots)
         int my_q = -1;
         uint32_t my_n = 0;
         if (!ex && cn[SQ_FREE] >= 64u) { my_q = SQ_FREE; my_n = 64u; }
@@ -350,67 +450,63 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
             if (cn[SQ_STEP] > best) { best = cn[SQ_STEP]; my_q = SQ_STEP; }
             if (cn[SQ_BEGIN] > best) { best = cn[SQ_BEGIN]; my_q = SQ_BEGIN; }
             my_n = best;
-            if (best == 0u || (best < (uint32_t)partial_min && lazy < 2u)) {      // nothing, or little and worth a moment's wait
-                if (best) lazy++;
-                idle++;
-                __builtin_amdgcn_s_sleep(8);
-                continue;
-            }
+            if (best == 0u || (best < (uint32_t)partial_min && lazy < 2u)) { my_q = -1; if (best) lazy++; }   // nothing, or little and worth a moment's wait
         }
-        lazy = 0;
         uint32_t got = 0;
-        if (lane == 0) got = atomicCAS(&ctl[my_q], hd[my_q], hd[my_q] + my_n) == hd[my_q] ? 1u : 0u;
-        if (!sq_rfl(got)) continue;                               // another wave took from this queue meanwhile: look again
-        const uint32_t my_first = hd[my_q];
-        wtrips++;
-#pragma unroll
-        for (int k = 0; k < SQ_NQ; k++) if (k == my_q) { q_trips[k]++; q_lanes[k] += my_n; }
-        const bool act = (uint32_t)lane < my_n;
-        uint32_t slot = 0;
-        if (act) {
-            const uint32_t a = my_first + (uint32_t)lane, want = SQF_FULL | (((a >> QLG) & 1u) ? SQF_LAP : 0u);
-            volatile uint16_t *ep = vq + (size_t)my_q * QCAP + (a & SM);
-            uint32_t e = *ep;
-            while ((e & (SQF_FULL | SQF_LAP)) != want) { __builtin_amdgcn_s_sleep(1); e = *ep; }
-            slot = e & 0x3FFFu;
-            *ep = (uint16_t)(want & SQF_LAP);                     // EMPTY, this lap
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      // the slot's state and words were stored before its entry
-        int nq = SQ_FREE;                                         // the queue this lane's slot goes to
+        if (my_q >= 0 && lane == 0) got = atomicCAS(&ctl[my_q], hd[my_q], hd[my_q] + my_n) == hd[my_q] ? 1u : 0u;   // a failed swap: another wave took from this queue meanwhile, look again
+        const bool go = my_q >= 0 && sq_rfl(got) != 0u;
+        if (go) {
+            lazy = 0;
+            const uint32_t my_first = hd[my_q];
+            wtrips++;
+            if (lane == 0) { atomicAdd(&ctl[16 + my_q], 1u); atomicAdd(&ctl[24 + my_q], my_n); }
+            const bool act = (uint32_t)lane < my_n;
+            uint32_t slot = 0;
+            if (act) {
+                const uint32_t a = my_first + (uint32_t)lane, want = SQF_FULL | (((a >> QLG) & 1u) ? SQF_LAP : 0u);
+                uint16_t *ep = q + (size_t)my_q * QCAP + (a & SM);
+                uint32_t e = sqf_ld16(ep);
+                while ((e & (SQF_FULL | SQF_LAP)) != want) { __builtin_amdgcn_s_sleep(1); e = sqf_ld16(ep); }
+                slot = e & 0x3FFFu;
+                sqf_st16(ep, want & SQF_LAP);                     // EMPTY, this lap
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      // the slot's state and words were stored before its entry
+            int nq = SQ_FREE;                                     // the queue this lane's slot goes to
+            SqfDelta dl = {0u, 0u, 0u, 0u};
 
-        if (my_q == SQ_FREE) {
-            // ---- refill: the next my_n reads of the batch move into the free slots ----
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(next_read, my_n);
-            base = sq_rfl(base);
-            const uint32_t avail = base < (unsigned int)n_reads ? (unsigned int)n_reads - base : 0u;
-            const uint32_t take = avail < my_n ? avail : my_n;
-            if (take < my_n && lane == 0) vctl[5] = 1u;
-            if (act && (uint32_t)lane < take) {
-                const uint32_t r = base + (uint32_t)lane;
-                tab[wave * 64 + lane] = (uint16_t)slot;
-                st[slot * 3] = make_uint4(r, (uint32_t)rlen[r], 0u, 0u);       // r | len, pos = 0 | nh, searches, trips = 0 | ns = 0
-                nq = SQ_BEGIN;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tab is read by the other lanes of this wave
-            const uint32_t total = take * (uint32_t)W;            // the reads are consecutive: one contiguous run of enc
-            const uint32_t *src = enc + (size_t)base * W;
-            for (uint32_t i0 = 0; i0 < total; i0 += 256u) {
-                uint32_t v[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < total ? src[i] : 0u; }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t i = i0 + (uint32_t)(k * 64 + lane);
-                    if (i < total) { const uint32_t rk = (i * w_magic) >> 20; rd[(size_t)(i - rk * (uint32_t)W) * NSLOT + tab[wave * 64 + rk]] = v[k]; }
+            if (my_q == SQ_FREE) {
+                // ---- refill: the next my_n reads of the batch move into the free slots ----
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(next_read, my_n);
+                base = sq_rfl(base);
+                const uint32_t avail = base < (unsigned int)n_reads ? (unsigned int)n_reads - base : 0u;
+                const uint32_t take = avail < my_n ? avail : my_n;
+                if (take < my_n && lane == 0) __hip_atomic_store(&ctl[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (act && (uint32_t)lane < take) {
+                    const uint32_t r = base + (uint32_t)lane;
+                    tab[wave * 64 + lane] = (uint16_t)slot;
+                    st[slot * 2] = make_uint4(r, (uint32_t)rlen[r], 0u, 0u);       // r | len, pos = 0, p = 0 | nothing yet | no occurrences
+                    nq = SQ_BEGIN;
                 }
-            }
-        } else if (my_q == SQ_BEGIN) nq = sq_trip<SQ_BEGIN>(env, act, slot, c, max_trips);
-        else if (my_q == SQ_STEP) nq = sq_trip<SQ_STEP>(env, act, slot, c, max_trips);
-        else if (my_q == SQ_CMP) nq = sq_trip<SQ_CMP>(env, act, slot, c, max_trips);
-        else nq = sq_trip<SQ_LOC>(env, act, slot, c, max_trips);
-        // ---- every slot of this trip goes to the queue of its new state: lane k reserves queue k's entries, one round trip for all five ----
-        {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tab is read by the other lanes of this wave
+                const uint32_t total = take * (uint32_t)W;            // the reads are consecutive: one contiguous run of enc
+                const uint32_t *src = enc + (size_t)base * W;
+                for (uint32_t i0 = 0; i0 < total; i0 += 256u) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < total ? src[i] : 0u; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t i = i0 + (uint32_t)(k * 64 + lane);
+                        if (i < total) { const uint32_t rk = (i * w_magic) >> 20; rd[(size_t)(i - rk * (uint32_t)W) * NSLOT + tab[wave * 64 + rk]] = v[k]; }
+                    }
+                }
+            } else if (my_q == SQ_BEGIN) nq = sqf_trip<SQ_BEGIN>(env, act, slot, dl);
+            else if (my_q == SQ_STEP) nq = sqf_trip<SQ_STEP>(env, act, slot, dl);
+            else if (my_q == SQ_CMP) nq = sqf_trip<SQ_CMP>(env, act, slot, dl);
+            else nq = sqf_trip<SQ_LOC>(env, act, slot, dl);
+            acc_steps += dl.steps; acc_blocks += dl.blocks; acc_lf += dl.lf_ref; max_trips = dl.max_trips > max_trips ? dl.max_trips : max_trips;
+            // ---- every slot of this trip goes to the queue of its new state: lane k reserves queue k's entries, one round trip for all five ----
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // state and words first, entries after
             unsigned long long m[SQ_NQ];
 #pragma unroll
@@ -425,25 +521,27 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
             if (act) {
                 const uint32_t a = base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
                 const uint32_t lap = ((a >> QLG) & 1u) ? SQF_LAP : 0u;
-                volatile uint16_t *ep = vq + (size_t)nq * QCAP + (a & SM);
-                while (*ep != (uint16_t)(lap ^ SQF_LAP)) __builtin_amdgcn_s_sleep(1);      // EMPTY of the previous lap (almost never waits)
-                *ep = (uint16_t)(SQF_FULL | lap | slot);
+                uint16_t *ep = q + (size_t)nq * QCAP + (a & SM);
+                while (sqf_ld16(ep) != (lap ^ SQF_LAP)) __builtin_amdgcn_s_sleep(1);      // EMPTY of the previous lap (almost never waits)
+                sqf_st16(ep, SQF_FULL | lap | slot);
+            }
+        } else if (my_q < 0) {
+            if (ex && cn[SQ_FREE] == (uint32_t)NSLOT) running = false;          // all slots free, nothing left to claim
+            else {
+                if (lane == 0) atomicAdd(&ctl[21], 1u);
+                __builtin_amdgcn_s_sleep(32);                                   // ~1 us: a trip in flight lasts several
             }
         }
+        if (++looks > SQF_MAX_LOOKS) { if (lane == 0) atomicMax(err, DG_E_SEEDQ); running = false; }
     }
     atomicMax(d_ctr_stripe(ctr) + CTR_MAXTRIPS, (unsigned long long)max_trips);
-    if (lane == 0) {
-        atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_PHASES, (unsigned long long)idle);                 // (here: looks that found nothing to do)
-        atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips);
-#pragma unroll
-        for (int k = 0; k < SQ_NQ; k++) if (q_trips[k]) { atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_TRIPS + k, (unsigned long long)q_trips[k]); atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_LANES + k, (unsigned long long)q_lanes[k]); }
+    if (lane == 0) { atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips); }
+    d_wave_add(ctr + CTR_STEPS, acc_steps);
+    d_wave_add(ctr + CTR_BLOCKS, acc_blocks);
+    d_wave_add(ctr + CTR_LF, acc_lf);
+    __syncthreads();                                              // every wave has left the loop: the workgroup's statistics are final
+    if (tid < SQ_NQ) {
+        atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_TRIPS + tid, (unsigned long long)ctl[16 + tid]); atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_LANES + tid, (unsigned long long)ctl[24 + tid]);
+        if (tid == 0) atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_PHASES, (unsigned long long)ctl[21]);          // (here: looks that found nothing to do)
     }
-    d_wave_add(ctr + CTR_STEPS, c.steps);
-    d_wave_add(ctr + CTR_BLOCKS, c.blocks);
-    d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
-    d_wave_add(ctr + CTR_BLOCKS_ACT, c.blocks_act);
-    d_wave_add(ctr + CTR_KTAB, c.ktab);
-    d_wave_add(ctr + CTR_LF, c.lf_ref);
-    d_wave_add(ctr + CTR_LF_ACT, c.lf_act);
-    d_wave_add(ctr + CTR_DIRECT, c.n_direct);
 }
