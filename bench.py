@@ -41,6 +41,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def kernel_sources_sha256() -> str:
+    """fingerprint of the device code (dart_amd/csrc/*.h, *.hip): ties the committed PMC passes (profiles/traffic.json) to the kernels that
+    are really running -- the GPU box has no .git, so a commit id is not available there"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dart_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def host_cores() -> int:
     """cores this process may really use: the cgroup CPU quota when there is one (the GPU boxes expose 256 hardware threads but
     grant a 16-core share per GPU), else the affinity mask"""
@@ -83,7 +95,7 @@ def genome_spec(arg):
     return "%s synthetic genome (%d bp" % ("chr20-sized" if n == CHR20_LEN else "single-chromosome", n), ["chr20"], [n]
 
 
-def prepare_index(cache_dir, genome, rank, barrier, n_introns=0, repeat_scale=1.0):
+def prepare_index(cache_dir, genome, rank, barrier, n_introns=0, repeat_scale=1.0, model="planted"):
     """genome: a length in bp (one chromosome) or (names, lengths).  Rank 0 generates and indexes it once per box."""
     import numpy as np
     import torch
@@ -91,12 +103,12 @@ def prepare_index(cache_dir, genome, rank, barrier, n_introns=0, repeat_scale=1.
     names, lengths = (["chr20"], [int(genome)]) if not isinstance(genome, (tuple, list)) else genome
     total = sum(lengths)
     prefix = os.path.join(cache_dir, "g%d" % total + ("c%d" % len(lengths) if len(lengths) > 1 else "") + ("_i%d" % n_introns if n_introns else "") +
-                          ("_r%g" % repeat_scale if repeat_scale != 1.0 else ""))
+                          ("_r%g" % repeat_scale if repeat_scale != 1.0 else "") + ("_%s" % model if model != "planted" else ""))
     done = prefix + ".done"
     if rank == 0 and not os.path.exists(done):
         os.makedirs(cache_dir, exist_ok=True)
         t = time.time()
-        g = synth.make_genome(lengths, seed=20, repeat_scale=repeat_scale, n_introns=n_introns, names=names)
+        g = synth.make_genome(lengths, seed=20, repeat_scale=repeat_scale, n_introns=n_introns, names=names, model=model)
         np.save(prefix + ".codes.npy", g.codes)
         np.save(prefix + ".introns.npy", g.introns)
         log("[bench] genome %d bp generated in %.1f s" % (total, time.time() - t))
@@ -126,12 +138,19 @@ def self_launch(args, argv):
 class Batch:
     """one distinct batch of pairs: ASCII and packed forms in page-locked host memory"""
 
-    def __init__(self, lib, g, pairs, rlen, seed, sub_rate, indel_frac, spliced, want_truth=False):
+    def __init__(self, lib, g, pairs, rlen, seed, sub_rate, indel_frac, spliced, want_truth=False, rows=None):
+        """rows = (a, b): only pairs [a, b) of the batch that `seed` generates (a rank's share of a global batch in --total-pairs mode;
+        the batch is a pure function of (seed, pairs), so the union over ranks is the same reads whatever the number of ranks)"""
         import numpy as np
         from dart_amd import synth, host
         r = synth.make_reads(g, pairs, rlen=rlen, seed=seed, sub_rate=sub_rate, indel_frac=indel_frac, n_frac=0.002, spliced_frac=spliced, return_truth=want_truth)
         m1, m2 = r[0], r[1]
         self.truth = r[2] if want_truth else None
+        self.seed, self.rows = seed, rows
+        if rows is not None:
+            m1, m2 = m1[rows[0]:rows[1]], m2[rows[0]:rows[1]]
+            if self.truth is not None:
+                self.truth = {k: v[rows[0]:rows[1]] for k, v in self.truth.items()}
         arr = host.interleave_pairs(m1, m2)
         so, rl, flat = host.pack_reads(arr)
         words, nlist = host.pack_reads_2bit(arr)
@@ -167,6 +186,11 @@ class Worker:
         records = records or self.records
         if mode != "resident":
             self.last_records = records
+        self.last_empty = b.n == 0
+        if b.n == 0:                                   # (a rank whose share of the step has fewer batches than another's: it still takes part in the gather)
+            for k in range(3):
+                self.used[k] = 0
+            return
         if records == "compact" and mode in ("packed", "ascii"):
             pk = mode == "packed"
             rc = lib.dg_map_batch_compact(g.ctx, b.n, None if pk else b.so.a.ctypes.data, None if pk else b.rl.a.ctypes.data, None if pk else b.seq.a.ctypes.data,
@@ -210,6 +234,9 @@ def main():
     ap.add_argument("--batches", type=int, default=10, help="distinct batches per step and GPU (10 x 1 M pairs = BASELINE configs[2])")
     ap.add_argument("--genome", default=os.environ.get("DART_BENCH_GENOME", "grch38"),
                     help="grch38 (default: 24 chromosomes with GRCh38 sizes, 3.09 Gbp) | chr20 | <bp> (one chromosome)")
+    ap.add_argument("--genome-model", choices=["planted", "human"], default="planted",
+                    help="planted (default, SURVEY 8d): i.i.d. + planted repeat families, ~18 %% of the genome; human: about half of the genome in human-like repeat "
+                         "classes (SINE/LINE/older interspersed families, segmental duplications, satellites, microsatellites: dart_amd/synth.py)")
     ap.add_argument("--repeat-scale", type=float, default=1.0, help="scales the planted repeat families of the synthetic genome (1.0 = SURVEY 8d's: ~18 %% of the genome)")
     ap.add_argument("--mis", type=int, default=5, help="-mis N (MaxMismatch); the reference default is 0, see DESIGN.md")
     ap.add_argument("--input", choices=["packed", "ascii"], default="packed", help="entry point that carries the reads in the timed region")
@@ -221,7 +248,17 @@ def main():
     ap.add_argument("--max-intron", type=int, default=500000)
     ap.add_argument("--sub-rate", type=float, default=0.01, help="per-base substitution rate of the synthetic reads (experiments only; the bench line is quoted at the default)")
     ap.add_argument("--indel-frac", type=float, default=0.02, help="fraction of reads carrying one short indel (experiments only)")
-    ap.add_argument("--no-gather", action="store_true", help="N>1 only: do not gather the per-read records to rank 0")
+    ap.add_argument("--gather", choices=["full", "reads", "none"], default="full",
+                    help="N>1 only, inside the timed region: full = every rank's compact records of every batch -- per-read records, reports, stored CIGAR ops, "
+                         "junction tuples -- go HBM -> HBM to rank 0 over RCCL, sizes first (the SAM-order gather of north_star: the reference has ONE ordered writer); "
+                         "reads = the per-read records only (round 2); none")
+    ap.add_argument("--no-gather", action="store_true", help="= --gather none")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="STRONG scaling (BASELINE configs[3]: 50 M pairs sharded over 8 GPUs): a step = this many pairs in all, sharded over the ranks in contiguous, "
+                         "balanced pair ranges (dart_amd/dist.py); the reads are the same whatever the number of ranks.  Default 0 = weak scaling: --batches per rank")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="N>1, after the timed region: rank 0 expands what it gathered from every rank for one step and compares it, batch by batch, with its own "
+                         "single-rank mapping of the same reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (other entry point, device-resident)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "12")),
@@ -262,7 +299,7 @@ def main():
 
     label, gnames, glens = genome_spec(args.genome)
     try:
-        prefix, g = prepare_index(args.cache, (gnames, glens), rank, barrier, args.introns, args.repeat_scale)
+        prefix, g = prepare_index(args.cache, (gnames, glens), rank, barrier, args.introns, args.repeat_scale, args.genome_model)
     except Exception as e:                         # e.g. not enough memory for the 6.2 G-symbol suffix sort: say so, use chr20
         if world > 1 or len(glens) == 1:
             raise
@@ -270,7 +307,7 @@ def main():
         torch.cuda.empty_cache()
         label, gnames, glens = genome_spec("chr20")
         label = "FALLBACK (GRCh38-sized index build failed) " + label
-        prefix, g = prepare_index(args.cache, (gnames, glens), rank, barrier, args.introns, args.repeat_scale)
+        prefix, g = prepare_index(args.cache, (gnames, glens), rank, barrier, args.introns, args.repeat_scale, args.genome_model)
     ix = host.Index(prefix)
     params = host.default_params(paired=1, max_mismatch=args.mis, max_intron=args.max_intron)
     t = time.time()
@@ -281,10 +318,31 @@ def main():
 
     # ---- the step's distinct batches, in page-locked host memory ----
     t = time.time()
-    nb = max(1, args.batches)
+    strong = args.total_pairs > 0
+    if not strong:
+        specs = [(1000 + 100 * rank + j, None) for j in range(max(1, args.batches))]
+    else:
+        # this rank's contiguous share [lo, hi) of the step's pairs, cut at the boundaries of the global batches (global batch j = seed 1000 + j)
+        from dart_amd import dist as ddist
+        lo, hi = ddist.shard_bounds_balanced(args.total_pairs, world, rank)
+        specs = []
+        p = lo
+        while p < hi:
+            j = p // args.pairs
+            e = min(hi, (j + 1) * args.pairs, args.total_pairs)
+            specs.append((1000 + j, (p - j * args.pairs, e - j * args.pairs)))
+            p = e
+        n_local = len(specs)
+        if dist is not None:                           # every rank takes part in the same number of gathers: pad with empty batches
+            tt = torch.tensor([n_local], dtype=torch.int64, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            specs += [(0, (0, 0))] * (int(tt.item()) - n_local)
+    nb = len(specs)
     with ThreadPoolExecutor(max_workers=min(4, nb)) as ex:
-        batches = list(ex.map(lambda j: Batch(gpu.lib, g, args.pairs, args.rlen, 1000 + 100 * rank + j, args.sub_rate, args.indel_frac, args.spliced, want_truth=(j == 0)), range(nb)))
-    n_reads = batches[0].n
+        batches = list(ex.map(lambda js: Batch(gpu.lib, g, args.pairs if js[1] is None else min(args.pairs, args.total_pairs - (js[0] - 1000) * args.pairs) if js[1][1] else 1,
+                                               args.rlen, js[0], args.sub_rate, args.indel_frac, args.spliced, want_truth=(js is specs[0]), rows=js[1]), specs))
+    n_reads = max(b.n for b in batches)
+    reads_per_step = 2 * args.total_pairs if strong else 2 * args.pairs * nb * world          # whole job, all ranks
     if rank == 0:
         log("[bench] %d distinct batches of %d pairs generated in %.1f s" % (nb, args.pairs, time.time() - t))
 
@@ -295,11 +353,37 @@ def main():
     for k, w in enumerate(workers):                # sizes every context's device buffers before any counted step (distinct batches)
         w.map(batches[k % nb])
         w.kern = {}; w.n_runs = 0
-    do_gather = dist is not None and not args.no_gather
+    gather_mode = "none" if (dist is None or args.no_gather) else args.gather
+    if gather_mode == "full" and args.records != "compact":
+        gather_mode = "reads"
+    do_gather = gather_mode != "none"
     gather_buf = None
+    gather_dev = "cpu" if rehearse else "cuda"
+    recv_bufs = None                                # rank 0: [source rank][array] byte buffers in HBM for what the other ranks send
+    if gather_mode == "full" and rank == 0:
+        cap = workers[0].caps
+        recv_bufs = [None] + [[torch.empty(n_reads * 12, dtype=torch.uint8, device=gather_dev), torch.empty(int(cap[0]) * 16, dtype=torch.uint8, device=gather_dev),
+                               torch.empty(int(cap[1]) * 4, dtype=torch.uint8, device=gather_dev), torch.empty(int(cap[2]) * 24, dtype=torch.uint8, device=gather_dev)] for _ in range(1, world)]
+    gathered = None                                 # --verify-gather: rank 0 keeps what arrived, per (source rank, batch)
+    gather_bytes = [0]
 
-    def gather(w):
+    def gather(w, item=None):
         nonlocal gather_buf
+        if gather_mode == "full":
+            from dart_amd import dist as ddist
+            parts = [torch.empty(0, dtype=torch.uint8, device=gather_dev)] * 4 if w.last_empty else w.gpu.device_records_compact()
+            if rehearse:
+                parts = [p_.cpu() for p_ in parts]
+            counts = ddist.gather_compact_to_rank0(parts, recv_bufs, world, rank)
+            if not rehearse:
+                torch.cuda.current_stream().synchronize()   # the context's next run overwrites these records
+            if rank == 0:
+                gather_bytes[0] += int(counts[1:].sum())
+                if gathered is not None and item is not None:
+                    for r in range(world):
+                        src = parts if r == 0 else [recv_bufs[r][k][:int(counts[r, k])] for k in range(4)]
+                        gathered[(r, item % nb)] = [x.cpu().numpy().copy() for x in src]
+            return
         local_t = w.gpu.device_reads_tensor(compact=(w.last_records == "compact"))      # 12 (or 36) bytes per read, straight from HBM
         if rehearse:
             local_t = local_t.cpu()
@@ -342,7 +426,7 @@ def main():
             if errs:
                 break
             if do_gather:
-                gather(ws[k])
+                gather(ws[k], first_item + i)
                 free[k].release()
         for k in range(len(ws)):
             free[k].release()
@@ -373,27 +457,32 @@ def main():
         for k, v in w.kern.items():
             kern[k] = kern.get(k, 0.0) + v
     kern = {k: v / max(runs, 1) for k, v in kern.items()}
+    # the spread of the figure: two more runs of the same K steps (the line's `value` is the first, the contract's)
+    repeats = [elapsed] + [timed(args.steps * nb, args.input) for _ in range(0 if args.no_secondary else 2)]
     counters = workers[0].gpu.counters()
     # batches a context had to run again since it was created, over all contexts: capacities that grew (expected while the first batches
     # size the buffers), scans that did not complete (dg_scan.h: should be 0)
     for key in ("reruns_capacity_total", "reruns_scan_total"):
         counters[key] = sum(w.gpu.counters().get(key, 0) for w in workers)
+    if counters["reruns_scan_total"]:
+        log("[bench] FAILED: %d batch(es) were run again because a device-side scan gave up (dg_scan.h): %s" % (counters["reruns_scan_total"], [w.gpu.lib.dg_last_error(w.gpu.ctx) for w in workers]))
+        sys.exit(3)
 
     # ---- secondary rates, outside the timed region (fewer items) ----
     secondary = {}
     if not args.no_secondary:
         items = min(args.steps, 3) * nb
         other = "ascii" if args.input == "packed" else "packed"
-        secondary["value_%s_input" % other] = round(2 * args.pairs * world * items / timed(items, other) / 1e6, 3)
+        secondary["value_%s_input" % other] = round(reads_per_step / nb * items / timed(items, other) / 1e6, 3)
         other_rec = "full" if args.records == "compact" else "compact"
         for w in workers:
             w.records = other_rec
-        secondary["value_%s_records" % other_rec] = round(2 * args.pairs * world * items / timed(items, args.input) / 1e6, 3)
+        secondary["value_%s_records" % other_rec] = round(reads_per_step / nb * items / timed(items, args.input) / 1e6, 3)
         for w in workers:
             w.records = args.records
         gsave, do_gather = do_gather, False
         run_items(len(workers), "resident")                # (every context holds the batch it mapped last)
-        secondary["value_device_resident"] = round(2 * args.pairs * world * items / timed(items, "resident") / 1e6, 3)
+        secondary["value_device_resident"] = round(reads_per_step / nb * items / timed(items, "resident") / 1e6, 3)
         do_gather = gsave
     # the same item with ONE batch in flight, for per-kernel durations without other batches' kernels sharing the GPU
     w0 = workers[0]; w0.kern = {}; w0.n_runs = 0
@@ -403,12 +492,49 @@ def main():
     iso = {k: v / 2 for k, v in w0.kern.items()}
     barrier(); torch.cuda.synchronize()
 
+    # ---- --verify-gather: one more step, untimed; rank 0 keeps what the gather delivered and compares it with its own mapping of the same reads ----
+    gather_verified = None
+    if args.verify_gather and gather_mode == "full":
+        if rank == 0:
+            gathered = {}
+        run_items(nb, args.input)
+        if rank == 0:
+            from dart_amd import dist as ddist
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import common
+            ok = True
+            for r in range(world):
+                if strong:
+                    lo, hi = ddist.shard_bounds_balanced(args.total_pairs, world, r)
+                    sp = []
+                    p_ = lo
+                    while p_ < hi:
+                        j = p_ // args.pairs
+                        e = min(hi, (j + 1) * args.pairs, args.total_pairs)
+                        sp.append((1000 + j, (p_ - j * args.pairs, e - j * args.pairs), min(args.pairs, args.total_pairs - j * args.pairs)))
+                        p_ = e
+                else:
+                    sp = [(1000 + 100 * r + j, None, args.pairs) for j in range(nb)]
+                for i, (seed, rows, n_gen) in enumerate(sp):
+                    rb_, pb_, cb_, sb_ = gathered[(r, i)]
+                    b = Batch(gpu.lib, g, n_gen, args.rlen, seed, args.sub_rate, args.indel_frac, args.spliced, rows=rows)
+                    workers[0].map(b, args.input); want = workers[0].result()
+                    rc_ = rb_.view(host.READ_C); pc_ = pb_.view(host.REPORT_C)
+                    reads_x, rep_x, cig_x = host.expand_compact(rc_, pc_, cb_.view(np.uint32), np.full(len(rc_), args.rlen, np.uint16))
+                    got = host.BatchResult(reads_x, rep_x, cig_x, sb_.view(host.SJ_OUT))
+                    try:
+                        common.assert_same(got, (want.reads, want.reports, want.cigar, want.sj))
+                    except AssertionError as e_:
+                        ok = False
+                        log("[bench] gathered records of rank %d batch %d differ from the single-rank mapping: %s" % (r, i, str(e_)[:300]))
+            gather_verified = ok
+            gathered = None
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    reads_per_step = 2 * args.pairs * nb * world
     value = reads_per_step * args.steps / elapsed / 1e6
 
     # ---- roofline of the dominant kernel: algorithmic bytes (reference algorithm + layout) of one launch / its mean
@@ -427,14 +553,18 @@ def main():
     dom_bytes = alg.get(dom)
     if dom_bytes is None:      # pair / report kernels: their own input and output (seeds in, records out, read bases compared)
         dom_bytes = 8 * counters["seeds"] + 90 * n_reads
-    achieved = dom_bytes / (kern[dom] * 1e-3) / 1e9
+    # PMC traffic of the dominant kernel: only from passes taken with THESE kernel sources on THIS workload (profiles/run_profile.sh stores the
+    # fingerprint of the bench line it profiled in profiles/traffic.json); anything else says nothing about this run
+    fingerprint = {"csrc_sha256": kernel_sources_sha256(),
+                   "workload": "genome=%s model=%s pairs=%d rlen=%d spliced=%g introns=%d repeat_scale=%g mis=%d sub=%g indel=%g" %
+                               (args.genome, args.genome_model, args.pairs, args.rlen, args.spliced, args.introns, args.repeat_scale, args.mis, args.sub_rate, args.indel_frac)}
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    # the committed PMC passes were taken on the default workload: their bytes say nothing about another genome, read shape or batch size
-    default_workload = (args.genome == "grch38" and args.pairs == 1000000 and args.rlen == 101 and args.spliced == 0.0 and args.repeat_scale == 1.0 and args.mis == 5)
-    if os.path.exists(tpath) and default_workload:
+    if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom)
+            tj = json.load(open(tpath))
+            if tj.get("_fingerprint") == fingerprint:
+                traffic = tj.get(dom)
         except Exception:
             traffic = None
     own = {
@@ -444,27 +574,37 @@ def main():
                   + 56 * n_reads + 16 * counters["seeds"],
         "k_locate": 64 * counters.get("lf_steps_executed", 0) + 8 * counters["sa_lookups"] + 8 * counters["seeds"],
     }
+    own_bytes = int(own.get(dom, dom_bytes))
+    ms_alone = iso.get(dom) or kern[dom]
+    # `achieved` is a HARDWARE statement: the bytes the dominant kernel really moves through the memory side (PMC FETCH_SIZE + WRITE_SIZE of one
+    # launch; without a matching profile: the bytes it requests, from the live counters -- a lower bound) over the launch's stand-alone
+    # duration, against 8 TB/s.  The rate on the REFERENCE algorithm's bytes stays beside it as `algorithmic_*`: the prefix
+    # table, the full SA and the direct text comparison remove most of those bytes, so that rate is a work-elimination factor, not a
+    # fraction of any hardware limit.
+    moved = traffic if traffic else own_bytes
+    achieved = moved / (ms_alone * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(dom_bytes), "kernel_ms": round(kern[dom], 4),
-                "kernel_ms_one_batch_in_flight": round(iso.get(dom, 0.0), 4),
-                "achieved_one_batch_in_flight": round(dom_bytes / (iso[dom] * 1e-3) / 1e9, 2) if iso.get(dom) else None,
-                "own_requested_bytes_per_launch": int(own.get(dom, dom_bytes)),
+                "achieved_basis": ("PMC FETCH_SIZE + WRITE_SIZE bytes of one launch (profiles/traffic.json: same kernel sources, same workload)" if traffic else
+                                   "bytes the kernel requests per launch, from its live work counters (no PMC pass matches these kernel sources and this workload): a lower bound of the traffic")
+                                  + " / the launch's stand-alone HIP-event duration measured in this run",
+                "kernel_ms_standalone": round(ms_alone, 4), "kernel_ms_in_timed_region": round(kern[dom], 4),
+                "own_requested_bytes_per_launch": own_bytes,
                 # what the memory system allows for THIS access pattern: random 64-byte lines over 8 ... 119 GB run at 48 G lines/s = 3.1 TB/s from
-                # 4 waves per CU on, ~1 us per dependent line (profiles/r02/tlb_probe_big_footprints.txt); the PMC traffic of one launch over
-                # its duration alone on the GPU, against that
+                # 4 waves per CU on, ~1 us per dependent line (profiles/r02/tlb_probe_big_footprints.txt)
                 "random_64B_line_ceiling_GBps": 3100.0,
-                "traffic_GBps_one_batch_in_flight": round(traffic / (iso[dom] * 1e-3) / 1e9, 1) if traffic and iso.get(dom) else None,
-                "frac_of_random_line_ceiling_one_batch_in_flight": round(traffic / (iso[dom] * 1e-3) / 1e9 / 3100.0, 4) if traffic and iso.get(dom) else None,
+                "frac_of_random_line_ceiling": round(achieved / 3100.0, 4),
+                "algorithmic_bytes_per_launch": int(dom_bytes),
+                "algorithmic_GBps_standalone": round(dom_bytes / (ms_alone * 1e-3) / 1e9, 1),
+                "algorithmic_GBps_in_timed_region": round(dom_bytes / (kern[dom] * 1e-3) / 1e9, 1),
+                "work_elimination": round(dom_bytes / moved, 2),
                 "fm_bytes_per_read": round(per_read_B, 1),
-                # SURVEY 8d's whole-job form: reads/s x algorithmic bytes per read (this GPU's share of `value`), against the same 8 TB/s
+                # SURVEY 8d's whole-job form: reads/s x algorithmic bytes per read (this GPU's share of `value`)
                 "whole_job_algorithmic_GBps_per_gpu": round(value / world * 1e6 * per_read_B / 1e9, 1),
-                "whole_job_frac_per_gpu": round(value / world * 1e6 * per_read_B / 8e12, 4),
-                "note": "achieved = reference-algorithm bytes of one launch (SURVEY 8d: what bwt_2occ4/bwt_sa would fetch for these reads; one launch = one batch of "
-                        "%d reads) / the launch's mean HIP-event duration in the timed region, where it shares the GPU with the other batches in flight; "
-                        "*_one_batch_in_flight = the same launch alone on the GPU (measured after the timed region). The k-mer prefix table, the full SA and the "
-                        "direct text comparison make the kernel request far fewer bytes than the reference algorithm (own_requested_*), so the algorithmic rate "
-                        "can exceed what the kernel really moves" % n_reads}
+                "fingerprint": fingerprint,
+                "note": "one launch = one batch of %d reads.  achieved / frac = real bytes over the stand-alone duration (see achieved_basis); algorithmic_* = what the "
+                        "reference's algorithm and layout would fetch for the same reads (SURVEY 8d: 64 B per Occ block of bwt_2occ4, per LF step, 8 B per SA entry), "
+                        "kept as a work-elimination factor" % n_reads}
 
     # ---- CPU baseline: the oracle ("port") on a bounded sample of the same reads, all host cores ----
     cpu = None
@@ -498,8 +638,14 @@ def main():
             o1 = orc.map_batch(orc.params(paired=1, max_mismatch=args.mis, max_intron=args.max_intron), b1.so.a[:n1], b1.rl.a[:n1], b1.seq.a, threads=cores)
             workers[1].map(b1, args.input)
             same = same and same_as_oracle(workers[1].result(), o1[0], o1[1], o1[2], n1)
+        # one core beside all cores (SURVEY 8d "plus -t 1"), on a smaller head of the same sample
+        n1t = min(ns, 2 * max(2000, args.cpu_sample_pairs // 8))
+        t = time.perf_counter()
+        orc.map_batch(orc.params(paired=1, max_mismatch=args.mis, max_intron=args.max_intron), so[:n1t], rl[:n1t], flat, threads=1)
+        dt1 = time.perf_counter() - t
         cpu = {"value": round(ns / dt / 1e6, 5), "unit": "M reads/s", "cores": cores, "kind": "port",
                "sample": "first %d pairs of batch 0, oracle/dart_oracle.c with %d threads, %.1f s wall" % (ns // 2, cores, dt),
+               "value_t1": round(n1t / dt1 / 1e6, 5), "sample_t1": "first %d pairs of batch 0, 1 thread, %.1f s wall" % (n1t // 2, dt1),
                "gpu_records_identical_on_sample": same}
         log("[bench] oracle counters on sample:", orc.counters)
 
@@ -518,10 +664,12 @@ def main():
     line = {
         "metric": "M paired-end reads/sec (2x%d bp vs GRCh38-sized index), host to host; records bit-identical to CPU dart" % args.rlen,
         "value": round(value, 4), "unit": "M reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "u64/u8 integer", "data": "synthetic",
-        "config": {"workload": label + ", i.i.d. + planted repeat families x%g: SURVEY 8d), %d M DISTINCT pairs 2x%d bp per GPU and step (%d batches of %d pairs), %s-mis %d, host-to-host"
-                               % (args.repeat_scale, round(nb * args.pairs / 1e6), args.rlen, nb, args.pairs,
+        "value_repeats": [round(reads_per_step * args.steps / e / 1e6, 2) for e in repeats],
+        "config": {"workload": label + ", %s), %d M DISTINCT pairs 2x%d bp per GPU and step (%d batches of %d pairs), %s-mis %d, host-to-host"
+                               % ("i.i.d. + planted repeat families x%g: SURVEY 8d" % args.repeat_scale if args.genome_model == "planted" else
+                                  "human-like repeat content, about half of the genome: SINE/LINE/older interspersed families, segmental duplications, satellites, microsatellites", round(nb * args.pairs / 1e6), args.rlen, nb, args.pairs,
                                   ("%.0f %% of the reads spliced over %d planted introns, -max_intron %d, " % (100 * args.spliced, args.introns, args.max_intron)) if args.spliced else "", args.mis),
                    "input": ("packed reads (2 bit/base + N list, dg_map_batch_packed): %.1f MB per batch" if args.input == "packed" else "ASCII reads (dg_map_batch): %.1f MB per batch") % (in_bytes / 1e6),
                    "output": ("%s + CIGAR ops + junction tuples into page-locked host arrays: %%.1f MB per batch" %
@@ -529,9 +677,13 @@ def main():
                    "host_link": "57 GB/s in total, both directions together (profiles/probes/pcie_probe.py): bytes in + bytes out per read bound this rate",
                    "timed_region": "first batch handed over in host memory -> last record back in host memory (H2D + all kernels + D2H, %d batches in flight)" % len(workers),
                    "pairs_per_gpu_per_step": nb * args.pairs, "read_len": args.rlen, "spliced_fraction": args.spliced, "batches_in_flight_per_gpu": len(workers),
-                   "synthetic_genome_repeat_content": "planted repeat families cover ~18 %% of the genome at --repeat-scale 1 (real human DNA: ~50 %%, which would move work "
-                                                      "from k_pair to the wave-per-unit kernels and the general report path)",
-                   "parallelism": ("reads sharded x%d, index replicated" % world) + (", RCCL gather of the per-read records (%d B per read) to rank 0 inside the timed region" % (12 if args.records == "compact" else 36) if do_gather else ", no data-path collective")},
+                   "synthetic_genome_repeat_content": ("planted repeat families cover ~18 %% of the genome at --repeat-scale 1 (real human DNA: ~50 %%; `--genome-model human` runs that: "
+                                                       "profiles/r03/ holds its line beside this one)") if args.genome_model == "planted" else
+                                                      "human-like: ~50 %% of the genome in repeat classes with human-like copy numbers and divergences (dart_amd/synth.py::_make_genome_human)",
+                   "parallelism": ("reads sharded x%d (%s), index replicated" % (world, "one job of %d pairs per step cut into contiguous balanced pair ranges" % args.total_pairs if strong else "every rank maps its own batches")) +
+                                  ({"full": ", SAM-order gather inside the timed region: every rank's compact records of every batch (per-read records, reports, stored CIGAR ops, junction tuples) HBM -> HBM to rank 0 over RCCL, sizes first",
+                                    "reads": ", RCCL gather of the per-read records (%d B per read) to rank 0 inside the timed region" % (12 if args.records == "compact" else 36),
+                                    "none": ", no data-path collective"}[gather_mode])},
         "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
         "kernels_ms_one_batch_in_flight": {k: round(v, 4) for k, v in iso.items()},
         "counters_per_launch": counters,
@@ -539,6 +691,8 @@ def main():
         "cpu_baseline": cpu,
         "accuracy": accuracy,
     }
+    if gather_mode == "full":
+        line["gather"] = {"mode": "full", "bytes_received_by_rank0_total": gather_bytes[0], "verified_against_single_rank_mapping": gather_verified}
     line.update(secondary)
     print(json.dumps(line), flush=True)
     if dist is not None:

@@ -1286,6 +1286,15 @@ extern "C" int dg_batch_device_ptrs_compact(dg_ctx *c, void *ptrs[2])
     return DG_OK;
 }
 
+extern "C" int dg_batch_device_records_compact(dg_ctx *c, void *ptrs[4], size_t counts[4])
+{
+    if (!c || !ptrs || !counts) return DG_ERR_ARG;
+    if (!c->packed_valid) { snprintf(c->err, 512, "dg_batch_device_records_compact: the last batch has no compact records (use dg_map_batch_compact / dg_batch_download_compact)"); return DG_ERR_ARG; }
+    ptrs[0] = c->reads_c.p; ptrs[1] = c->reports_c.p; ptrs[2] = c->cig_c.p; ptrs[3] = c->sjfinal.p;
+    counts[0] = (size_t)c->n_reads; counts[1] = c->used[0]; counts[2] = (size_t)c->h_tail->sizes.pad[0]; counts[3] = c->used[2];
+    return DG_OK;
+}
+
 // ---- roofline calibration (not in the public header): random 64-byte block reads over the resident
 // Occ array, the access pattern of k_seed / k_locate without any of their arithmetic.
 // dependent = 1: the next block index depends on the loaded data (a chain per lane, like an FM walk);

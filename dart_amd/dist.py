@@ -20,6 +20,41 @@ def shard_bounds(n_pairs: int, world: int, rank: int):
     return lo, min(n_pairs, lo + per)
 
 
+def shard_bounds_balanced(n_pairs: int, world: int, rank: int):
+    """Contiguous pair ranges whose sizes differ by at most one pair (50 M pairs over 8 ranks: 6.25 M each); input order = rank order."""
+    return n_pairs * rank // world, n_pairs * (rank + 1) // world
+
+
+def gather_compact_to_rank0(parts, recv_bufs, world: int, rank: int):
+    """The SAM-order gather of one batch per rank (north_star; Mapping.cpp:644-664 has ONE ordered writer): every rank hands its four
+    compact record arrays (uint8 tensors, in HBM under RCCL) to rank 0, sizes first, then point-to-point sends of exactly the bytes
+    used -- xGMI is point-to-point, and 30 bytes per read are far below one link.  recv_bufs[r][k] (rank 0 only): byte buffers that
+    hold rank r's arrays.  Returns on rank 0 the byte counts [world][4]; rank 0's own arrays stay where they are (parts)."""
+    dev = parts[0].device
+    sizes = torch.tensor([int(p.numel()) for p in parts], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    ops = []
+    if rank == 0:
+        counts = torch.stack(all_sizes).cpu().numpy()
+        for r in range(1, world):
+            for k in range(4):
+                nb = int(counts[r, k])
+                if nb:
+                    if nb > recv_bufs[r][k].numel():
+                        raise RuntimeError("gather buffer for rank %d array %d too small: %d > %d bytes" % (r, k, nb, recv_bufs[r][k].numel()))
+                    ops.append(dist.P2POp(dist.irecv, recv_bufs[r][k][:nb], r))
+    else:
+        counts = None
+        for k in range(4):
+            if parts[k].numel():
+                ops.append(dist.P2POp(dist.isend, parts[k], 0))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return counts
+
+
 def gather_records(reads: np.ndarray, reports: np.ndarray, cigar: np.ndarray, sj: np.ndarray, device=None):
     """Gathers one rank's records to rank 0 and rebases the offsets so that rank 0 holds one record set
     in global read order.  Returns (reads, reports, cigar, sj) on rank 0, None elsewhere."""

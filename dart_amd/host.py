@@ -164,6 +164,7 @@ def _load_lib():
     lib.dg_batch_download.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.dg_batch_device_ptrs.argtypes = [vp, vp]
     lib.dg_batch_device_ptrs_compact.argtypes = [vp, vp]
+    lib.dg_batch_device_records_compact.argtypes = [vp, vp, vp]
     lib.dg_last_timings.argtypes = [vp, vp, vp, C.c_int]
     lib.dg_last_counters.argtypes = [vp, vp, C.c_int]
     lib.dg_probe_seeds.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
@@ -371,6 +372,26 @@ class DartGPU:
         v = _View()
         v.__cuda_array_interface__ = {"shape": (self._n, READ_C.itemsize if compact else READ_OUT.itemsize), "typestr": "|u1", "data": (int(ptrs[0]), False), "version": 2}
         return torch.as_tensor(v, device="cuda")
+
+    def device_records_compact(self):
+        """the four compact record arrays of the last compact run as torch uint8 views of HBM (dg_batch_device_records_compact):
+        [dg_read_c bytes, dg_report_c bytes, stored CIGAR ops bytes, dg_sj_out bytes] -- for the RCCL gather to the writing rank"""
+        import torch
+        ptrs = (C.c_void_p * 4)(); counts = (C.c_size_t * 4)()
+        self._chk(self.lib.dg_batch_device_records_compact(self.ctx, ptrs, counts), "dg_batch_device_records_compact")
+        out = []
+        for k, item in enumerate((READ_C.itemsize, REPORT_C.itemsize, 4, SJ_OUT.itemsize)):
+            nbytes = int(counts[k]) * item
+
+            class _View:
+                pass
+            v = _View()
+            if nbytes == 0 or not ptrs[k]:
+                out.append(torch.empty(0, dtype=torch.uint8, device="cuda"))
+                continue
+            v.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptrs[k]), False), "version": 2}
+            out.append(torch.as_tensor(v, device="cuda"))
+        return out
 
     def timings(self):
         names = (C.c_char_p * 16)()

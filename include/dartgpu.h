@@ -148,6 +148,11 @@ int dg_batch_download(dg_ctx *, dg_read_out *, dg_report_out *, uint32_t *cigar_
 int dg_batch_device_ptrs(dg_ctx *, void *ptrs[4]);
 /* the compact records of the last dg_batch_download_compact / dg_map_batch_compact in HBM: [0] dg_read_c[n_reads], [1] dg_report_c[used0] */
 int dg_batch_device_ptrs_compact(dg_ctx *, void *ptrs[2]);
+/* ALL compact records of the last dg_map_batch_compact / dg_batch_download_compact in HBM, with their element counts -- what a multi-GPU
+ * host hands to RCCL for the SAM-order gather to the rank that writes (Mapping.cpp:644-664 is ONE ordered writer; bench.py --gather full):
+ *   ptrs[0] dg_read_c[counts[0]]   ptrs[1] dg_report_c[counts[1]]   ptrs[2] stored CIGAR ops u32[counts[2]], in report order
+ *   ptrs[3] dg_sj_out[counts[3]], grouped by read in read order (read_idx is the read's index inside the batch)                    */
+int dg_batch_device_records_compact(dg_ctx *, void *ptrs[4], size_t counts[4]);
 
 /* per-kernel device time of the last dg_batch_run, measured with HIP events on the library's
  * stream: names[i] -> ms[i]; returns the number of entries written (<= cap)                   */

@@ -16,14 +16,22 @@ for k, c in acc.items():
         continue
     b = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) + (sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) if "WRITE_SIZE" in c else 0.0)
     name = short(k)
-    if name in ("k_seed_heavy", "k_seed_q"):
+    if name in ("k_seed_heavy", "k_seed_q", "k_seed_qf"):
         name = "k_seed"                      # bench.py times the two seeding kernels as one stage
     out[name] += b * 1024.0
 doc = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes), profiles/run_profile.sh %s, "
-                      "default bench workload, one batch in flight (2 M reads per launch), mean per launch; bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; k_seed = k_seed_q (or k_seed) + "
+                      "default bench workload, one batch in flight (2 M reads per launch), mean per launch; bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; k_seed = k_seed_qf (or k_seed_q / k_seed) + "
                       "k_seed_heavy, k_report = mean of its two passes. For these 64-byte random reads "
                       "FETCH_SIZE*1024/64 equals TCC_MISS_sum, i.e. one 64-B fabric request per line; the 2x correction of MI355X_MICROARCH.md "
                       "applies to wide coalesced streams and is NOT applied here (uncalibrated for this access width)." % tag}
+# the bench line of the profiled command says which kernel sources and which workload these passes belong to; bench.py reports
+# `roofline.traffic` only when its own fingerprint equals this one
+try:
+    line = [l for l in open(os.path.join(root, "bench_trace.json")) if l.startswith("{")][-1]
+    doc["_fingerprint"] = json.loads(line)["roofline"]["fingerprint"]
+except Exception as e:
+    doc["_fingerprint"] = None
+    print("no fingerprint (%r): bench.py will not use this file" % (e,), file=sys.stderr)
 doc.update({k: int(v) for k, v in sorted(out.items())})
 json.dump(doc, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json"), "w"), indent=1)
 print(json.dumps(doc, indent=1))

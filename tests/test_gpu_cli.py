@@ -109,6 +109,25 @@ def test_dart_cli_awkward_fastq(host_path, workdir):
         assert open(os.path.join(d, "orc.j")).read() == open(os.path.join(d, "gpu.j")).read()
 
 
+@pytest.mark.parametrize("host_path", ["parallel", "streaming"])
+def test_dart_cli_three_contexts_in_flight_keep_input_order(host_path, workdir):
+    """DART_GPUS=1 DART_INFLIGHT=3 (three contexts on the device, each with its own host thread, batches finishing out of order) and small
+    batches: the SAM is still the oracle command line's, byte for byte -- the ordered writer puts batch k behind batch k-1 whichever
+    context finished first (the reference's only multi-worker guarantee is its OutputLock, Mapping.cpp:644-664: ours is stronger, input order).
+    DART_GPUS=n (n devices in one process) adds devices to the same pool of contexts: ordering is the same mechanism."""
+    oracle_py.build()
+    c, d = cli_inputs.make(workdir)
+    env = dict(os.environ, DART_BATCH="4000", DART_GPUS="1", DART_INFLIGHT="3")
+    if host_path == "streaming":
+        env["DART_STREAMING"] = "1"
+    flags = ["-f", "q1.fq", "q1.fq", "q1.fq", "-f2", "q2.fq", "q2.fq", "q2.fq", "-mis", "5"]          # three libraries: 9 000 pairs, several batches per library
+    subprocess.run([DART, "-i", c["prefix"]] + flags + ["-o", "gpu3.sam", "-j", "gpu3.j", "-t", "4"], cwd=d, stdout=subprocess.DEVNULL, check=True, env=env)
+    subprocess.run([oracle_py.ORACLE_CLI, "-i", c["prefix"]] + flags + ["-o", "orc3.sam", "-j", "orc3.j"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    a, b_ = open(os.path.join(d, "orc3.sam")).read(), open(os.path.join(d, "gpu3.sam")).read()
+    assert a == b_, common.first_diff(b_, a)
+    assert open(os.path.join(d, "orc3.j")).read() == open(os.path.join(d, "gpu3.j")).read()
+
+
 def test_dart_cli_error_behaviour(workdir):
     r = subprocess.run([DART, "-intron", "5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"Error! Unknow parameter: -intron" in r.stderr
@@ -128,11 +147,30 @@ def test_bench_two_ranks_through_the_self_launcher(workdir):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--genome", "3000000", "--pairs", "20000", "--batches", "3", "--steps", "2",
-                        "--warmup", "1", "--inflight", "2", "--cpu-sample-pairs", "4000"], env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--inflight", "2", "--cpu-sample-pairs", "4000", "--verify-gather"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and "gather" in line["config"]["parallelism"] and "host-to-host" in line["config"]["workload"]
-    assert line["cpu_baseline"]["gpu_records_identical_on_sample"] is True
+    assert line["scaling"] == "weak" and line["gather"]["mode"] == "full" and line["gather"]["bytes_received_by_rank0_total"] > 0
+    assert line["gather"]["verified_against_single_rank_mapping"] is True          # rank 0's gathered record set == its own mapping of the same reads
+    assert line["cpu_baseline"]["gpu_records_identical_on_sample"] is True and line["cpu_baseline"]["value_t1"] > 0
     assert line["roofline"]["frac"] > 0 and line["accuracy"]["correct_frac"] > 0.9
+
+
+def test_bench_two_ranks_strong_scaling_one_job_sharded(workdir):
+    """BASELINE configs[3] as written -- ONE job sharded over the ranks (`--total-pairs`, "scaling": "strong"), here 70 001 pairs over two ranks
+    (35 000 + 35 001: a partial last batch and ranks with different batch counts), the full SAM-order gather inside the timed region, and rank 0's
+    gathered records compared with its own single-rank mapping of the same reads.  gloo on one GPU (DART_BENCH_REHEARSE=1): logic, not speed."""
+    import json, subprocess, sys
+    env = dict(os.environ, DART_BENCH_REHEARSE="1", DART_BENCH_CACHE=os.path.join(workdir, "bench2_cache"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--genome", "3000000", "--pairs", "20000", "--total-pairs", "70001", "--steps", "2",
+                        "--warmup", "1", "--inflight", "2", "--no-cpu-baseline", "--no-secondary", "--verify-gather"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "70001 pairs" in line["config"]["parallelism"]
+    assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - 2 * 70001) < 2          # value = the whole job's reads over the step time
+    assert line["gather"]["verified_against_single_rank_mapping"] is True
