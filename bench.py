@@ -187,6 +187,7 @@ class Worker:
         if mode != "resident":
             self.last_records = records
         self.last_empty = b.n == 0
+        self.last_n = b.n
         if b.n == 0:                                   # (a rank whose share of the step has fewer batches than another's: it still takes part in the gather)
             for k in range(3):
                 self.used[k] = 0
@@ -216,9 +217,9 @@ class Worker:
         from dart_amd import host
         u = [int(x) for x in self.used]
         if self.last_records == "compact":
-            r, p, cg = host.expand_compact(self.c_r.copy(), self.c_p[:u[0]].copy(), self.o_c.a[:u[1]].copy(), np.full(len(self.c_r), self.last_rlen, np.uint16))
+            r, p, cg = host.expand_compact(self.c_r[:self.last_n].copy(), self.c_p[:u[0]].copy(), self.o_c.a[:u[1]].copy(), np.full(self.last_n, self.last_rlen, np.uint16))
             return host.BatchResult(r, p, cg, self.o_s.a[:u[2]].copy())
-        return host.BatchResult(self.o_r.a.copy(), self.o_p.a[:u[0]].copy(), self.o_c.a[:u[1]].copy(), self.o_s.a[:u[2]].copy())
+        return host.BatchResult(self.o_r.a[:self.last_n].copy(), self.o_p.a[:u[0]].copy(), self.o_c.a[:u[1]].copy(), self.o_s.a[:u[2]].copy())
 
     def out_bytes(self, n):
         u = [int(x) for x in self.used]
@@ -420,16 +421,21 @@ def main():
         th = [threading.Thread(target=work, args=(k,)) for k in range(len(ws))]
         for t_ in th:
             t_.start()
-        for i in range(n_items):
-            k = i % len(ws)
-            done[k].acquire()
-            if errs:
-                break
-            if do_gather:
-                gather(ws[k], first_item + i)
-                free[k].release()
-        for k in range(len(ws)):
-            free[k].release()
+        try:
+            for i in range(n_items):
+                k = i % len(ws)
+                done[k].acquire()
+                if errs:
+                    break
+                if do_gather:
+                    gather(ws[k], first_item + i)
+                    free[k].release()
+        except BaseException as e:                          # (a failing gather must not leave the context threads waiting for their turn for ever)
+            errs.append(e)
+        finally:
+            for k in range(len(ws)):
+                for _ in range(n_items):
+                    free[k].release()
         for t_ in th:
             t_.join()
         if errs:
@@ -470,6 +476,8 @@ def main():
 
     # ---- secondary rates, outside the timed region (fewer items) ----
     secondary = {}
+    gather_timed = do_gather
+    do_gather = False                                      # (the secondary rates are per-GPU diagnostics of other entry points: no gather)
     if not args.no_secondary:
         items = min(args.steps, 3) * nb
         other = "ascii" if args.input == "packed" else "packed"
@@ -480,16 +488,16 @@ def main():
         secondary["value_%s_records" % other_rec] = round(reads_per_step / nb * items / timed(items, args.input) / 1e6, 3)
         for w in workers:
             w.records = args.records
-        gsave, do_gather = do_gather, False
         run_items(len(workers), "resident")                # (every context holds the batch it mapped last)
         secondary["value_device_resident"] = round(reads_per_step / nb * items / timed(items, "resident") / 1e6, 3)
-        do_gather = gsave
     # the same item with ONE batch in flight, for per-kernel durations without other batches' kernels sharing the GPU
     w0 = workers[0]; w0.kern = {}; w0.n_runs = 0
-    gsave, do_gather = do_gather, False
+    if args.no_secondary:
+        w0.map(batches[0], args.input)                     # (resident runs need an uploaded batch)
+        w0.kern = {}; w0.n_runs = 0
     run_items(2, "resident", [w0])
-    do_gather = gsave
     iso = {k: v / 2 for k, v in w0.kern.items()}
+    do_gather = gather_timed
     barrier(); torch.cuda.synchronize()
 
     # ---- --verify-gather: one more step, untimed; rank 0 keeps what the gather delivered and compares it with its own mapping of the same reads ----

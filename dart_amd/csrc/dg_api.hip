@@ -35,9 +35,9 @@ template <typename T> struct DBuf {
 };
 
 #define N_TIMERS 20
-#define N_TOPS 32               // small device counters of a batch (bump tops, tickets, list sizes), zeroed per run
+#define N_TOPS 128              // small device counters of a batch (bump tops, tickets, list sizes, class histogram), zeroed per run
 enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAVY_UNITS, TOP_SEED_NEXT, TOP_SEED_HEAVY,
-       TOP_WORK = 16, TOP_TICKET_PAIR, TOP_TICKET_EMIT, TOP_RESEED_COUNT /* 19..21 */, TOP_RESEED_TICKET = 22 /* 22..24 */ };
+       TOP_WORK = 16, TOP_TICKET_PAIR, TOP_TICKET_EMIT, TOP_TICKET_SEED = 25, TOP_ORDER_INFO = 28 /* 28..30 */, TOP_CLASS_HIST = 32 /* 32..63 */, TOP_CLASS_FILL = 64 /* 64..95 */, TOP_RESEED_COUNT /* 19..21 */, TOP_RESEED_TICKET = 22 /* 22..24 */ };
 
 struct dg_ctx {
     int device = 0;
@@ -163,6 +163,66 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t *out, const uint32_t 
     if (i < n) out[i] += tile_sums[i / SCAN_TILE];
 }
 
+// seeds per read -> where every read's seeds start (exclusive scan; seed_off[n] = total, flagged when it exceeds the capacity), the read
+// that owns the first seed of every 64-seed tile (k_locate's entry point) and the list of units with more seeds than a lane of k_pair
+// holds (k_chain_heavy's work list) -- ONE launch with a single-pass scan (dg_scan.h).  Round 2: three scan launches, k_tile_reads and
+// k_heavy_list, each a pass over the 2 M counts.  Thread = 8 consecutive reads (so both mates of a pair are in one thread).
+#define SO_PER 8
+__global__ void __launch_bounds__(256)
+k_seed_offsets(int n_reads, int paired, const uint32_t *__restrict__ nseeds, uint32_t *__restrict__ seed_off, uint32_t *__restrict__ tile_read, uint32_t n_tile_read,
+               uint32_t *__restrict__ heavy_list, unsigned int *n_heavy, uint32_t *total_copy, uint32_t cap, TileScan ts, int *err)
+{
+    __shared__ unsigned long long s_scan[16];
+    __shared__ unsigned int s_tile;
+    if (*err >= DG_ABORT) return;          // raised before this launch (the seeding kernel's safety net): nseeds cannot be trusted.  DG_E_SEEDS is raised
+                                           // below by the workgroup with the LAST ticket, when every other workgroup is past this line
+    const unsigned int tile = d_tile_ticket(ts, &s_tile);
+    const uint32_t first = tile * (256u * SO_PER) + threadIdx.x * SO_PER;
+    uint32_t v[SO_PER], sum = 0;
+    if (first + SO_PER <= (uint32_t)n_reads) {
+        const uint4 a = *(const uint4 *)(nseeds + first), b = *(const uint4 *)(nseeds + first + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < SO_PER; i++) v[i] = first + i < (uint32_t)n_reads ? nseeds[first + i] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < SO_PER; i++) sum += v[i];
+    Triple mine, tot;
+    mine.x = sum; mine.y = 0; mine.z = 0;
+    const Triple inb = d_block_exclusive(mine, tot, s_scan);
+    const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 12, err);
+    uint32_t run = base.x + inb.x;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < SO_PER; i++) {
+        const uint32_t r = first + i;
+        if (r < (uint32_t)n_reads) {
+            seed_off[r] = run;
+            for (uint32_t t = (run + 63u) >> 6; (t << 6) < run + v[i] && t < n_tile_read; t++) tile_read[t] = r;       // (a read with seeds; tiles beyond the capacity: the batch runs again)
+        }
+        // units with more seeds than k_pair's lanes hold: a pair = reads 2k, 2k+1 of this thread; order of the list is irrelevant
+        const bool unit_end = paired ? (i & 1) == 1 : true;
+        const uint32_t useeds = paired ? ((i & 1) ? v[i - ((i & 1) ? 1 : 0)] + v[i] : 0u) : v[i];
+        const bool heavy = unit_end && r < (uint32_t)n_reads && useeds > (uint32_t)UNIT_MAX_SEEDS;
+        const unsigned long long m = __ballot(heavy);
+        if (m) {
+            unsigned int hb = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) hb = atomicAdd(n_heavy, (unsigned int)__popcll(m));
+            hb = (unsigned int)__shfl((int)hb, leader, 64);
+            if (heavy) heavy_list[hb + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = paired ? r >> 1 : r;
+        }
+        run += v[i];
+    }
+    if (tile == gridDim.x - 1 && threadIdx.x == 0) {
+        const uint32_t total = base.x + tot.x;
+        seed_off[n_reads] = total;
+        if (total_copy) *total_copy = total;
+        if (total > cap) atomicMax(err, DG_E_SEEDS);       // the consumers of these offsets return at once (DG_ABORT); the host grows the buffer
+    }
+}
+
 static std::atomic<uint64_t> g_phase_ns[4];
 static void caps_publish(std::atomic<size_t> &a, size_t v) { size_t cur = a.load(); while (cur < v && !a.compare_exchange_weak(cur, v)) { } }
 static void caps_adopt(size_t &mine, const std::atomic<size_t> &a) { const size_t v = a.load(); if (v > mine) mine = v; }
@@ -188,83 +248,7 @@ static hipError_t scan_u32(dg_ctx *c, const uint32_t *in, uint32_t *out, uint32_
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------
-// work ordering for k_report: reads are binned by a cost key (scored candidates, their seeds,
-// re-seed jobs) with a counting sort, heaviest first, and waves pull 64 reads at a time from that
-// list.  Lanes of one wave then walk similar paths (less divergence) and the heavy tail starts
-// first (longest-processing-time scheduling).
-// ------------------------------------------------------------------------------------------
-#define COST_CLASSES 32
-#define DIAG_DONE DONE_BY_PAIR  // key of the reads k_pair has finished (they sort behind every other class)
-// pass 1: class of every read + per-(class, block) counts, laid out class-major for one scan
-__global__ void __launch_bounds__(256)
-k_cost(int n_reads, int n_blocks, const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
-       uint8_t *__restrict__ key, uint32_t *__restrict__ counts, const int *__restrict__ abort_p)
-{
-    __shared__ uint32_t sh[COST_CLASSES];
-    if (*abort_p >= DG_ABORT) return;
-    if (threadIdx.x < COST_CLASSES) sh[threadIdx.x] = 0;
-    __syncthreads();
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t k = COST_CLASSES;
-    if (r < n_reads) {
-        const DCand *cd = cands + seed_off[r];
-        const int nc = (int)ncand[r];
-        // Reads of one class do the same things in the same order, so a wave's lanes stay converged in k_report:
-        // 0 = waits for k_reseed; 1-4 = some pair is too big for the register-only path (by seed count);
-        // 5-14 = small pairs only, by (live candidates, seeds); 15 = nothing to report  (x 2, see below)
-        // every class is split in two: first the reads with two seeds on different diagonals (an nw_alignment is certain: about one
-        // read in eight, but met in every 64-read chunk while they were mixed in), then the rest
-        uint32_t tot = 0, live = 0; bool has_jobs = false, big = false, nw = false;
-        const bool done = key[r] == DIAG_DONE;            // k_pair has written this read's records already
-        if (!done) for (int i = 0; i < nc; i++) if (cd[i].Score != 0) {
-            live++; tot += (uint32_t)cd[i].n_a; has_jobs = has_jobs || cd[i].job_count > 0; big = big || (cd[i].final_n & 1) != 0; nw = nw || (cd[i].final_n & 2) != 0;
-        }
-        if (has_jobs) k = 0;
-        else if (live == 0) k = 15;
-        else if (big) k = tot > 12 ? 1u : tot > 6 ? 2u : tot > 3 ? 3u : 4u;
-        else if (live >= 3) k = tot > 8 ? 5u : 6u;
-        else if (live == 2) k = tot > 4 ? 7u : tot > 2 ? 8u : 9u;
-        else k = tot >= 5 ? 10u : tot == 4 ? 11u : tot == 3 ? 12u : tot == 2 ? 13u : 14u;
-        k = done ? (uint32_t)DIAG_DONE : 2 * k + ((nw || k == 15) ? 0u : 1u);    // (class 15 not done cannot occur; its key 30 keeps 31 for the done reads)
-        key[r] = (uint8_t)k;
-    }
-    // only the classes that occur in the wave (two to four of the 32: most reads are "done")
-    for (unsigned long long rem = __ballot(k < COST_CLASSES); rem; ) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)k, __ffsll((long long)rem) - 1);
-        const unsigned long long m = __ballot(k == c);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&sh[c], (uint32_t)__popcll(m));
-        rem &= ~m;
-    }
-    __syncthreads();
-    if (threadIdx.x < COST_CLASSES) counts[(size_t)threadIdx.x * n_blocks + blockIdx.x] = sh[threadIdx.x];
-}
-// pass 2 (after an exclusive scan of counts): stable scatter -- inside a class reads keep index order
-__global__ void __launch_bounds__(256)
-k_cost_scatter(int n_reads, int n_blocks, const uint8_t *__restrict__ key, const uint32_t *__restrict__ offs, uint32_t *__restrict__ perm, const int *__restrict__ abort_p)
-{
-    __shared__ uint32_t wave_cnt[4][COST_CLASSES];
-    if (*abort_p >= DG_ABORT) return;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const uint32_t k = r < n_reads ? key[r] : COST_CLASSES;
-    uint32_t my_rank = 0;
-    if (ln < COST_CLASSES) wave_cnt[wv][ln] = 0;
-    for (unsigned long long rem = __ballot(k < COST_CLASSES); rem; ) {          // only the classes that occur in the wave
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)k, __ffsll((long long)rem) - 1);
-        const unsigned long long m = __ballot(k == c);
-        if (k == c) my_rank = (uint32_t)__popcll(m & ((1ull << ln) - 1ull));
-        if (ln == 0) wave_cnt[wv][c] = (uint32_t)__popcll(m);
-        rem &= ~m;
-    }
-    __syncthreads();
-    if (r < n_reads) {
-        uint32_t before = 0;
-        for (int w = 0; w < wv; w++) before += wave_cnt[w][k];
-        perm[offs[(size_t)k * n_blocks + blockIdx.x] + before + my_rank] = (uint32_t)r;
-    }
-}
-
+#define COST_CLASSES DG_COST_CLASSES       // (the work order of k_report: keys and histogram in k_prep, the list in k_order_reads: dg_reseed.h)
 // ------------------------------------------------------------------------------------------
 // k_report: persistent waves; one lane = one read at a time (GenMappingReport,
 // AlignmentCandidates.cpp:1079-1207); results go to the read's dg_read_out / dg_report_out slots
@@ -302,7 +286,7 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
     // out in groups of g < 64 reads, g ~ one group per wave: 64 such reads in ONE wave were the kernel's critical
     // path (one chunk = 7 M cycles, as long as everything else together).
     const unsigned int n_jobreads = *n_jobreads_p;
-    const unsigned int lo = job_part ? 0u : n_jobreads, hi = job_part ? n_jobreads : *single_first_p;   // key 31: finished by k_report_diag
+    const unsigned int lo = job_part ? 0u : n_jobreads, hi = job_part ? n_jobreads : *single_first_p;   // (end of the list: reads that k_pair finished are not on it)
     const unsigned int n_heavy = job_part ? hi - lo : *heavy_end_p - n_jobreads;
     // few heavy reads (the usual case: some dozens per million): ONE read per wave, lane = candidate
     const bool cpar = n_heavy <= 2u * gridDim.x;
@@ -836,9 +820,8 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
 #define TICK(name) do { if (c->n_t < N_TIMERS) { c->tname[c->n_t] = name; HIPCHK(hipEventRecord(c->ev[c->n_t + 1], c->stream)); c->n_t++; } } while (0)
 
 // the kernels of the seeding + locate stage up to the located, unsorted seeds (shared by dg_batch_run and dg_probe_seeds)
-static int enqueue_seeding(dg_ctx *c, int n, int H, bool timed)
+static int enqueue_seeding(dg_ctx *c, int n, int H, bool timed, bool paired_units)
 {
-    const uint32_t nb = (uint32_t)((n + 255) / 256);
     HIPCHK(c->hits.ensure((size_t)n * H)); HIPCHK(c->nhits.ensure(n)); HIPCHK(c->nseeds.ensure(n)); HIPCHK(c->seed_off.ensure((size_t)n + 1));
     if (c->shared_caps) caps_adopt(c->cap_seeds, c->shared_caps->seeds);
     if (c->cap_seeds < (size_t)n * 3 + 1024) c->cap_seeds = (size_t)n * 3 + 1024;              // first guess: ~2.5 seeds per read; grows by itself
@@ -846,9 +829,15 @@ static int enqueue_seeding(dg_ctx *c, int n, int H, bool timed)
     if (timed) c->tname[c->n_t] = "k_encode";
     HIPCHK(launch_seed(c, n, H, timed ? c->ev[c->n_t + 1] : nullptr));
     if (timed) { c->n_t++; TICK("k_seed"); }
-    HIPCHK(scan_u32(c, c->nseeds.p, c->seed_off.p, (uint32_t)n, &c->d_sizes->total_seeds, (uint32_t)c->cap_seeds, DG_E_SEEDS));
-    if (timed) TICK("scan_seeds");
-    k_tile_reads<<<nb, 256, 0, c->stream>>>(n, c->seed_off.p, c->tile_read.p, c->d_err);
+    {
+        const int paired = (paired_units && (n % 2 == 0)) ? 1 : 0;
+        HIPCHK(c->heavy.ensure((size_t)n + 16));
+        const TileScan ts_seed{c->scan_state.p, c->d_tops + TOP_TICKET_SEED, c->scan_epoch, 1u << 20, c->d_sizes->scan_dbg};
+        k_seed_offsets<<<(unsigned)((n + 256 * SO_PER - 1) / (256 * SO_PER)), 256, 0, c->stream>>>(n, paired, c->nseeds.p, c->seed_off.p, c->tile_read.p, (uint32_t)c->tile_read.cap,
+                                                                                                 c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, &c->d_sizes->total_seeds, (uint32_t)c->cap_seeds, ts_seed, c->d_err);
+        HIPCHK(hipGetLastError());
+    }
+    if (timed) TICK("seed_offsets");
     k_locate<<<(unsigned)((c->cap_seeds + 255) / 256), 256, 0, c->stream>>>(c->ix, n, H, c->hits.p, c->tile_read.p, c->seed_off.p, c->seeds.p, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     if (timed) TICK("k_locate");
@@ -866,14 +855,18 @@ k_batch_begin(unsigned long long *ctr, unsigned int *tops, int *err, DSizes *siz
     if (threadIdx.x == 0) *err = 0;
 }
 
-static int zero_batch_state(dg_ctx *c, int n_units)
+// the look-back state of the batch's three single-pass scans in c->scan_state: [seed offsets | k_pair | k_emit_slow]
+static size_t scan_tiles_seed(int n_reads) { return (size_t)(n_reads + 256 * SO_PER - 1) / (256 * SO_PER) + 1; }
+static size_t scan_tiles_pair(int n_units) { return (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1; }
+
+static int zero_batch_state(dg_ctx *c, int n_reads, int n_units)
 {
     k_batch_begin<<<1, 256, 0, c->stream>>>(c->d_ctr, c->d_tops, c->d_err, c->d_sizes);
     HIPCHK(hipGetLastError());
     // the look-back state of the two single-pass scans is NOT zeroed per batch: its words carry the run's epoch (dg_scan.h).
     // Zeroed once, when (re)allocated: epoch 0 is never used.
-    const size_t tiles = (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1, tiles2 = (size_t)(2 * n_units + 255) / 256 + 1;
-    const size_t words = SCAN_WORDS * (tiles + tiles2);
+    const size_t tiles2 = (size_t)(2 * n_units + 255) / 256 + 1;
+    const size_t words = SCAN_WORDS * (scan_tiles_seed(n_reads) + scan_tiles_pair(n_units) + tiles2);
     if (words > c->scan_state.cap) {
         HIPCHK(c->scan_state.ensure(words));
         HIPCHK(hipMemsetAsync(c->scan_state.p, 0, c->scan_state.cap * 8, c->stream));
@@ -895,9 +888,9 @@ static int enqueue_run(dg_ctx *c)
     c->n_t = 0;
     const int H = c->max_rlen / 16 + 1;
     const uint32_t nb = (uint32_t)((n + 255) / 256);
-    { const int zr = zero_batch_state(c, n_units); if (zr) return zr; }
+    { const int zr = zero_batch_state(c, n, n_units); if (zr) return zr; }
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    { const int rc = enqueue_seeding(c, n, H, true); if (rc) return rc; }
+    { const int rc = enqueue_seeding(c, n, H, true, c->pr.paired != 0); if (rc) return rc; }
 
     // capacities of the data-dependent buffers (sticky; see dg_ctx)
     if (c->shared_caps) { caps_adopt(c->cap_rep, c->shared_caps->rep); caps_adopt(c->cap_cig, c->shared_caps->cig); caps_adopt(c->cap_work, c->shared_caps->work); }
@@ -905,15 +898,14 @@ static int enqueue_run(dg_ctx *c)
     if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep;
     if (c->cap_work < (size_t)n * 8 + 65536) c->cap_work = (size_t)n * 8 + 65536;
     const size_t cigcap = (size_t)n * 48 + c->cap_rep * (16 + CIG_SLOT) + 4096, sjcap = (size_t)n * 4 + 1024;
-    HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n)); HIPCHK(c->done.ensure((size_t)n + 16));
+    HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n)); HIPCHK(c->done.ensure((size_t)n + 16));      // done: class key per listed read
     HIPCHK(c->heavy.ensure((size_t)n_units + 16)); HIPCHK(c->slow_units.ensure((size_t)n_units + 16));
     HIPCHK(c->reports.ensure(c->cap_rep + 1)); HIPCHK(c->work.ensure(c->cap_work + 16)); HIPCHK(c->jobs.ensure(c->cap_seeds + 16)); HIPCHK(c->job_lists.ensure(3 * c->jobs.cap + 16));
     HIPCHK(c->cigpool.ensure(cigcap)); HIPCHK(c->cigfinal.ensure(c->cap_cig + 16)); HIPCHK(c->sjpool.ensure(sjcap)); HIPCHK(c->sjfinal.ensure(sjcap));
-    HIPCHK(c->perm.ensure((size_t)n + 16)); HIPCHK(c->hist.ensure((size_t)COST_CLASSES * nb * 2 + 16));
+    HIPCHK(c->perm.ensure((size_t)n + 16));
     unsigned int *tops = c->d_tops;
 
     // units with more seeds than a lane of k_pair holds: a wave each, before k_pair (which needs their candidate counts)
-    k_heavy_list<<<(uint32_t)((n_units + 255) / 256), 256, 0, c->stream>>>(n_units, paired, c->seed_off.p, c->heavy.p, tops + TOP_HEAVY_UNITS, c->d_err);
     k_chain_heavy<<<c->n_cu * 8, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p,
                                                      c->heavy.p, tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
@@ -928,13 +920,13 @@ static int enqueue_run(dg_ctx *c)
     }
 #endif
     TICK("k_chain_heavy");
-    const size_t tiles = (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1;
+    const size_t tiles_s = scan_tiles_seed(n), tiles = scan_tiles_pair(n_units);
     const uint32_t budget = (c->env_scan_budget > 0 && c->attempt_no == 0) ? (uint32_t)c->env_scan_budget : (1u << 20);   // ~2 s of polling
-    TileScan ts_pair{c->scan_state.p, tops + TOP_TICKET_PAIR, c->scan_epoch, budget, c->d_sizes->scan_dbg};
-    TileScan ts_emit{c->scan_state.p + SCAN_WORDS * tiles, tops + TOP_TICKET_EMIT, c->scan_epoch, budget, c->d_sizes->scan_dbg};
+    TileScan ts_pair{c->scan_state.p + SCAN_WORDS * tiles_s, tops + TOP_TICKET_PAIR, c->scan_epoch, budget, c->d_sizes->scan_dbg};
+    TileScan ts_emit{c->scan_state.p + SCAN_WORDS * (tiles_s + tiles), tops + TOP_TICKET_EMIT, c->scan_epoch, budget, c->d_sizes->scan_dbg};
     const int try_fast = (c->env_no_fast || c->ix.n_chr > 0xFFFF) ? 0 : 1;
     k_pair<<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
-        c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p, c->done.p,
+        c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
         c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_pair");
@@ -952,7 +944,7 @@ static int enqueue_run(dg_ctx *c)
     unsigned slow_grid = (unsigned)c->n_cu * 4u;
     if ((size_t)slow_grid * 256 > (size_t)n) slow_grid = nb;
     k_prep<<<slow_grid, 256, 0, c->stream>>>(c->pr, paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work.p, tops + TOP_WORK,
-                                             (uint32_t)c->cap_work, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_err, c->rlen.p);
+                                             (uint32_t)c->cap_work, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_err, c->rlen.p, c->done.p, tops + TOP_CLASS_HIST);
     HIPCHK(hipGetLastError());
     TICK("k_prep");
     // k_reseed runs on a second stream, concurrently with the report of every read that has no re-seeding job; only the job reads wait for it
@@ -968,13 +960,11 @@ static int enqueue_run(dg_ctx *c)
     k_reseed<4><<<c->n_cu * 4, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + 2 * (size_t)jobcap, tops + TOP_RESEED_COUNT + 2, tops + TOP_RESEED_TICKET + 2, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_reseed1, c->stream2));
-    k_cost<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->seed_off.p, c->cands.p, c->ncand.p, c->done.p, c->hist.p, c->d_err);
-    uint32_t *class_offs = c->hist.p + (size_t)COST_CLASSES * nb + 8;
-    HIPCHK(scan_u32(c, c->hist.p, class_offs, COST_CLASSES * nb));
-    k_cost_scatter<<<nb, 256, 0, c->stream>>>(n, (int)nb, c->done.p, class_offs, c->perm.p, c->d_err);
-    const uint32_t *n_jobreads_p = class_offs + (size_t)2 * nb;       // start of class 1 (key 2) = number of class-0 (job) reads
-    const uint32_t *heavy_end_p = class_offs + (size_t)8 * nb;        // start of class 4 (key 8) = end of the heavy classes 1-3
-    const uint32_t *single_first_p = class_offs + (size_t)DIAG_DONE * nb;   // start of key 31: the reads k_pair finished
+    k_order_reads<<<slow_grid, 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->done.p, tops + TOP_CLASS_HIST, tops + TOP_CLASS_FILL, c->perm.p, tops + TOP_ORDER_INFO, c->d_err);
+    HIPCHK(hipGetLastError());
+    const uint32_t *n_jobreads_p = tops + TOP_ORDER_INFO;             // reads of class 0 (they wait for k_reseed)
+    const uint32_t *heavy_end_p = tops + TOP_ORDER_INFO + 1;          // end of the heavy classes 1-3
+    const uint32_t *single_first_p = tops + TOP_ORDER_INFO + 2;       // end of the list
     TICK("order");
     // one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves
     const int blocks_main = blocks > c->n_cu * 4 ? blocks - c->n_cu : blocks;
@@ -1433,17 +1423,16 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
     uint32_t total = 0;
     for (int attempt = 0; ; attempt++) {
         c->n_t = 0;
-        if ((rc = zero_batch_state(c, n))) return rc;
-        if ((rc = enqueue_seeding(c, n, H, false))) return rc;
+        if ((rc = zero_batch_state(c, n, n))) return rc;
+        if ((rc = enqueue_seeding(c, n, H, false, false))) return rc;
         // the production sorters, every read on its own (unpaired): k_chain_heavy for the long lists, k_pair (candidate stage
         // only, sorted seeds written back for every read) for the rest
         HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n)); HIPCHK(c->done.ensure((size_t)n + 16));
         HIPCHK(c->heavy.ensure((size_t)n + 16)); HIPCHK(c->slow_units.ensure((size_t)n + 16)); HIPCHK(c->reports.ensure(16)); HIPCHK(c->cigfinal.ensure(16));
-        k_heavy_list<<<(n + 255) / 256, 256, 0, c->stream>>>(n, 0, c->seed_off.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_err);
         k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
-        TileScan ts{c->scan_state.p, c->d_tops + TOP_TICKET_PAIR, c->scan_epoch, 1u << 20, c->d_sizes->scan_dbg};
+        TileScan ts{c->scan_state.p + SCAN_WORDS * scan_tiles_seed(n), c->d_tops + TOP_TICKET_PAIR, c->scan_epoch, 1u << 20, c->d_sizes->scan_dbg};
         k_pair<<<(unsigned)((n + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
-            c->ix, c->pr, n, 0, 0, 1, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p, c->done.p,
+            c->ix, c->pr, n, 0, 0, 1, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
             c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, 0xFFFFFFFFu, 0xFFFFFFFFu, ts, c->d_sizes, c->d_tops + TOP_CIG, c->d_ctr, c->d_err);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&c->h_tail->sizes, c->d_sizes, sizeof(DSizes), hipMemcpyDeviceToHost, c->stream));

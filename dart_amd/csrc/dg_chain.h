@@ -399,20 +399,3 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
     }
     if (lane == 0 && nc_total) atomicAdd(d_ctr_stripe(ctr) + CTR_CANDS, nc_total);
 }
-
-// list of heavy units (order irrelevant: every unit writes only its own slots)
-__global__ void __launch_bounds__(256)
-k_heavy_list(int n_units, int paired, const uint32_t *__restrict__ seed_off, uint32_t *__restrict__ heavy_list, unsigned int *n_heavy,
-             const int *__restrict__ abort_p)
-{
-    if (*abort_p >= DG_ABORT) return;
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool heavy = u < n_units && d_unit_is_heavy(seed_off, paired, u);
-    const unsigned long long m = __ballot(heavy);
-    if (!m) return;
-    unsigned int base = 0;
-    const int lane = threadIdx.x & 63;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_heavy, (unsigned int)__popcll(m));
-    base = (unsigned int)__shfl((int)base, __ffsll((long long)m) - 1, 64);
-    if (heavy) heavy_list[base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)u;
-}

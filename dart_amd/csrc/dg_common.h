@@ -100,7 +100,7 @@ struct DParams {
 #define DG_E_CIGFINAL 13
 #define DG_E_SCAN 14             // a look-back of a single-pass scan ran out of its poll budget (dg_scan.h): the host logs what it saw and runs the batch again
 #define DG_E_SEEDQ 15            // the seeding kernel's safety net (dg_seedq.h): raised BEFORE k_pair is launched, which then returns at once like on DG_E_SEEDS
-#define DONE_BY_PAIR 31          // done[r]: k_pair finished this read's records (it sorts behind every class of the general path's work order)
+#define DG_COST_CLASSES 32       // k_report's work order: cost classes of the reads on the general path's list (k_prep, dg_reseed.h)
 // sizes the device reports at the end of a batch (one small D2H copy)
 struct DSizes { uint32_t total_seeds, total_rep, total_work, total_cig, total_sj, n_jobs, n_slow_units, n_heavy_units, cig_fast, pad[3];
                 unsigned long long scan_dbg[8]; };      // scan_dbg: what a look-back that ran out of budget saw (dg_scan.h, SCAN_DBG_WORDS)

@@ -786,23 +786,13 @@ k_build_sa_dense(const DIndex ix, int intv, uint64_t n_entries, uint64_t *__rest
 // ---------------------------------------------------------------------------------------------
 // k_locate: SA interval rows -> text positions (bwt_sa :127-137) -> seeds.
 // One wave = 64 consecutive seed OCCURRENCES (a repeat-family read has hundreds, a clean read one
-// or two: per-read work units leave the kernel waiting for its heaviest wave).  k_tile_reads
+// or two: per-read work units leave the kernel waiting for its heaviest wave).  k_seed_offsets (dg_api.hip)
 // records, for every tile of 64 seeds, the read that holds the tile's first seed; the wave loads
 // the scan values of the next 64 reads with one coalesced load and each lane finds its read with a
 // 6-step shuffle search (windows of 64 reads are walked when a tile spans more, i.e. across reads
 // without seeds), then its hit among the read's <= H hits.  Seeds come out coalesced, in
 // (read, hit, SA-interval row) order as in the reference.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_tile_reads(int n_reads, const uint32_t *__restrict__ seed_off, uint32_t *__restrict__ tile_read, const int *__restrict__ abort_p)
-{
-    if (*abort_p >= DG_ABORT) return;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint32_t first = seed_off[r], end = seed_off[r + 1];
-    if (end == first) return;
-    for (uint32_t t = (first + 63) >> 6; (t << 6) < end; t++) tile_read[t] = (uint32_t)r;
-}
 
 // grid = enough waves for the buffer's capacity; the real seed count is read from the scan (seed_off[n_reads])
 __global__ void __launch_bounds__(256)

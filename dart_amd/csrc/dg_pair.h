@@ -376,7 +376,7 @@ __host__ __device__ inline uint32_t d_unit_emit_read(bool first, const DRead &rd
 // scanned offsets are the read-order layout of the records).  Units with more than PU_SEEDS seeds were chained by
 // k_chain_heavy before this launch: they only take part in the scan (ncand from memory) and go on the general path's list.
 //   scan counters: x = reports of the unit, y = 1 if the unit goes to the general path, z = CIGAR ops of a finished unit
-// Outputs for every read: rep_off[r], done[r] (DONE_BY_PAIR: records complete; 0xFF: general path).  Finished units:
+// Outputs for every read: rep_off[r].  Finished units:
 // rout / reports / cigar.  Other units: slow_units[] (ascending), their sorted seeds, DCand records and ncand.
 // The workgroup that drew the last ticket also writes the totals (its inclusive prefix is the grand total).
 // ---------------------------------------------------------------------------------------------
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(PU_THREADS)
 k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast, int write_all_sorted,
        const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen,
        const uint32_t *__restrict__ seed_off, SKey *__restrict__ seeds, DCand *__restrict__ cands, uint32_t *__restrict__ ncand,
-       uint32_t *__restrict__ rep_off, uint8_t *__restrict__ done, uint32_t *__restrict__ slow_units,
+       uint32_t *__restrict__ rep_off, uint32_t *__restrict__ slow_units,
        dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *__restrict__ cigar,
        uint32_t cap_rep, uint32_t cap_cig, TileScan ts, DSizes *sizes, unsigned int *pool_top, unsigned long long *ctr, int *err)
 {
@@ -442,7 +442,6 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
         if (paired) rep_off[r1 + 1] = rep0 + nrep1;
         if (!heavy) n_cands = (unsigned long long)(st.nc[0] + st.nc[1]);
         if (st.fast) {
-            done[r1] = DONE_BY_PAIR; if (paired) done[r1 + 1] = DONE_BY_PAIR;
             if ((uint64_t)rep0 + mine.x > cap_rep) atomicMax(err, DG_E_REPORTS);
             else if (cig0 + st.n_cig > cap_cig) atomicMax(err, DG_E_CIGFINAL);
             else {
@@ -452,7 +451,6 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
                 n_nw = st.n_nw; n_cells = st.n_cells;
             }
         } else {
-            done[r1] = 0xFF; if (paired) done[r1 + 1] = 0xFF;
             slow_units[slow_at] = (uint32_t)u;
             if ((uint64_t)rep0 + mine.x > cap_rep) atomicMax(err, DG_E_REPORTS);       // its reports would not fit either
         }

@@ -35,7 +35,7 @@
 __global__ void __launch_bounds__(256)
 k_prep(const DParams pr, int paired, const uint32_t *__restrict__ slow_units, const DSizes *__restrict__ sizes, const uint32_t *__restrict__ seed_off,
        const SKey *__restrict__ seeds, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, DSeed *__restrict__ work, unsigned int *worktop, uint32_t workcap,
-       DJob *__restrict__ jobs, unsigned int *jobtop, uint32_t jobcap, int *err, const uint16_t *__restrict__ rlen)
+       DJob *__restrict__ jobs, unsigned int *jobtop, uint32_t jobcap, int *err, const uint16_t *__restrict__ rlen, uint8_t *__restrict__ key, unsigned int *class_hist)
 {
     if (*err >= DG_ABORT) return;
     const unsigned int n_items = sizes->n_slow_units * (paired ? 2u : 1u);
@@ -57,6 +57,7 @@ k_prep(const DParams pr, int paired, const uint32_t *__restrict__ slow_units, co
         wave_base = __shfl(wave_base, 0, 64);
         if ((uint64_t)wave_base + wave_total > workcap) { if (lane == 0) atomicMax(err, DG_E_WORK); continue; }   // (worktop keeps the need)
         uint32_t wo = wave_base + incl - need;
+        uint32_t k_tot = 0, k_live = 0; bool k_jobs = false, k_big = false, k_nw = false;     // the read's shape, for k_report's work order (below)
         for (int i = 0; i < nc; i++) {
             DCand &c = cd[i];
             c.final_n = 0; c.n_a = 0; c.job_count = 0; c.job_first = 0;
@@ -80,9 +81,10 @@ k_prep(const DParams pr, int paired, const uint32_t *__restrict__ slow_units, co
                 if (rGaps > PM_MAX || rGaps + pd > PM_MAX) big = 1;
                 if (pd != 0) indel = 2;
             }
-            c.final_n = big | indel;                         // scheduling hints for k_cost only (k_report sets the real value): bit 0 = some
+            c.final_n = big | indel;                         // scheduling hints only (k_report sets the real value): bit 0 = some
                                                              // segment pair is longer than PM_MAX (string path, maybe a wave-wide alignment),
                                                              // bit 1 = two seeds on different diagonals (an nw_alignment is certain)
+            k_live++; k_tot += (uint32_t)n; k_jobs = k_jobs || cnt > 0; k_big = k_big || big != 0; k_nw = k_nw || indel != 0;
             if (cnt == 0) continue;
             const unsigned int first = atomicAdd(jobtop, (unsigned int)cnt);
             if (first + (unsigned int)cnt > jobcap) { atomicMax(err, DG_E_JOBS); continue; }
@@ -101,6 +103,68 @@ k_prep(const DParams pr, int paired, const uint32_t *__restrict__ slow_units, co
                     jobs[first + w++] = j;
                 }
             }
+        }
+        // ---- work order of k_report: the read's cost class (reads of one class do the same things in the same order, so a wave's lanes stay
+        // converged): 0 = waits for k_reseed; 1-4 = some pair is too big for the register-only path (by seed count); 5-14 = small pairs only, by
+        // (live candidates, seeds); 15 = nothing to report.  Every class is split in two: first the reads with two seeds on different
+        // diagonals (an nw_alignment is certain), then the rest.  Round 2 classified all 2 M reads of the batch in two more launches and a
+        // three-launch scan (k_cost / k_cost_scatter); only the ~5 % on this list need an order.
+        uint32_t kc = DG_COST_CLASSES;
+        if (on) {
+            if (k_jobs) kc = 0;
+            else if (k_live == 0) kc = 15;
+            else if (k_big) kc = k_tot > 12 ? 1u : k_tot > 6 ? 2u : k_tot > 3 ? 3u : 4u;
+            else if (k_live >= 3) kc = k_tot > 8 ? 5u : 6u;
+            else if (k_live == 2) kc = k_tot > 4 ? 7u : k_tot > 2 ? 8u : 9u;
+            else kc = k_tot >= 5 ? 10u : k_tot == 4 ? 11u : k_tot == 3 ? 12u : k_tot == 2 ? 13u : 14u;
+            kc = 2 * kc + ((k_nw || kc == 15) ? 0u : 1u);
+            key[r] = (uint8_t)kc;
+        }
+        for (unsigned long long rem = __ballot(kc < DG_COST_CLASSES); rem; ) {          // only the classes that occur in the wave
+            const uint32_t cls = (uint32_t)__builtin_amdgcn_readlane((int)kc, __ffsll((long long)rem) - 1);
+            const unsigned long long m = __ballot(kc == cls);
+            if (lane == 0) atomicAdd(class_hist + cls, (unsigned int)__popcll(m));
+            rem &= ~m;
+        }
+    }
+}
+
+// k_report's work list from the keys and the class histogram of k_prep: perm = the listed reads grouped by class, class 0 first (any order
+// inside a class: the order decides who computes what when, never a result); info[0] = reads of class 0 (they wait for k_reseed), info[1] =
+// end of the heavy classes 1-3 (keys 2..7), info[2] = all listed reads.  One launch over the list.
+__global__ void __launch_bounds__(256)
+k_order_reads(int paired, const uint32_t *__restrict__ slow_units, const DSizes *__restrict__ sizes, const uint8_t *__restrict__ key, const unsigned int *__restrict__ class_hist,
+              unsigned int *class_fill, uint32_t *__restrict__ perm, uint32_t *__restrict__ info, const int *__restrict__ abort_p)
+{
+    __shared__ uint32_t s_start[DG_COST_CLASSES];
+    if (*abort_p >= DG_ABORT) return;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {                                        // exclusive scan of the 32 class totals by the first wave
+        uint32_t v = lane < DG_COST_CLASSES ? class_hist[lane] : 0u, incl = v;
+        for (int o = 1; o < DG_COST_CLASSES; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (lane < DG_COST_CLASSES) s_start[lane] = incl - v;
+        if (blockIdx.x == 0) {
+            if (lane == 1) info[0] = incl;                         // keys 0 and 1 = class 0
+            if (lane == 7) info[1] = incl;                         // keys 0..7 = classes 0..3
+            if (lane == DG_COST_CLASSES - 1) info[2] = incl;
+        }
+    }
+    __syncthreads();
+    const unsigned int n_items = sizes->n_slow_units * (paired ? 2u : 1u);
+    for (unsigned int base = blockIdx.x * blockDim.x; base < n_items; base += gridDim.x * blockDim.x) {
+        const unsigned int it = base + threadIdx.x;
+        const bool on = it < n_items;
+        const uint32_t r = on ? (paired ? 2u * slow_units[it >> 1] + (it & 1u) : slow_units[it]) : 0u;
+        const uint32_t kc = on ? key[r] : DG_COST_CLASSES;
+        for (unsigned long long rem = __ballot(kc < DG_COST_CLASSES); rem; ) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const uint32_t cls = (uint32_t)__builtin_amdgcn_readlane((int)kc, leader);
+            const unsigned long long m = __ballot(kc == cls);
+            uint32_t b = 0;
+            if (lane == leader) b = atomicAdd(class_fill + cls, (unsigned int)__popcll(m));
+            b = (uint32_t)__shfl((int)b, leader, 64);
+            if (kc == cls) perm[s_start[cls] + b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+            rem &= ~m;
         }
     }
 }

@@ -8,7 +8,7 @@
 //
 // Protocol (per scanned launch): workgroups take a ticket (tile number = order of arrival, so every predecessor of a tile has
 // started and never waits for a later one -- no deadlock whatever order the hardware starts workgroups in).  A tile's state is
-// three 64-bit words, one per counter, each self-describing and written with one store:
+// four 64-bit words, one per counter, each self-describing and written with one store:
 //   word k = tag << 32 | value_k          tag = epoch << 2 | status
 //   status 1 = the values are the tile's own totals, 2 = the inclusive prefix up to and including the tile
 //   epoch    = the number of the run (dg_ctx::scan_epoch, 30 bits, never 0, different for every enqueued run of a context)
@@ -23,8 +23,8 @@
 #include "dg_common.h"
 
 struct TileScan { unsigned long long *w; unsigned int *ticket; uint32_t epoch, budget; unsigned long long *dbg; };
-struct Triple { uint32_t x, y; uint64_t z; };        // (z stays 64-bit for the callers' arithmetic; a published z is < 2^32: it counts CIGAR ops of one batch)
-#define SCAN_WORDS 3            // state words per tile
+struct Triple { uint32_t x, y; uint64_t z; uint32_t w; };   // four counters (the name is older than the fourth); z stays 64-bit for the callers' arithmetic, a published z is < 2^32: it counts CIGAR ops of one batch
+#define SCAN_WORDS 4            // state words per tile
 #define SCAN_DBG_WORDS 8        // what a poller that ran out of budget saw: tile, stuck predecessor, its three words, epoch, polls, lane
 
 // RELAXED on purpose: a state word carries its whole message (tag + value in one 64-bit access that goes to the device-coherent
@@ -34,11 +34,11 @@ __device__ __forceinline__ unsigned long long ts_load(const unsigned long long *
 __device__ __forceinline__ void ts_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __host__ __device__ __forceinline__ uint32_t ts_tag(uint32_t epoch, int st) { return (epoch << 2) | (uint32_t)st; }
 __host__ __device__ __forceinline__ unsigned long long ts_pack(uint32_t tag, uint32_t v) { return ((unsigned long long)tag << 32) | (unsigned long long)v; }
-__device__ __forceinline__ void ts_publish(const TileScan &ts, unsigned int tile, int st, uint32_t x, uint32_t y, uint32_t z)
+__device__ __forceinline__ void ts_publish(const TileScan &ts, unsigned int tile, int st, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
 {
     const uint32_t tag = ts_tag(ts.epoch, st);
     unsigned long long *p = ts.w + (size_t)tile * SCAN_WORDS;
-    ts_store(p, ts_pack(tag, x)); ts_store(p + 1, ts_pack(tag, y)); ts_store(p + 2, ts_pack(tag, z));
+    ts_store(p, ts_pack(tag, x)); ts_store(p + 1, ts_pack(tag, y)); ts_store(p + 2, ts_pack(tag, z)); ts_store(p + 3, ts_pack(tag, w));
 }
 
 // ticket of this workgroup (call once, by every thread; sh = one u32 of LDS)
@@ -50,25 +50,25 @@ __device__ __forceinline__ unsigned int d_tile_ticket(const TileScan &ts, unsign
 }
 
 // exclusive prefix of this tile's totals over all earlier tiles; every thread of the workgroup calls it with the tile's totals
-// (only thread 0's copy is published) and gets the same result.  sh = 4 u64 of LDS.  Workgroups must have >= 64 threads.
+// (only thread 0's copy is published) and gets the same result.  sh = 4 u64 of LDS (behind d_block_exclusive's 16).  Workgroups must have >= 64 threads.
 // Only DG_E_SCAN (another poller of this run gave up: the host runs the batch again) ends a look-back early; a capacity overflow
 // raised inside the same launch does not -- the totals the host grows its buffers from stay exact.
 __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile, Triple own, unsigned long long *sh, int *err)
 {
     if (threadIdx.x < 64) {
         const int lane = (int)threadIdx.x;
-        uint64_t sx = 0, sy = 0, sz = 0;
+        uint64_t sx = 0, sy = 0, sz = 0, sw = 0;
         if (tile > 0) {
-            if (lane == 0) ts_publish(ts, tile, 1, own.x, own.y, (uint32_t)own.z);
+            if (lane == 0) ts_publish(ts, tile, 1, own.x, own.y, (uint32_t)own.z, own.w);
             long long base = (long long)tile - 1;
             unsigned int polls = 0;
             const uint32_t want1 = ts_tag(ts.epoch, 1), want2 = ts_tag(ts.epoch, 2);
             while (true) {
                 const long long t = base - lane;
-                unsigned long long va = ts_pack(want2, 0), vb = va, vc = va;             // before tile 0: an inclusive prefix of nothing
-                if (t >= 0) { const unsigned long long *p = ts.w + (size_t)t * SCAN_WORDS; va = ts_load(p); vb = ts_load(p + 1); vc = ts_load(p + 2); }
-                const uint32_t ta = (uint32_t)(va >> 32), tb = (uint32_t)(vb >> 32), tc = (uint32_t)(vc >> 32);
-                const bool ready = ta == tb && tb == tc && (ta == want1 || ta == want2);   // (a torn triple shows different tags and is polled again)
+                unsigned long long va = ts_pack(want2, 0), vb = va, vc = va, vd = va;    // before tile 0: an inclusive prefix of nothing
+                if (t >= 0) { const unsigned long long *p = ts.w + (size_t)t * SCAN_WORDS; va = ts_load(p); vb = ts_load(p + 1); vc = ts_load(p + 2); vd = ts_load(p + 3); }
+                const uint32_t ta = (uint32_t)(va >> 32), tb = (uint32_t)(vb >> 32), tc = (uint32_t)(vc >> 32), td = (uint32_t)(vd >> 32);
+                const bool ready = ta == tb && tb == tc && tc == td && (ta == want1 || ta == want2);   // (a torn state shows different tags and is polled again)
                 const unsigned long long m_incl = __ballot(ready && ta == want2), m_wait = __ballot(!ready);
                 int upto = -1;                                                          // lanes 0..upto are summed; -1 = poll again
                 bool done = false;
@@ -77,9 +77,10 @@ __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile,
                     if (!(m_wait & ((1ull << f) - 1ull))) { upto = f; done = true; }
                 } else if (!m_wait) upto = 63;
                 if (upto >= 0) {
-                    uint64_t x = lane <= upto ? (va & 0xFFFFFFFFull) : 0, y = lane <= upto ? (vb & 0xFFFFFFFFull) : 0, z = lane <= upto ? (vc & 0xFFFFFFFFull) : 0;
-                    for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); z += __shfl_xor(z, o, 64); }
-                    sx += x; sy += y; sz += z;
+                    uint64_t x = lane <= upto ? (va & 0xFFFFFFFFull) : 0, y = lane <= upto ? (vb & 0xFFFFFFFFull) : 0, z = lane <= upto ? (vc & 0xFFFFFFFFull) : 0,
+                             w = lane <= upto ? (vd & 0xFFFFFFFFull) : 0;
+                    for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); z += __shfl_xor(z, o, 64); w += __shfl_xor(w, o, 64); }
+                    sx += x; sy += y; sz += z; sw += w;
                     if (done) break;
                     base -= 64;
                 } else {
@@ -95,7 +96,7 @@ __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile,
                         // the nearest predecessor this wave still waits for, and what its words look like from here
                         const int stuck = __ffsll((long long)m_wait) - 1;
                         if (lane == stuck && ts.dbg && atomicCAS(ts.dbg, 0ull, (unsigned long long)tile + 1ull) == 0ull) {
-                            ts.dbg[1] = (unsigned long long)t; ts.dbg[2] = va; ts.dbg[3] = vb; ts.dbg[4] = vc;
+                            ts.dbg[1] = (unsigned long long)t; ts.dbg[2] = va; ts.dbg[3] = vb; ts.dbg[4] = vc ^ (vd & 0xFFFFFFFFull);      // (the fourth word's value folded in: it carries the same tag)
                             ts.dbg[5] = ts.epoch; ts.dbg[6] = polls; ts.dbg[7] = (unsigned long long)lane;
                         }
                         if (lane == 0) atomicMax(err, DG_E_SCAN);
@@ -106,34 +107,34 @@ __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile,
             }
         }
         if (lane == 0) {
-            ts_publish(ts, tile, 2, (uint32_t)sx + own.x, (uint32_t)sy + own.y, (uint32_t)(sz + own.z));
-            sh[0] = sx; sh[1] = sy; sh[2] = sz;
+            ts_publish(ts, tile, 2, (uint32_t)sx + own.x, (uint32_t)sy + own.y, (uint32_t)(sz + own.z), (uint32_t)sw + own.w);
+            sh[0] = sx; sh[1] = sy; sh[2] = sz; sh[3] = sw;
         }
     }
     __syncthreads();
-    Triple r; r.x = (uint32_t)sh[0]; r.y = (uint32_t)sh[1]; r.z = sh[2];
+    Triple r; r.x = (uint32_t)sh[0]; r.y = (uint32_t)sh[1]; r.z = sh[2]; r.w = (uint32_t)sh[3];
     __syncthreads();
     return r;
 }
 
-// exclusive prefix of three per-thread counts inside a 256-thread workgroup + the workgroup totals.  sh = 3 * 4 u64 of LDS.
+// exclusive prefix of four per-thread counts inside a 256-thread workgroup + the workgroup totals.  sh = 4 * 4 u64 of LDS.
 __device__ inline Triple d_block_exclusive(Triple v, Triple &total, unsigned long long *sh)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    uint64_t x = v.x, y = v.y, z = v.z;
+    uint64_t x = v.x, y = v.y, z = v.z, q = v.w;
     for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t px = __shfl_up(x, o, 64), py = __shfl_up(y, o, 64), pz = __shfl_up(z, o, 64);
-        if (lane >= o) { x += px; y += py; z += pz; }
+        const uint64_t px = __shfl_up(x, o, 64), py = __shfl_up(y, o, 64), pz = __shfl_up(z, o, 64), pq = __shfl_up(q, o, 64);
+        if (lane >= o) { x += px; y += py; z += pz; q += pq; }
     }
-    if (lane == 63) { sh[wv] = x; sh[4 + wv] = y; sh[8 + wv] = z; }
+    if (lane == 63) { sh[wv] = x; sh[4 + wv] = y; sh[8 + wv] = z; sh[12 + wv] = q; }
     __syncthreads();
-    uint64_t bx = 0, by = 0, bz = 0, tx = 0, ty = 0, tz = 0;
+    uint64_t bx = 0, by = 0, bz = 0, bq = 0, tx = 0, ty = 0, tz = 0, tq = 0;
     for (int w = 0; w < nw; w++) {
-        if (w < wv) { bx += sh[w]; by += sh[4 + w]; bz += sh[8 + w]; }
-        tx += sh[w]; ty += sh[4 + w]; tz += sh[8 + w];
+        if (w < wv) { bx += sh[w]; by += sh[4 + w]; bz += sh[8 + w]; bq += sh[12 + w]; }
+        tx += sh[w]; ty += sh[4 + w]; tz += sh[8 + w]; tq += sh[12 + w];
     }
     __syncthreads();
-    total.x = (uint32_t)tx; total.y = (uint32_t)ty; total.z = tz;
-    Triple r; r.x = (uint32_t)(bx + x - v.x); r.y = (uint32_t)(by + y - v.y); r.z = bz + z - v.z;
+    total.x = (uint32_t)tx; total.y = (uint32_t)ty; total.z = tz; total.w = (uint32_t)tq;
+    Triple r; r.x = (uint32_t)(bx + x - v.x); r.y = (uint32_t)(by + y - v.y); r.z = bz + z - v.z; r.w = (uint32_t)(bq + q - v.w);
     return r;
 }

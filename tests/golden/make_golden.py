@@ -24,6 +24,12 @@ CASES = {
                           spliced=0.3, paired=True, sub=0.005, flags=[["-mis", "5"], ["-mis", "2", "-min_intron", "10", "-max_intron", "200000"]]),
 }
 
+# chr20-sized genomes whose reference-built index files are pinned by digest (the files themselves are ~100 MB)
+BIG_INDEX = {
+    "chr20_planted": dict(lengths=[64444167], gseed=20, names=["chr20"], model="planted"),       # = bench.py --genome chr20
+    "chr20_human": dict(lengths=[64444167], gseed=20, names=["chr20"], model="human"),           # = bench.py --genome chr20 --genome-model human
+}
+
 def case_inputs(spec, d):
     g = synth.make_genome(spec["lengths"], seed=spec["gseed"], repeat_scale=spec["rscale"], n_introns=spec["nintr"])
     m1, m2 = synth.make_reads(g, spec["npairs"], rlen=spec["rlen"], seed=spec["rseed"], spliced_frac=spec["spliced"],
@@ -116,7 +122,19 @@ def main():
     out = out[out.index("\n") + 1:] if out.startswith("Load") else out
     with gzip.GzipFile(os.path.join(HERE, "bwt_search_known_answers.txt.gz"), "wb", mtime=0) as f:
         f.write(out.encode())
-    json.dump({"cases": CASES, "manifest": manifest}, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+    # the reference indexer's files for genomes of the bench's size class (64 444 167 bp, one chromosome: BASELINE configs[1]) -- the large
+    # paths of the GPU index builder (tests/test_gpu_index.py::test_gpu_index_builder_matches_reference_indexer_at_chr20_size) are pinned on
+    # these, not only the <= 500 kb cases above.  ~40 s of the reference's bwt_index per genome.
+    big = {}
+    for bname, kw in BIG_INDEX.items():
+        g = synth.make_genome(kw["lengths"], seed=kw["gseed"], names=kw["names"], model=kw["model"])
+        fa = os.path.join(d, bname + ".fa"); g.write_fasta(fa)
+        subprocess.check_call([IDX, fa, os.path.join(d, bname)], stdout=subprocess.DEVNULL)
+        big[bname] = {"spec": kw, "codes_sha256": digest(g.codes),
+                      "index_sha256": {ext: hashlib.sha256(open(os.path.join(d, bname + "." + ext), "rb").read()).hexdigest() for ext in ("bwt", "sa", "pac", "ann", "amb")}}
+        for ext in ("fa", "bwt", "sa", "pac", "ann", "amb"):
+            os.remove(os.path.join(d, bname + "." + ext))
+    json.dump({"cases": CASES, "manifest": manifest, "big_index": big}, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     print("golden written:", sorted(os.listdir(HERE)))
 
 if __name__ == "__main__":

@@ -28,6 +28,28 @@ def test_gpu_index_builder_matches_reference_indexer(name, sorter, workdir, monk
         assert common.sha(prefix + "." + ext) == want, "GPU-built .%s differs from the reference bwt_index output (%s sorter)" % (ext, sorter)
 
 
+@pytest.mark.parametrize("sorter", ["plain", "bucketed"])
+@pytest.mark.parametrize("name", sorted(common.MANIFEST["big_index"]))
+def test_gpu_index_builder_matches_reference_indexer_at_chr20_size(name, sorter, workdir, monkeypatch):
+    """the same at the bench's size class: a 64 444 167 bp chromosome (129 M-symbol text, 2^27 sampled rows ...), the planted-repeat genome of
+    `bench.py --genome chr20` and the human-like one (deep repeats: many doubling rounds), each through both suffix sorters -- the GPU-built
+    .bwt/.sa/.pac/.ann/.amb must be the bytes the REFERENCE's bwt_index wrote for that genome (digests made by tests/golden/make_golden.py in
+    the container that has the reference; the files are ~100 MB).  The GRCh38-sized tests use the same builder on a larger text."""
+    import hashlib
+    ent = common.MANIFEST["big_index"][name]; spec = ent["spec"]
+    g = synth.make_genome(spec["lengths"], seed=spec["gseed"], names=spec["names"], model=spec["model"])
+    assert hashlib.sha256(g.codes.tobytes()).hexdigest() == ent["codes_sha256"], "synthetic generator drifted from the genome the reference indexed"
+    if sorter == "bucketed":
+        monkeypatch.setenv("DART_SA_BUCKETED", "1")
+    else:
+        monkeypatch.delenv("DART_SA_BUCKETED", raising=False)
+    prefix = os.path.join(workdir, "gpuidx_%s_%s" % (name, sorter))
+    index_build.build_index_from_genome(g, prefix, device="cuda")
+    for ext, want in ent["index_sha256"].items():
+        assert common.sha(prefix + "." + ext) == want, "GPU-built .%s differs from the reference bwt_index output (%s, %s sorter)" % (ext, name, sorter)
+        os.remove(prefix + "." + ext)
+
+
 def test_gpu_radix_sort_matches_stable_sort():
     """dg_sort_pairs (dart_amd/csrc/dg_sort.h), the index builder's sorter: random keys of several widths and counts (not multiples of
     the 4096-pair tile, heavy duplicates, a single distinct key) against torch's stable sort -- keys AND the order of equal keys"""
