@@ -64,7 +64,7 @@ struct dg_ctx {
     DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint32_t> job_lists; DBuf<uint8_t> done; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
-    DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c; DBuf<uint32_t> cig_cnt, cig_off, cig_c;     // compact download: records, stored-op counts / offsets / ops
+    DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c; DBuf<uint32_t> cig_c;     // compact records and their stored CIGAR ops (written by k_pair / k_emit_slow)
     DBuf<unsigned char> ws;
     DBuf<unsigned long long> scan_state;
     uint32_t scan_epoch = 0;      // number of the enqueued run, carried by every state word of its single-pass scans (dg_scan.h); never 0
@@ -74,14 +74,14 @@ struct dg_ctx {
     struct SharedCaps { std::atomic<size_t> seeds{0}, rep{0}, work{0}, cig{0}; } *shared_caps = nullptr;
     bool owns_shared_caps = false;
     unsigned long long *d_ctr = nullptr; unsigned int *d_tops = nullptr; int *d_err = nullptr; DSizes *d_sizes = nullptr; unsigned int *d_input_bad = nullptr;
-    struct HostTail { DSizes sizes; int err; unsigned int input_bad; unsigned int tops[N_TOPS]; uint64_t ctr_stripes[CTR_STRIPES * CTR_STRIDE]; } *h_tail = nullptr;   // pinned
+    struct HostTail { DSizes sizes; int err; unsigned int input_bad; unsigned int tops[N_TOPS]; unsigned long long ctr[CTR_STRIDE]; } *h_tail = nullptr;   // page-locked; written by k_batch_end
     size_t used[3] = {0, 0, 0};
     bool enqueued = false;
     // timings
     hipEvent_t ev[N_TIMERS + 1]; const char *tname[N_TIMERS]; int n_t = 0; float tms[N_TIMERS];
     uint64_t counters[CTR_N];
     uint64_t reruns_capacity = 0, reruns_scan = 0;      // since dg_init / dg_clone
-    bool pack_in_run = false, packed_valid = false;     // compact records: built inside the run / present for the batch that ran last
+    bool want_compact = true, packed_valid = false;     // compact records: written by this run's kernels too / present for the batch that ran last
     int n_cu = 256, runs_of_last_batch = 0, attempt_no = 0;
     // environment switches, read once per context (not per batch)
     int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
@@ -108,7 +108,7 @@ static int fail(dg_ctx *c, int code, const char *what, hipError_t e)
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(c, DG_ERR_HIP, #call, _e); } while (0)
 
 // ------------------------------------------------------------------------------------------
-// small utility kernels: exclusive scan (3 phases), field extraction, compaction
+// small utility kernels: exclusive scan in three phases (the index builder's sorter, dg_sort_pairs; the mapping path scans in single passes, dg_scan.h)
 // ------------------------------------------------------------------------------------------
 #define SCAN_TILE 2048
 __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t *in, uint32_t *out, uint32_t *tile_sums, uint32_t n)
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256)
 k_seed_offsets(int n_reads, int paired, const uint32_t *__restrict__ nseeds, uint32_t *__restrict__ seed_off, uint32_t *__restrict__ tile_read, uint32_t n_tile_read,
                uint32_t *__restrict__ heavy_list, unsigned int *n_heavy, uint32_t *total_copy, uint32_t cap, TileScan ts, int *err)
 {
-    __shared__ unsigned long long s_scan[16];
+    __shared__ unsigned long long s_scan[20];
     __shared__ unsigned int s_tile;
     if (*err >= DG_ABORT) return;          // raised before this launch (the seeding kernel's safety net): nseeds cannot be trusted.  DG_E_SEEDS is raised
                                            // below by the workgroup with the LAST ticket, when every other workgroup is past this line
@@ -189,9 +189,9 @@ k_seed_offsets(int n_reads, int paired, const uint32_t *__restrict__ nseeds, uin
 #pragma unroll
     for (int i = 0; i < SO_PER; i++) sum += v[i];
     Triple mine, tot;
-    mine.x = sum; mine.y = 0; mine.z = 0;
+    mine.x = sum; mine.y = 0; mine.z = 0; mine.w = 0;
     const Triple inb = d_block_exclusive(mine, tot, s_scan);
-    const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 12, err);
+    const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 16, err);
     uint32_t run = base.x + inb.x;
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -235,20 +235,6 @@ static hipError_t wait_stream(dg_ctx *c)
     return e != hipSuccess ? e : hipEventSynchronize(c->ev_wait);
 }
 
-// out[0..n) = exclusive scan of in, out[n] = total (also stored at total_copy; flagged in *err when it exceeds cap)
-static hipError_t scan_u32(dg_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total_copy = nullptr, uint32_t cap = 0, int code = 0)
-{
-    if (n == 0) return hipMemsetAsync(out, 0, 4, c->stream);
-    const uint32_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipError_t e = c->tile_sums.ensure(tiles + 1);
-    if (e != hipSuccess) return e;
-    k_scan_tiles<<<tiles, 256, 0, c->stream>>>(in, out, c->tile_sums.p, n);
-    k_scan_top<<<1, 256, 0, c->stream>>>(c->tile_sums.p, tiles, out + n, total_copy, cap, code ? c->d_err : nullptr, code);
-    k_scan_add<<<(n + 255) / 256, 256, 0, c->stream>>>(out, c->tile_sums.p, n);
-    return hipGetLastError();
-}
-
-#define COST_CLASSES DG_COST_CLASSES       // (the work order of k_report: keys and histogram in k_prep, the list in k_order_reads: dg_reseed.h)
 // ------------------------------------------------------------------------------------------
 // k_report: persistent waves; one lane = one read at a time (GenMappingReport,
 // AlignmentCandidates.cpp:1079-1207); results go to the read's dg_read_out / dg_report_out slots
@@ -384,9 +370,9 @@ k_finalize(const DIndex ix, const DParams pr, int paired, const uint32_t *__rest
 __global__ void __launch_bounds__(256)
 k_emit_slow(int paired, const uint32_t *__restrict__ slow_units, DSizes *sizes, dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports,
             const uint32_t *__restrict__ cigpool, uint32_t *__restrict__ cigfinal, uint32_t cap_cig, const dg_sj_out *__restrict__ sjpool, dg_sj_out *__restrict__ sjfinal,
-            TileScan ts, int *err)
+            TileScan ts, int *err, const uint16_t *__restrict__ rlen, const CompactOut co)
 {
-    __shared__ unsigned long long s_scan[16];
+    __shared__ unsigned long long s_scan[20];
     __shared__ unsigned int s_tile;
     const int e0 = *err;
     if (e0 >= DG_ABORT && e0 != DG_E_CIGFINAL) return;            // (DG_E_CIGFINAL may have been raised by an earlier workgroup of this launch)
@@ -399,20 +385,31 @@ k_emit_slow(int paired, const uint32_t *__restrict__ slow_units, DSizes *sizes, 
     dg_read_out o;
     o.n_rep = 0; o.rep_off = 0; o.n_sj = 0; o.sj_off = 0;
     if (on) o = rout[r];
-    uint32_t ncig = 0;
-    for (int i = 0; i < (on ? o.n_rep : 0); i++) ncig += reports[o.rep_off + i].n_cigar;
+    uint32_t ncig = 0, ncigc = 0;
+    const uint32_t full_match = on ? (uint32_t)rlen[r] << 4 : 0u;                      // "<rlen>M": not stored in the compact op array
+    for (int i = 0; i < (on ? o.n_rep : 0); i++) {
+        const dg_report_out &rp = reports[o.rep_off + i];
+        ncig += rp.n_cigar;
+        if (co.reads) ncigc += (rp.n_cigar == 1u && cigpool[rp.cigar_off] == full_match) ? 0u : rp.n_cigar;
+    }
     Triple mine, tot;
-    mine.x = ncig; mine.y = on ? (uint32_t)o.n_sj : 0u; mine.z = 0;
+    mine.x = ncig; mine.y = on ? (uint32_t)o.n_sj : 0u; mine.z = 0; mine.w = ncigc;
     const Triple inb = d_block_exclusive(mine, tot, s_scan);
-    const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 12, err);
-    const uint32_t cig_fast = sizes->cig_fast;
+    const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 16, err);
+    const uint32_t cig_fast = sizes->cig_fast, cigc_fast = sizes->pad[2];
     if (on) {
-        uint32_t dst = cig_fast + base.x + inb.x;
+        uint32_t dst = cig_fast + base.x + inb.x, dstc = cigc_fast + base.w + inb.w;
+        bool fits = true;
         if ((uint64_t)dst + ncig > cap_cig) atomicMax(err, DG_E_CIGFINAL);
         else for (int i = 0; i < o.n_rep; i++) {
             dg_report_out &rp = reports[o.rep_off + i];
             const uint32_t m = rp.n_cigar, src = rp.cigar_off;
+            const bool plain = m == 1u && cigpool[src] == full_match;
             for (uint32_t k = 0; k < m; k++) cigfinal[dst + k] = cigpool[src + k];
+            if (co.reads) {                                        // the compact form of the same report; its stored ops lie in the op array's second region
+                if (!plain) { for (uint32_t k = 0; k < m; k++) co.cigar[dstc + k] = cigpool[src + k]; dstc += m; }
+                dg_report_c q; fits = d_compact_report(rp, plain, true, q) && fits; co.reports[o.rep_off + i] = q;
+            }
             rp.cigar_off = dst; dst += m;
         }
         if (o.n_sj > 0) {
@@ -420,9 +417,10 @@ k_emit_slow(int paired, const uint32_t *__restrict__ slow_units, DSizes *sizes, 
             for (int k = 0; k < o.n_sj; k++) sjfinal[sd + k] = sjpool[o.sj_off + k];
             rout[r].sj_off = (int32_t)sd;
         }
+        if (co.reads) { dg_read_c oc; fits = d_compact_read(o, oc) && fits; co.reads[r] = oc; if (!fits) *co.bad = 1u; }
     }
     const unsigned int last = n_items ? (n_items - 1u) / 256u : 0u;
-    if (tile == last && threadIdx.x == 0) { sizes->total_cig = cig_fast + base.x + tot.x; sizes->total_sj = base.y + tot.y; }
+    if (tile == last && threadIdx.x == 0) { sizes->total_cig = cig_fast + base.x + tot.x; sizes->total_sj = base.y + tot.y; sizes->pad[0] = cigc_fast + base.w + tot.w; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -465,7 +463,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
     c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_lists.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
-    c->ws.release(); c->scan_state.release(); c->reads_c.release(); c->reports_c.release(); c->cig_cnt.release(); c->cig_off.release(); c->cig_c.release();
+    c->ws.release(); c->scan_state.release(); c->reads_c.release(); c->reports_c.release(); c->cig_c.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
@@ -859,6 +857,23 @@ k_batch_begin(unsigned long long *ctr, unsigned int *tops, int *err, DSizes *siz
 static size_t scan_tiles_seed(int n_reads) { return (size_t)(n_reads + 256 * SO_PER - 1) / (256 * SO_PER) + 1; }
 static size_t scan_tiles_pair(int n_units) { return (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1; }
 
+// the tail of a batch: sizes, status word, tops and the work counters (their 64 stripes summed -- or, for the two maxima, maximised -- here)
+// written straight into the context's page-locked host block by ONE launch (round 2: four device-to-host copies)
+__global__ void __launch_bounds__(256)
+k_batch_end(const DSizes *__restrict__ sizes, const int *__restrict__ err, const unsigned int *__restrict__ tops, const unsigned long long *__restrict__ ctr, dg_ctx::HostTail *out)
+{
+    const int t = threadIdx.x;
+    if (t < (int)(sizeof(DSizes) / 4)) ((uint32_t *)&out->sizes)[t] = ((const uint32_t *)sizes)[t];
+    if (t < N_TOPS) out->tops[t] = tops[t];
+    if (t == 0) out->err = *err;
+    if (t < CTR_STRIDE) {
+        const bool is_max = t == CTR_MAXTRIPS || t == CTR_WTRIPS_MAX;
+        unsigned long long v = 0;
+        for (int s_ = 0; s_ < CTR_STRIPES; s_++) { const unsigned long long x = ctr[s_ * CTR_STRIDE + t]; v = is_max ? (x > v ? x : v) : v + x; }
+        out->ctr[t] = v;
+    }
+}
+
 static int zero_batch_state(dg_ctx *c, int n_reads, int n_units)
 {
     k_batch_begin<<<1, 256, 0, c->stream>>>(c->d_ctr, c->d_tops, c->d_err, c->d_sizes);
@@ -876,7 +891,6 @@ static int zero_batch_state(dg_ctx *c, int n_reads, int n_units)
     return DG_OK;
 }
 
-static int enqueue_pack(dg_ctx *c);      // (compact records, below)
 
 // Enqueues the whole path of the uploaded batch on the context's stream and returns without waiting: no size is read back
 // in between.  finish_run() waits, learns the sizes, and runs the batch again if a capacity was too small.
@@ -925,9 +939,15 @@ static int enqueue_run(dg_ctx *c)
     TileScan ts_pair{c->scan_state.p + SCAN_WORDS * tiles_s, tops + TOP_TICKET_PAIR, c->scan_epoch, budget, c->d_sizes->scan_dbg};
     TileScan ts_emit{c->scan_state.p + SCAN_WORDS * (tiles_s + tiles), tops + TOP_TICKET_EMIT, c->scan_epoch, budget, c->d_sizes->scan_dbg};
     const int try_fast = (c->env_no_fast || c->ix.n_chr > 0xFFFF) ? 0 : 1;
+    // the compact record types are written by the kernels that write the full ones (unless the caller is known to take the full ones: dg_map_batch)
+    CompactOut co{nullptr, nullptr, nullptr, nullptr};
+    if (c->want_compact) {
+        HIPCHK(c->reads_c.ensure((size_t)n + 1)); HIPCHK(c->reports_c.ensure(c->cap_rep + 1)); HIPCHK(c->cig_c.ensure(c->cap_cig + 16));
+        co = CompactOut{c->reads_c.p, c->reports_c.p, c->cig_c.p, &c->d_sizes->pad[1]};
+    }
     k_pair<<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
         c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
-        c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err);
+        c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err, co);
     HIPCHK(hipGetLastError());
     TICK("k_pair");
 
@@ -1002,15 +1022,12 @@ static int enqueue_run(dg_ctx *c)
     k_finalize<<<slow_grid, 256, 0, c->stream>>>(c->ix, c->pr, paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->cands.p, c->ncand.p, c->work.p,
                                                  c->reads_out.p, c->reports.p, c->sjpool.p, (uint32_t)sjcap, tops, c->d_err);
     k_emit_slow<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->reads_out.p, c->reports.p, c->cigpool.p, c->cigfinal.p,
-                                                                    (uint32_t)c->cap_cig, c->sjpool.p, c->sjfinal.p, ts_emit, c->d_err);
+                                                                    (uint32_t)c->cap_cig, c->sjpool.p, c->sjfinal.p, ts_emit, c->d_err, c->rlen.p, co);
     HIPCHK(hipGetLastError());
     TICK("k_finalize");
-    if (c->pack_in_run) { const int prc = enqueue_pack(c); if (prc) return prc; }
     // the tail: sizes, status, counters -> pinned host memory, one copy each
-    HIPCHK(hipMemcpyAsync(&c->h_tail->sizes, c->d_sizes, sizeof(DSizes), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&c->h_tail->err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_tail->tops, c->d_tops, N_TOPS * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_tail->ctr_stripes, c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
+    k_batch_end<<<1, 256, 0, c->stream>>>(c->d_sizes, c->d_err, c->d_tops, c->d_ctr, c->h_tail);
+    HIPCHK(hipGetLastError());
     TICK("tail");
     c->enqueued = true;
     return DG_OK;
@@ -1057,12 +1074,8 @@ static int finish_run(dg_ctx *c, size_t used[3])
     c->enqueued = false;
     for (int i = 0; i < c->n_t; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]); c->tms[i] = ms; }
     if (c->n_t < N_TIMERS) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_reseed0, c->ev_reseed1); c->tname[c->n_t] = "k_reseed(overlapped)"; c->tms[c->n_t] = ms; c->n_t++; }
-    for (int k = 0; k < CTR_N; k++) {
-        uint64_t v = 0;
-        const bool is_max = k == CTR_MAXTRIPS || k == CTR_WTRIPS_MAX;
-        for (int s = 0; s < CTR_STRIPES; s++) { const uint64_t x = c->h_tail->ctr_stripes[s * CTR_STRIDE + k]; v = is_max ? (x > v ? x : v) : v + x; }
-        c->counters[k] = v;
-    }
+    static_assert(CTR_N <= CTR_STRIDE, "the work counters fill one stripe");
+    for (int k = 0; k < CTR_N; k++) c->counters[k] = c->h_tail->ctr[k];
     if (c->counters[CTR_STEPS_ACT] == 0 && c->counters[CTR_SQ_LANES + SQ_STEP]) {
         // k_seed_qf keeps no per-lane tallies of its own work (they cost registers and moves in its loop): what it executed follows from the
         // slots its trips served -- one Occ step (one block; two when the interval straddles blocks, not counted) per slot of a step trip, one
@@ -1075,7 +1088,7 @@ static int finish_run(dg_ctx *c, size_t used[3])
     const int derr = c->h_tail->err;
     if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == DG_E_CIGAR ? "cigar" : (derr == DG_E_SJ ? "splice junction" : "reseed jobs")); return DG_ERR_INTERNAL; }
     c->used[0] = sz.total_rep; c->used[1] = sz.total_cig; c->used[2] = sz.total_sj;
-    c->packed_valid = c->pack_in_run;
+    c->packed_valid = c->want_compact;
     if (used) { used[0] = c->used[0]; used[1] = c->used[1]; used[2] = c->used[2]; }
     return DG_OK;
 }
@@ -1109,68 +1122,6 @@ static int enqueue_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint3
     return DG_OK;
 }
 
-// full records -> compact records (include/dartgpu.h); *bad is raised when a field does not fit.  One thread per read: the read's record,
-// the records of its reports, and per report how many CIGAR ops will be stored (0 for the plain full-length match "<rlen>M")
-__global__ void __launch_bounds__(256)
-k_pack_records(uint32_t n_reads, const dg_read_out *__restrict__ ro, const dg_report_out *__restrict__ po, const uint32_t *__restrict__ cig,
-               const uint16_t *__restrict__ rlen, dg_read_c *__restrict__ rc, dg_report_c *__restrict__ pc, uint32_t *__restrict__ n_ops, uint32_t *bad,
-               const int *__restrict__ abort_p)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_reads || *abort_p >= DG_ABORT) return;
-    const dg_read_out r = ro[i];
-    dg_read_c o;
-    o.score = (uint16_t)r.score; o.sub_score = (uint16_t)r.sub_score; o.mis_num = (uint16_t)r.mis_num; o.mapq = (uint8_t)r.mapq; o.n_sj = (uint8_t)r.n_sj;
-    o.n_rep = (uint16_t)r.n_rep; o.best = (uint16_t)r.best;
-    bool over = (uint32_t)r.score > 0xFFFFu || (uint32_t)r.sub_score > 0xFFFFu || (uint32_t)r.mis_num > 0xFFFFu || (uint32_t)r.mapq > 0xFFu || (uint32_t)r.n_sj > 0xFFu ||
-                (uint32_t)r.n_rep > 0xFFFFu || (uint32_t)r.best > 0xFFFFu;
-    rc[i] = o;
-    const uint32_t full_match = (uint32_t)rlen[i] << 4;                       // "<rlen>M"
-    for (int32_t k = 0; k < r.n_rep; k++) {
-        const uint32_t j = (uint32_t)r.rep_off + (uint32_t)k;
-        const dg_report_out p = po[j];
-        dg_report_c q;
-        q.pos = (int32_t)p.pos; q.aln_score = (uint16_t)p.aln_score; q.flag = (uint16_t)p.flag; q.paired_idx = (int16_t)p.paired_idx;
-        q.chr = p.chr < 0 ? (uint16_t)0xFFFFu : (uint16_t)p.chr; q.sj_type = (int8_t)p.sj_type; q.bdir = (uint8_t)p.bdir; q.pad = 0;
-        const bool plain = p.n_cigar == 1u && cig[p.cigar_off] == full_match;
-        q.n_cigar = plain ? (uint8_t)DG_CIGAR_FULL_MATCH : (uint8_t)p.n_cigar;
-        n_ops[j] = plain ? 0u : p.n_cigar;
-        over = over || p.pos != (int64_t)(int32_t)p.pos || (uint32_t)p.aln_score > 0xFFFFu || (uint32_t)p.flag > 0xFFFFu || p.paired_idx > 32767 || p.paired_idx < -1 ||
-               p.chr >= 0xFFFF || p.n_cigar > 254u || p.sj_type < -128 || p.sj_type > 127 || (uint32_t)p.bdir > 1u;
-        pc[j] = q;
-    }
-    if (over) atomicMax(bad, 1u);
-}
-
-// the stored CIGAR ops, report by report (op_off = exclusive scan of n_ops; the grid covers the report CAPACITY: slots behind the
-// last report hold a count of zero)
-__global__ void __launch_bounds__(256)
-k_pack_cigar(uint32_t n_rep, const dg_report_out *__restrict__ po, const uint32_t *__restrict__ cig, const uint32_t *__restrict__ op_off, uint32_t *__restrict__ out)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_rep) return;
-    const uint32_t a = op_off[j], n = op_off[j + 1] - a;
-    if (n == 0) return;
-    const uint32_t src = po[j].cigar_off;
-    for (uint32_t t = 0; t < n; t++) out[a + t] = cig[src + t];
-}
-
-// records -> compact records, on the context's stream, without knowing a size on the host: thread per read, the scan and the gather
-// run over the report CAPACITY (counts behind the last report are zero).  d_sizes->pad[0] = stored ops, pad[1] = a field did not fit.
-static int enqueue_pack(dg_ctx *c)
-{
-    const size_t n = (size_t)c->n_reads, cap = c->cap_rep;
-    HIPCHK(c->reads_c.ensure(n + 1)); HIPCHK(c->reports_c.ensure(cap + 1)); HIPCHK(c->cig_cnt.ensure(cap + 1)); HIPCHK(c->cig_off.ensure(cap + 2)); HIPCHK(c->cig_c.ensure(c->cap_cig + 1));
-    HIPCHK(hipMemsetAsync(c->cig_cnt.p, 0, (cap + 1) * 4, c->stream));
-    HIPCHK(hipMemsetAsync(&c->d_sizes->pad[0], 0, 8, c->stream));
-    k_pack_records<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((uint32_t)n, c->reads_out.p, c->reports.p, c->cigfinal.p, c->rlen.p, c->reads_c.p, c->reports_c.p, c->cig_cnt.p,
-                                                                      &c->d_sizes->pad[1], c->d_err);
-    HIPCHK(scan_u32(c, c->cig_cnt.p, c->cig_off.p, (uint32_t)cap, &c->d_sizes->pad[0]));
-    k_pack_cigar<<<(unsigned)((cap + 255) / 256), 256, 0, c->stream>>>((uint32_t)cap, c->reports.p, c->cigfinal.p, c->cig_off.p, c->cig_c.p);
-    HIPCHK(hipGetLastError());
-    return DG_OK;
-}
-
 extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3], size_t *n_ops_out)
 {
     if (!c || !caps) return DG_ERR_ARG;
@@ -1182,12 +1133,9 @@ extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *
     }
     const size_t n = (size_t)c->n_reads, nr = c->used[0];
     if (n == 0) return DG_OK;
-    if (!c->packed_valid) {                       // (dg_map_batch_compact packs inside the run: its counts arrive with the batch's sizes)
-        const int rc = enqueue_pack(c);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(&c->h_tail->sizes.pad[0], &c->d_sizes->pad[0], 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(wait_stream(c));
-        c->packed_valid = true;
+    if (!c->packed_valid) {                       // (dg_batch_run and dg_map_batch_compact write the compact records beside the full ones; dg_map_batch* do not)
+        snprintf(c->err, 512, "dg_batch_download_compact: the last batch was mapped through dg_map_batch / dg_map_batch_packed, which write the full records only");
+        return DG_ERR_ARG;
     }
     if (c->h_tail->sizes.pad[1]) { snprintf(c->err, 512, "a record field does not fit the compact types: use dg_batch_download"); return DG_ERR_RANGE; }
     const size_t n_ops = (size_t)c->h_tail->sizes.pad[0];
@@ -1210,9 +1158,7 @@ extern "C" int dg_map_batch_compact(dg_ctx *c, int n_reads, const uint32_t *seq_
     int rc = words ? enqueue_upload_packed(c, n_reads, rlen_all, rlen, words_per_read, words, nlist, n_n) : enqueue_upload(c, n_reads, seq_off, rlen, seq);
     if (rc) return rc;
     const auto t1 = std::chrono::steady_clock::now();
-    c->pack_in_run = true;                                  // the compact records are built at the end of the run: one host round trip less
-    rc = dg_batch_run(c, used);
-    c->pack_in_run = false;
+    rc = dg_batch_run(c, used);                             // (writes the compact records beside the full ones)
     if (rc) return rc;
     const auto t2 = std::chrono::steady_clock::now();
     size_t n_ops = 0;
@@ -1247,7 +1193,10 @@ extern "C" int dg_map_batch(dg_ctx *c, int n_reads, const uint32_t *seq_off, con
     if (!c || !caps) return DG_ERR_ARG;
     int rc = enqueue_upload(c, n_reads, seq_off, rlen, seq);
     if (rc) return rc;
-    if ((rc = dg_batch_run(c, used))) return rc;
+    c->want_compact = false;                                // this caller takes the full records
+    rc = dg_batch_run(c, used);
+    c->want_compact = true;
+    if (rc) return rc;
     return dg_batch_download(c, ro, po, cig, so, caps);
 }
 
@@ -1258,7 +1207,10 @@ extern "C" int dg_map_batch_packed(dg_ctx *c, int n_reads, int rlen_all, const u
     if (!c || !caps) return DG_ERR_ARG;
     int rc = enqueue_upload_packed(c, n_reads, rlen_all, rlen, words_per_read, words, nlist, n_n);
     if (rc) return rc;
-    if ((rc = dg_batch_run(c, used))) return rc;
+    c->want_compact = false;
+    rc = dg_batch_run(c, used);
+    c->want_compact = true;
+    if (rc) return rc;
     return dg_batch_download(c, ro, po, cig, so, caps);
 }
 
@@ -1433,10 +1385,10 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
         TileScan ts{c->scan_state.p + SCAN_WORDS * scan_tiles_seed(n), c->d_tops + TOP_TICKET_PAIR, c->scan_epoch, 1u << 20, c->d_sizes->scan_dbg};
         k_pair<<<(unsigned)((n + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
             c->ix, c->pr, n, 0, 0, 1, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
-            c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, 0xFFFFFFFFu, 0xFFFFFFFFu, ts, c->d_sizes, c->d_tops + TOP_CIG, c->d_ctr, c->d_err);
+            c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, 0xFFFFFFFFu, 0xFFFFFFFFu, ts, c->d_sizes, c->d_tops + TOP_CIG, c->d_ctr, c->d_err, CompactOut{nullptr, nullptr, nullptr, nullptr});
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&c->h_tail->sizes, c->d_sizes, sizeof(DSizes), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(&c->h_tail->err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        k_batch_end<<<1, 256, 0, c->stream>>>(c->d_sizes, c->d_err, c->d_tops, c->d_ctr, c->h_tail);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
         total = c->h_tail->sizes.total_seeds;
         if (c->h_tail->err == DG_E_SEEDS && attempt < 3) { c->cap_seeds = (size_t)total + total / 4 + 1024; continue; }

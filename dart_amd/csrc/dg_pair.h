@@ -334,16 +334,58 @@ __host__ __device__ inline void d_unit_process(const DIndex &ix, const DParams &
     st.fast = true; st.n_cig = n_cig; st.n_nw = n_nw; st.n_cells = n_cells;
 }
 
-// the records of one read of a fast unit, written at their final places; returns the CIGAR ops written
+// ---- the compact record types (include/dartgpu.h: dg_read_c 12 bytes, dg_report_c 16 bytes), written by the kernels that write the full
+// records (k_pair for the units it finishes, k_emit_slow for the general path's) -- round 2 re-read the full records in two more launches
+// and a three-launch scan.  `slow` marks a report whose stored CIGAR ops lie in the second region of the op array (dartgpu.h).
+// Returns false when a field does not fit (the host then answers DG_ERR_RANGE: the caller takes the full records).
+struct CompactOut { dg_read_c *reads; dg_report_c *reports; uint32_t *cigar; unsigned int *bad; };
+__host__ __device__ __forceinline__ bool d_compact_read(const dg_read_out &r, dg_read_c &o)
+{
+    o.score = (uint16_t)r.score; o.sub_score = (uint16_t)r.sub_score; o.mis_num = (uint16_t)r.mis_num; o.mapq = (uint8_t)r.mapq; o.n_sj = (uint8_t)r.n_sj;
+    o.n_rep = (uint16_t)r.n_rep; o.best = (uint16_t)r.best;
+    return !((uint32_t)r.score > 0xFFFFu || (uint32_t)r.sub_score > 0xFFFFu || (uint32_t)r.mis_num > 0xFFFFu || (uint32_t)r.mapq > 0xFFu || (uint32_t)r.n_sj > 0xFFu ||
+             (uint32_t)r.n_rep > 0xFFFFu || (uint32_t)r.best > 0xFFFFu);
+}
+// plain = the CIGAR is the single op "<read length>M" and is not stored
+__host__ __device__ __forceinline__ bool d_compact_report(const dg_report_out &p, bool plain, bool slow, dg_report_c &q)
+{
+    q.pos = (int32_t)p.pos; q.aln_score = (uint16_t)p.aln_score; q.flag = (uint16_t)p.flag; q.paired_idx = (int16_t)p.paired_idx;
+    q.chr = p.chr < 0 ? (uint16_t)0xFFFFu : (uint16_t)p.chr; q.sj_type = (int8_t)p.sj_type; q.bdir = (uint8_t)p.bdir; q.pad = slow ? 1u : 0u;
+    q.n_cigar = plain ? (uint8_t)DG_CIGAR_FULL_MATCH : (uint8_t)p.n_cigar;
+    return !(p.pos != (int64_t)(int32_t)p.pos || (uint32_t)p.aln_score > 0xFFFFu || (uint32_t)p.flag > 0xFFFFu || p.paired_idx > 32767 || p.paired_idx < -1 ||
+             p.chr >= 0xFFFF || p.n_cigar > 254u || p.sj_type < -128 || p.sj_type > 127 || (uint32_t)p.bdir > 1u);
+}
+
+// stored (compact) CIGAR ops of the reports of one read of a fast unit: 0 for a plain full-length match, else 1 + soft clips
+template <int S>
+__host__ __device__ inline uint32_t d_unit_compact_ops(const DRead &rd, const RepLds<S> &p)
+{
+    uint32_t n = 0;
+    for (int i = 0; i < rd.CanNum; i++) {
+        const int s = p.slot(i);
+        if (s == 15) continue;
+        const uint64_t w0 = p.rw[(2 * s) * S], w1 = p.rw[(2 * s + 1) * S];
+        if (!((w0 >> 61) & 1ull)) continue;
+        const uint32_t head = (uint32_t)(w1 & 0xFFFu), tail = (uint32_t)((w1 >> 24) & 0xFFFu);
+        n += (head || tail) ? 1u + (head > 0) + (tail > 0) : 0u;
+    }
+    return n;
+}
+
+// the records of one read of a fast unit, written at their final places; returns the CIGAR ops written.  co.reads != nullptr: the compact
+// records too (the read's at co.reads, its reports at co.reports + rep_off, its stored ops from co.cigar + cigc_off on)
 template <int S>
 __host__ __device__ inline uint32_t d_unit_emit_read(bool first, const DRead &rd, const RepLds<S> &p, uint32_t rep_off, uint32_t cig_off,
-                                                     dg_read_out *rout_r, dg_report_out *reports, uint32_t *cigar)
+                                                     dg_read_out *rout_r, dg_report_out *reports, uint32_t *cigar, const CompactOut &co = CompactOut{nullptr, nullptr, nullptr, nullptr},
+                                                     dg_read_c *rc_r = nullptr, uint32_t cigc_off = 0)
 {
     dg_read_out o;
     o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = rd.mapq; o.n_rep = rd.CanNum; o.best = rd.iBest;
     o.rep_off = (int32_t)rep_off; o.sj_off = 0; o.n_sj = 0;
     *rout_r = o;
-    uint32_t used = 0;
+    bool fits = true;
+    if (co.reads) { dg_read_c oc; fits = d_compact_read(o, oc); *rc_r = oc; }
+    uint32_t used = 0, used_c = 0;
     for (int i = 0; i < rd.CanNum; i++) {
         dg_report_out rp;
         rp.aln_score = 0; rp.sj_type = -1; rp.flag = p.flag(i); rp.paired_idx = p.mate(i); rp.chr = -1; rp.bdir = 0; rp.pos = 0;
@@ -364,10 +406,13 @@ __host__ __device__ inline uint32_t d_unit_emit_read(bool first, const DRead &rd
                 c[m++] = CIG(span, OP_M);
                 if (trail) c[m++] = CIG(trail, OP_S);
                 rp.n_cigar = m; used += m;
+                if (co.reads && m > 1) { for (uint32_t k = 0; k < m; k++) co.cigar[cigc_off + used_c + k] = c[k]; used_c += m; }   // ("<span>M" alone = the whole read: not stored)
             }
         }
         reports[rep_off + (uint32_t)i] = rp;
+        if (co.reads) { dg_report_c q; fits = d_compact_report(rp, rp.n_cigar == 1u, false, q) && fits; co.reports[rep_off + (uint32_t)i] = q; }
     }
+    if (co.reads && !fits) *co.bad = 1u;
     return used;
 }
 
@@ -388,12 +433,12 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
        const uint32_t *__restrict__ seed_off, SKey *__restrict__ seeds, DCand *__restrict__ cands, uint32_t *__restrict__ ncand,
        uint32_t *__restrict__ rep_off, uint32_t *__restrict__ slow_units,
        dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *__restrict__ cigar,
-       uint32_t cap_rep, uint32_t cap_cig, TileScan ts, DSizes *sizes, unsigned int *pool_top, unsigned long long *ctr, int *err)
+       uint32_t cap_rep, uint32_t cap_cig, TileScan ts, DSizes *sizes, unsigned int *pool_top, unsigned long long *ctr, int *err, const CompactOut co)
 {
     __shared__ SKey s_key[PU_SEEDS * PU_THREADS];
     __shared__ uint32_t s_cw[PU_SEEDS * PU_THREADS];
     __shared__ uint64_t s_rw[2 * PU_SLOTS * PU_THREADS];
-    __shared__ unsigned long long s_scan[16];
+    __shared__ unsigned long long s_scan[20];
     __shared__ unsigned int s_tile;
     { const int e0 = *err; if (e0 == DG_E_SEEDS || e0 == DG_E_SEEDQ) return; }   // both are raised before this launch (the only earlier aborts: seeds that
                                                        // do not fit, the seeding kernel's safety net: seed_off / nseeds cannot be trusted); errors
@@ -432,8 +477,15 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
     const uint32_t nrep1 = valid ? (uint32_t)(st.nc[0] > 0 ? st.nc[0] : 1) : 0u, nrep2 = (valid && paired) ? (uint32_t)(st.nc[1] > 0 ? st.nc[1] : 1) : 0u;
     Triple mine, tot;
     mine.x = nrep1 + nrep2; mine.y = (valid && !st.fast) ? 1u : 0u; mine.z = st.fast ? st.n_cig : 0u;
+    uint32_t cc1 = 0;                                    // stored compact ops of mate 1 (mate 2's follow)
+    mine.w = 0;
+    if (co.reads && st.fast) {
+        RepLds<PU_THREADS> q1{cw, rw, st.nc[0], st.flag0[0]}, q2{cw + st.nc[0] * PU_THREADS, rw, st.nc[1], st.flag0[1]};
+        cc1 = d_unit_compact_ops<PU_THREADS>(st.rd[0], q1);
+        mine.w = cc1 + (paired ? d_unit_compact_ops<PU_THREADS>(st.rd[1], q2) : 0u);
+    }
     const Triple inb = d_block_exclusive(mine, tot, s_scan);
-    const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 12, err);
+    const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 16, err);
     const uint32_t rep0 = base.x + inb.x, slow_at = base.y + inb.y;
     const uint64_t cig0 = base.z + inb.z;
     unsigned long long n_cands = 0, n_nw = 0, n_cells = 0;
@@ -446,8 +498,9 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
             else if (cig0 + st.n_cig > cap_cig) atomicMax(err, DG_E_CIGFINAL);
             else {
                 RepLds<PU_THREADS> p1{cw, rw, st.nc[0], st.flag0[0]}, p2{cw + st.nc[0] * PU_THREADS, rw, st.nc[1], st.flag0[1]};
-                const uint32_t c1 = d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar);
-                if (paired) d_unit_emit_read<PU_THREADS>(false, st.rd[1], p2, rep0 + nrep1, (uint32_t)cig0 + c1, rout + r1 + 1, reports, cigar);
+                const uint32_t cigc0 = base.w + inb.w;               // (stored ops never outnumber the full ones: the same capacity covers them)
+                const uint32_t c1 = d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar, co, co.reads ? co.reads + r1 : nullptr, cigc0);
+                if (paired) d_unit_emit_read<PU_THREADS>(false, st.rd[1], p2, rep0 + nrep1, (uint32_t)cig0 + c1, rout + r1 + 1, reports, cigar, co, co.reads ? co.reads + r1 + 1 : nullptr, cigc0 + cc1);
                 n_nw = st.n_nw; n_cells = st.n_cells;
             }
         } else {
@@ -474,6 +527,7 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
     if (tile == gridDim.x - 1 && threadIdx.x == 0) {
         sizes->total_rep = base.x + tot.x; sizes->n_slow_units = base.y + tot.y; sizes->cig_fast = (uint32_t)(base.z + tot.z);
         sizes->total_cig = sizes->cig_fast;                          // (k_emit_slow adds the general path's)
+        sizes->pad[2] = base.w + tot.w;                              // stored compact ops of the finished units: the general path's follow behind them
         *pool_top = (base.x + tot.x) * CIG_SLOT;                     // the report kernel's CIGAR pool: one slot group per report, overflow area behind
     }
     d_wave_add(ctr + CTR_CANDS, n_cands);

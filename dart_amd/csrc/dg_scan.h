@@ -12,7 +12,7 @@
 //   word k = tag << 32 | value_k          tag = epoch << 2 | status
 //   status 1 = the values are the tile's own totals, 2 = the inclusive prefix up to and including the tile
 //   epoch    = the number of the run (dg_ctx::scan_epoch, 30 bits, never 0, different for every enqueued run of a context)
-// A reader accepts a tile when its three words carry the SAME tag and that tag's epoch is the reader's own: a word left by an
+// A reader accepts a tile when its four words carry the SAME tag and that tag's epoch is the reader's own: a word left by an
 // earlier run of the context (any status, any value) is "nothing yet", so the arrays are never zeroed between runs (they are
 // zeroed once, when allocated) and no stale word can be taken for a result -- round 2 zeroed them with a fill launch per batch and
 // trusted that no cached copy of a previous batch's word survived it.  The first wave of the workgroup looks back 64 tiles at a
@@ -25,7 +25,7 @@
 struct TileScan { unsigned long long *w; unsigned int *ticket; uint32_t epoch, budget; unsigned long long *dbg; };
 struct Triple { uint32_t x, y; uint64_t z; uint32_t w; };   // four counters (the name is older than the fourth); z stays 64-bit for the callers' arithmetic, a published z is < 2^32: it counts CIGAR ops of one batch
 #define SCAN_WORDS 4            // state words per tile
-#define SCAN_DBG_WORDS 8        // what a poller that ran out of budget saw: tile, stuck predecessor, its three words, epoch, polls, lane
+#define SCAN_DBG_WORDS 8        // what a poller that ran out of budget saw: tile, stuck predecessor, its words, epoch, polls, lane
 
 // RELAXED on purpose: a state word carries its whole message (tag + value in one 64-bit access that goes to the device-coherent
 // level, `sc1`), nothing else is published through it.  Acquire / release at agent scope cost a `buffer_inv sc1` per poll and a

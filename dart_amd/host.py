@@ -41,8 +41,10 @@ assert READ_OUT.itemsize == 36 and REPORT_OUT.itemsize == 40 and SJ_OUT.itemsize
 
 def expand_compact(reads_c, reports_c, cigar_c, rlen):
     """dg_read_c / dg_report_c arrays + the stored CIGAR ops + the read lengths -> (reads, reports, cigar ops) in the full record
-    dtypes: rep_off / sj_off as running sums, cigar_off as the running sum of the op counts, a report marked DG_CIGAR_FULL_MATCH
-    gets its "<length of its read>M" back.  The reference expansion of include/dartgpu.h's compact layout."""
+    dtypes: rep_off / sj_off as running sums; a report marked DG_CIGAR_FULL_MATCH gets its "<length of its read>M" back; the stored ops
+    lie in two regions (include/dartgpu.h): first, report by report, those of the reports with pad bit 0 clear, then those of the
+    reports with it set -- a report's ops start at the running sum of the stored counts inside its region.  The reference expansion
+    of the compact layout."""
     n = len(reads_c)
     r = np.zeros(n, READ_OUT)
     for f in ("score", "sub_score", "mis_num", "mapq", "n_rep", "best", "n_sj"):
@@ -58,6 +60,7 @@ def expand_compact(reads_c, reports_c, cigar_c, rlen):
         p[f] = reports_c[f]
     p["chr"] = np.where(reports_c["chr"] == 0xFFFF, -1, reports_c["chr"].astype(np.int32))
     plain = reports_c["n_cigar"] == CIGAR_FULL_MATCH
+    second = (reports_c["pad"] & 1) != 0
     stored = np.where(plain, 0, reports_c["n_cigar"]).astype(np.int64)
     full = np.where(plain, 1, reports_c["n_cigar"]).astype(np.int64)
     p["n_cigar"] = full
@@ -66,10 +69,14 @@ def expand_compact(reads_c, reports_c, cigar_c, rlen):
     cig = np.zeros(int(full.sum()), np.uint32)
     owner = np.repeat(np.arange(n), nrep)                         # the read of every report
     cig[off_full[plain]] = np.asarray(rlen, np.uint32)[owner[plain]] << 4
-    st = stored[~plain]                                           # the stored ops lie one report after the other
-    if st.sum():
-        dst = np.repeat(off_full[~plain] - (np.cumsum(st) - st), st) + np.arange(int(st.sum()))
-        cig[dst] = np.asarray(cigar_c[:int(st.sum())], np.uint32)
+    # where a report's stored ops start: the running sum inside its region; the second region begins behind the whole first one
+    s1 = np.where(second, 0, stored); s2 = np.where(second, stored, 0)
+    src = np.where(second, int(s1.sum()) + np.cumsum(s2) - s2, np.cumsum(s1) - s1)
+    sel = stored > 0
+    if sel.any():
+        st = stored[sel]
+        k = np.arange(int(st.sum())) - np.repeat(np.cumsum(st) - st, st)
+        cig[np.repeat(off_full[sel], st) + k] = np.asarray(cigar_c, np.uint32)[np.repeat(src[sel], st) + k]
     return r, p, cig
 
 

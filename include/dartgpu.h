@@ -115,8 +115,9 @@ int dg_map_batch_packed(dg_ctx *, int n_reads, int rlen_all, const uint16_t *rle
  * says is not sent:
  *   rep_off    reports lie in read order: a read's reports start at the sum of n_rep of the reads before it
  *   sj_off     likewise the junction tuples: the sum of n_sj of the reads before it
- *   cigar_off  the CIGAR ops lie in REPORT order here (unlike the full records): a report's ops start at the sum of the stored
- *              op counts of the reports before it
+ *   cigar_off  the stored CIGAR ops lie in TWO regions, each in report order: first those of the reports whose `pad` bit 0 is clear (finished
+ *              by the fused kernel), behind them those of the reports with the bit set (the general report path); a report's ops start at
+ *              the sum of the stored op counts of the reports before it IN ITS REGION (+ the size of the whole first region for the second)
  *   n_cigar    DG_CIGAR_FULL_MATCH (255): the CIGAR is the single op "<length of the report's read>M" and is not stored
  *              (19 of 20 reports of a DNA run); otherwise the number of stored ops (at most 254)
  * Lossless while the fields fit (scores and mismatches < 65536, at most 65535 reports per read / chromosomes, at most 254 CIGAR
@@ -125,8 +126,10 @@ int dg_map_batch_packed(dg_ctx *, int n_reads, int rlen_all, const uint16_t *rle
 #define DG_CIGAR_FULL_MATCH 255
 typedef struct { uint16_t score, sub_score, mis_num; uint8_t mapq, n_sj; uint16_t n_rep, best; } dg_read_c;                             /* 12 bytes */
 typedef struct { int32_t pos; uint16_t aln_score, flag; int16_t paired_idx; uint16_t chr /* 0xFFFF = none */;
-                 uint8_t n_cigar; int8_t sj_type; uint8_t bdir, pad; } dg_report_c;                                                         /* 16 bytes */
-/* caps[1] counts stored ops (never more than the full records' op count, `used[1]` of dg_batch_run); *n_ops (may be NULL) = how many were written */
+                 uint8_t n_cigar; int8_t sj_type; uint8_t bdir, pad /* bit 0: stored ops in the second region */; } dg_report_c;            /* 16 bytes */
+/* caps[1] counts stored ops (never more than the full records' op count, `used[1]` of dg_batch_run); *n_ops (may be NULL) = how many were written.
+ * The compact records are written by the same kernels as the full ones during dg_batch_run / dg_map_batch_compact (not by dg_map_batch /
+ * dg_map_batch_packed, whose callers take the full records: DG_ERR_ARG here after those).                                                    */
 int dg_batch_download_compact(dg_ctx *, dg_read_c *, dg_report_c *, uint32_t *cigar_ops, dg_sj_out *, const size_t caps[3], size_t *n_ops);
 /* upload (ASCII when words == NULL, else packed as dg_map_batch_packed) + run + compact download in one call; used[1] = stored ops */
 int dg_map_batch_compact(dg_ctx *, int n_reads, const uint32_t *seq_off, const uint16_t *rlen, const char *seq,
@@ -150,7 +153,7 @@ int dg_batch_device_ptrs(dg_ctx *, void *ptrs[4]);
 int dg_batch_device_ptrs_compact(dg_ctx *, void *ptrs[2]);
 /* ALL compact records of the last dg_map_batch_compact / dg_batch_download_compact in HBM, with their element counts -- what a multi-GPU
  * host hands to RCCL for the SAM-order gather to the rank that writes (Mapping.cpp:644-664 is ONE ordered writer; bench.py --gather full):
- *   ptrs[0] dg_read_c[counts[0]]   ptrs[1] dg_report_c[counts[1]]   ptrs[2] stored CIGAR ops u32[counts[2]], in report order
+ *   ptrs[0] dg_read_c[counts[0]]   ptrs[1] dg_report_c[counts[1]]   ptrs[2] stored CIGAR ops u32[counts[2]], in the two regions described above
  *   ptrs[3] dg_sj_out[counts[3]], grouped by read in read order (read_idx is the read's index inside the batch)                    */
 int dg_batch_device_records_compact(dg_ctx *, void *ptrs[4], size_t counts[4]);
 
