@@ -37,7 +37,8 @@ template <typename T> struct DBuf {
 #define N_TIMERS 20
 #define N_TOPS 128              // small device counters of a batch (bump tops, tickets, list sizes, class histogram), zeroed per run
 enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAVY_UNITS, TOP_SEED_NEXT, TOP_SEED_HEAVY,
-       TOP_WORK = 16, TOP_TICKET_PAIR, TOP_TICKET_EMIT, TOP_TICKET_SEED = 25, TOP_ORDER_INFO = 28 /* 28..30 */, TOP_CLASS_HIST = 32 /* 32..63 */, TOP_CLASS_FILL = 64 /* 64..95 */, TOP_RESEED_COUNT /* 19..21 */, TOP_RESEED_TICKET = 22 /* 22..24 */ };
+       TOP_WORK = 16, TOP_TICKET_PAIR = 17, TOP_TICKET_EMIT = 18, TOP_RESEED_COUNT = 19 /* 19..21 */, TOP_RESEED_TICKET = 22 /* 22..24 */, TOP_TICKET_SEED = 25,
+       TOP_ORDER_INFO = 28 /* 28..30 */, TOP_CLASS_HIST = 32 /* 32..63 */, TOP_CLASS_FILL = 64 /* 64..95 */ };        // (explicit values: every index names its own word)
 
 struct dg_ctx {
     int device = 0;

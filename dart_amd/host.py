@@ -171,7 +171,8 @@ def _load_lib():
     lib.dg_batch_download.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.dg_batch_device_ptrs.argtypes = [vp, vp]
     lib.dg_batch_device_ptrs_compact.argtypes = [vp, vp]
-    lib.dg_batch_device_records_compact.argtypes = [vp, vp, vp]
+    if hasattr(lib, "dg_batch_device_records_compact"):      # (absent from older builds of the library loaded through DARTGPU_LIB for A/B runs)
+        lib.dg_batch_device_records_compact.argtypes = [vp, vp, vp]
     lib.dg_last_timings.argtypes = [vp, vp, vp, C.c_int]
     lib.dg_last_counters.argtypes = [vp, vp, C.c_int]
     lib.dg_probe_seeds.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
