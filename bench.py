@@ -261,6 +261,9 @@ def main():
                     help="N>1, after the timed region: rank 0 expands what it gathered from every rank for one step and compares it, batch by batch, with its own "
                          "single-rank mapping of the same reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cli-pairs", type=int, default=4000000,
+                    help="after the timed region: the product's `dart` command line end to end (FASTQ files -> SAM file, process start, index load and dg_init included) on "
+                         "this many 2x101 pairs against the chr20-sized genome; 0 = skip")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (other entry point, device-resident)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "12")),
                     help="batches in flight per GPU: contexts sharing one index, one host thread each (dg_clone)")
@@ -668,6 +671,39 @@ def main():
     except Exception as e:
         log("[bench] accuracy not computed:", repr(e))
 
+    # ---- the drop-in product end to end (SURVEY 8d "plus end-to-end wall"): `dart -i IDX -f 1.fq -f2 2.fq -o out.sam` as a child process ----
+    cli = None
+    dart_exe = os.path.join(ROOT, "dart_amd", "dart")
+    if args.cli_pairs > 0 and not args.no_cpu_baseline and os.path.exists(dart_exe):
+        try:
+            import shutil, tempfile
+            t = time.time()
+            cprefix, cg = prepare_index(args.cache, (["chr20"], [CHR20_LEN]), 0, lambda: None)
+            cm1, cm2 = synth.make_reads(cg, args.cli_pairs, rlen=101, seed=1000, sub_rate=0.01, indel_frac=0.02, n_frac=0.002)
+            need = args.cli_pairs * 2 * 520
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 1.3 * need else args.cache
+            d = tempfile.mkdtemp(prefix="dart_cli_", dir=base)
+            synth.write_fastq_fast(os.path.join(d, "1.fq"), cm1, 1); synth.write_fastq_fast(os.path.join(d, "2.fq"), cm2, 2)
+            del cm1, cm2
+            log("[bench] command-line run: %d pairs of FASTQ under %s prepared in %.1f s" % (args.cli_pairs, d, time.time() - t))
+            best = None
+            for _ in range(2):
+                t = time.perf_counter()
+                r = subprocess.run([dart_exe, "-i", cprefix, "-f", "1.fq", "-f2", "2.fq", "-o", "out.sam", "-j", "out.j", "-t", str(host_cores()), "-mis", str(args.mis)], cwd=d,
+                                   env=dict(os.environ, DART_TIMING="1", DART_INFLIGHT="2"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                dt = time.perf_counter() - t
+                if r.returncode != 0:
+                    raise RuntimeError("dart exited with %d: %s" % (r.returncode, r.stderr.decode()[-300:]))
+                if best is None or dt < best[0]:
+                    best = (dt, r.stderr.decode().strip().splitlines()[-1:], os.path.getsize(os.path.join(d, "out.sam")))
+            cli = {"value": round(2 * args.cli_pairs / best[0] / 1e6, 3), "unit": "M reads/s", "wall_s": round(best[0], 3), "sam_bytes": best[2],
+                   "what": "`dart -i <chr20-sized index> -f 1.fq -f2 2.fq -o out.sam -j out.j -t %d -mis %d` as a child process, %d pairs 2x101, files on %s: process start, index load, dg_init, "
+                           "FASTQ parsing, mapping, SAM formatting and writing; best of 2" % (host_cores(), args.mis, args.cli_pairs, base),
+                   "stages": best[1][0] if best[1] else None}
+            shutil.rmtree(d, ignore_errors=True)
+        except Exception as e:
+            log("[bench] command-line run failed:", repr(e))
+
     in_bytes = b0.bytes_packed if args.input == "packed" else b0.bytes_ascii
     line = {
         "metric": "M paired-end reads/sec (2x%d bp vs GRCh38-sized index), host to host; records bit-identical to CPU dart" % args.rlen,
@@ -699,6 +735,9 @@ def main():
         "cpu_baseline": cpu,
         "accuracy": accuracy,
     }
+    if cli:
+        line["value_cli_end_to_end"] = cli["value"]
+        line["cli_end_to_end"] = cli
     if gather_mode == "full":
         line["gather"] = {"mode": "full", "bytes_received_by_rank0_total": gather_bytes[0], "verified_against_single_rank_mapping": gather_verified}
     line.update(secondary)

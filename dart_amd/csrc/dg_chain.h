@@ -183,7 +183,9 @@ __host__ __device__ __forceinline__ uint32_t d_work_need(int count) { return 14u
 
 // A unit (pair / single read) goes to k_chain_heavy when its seeds do not fit k_pair's per-lane LDS slice: reads from repeat
 // families.  They are a small share of the input but their lists are 10-100x longer; a wave each.
+#ifndef UNIT_MAX_SEEDS
 #define UNIT_MAX_SEEDS 16
+#endif
 __device__ __forceinline__ bool d_unit_is_heavy(const uint32_t *seed_off, int paired, int u)
 {
     const int r1 = paired ? 2 * u : u;

@@ -128,9 +128,13 @@ struct RepMem {
 //            w0 = POS (32) | chromosome (16) << 32 | AlnScore (12) << 48 | bDir << 60 | has coordinates << 61
 //            w1 = leading S (12) | M (12) << 12 | trailing S (12) << 24 | FLAG (12) << 36 | mismatches (12) << 48
 // ---------------------------------------------------------------------------------------------
+#ifndef PU_THREADS
 #define PU_THREADS 256
+#endif
 #define PU_SEEDS UNIT_MAX_SEEDS
-#define PU_SLOTS 6            // 2 workgroups of 256 lanes per CU: (16 x 8 + 16 x 4 + 2 x 6 x 8) bytes per lane = 72 KB each
+#ifndef PU_SLOTS
+#define PU_SLOTS 6
+#endif                        // 2 workgroups of 256 lanes per CU: (16 x 8 + 16 x 4 + 2 x 6 x 8) bytes per lane = 72 KB each
 
 __host__ __device__ __forceinline__ uint32_t cw_make(int first, int count, int score) { return (uint32_t)first | ((uint32_t)count << 5) | ((uint32_t)score << 10) | (31u << 22) | (15u << 27); }
 __host__ __device__ __forceinline__ int cw_first(uint32_t w) { return (int)(w & 31u); }

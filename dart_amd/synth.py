@@ -349,6 +349,26 @@ def write_fastq(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I")) ->
         f.write(b"".join(chunk))
 
 
+def write_fastq_fast(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I"), chunk: int = 500000) -> None:
+    """FASTQ with fixed-width names "@r<9 digits>/<mate>": every record has the same length, so the file is assembled as a byte matrix
+    (a few million reads per second; write_fastq's per-read loop needs more than a minute for 16 M reads).  For throughput measurements."""
+    n, rlen = seqs.shape
+    hdr = 1 + 1 + 9 + 2 + 1                        # @ r ddddddddd / m \n
+    rec = hdr + rlen + 3 + rlen + 1
+    tmpl = np.full(rec, qual, dtype=np.uint8)
+    tmpl[0] = ord("@"); tmpl[1] = ord("r"); tmpl[11] = ord("/"); tmpl[12] = ord("0") + mate; tmpl[13] = 10
+    tmpl[hdr + rlen] = 10; tmpl[hdr + rlen + 1] = ord("+"); tmpl[hdr + rlen + 2] = 10; tmpl[rec - 1] = 10
+    d3 = np.array([[ord("0") + k // 100, ord("0") + k // 10 % 10, ord("0") + k % 10] for k in range(1000)], dtype=np.uint8)
+    out = np.tile(tmpl, (min(chunk, max(n, 1)), 1))                       # allocated (and paged in) once
+    with open(path, "wb") as f:
+        for c0 in range(0, n, chunk):
+            m = min(chunk, n - c0)
+            ids = np.arange(c0, c0 + m, dtype=np.int64)
+            out[:m, 2:5] = d3[ids // 1000000 % 1000]; out[:m, 5:8] = d3[ids // 1000 % 1000]; out[:m, 8:11] = d3[ids % 1000]
+            out[:m, hdr:hdr + rlen] = seqs[c0:c0 + m]
+            f.write(out[:m].tobytes())
+
+
 def write_fasta_reads(path: str, seqs: np.ndarray, mate: int) -> None:
     with open(path, "wb") as f:
         for i in range(seqs.shape[0]):
