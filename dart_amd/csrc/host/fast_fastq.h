@@ -315,6 +315,10 @@ static int run_fast_library(const char *f1, const char *f2, bool pair_end, int t
 {
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const int T = std::max(1, threads);
+    // T is the budget of ALL stages (the GPU boxes grant a CPU quota, not cores: more runnable threads than the quota means the whole process is
+    // throttled): the formatter takes what the writer (TWR threads), the assembler and the mapping threads leave.  DART_FMT_THREADS / DART_WRITE_THREADS override.
+    const int TWR = getenv("DART_WRITE_THREADS") ? std::max(1, atoi(getenv("DART_WRITE_THREADS"))) : 2;
+    const int TF = getenv("DART_FMT_THREADS") ? std::max(1, atoi(getenv("DART_FMT_THREADS"))) : std::max(1, T - TWR - 1);
     const char *wm = getenv("DART_WRITE");
     const bool use_mmap = wm && strcmp(wm, "mmap") == 0;          // default pwrite (measured on tmpfs: 5.1 GB/s against 3.2 GB/s through a shared mapping)
     double t = now();
@@ -469,7 +473,7 @@ static int run_fast_library(const char *f1, const char *f2, bool pair_end, int t
     // text buffers, so batch b+1 is formatted while batch b is written
     struct TextSet { std::vector<TextBuf> bufs; std::vector<Counters> cts; FastSlot *slot = nullptr; bool full = false; };
     TextSet sets[2];
-    for (auto &ts : sets) { ts.bufs.resize(T); ts.cts.resize(T); }
+    for (auto &ts : sets) { ts.bufs.resize(TF); ts.cts.resize(TF); }
     bool fmt_done = false;
     std::thread writer([&]() {
         int cur = 0;
@@ -478,20 +482,20 @@ static int run_fast_library(const char *f1, const char *f2, bool pair_end, int t
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return ts.full || fmt_done || failed; }); if (!ts.full) break; }
             const double tw = now();
             FastSlot *s = ts.slot;
-            std::vector<size_t> offs(T + 1, 0);
-            for (int k = 0; k < T; k++) offs[k + 1] = offs[k] + ts.bufs[k].n;
+            std::vector<size_t> offs(TF + 1, 0);
+            for (int k = 0; k < TF; k++) offs[k + 1] = offs[k] + ts.bufs[k].n;
             const uint64_t base = *file_off;
             char *win = nullptr; size_t win_len = 0; const uint64_t a0 = base & ~(uint64_t)4095;
-            if (use_mmap && offs[T] && ftruncate(fd, (off_t)(base + offs[T])) == 0) {      // copy into a shared mapping of the file's new part
-                win_len = (size_t)(base + offs[T] - a0);
+            if (use_mmap && offs[TF] && ftruncate(fd, (off_t)(base + offs[TF])) == 0) {      // copy into a shared mapping of the file's new part
+                win_len = (size_t)(base + offs[TF] - a0);
                 void *m = mmap(nullptr, win_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a0);
                 win = m == MAP_FAILED ? nullptr : (char *)m;
             }
-            const int TW = win ? std::max(1, T / 4) : 2;     // writes to one file serialise in the kernel: more threads only burn the CPU share
+            const int TW = win ? std::max(1, TF / 4) : TWR;     // writes to one file serialise in the kernel: more threads only burn the CPU share
             std::atomic<int> write_errno{0};                 // a full disk must not end as a holed SAM file and exit code 0
-            if (use_mmap && offs[T] && !win) write_errno = errno ? errno : EIO;
+            if (use_mmap && offs[TF] && !win) write_errno = errno ? errno : EIO;
             else parallel_for(TW, [&](int wt) {
-                for (int tid = wt; tid < T; tid += TW) {
+                for (int tid = wt; tid < TF; tid += TW) {
                     if (win) { memcpy(win + (base - a0) + offs[tid], ts.bufs[tid].b, ts.bufs[tid].n); continue; }
                     size_t done = 0;
                     while (done < ts.bufs[tid].n) {
@@ -508,8 +512,8 @@ static int run_fast_library(const char *f1, const char *f2, bool pair_end, int t
                 cv.notify_all();
                 break;
             }
-            *file_off = base + offs[T];
-            for (int k = 0; k < T; k++) { total.unique += ts.cts[k].unique; total.unmapped += ts.cts[k].unmapped; total.paired += ts.cts[k].paired; }
+            *file_off = base + offs[TF];
+            for (int k = 0; k < TF; k++) { total.unique += ts.cts[k].unique; total.unmapped += ts.cts[k].unmapped; total.paired += ts.cts[k].paired; }
             total.total += s->n;
             for (size_t k = 0; k < s->used[2]; k++) sjmap[std::make_pair(s->sj[k].g1, s->sj[k].g2)]++;   // UpdateLocal/GlobalSJMap, Mapping.cpp:532-577
             if (!silent) { fprintf(stdout, "\r%lld %s tags have been processed in %lld seconds...", total.total, pair_end ? "paired-end" : "singled-end", (long long)(time(NULL) - t0)); fflush(stdout); }
@@ -530,8 +534,8 @@ static int run_fast_library(const char *f1, const char *f2, bool pair_end, int t
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return !ts.full || failed; }); if (failed) break; }
         const double tf = now();
         const int n = s->n, n_pair_mode = (pair_end && !s->odd) ? n : 0;
-        parallel_for(T, [&](int tid) {
-            int lo = (int)((long long)n * tid / T) & ~1, hi = tid == T - 1 ? n : ((int)((long long)n * (tid + 1) / T) & ~1);
+        parallel_for(TF, [&](int tid) {
+            int lo = (int)((long long)n * tid / TF) & ~1, hi = tid == TF - 1 ? n : ((int)((long long)n * (tid + 1) / TF) & ~1);
             ts.bufs[tid].n = 0; ts.cts[tid] = Counters();
             format_views(s->view.data(), lo, hi, n_pair_mode, s->ro, s->po, s->cig, names, unique_only, multi, true, ts.bufs[tid], ts.cts[tid]);
         });

@@ -17,18 +17,22 @@ need = pairs * 2 * 560                     # FASTQ in + SAM out
 d = "/dev/shm/cli_e2e" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need * 1.2 else "/tmp/cli_e2e"
 os.makedirs(d, exist_ok=True)
 print("files under", d)
-synth.write_fastq(os.path.join(d, "1.fq"), m1, 1); synth.write_fastq(os.path.join(d, "2.fq"), m2, 2)
+synth.write_fastq_fast(os.path.join(d, "1.fq"), m1, 1); synth.write_fastq_fast(os.path.join(d, "2.fq"), m2, 2)
 dart = os.path.join(ROOT, "dart_amd", "dart")
-for env_extra in ({"DART_INFLIGHT": "2", "DART_STREAMING": "1"}, {"DART_INFLIGHT": "2"}, {"DART_INFLIGHT": "2", "DART_WRITE": "mmap"}, {"DART_INFLIGHT": "2", "DART_PINNED": "1"}, {"DART_INFLIGHT": "2", "DART_BATCH": "500000"}):
+variants = [{"DART_INFLIGHT": "2", "DART_STREAMING": "1"}, {"DART_INFLIGHT": "2"}, {"DART_INFLIGHT": "2", "DART_WRITE": "mmap"}, {"DART_INFLIGHT": "2", "DART_PINNED": "1"}, {"DART_INFLIGHT": "2", "DART_BATCH": "500000"}]
+if os.environ.get("CLI_E2E_VARIANTS"):          # "A=1,B=2;C=3": one run per ;-separated set
+    variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in os.environ["CLI_E2E_VARIANTS"].split(";")]
+for env_extra in variants:
     env = dict(os.environ, DART_TIMING="1", **env_extra)
     t = time.time()
     r = subprocess.run([dart, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-o", "gpu.sam", "-j", "gpu.j", "-t", "16", "-mis", "5"], cwd=d, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     dt = time.time() - t
     print(env_extra, "dart wall %.2f s = %.2f M reads/s (incl. index load + dg_init)" % (dt, 2 * pairs / dt / 1e6), r.stderr.decode().strip().splitlines()[-1:])
-t = time.time()
-r = subprocess.run([dart, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-bo", "gpu.bam", "-j", "gpu.j", "-t", "16", "-mis", "5"], cwd=d, env=dict(os.environ, DART_TIMING="1", DART_INFLIGHT="2"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-dt = time.time() - t
-print("-bo (BAM, 16 compression threads): dart wall %.2f s = %.2f M reads/s, %d bytes" % (dt, 2 * pairs / dt / 1e6, os.path.getsize(os.path.join(d, "gpu.bam"))), r.stderr.decode().strip().splitlines()[-1:])
+if os.environ.get("CLI_E2E_BAM", "1") == "1":
+  t = time.time()
+  r = subprocess.run([dart, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-bo", "gpu.bam", "-j", "gpu.j", "-t", "16", "-mis", "5"], cwd=d, env=dict(os.environ, DART_TIMING="1", DART_INFLIGHT="2"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+  dt = time.time() - t
+  print("-bo (BAM, 16 compression threads): dart wall %.2f s = %.2f M reads/s, %d bytes" % (dt, 2 * pairs / dt / 1e6, os.path.getsize(os.path.join(d, "gpu.bam"))), r.stderr.decode().strip().splitlines()[-1:])
 if os.environ.get("CLI_E2E_COMPARE", "1") == "1":
     oracle_py.build()
     t = time.time()
