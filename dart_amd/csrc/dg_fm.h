@@ -380,18 +380,23 @@ __device__ __forceinline__ void d_begin_finish(const DIndex &ix, int K, RB &rb, 
     s.x0 = d_L2(ix, cc) + 1; s.x1 = d_L2(ix, 3 - cc) + 1; s.x2 = d_L2(ix, cc + 1) - d_L2(ix, cc);
 }
 
-// modes 1,3,2: the addresses of this trip.  FIX >= 0: the caller knows the mode at compile time (only that mode's code is instantiated)
-template <int FIX = -1, class RM>
+// modes 1,3,2: the addresses of this trip.  MODES: bit m set = the search may be in mode m (only those modes' code is instantiated;
+// a search in another mode is left alone)
+#define TM_STEP 2
+#define TM_CMP 4
+#define TM_LOC 8
+#define TM_ALL 14
+template <int MODES = TM_ALL, class RM>
 __device__ __forceinline__ void d_trip_issue(const DIndex &ix, RM &rm, int len, bool direct, Search &s, SeedCtr &c, TripAddr &ta, TripData &t)
 {
-    const int mode = FIX >= 0 ? FIX : s.mode;
-    if (mode == 1) {
+    const int mode = MODES == TM_STEP ? 1 : MODES == TM_CMP ? 2 : MODES == TM_LOC ? 3 : s.mode;
+    if ((MODES & TM_STEP) && mode == 1) {
         if (s.p >= len || d_at(rm, s.p)) { t.aux = T_STOP; return; }
         d_extend_rows(ix, s.x1, s.x2, t.kk, t.ll);
         ta.pa = ix.bwt + ((t.kk >> 7) << 2);
         if ((t.ll >> 7) != (t.kk >> 7)) ta.pb = ix.bwt + ((t.ll >> 7) << 2);
         t.aux = T_STEP;
-    } else if (mode == 3) {                        // bwt_sa on the unique row, one LF step per trip
+    } else if ((MODES & TM_LOC) && mode == 3) {    // bwt_sa on the unique row, one LF step per trip
         if (s.lk & ((uint64_t)ix.sa_dense_intv - 1)) {
             if (s.lk == ix.primary) { t.aux = T_LF_PRIMARY; return; }
             t.kk = s.lk - (s.lk > ix.primary);
@@ -401,7 +406,7 @@ __device__ __forceinline__ void d_trip_issue(const DIndex &ix, RM &rm, int len, 
             ta.p8 = (const uint2_a4 *)(ix.sa_dense + (s.lk >> ix.sa_dense_shift));
             t.aux = T_SA;
         }
-    } else {                                       // mode 2: 64 text symbols = five pac words
+    } else if ((MODES & TM_CMP) && mode == 2) {    // 64 text symbols = five pac words
         const int64_t tt = s.tpos + (s.p - s.start), L = ix.l_pac;
         const uint32_t *pw = (const uint32_t *)ix.pac;
         int64_t f0 = -1;                           // first forward-strand symbol of the window
@@ -415,25 +420,26 @@ __device__ __forceinline__ void d_trip_issue(const DIndex &ix, RM &rm, int len, 
 }
 
 // modes 1,3,2: consume the loads; when the search finishes, mode becomes 0 and hit_len/located hold the result.
-// FIX == 2: the caller knows this is a text comparison (T_CMP / T_CMP_SLOW)
-template <int FIX = -1, class RB, class RM>
+// MODES: the modes the trip can have been issued in (step: T_STOP / T_STEP, locate: T_LF / T_LF_PRIMARY / T_SA, compare: T_CMP / T_CMP_SLOW); only
+// their code is instantiated -- with a run-time `aux` alone every instance carried all of it (the per-base slow text comparison included)
+template <int MODES = TM_ALL, class RB, class RM>
 __device__ __forceinline__ void d_trip_finish(const DIndex &ix, const DParams &pr, RB &rb, RM &rm, int len, Search &s, SeedCtr &c, const TripData &t)
 {
-    if (FIX != 2 && t.aux == T_STOP) d_search_end(pr, s);
-    else if (FIX != 2 && t.aux == T_STEP) {
+    if ((MODES & TM_STEP) && t.aux == T_STOP) d_search_end(pr, s);
+    else if ((MODES & TM_STEP) && t.aux == T_STEP) {
         const int cc = (int)d_at(rb, s.p);
         const uint32_t nb = (t.ll >> 7) != (t.kk >> 7) ? 2u : 1u;
         const bool ok = d_extend_finish(ix, cc, t.a, t.b, t.kk, t.ll, s.x0, s.x1, s.x2);
         s.ref_steps++; s.ref_blocks += nb; c.steps_act++; c.blocks_act += nb;
         if (ok) s.p++; else d_search_end(pr, s);
-    } else if (FIX != 2 && t.aux == T_LF) { s.lk = d_lf_finish(ix, t.a, t.kk); s.lsteps++; c.lf_act++; }
-    else if (FIX != 2 && t.aux == T_LF_PRIMARY) { s.lk = 0; s.lsteps++; c.lf_act++; }
-    else if (FIX != 2 && t.aux == T_SA) {
+    } else if ((MODES & TM_LOC) && t.aux == T_LF) { s.lk = d_lf_finish(ix, t.a, t.kk); s.lsteps++; c.lf_act++; }
+    else if ((MODES & TM_LOC) && t.aux == T_LF_PRIMARY) { s.lk = 0; s.lsteps++; c.lf_act++; }
+    else if ((MODES & TM_LOC) && t.aux == T_SA) {
         const uint64_t e = d_u64(t.s8.x, t.s8.y);
         s.tpos = (int64_t)(s.lsteps + (e & 0xFFFFFFFFFFull) - 1);
         s.lk = e;                                  // keeps the memoised reference LF count (bits 40..)
         s.mode = 2; c.n_direct++;
-    } else {                                       // T_CMP / T_CMP_SLOW: the interval is one text position: compare up to 64 bases
+    } else if ((MODES & TM_CMP) && (t.aux == T_CMP || t.aux == T_CMP_SLOW)) {      // the interval is one text position: compare up to 64 bases
         int nv = 64, chunk = 64;
         uint32_t T0, T1 = 0, T2 = 0, T3 = 0;
         if (t.aux == T_CMP) {

@@ -340,25 +340,34 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
                 mt = trips;
                 live = false;
             } else { nsearch++; beginning = true; d_begin_issue(ix, e.K, rb, rm, pos, s, c, ta, t); }
-        } else d_trip_issue<MODE == SQ_STEP ? 1 : (MODE == SQ_CMP ? 2 : 3)>(ix, rm, len, e.direct, s, c, ta, t);
+        } else d_trip_issue<MODE == SQ_STEP ? TM_STEP : (MODE == SQ_CMP ? TM_CMP : TM_LOC)>(ix, rm, len, e.direct, s, c, ta, t);
     }
     d_trip_load(ta, t);
+    // what a search does between two memory accesses: a one-row interval goes on to be located and compared with the text; a step whose next
+    // base is an N or past the read's end is the end of the search (what its next trip would find, without the trip)
+    auto between = [&]() {
+        if (e.direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
+        if (s.mode == 1 && (s.p >= len || d_at(rm, s.p))) d_search_end(e.pr, s);
+    };
     if (live) {
         if (MODE == SQ_BEGIN) { if (beginning) d_begin_finish(ix, e.K, rb, s, c, t); }
-        else if (MODE == SQ_CMP) d_trip_finish<2>(ix, e.pr, rb, rm, len, s, c, t);
-        else if (t.aux != T_NONE) d_trip_finish(ix, e.pr, rb, rm, len, s, c, t);
+        else if (t.aux != T_NONE) d_trip_finish<MODE == SQ_STEP ? TM_STEP : (MODE == SQ_CMP ? TM_CMP : TM_LOC)>(ix, e.pr, rb, rm, len, s, c, t);
+        between();
     }
-    if (MODE == SQ_BEGIN || MODE == SQ_LOC) {              // the first comparison of a search that has just found its text position
-        const bool go = live && s.mode == 2;
+    // A second access in the same trip where the first one has just produced its address: the first comparison of a search that has found its
+    // text position (begin: a located table entry; locate: the SA entry).  One more dependent load for those lanes, but no push / pop / state
+    // round trip in between: a fifth of all slot-trips were first comparisons.  (Chaining Occ steps the same way -- the first step behind a table
+    // entry, two steps per step trip -- was measured too: 6 % fewer instructions, the same time with twelve batches in flight, 10 % longer alone.)
+    if (MODE == SQ_BEGIN || MODE == SQ_LOC) {
+        constexpr int M2 = TM_CMP;
+        const bool go = live && ((M2 & TM_STEP) && s.mode == 1 || (M2 & TM_CMP) && s.mode == 2);
         TripData t2; t2.aux = T_NONE;
         TripAddr ta2 = {nullptr, nullptr, nullptr, nullptr};
-        if (go) d_trip_issue<2>(ix, rm, len, e.direct, s, c, ta2, t2);
+        if (go) d_trip_issue<M2>(ix, rm, len, e.direct, s, c, ta2, t2);
         d_trip_load(ta2, t2);
-        if (go) d_trip_finish<2>(ix, e.pr, rb, rm, len, s, c, t2);
+        if (go && t2.aux != T_NONE) { d_trip_finish<M2>(ix, e.pr, rb, rm, len, s, c, t2); between(); }
     }
     if (live) {
-        if (e.direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }   // unique: locate, then compare with the text
-        if (s.mode == 1 && (s.p >= len || d_at(rm, s.p))) d_search_end(e.pr, s);              // what its next trip would find (T_STOP), without the trip
         if (!finished && s.mode == 0) {          // a search just ended (or the table said "absent")
             if (s.hit_len) {
                 if (nh < e.H) {
