@@ -688,6 +688,9 @@ def main():
             log("[bench] command-line run: %d pairs of FASTQ under %s prepared in %.1f s" % (args.cli_pairs, d, time.time() - t))
             best = None
             for _ in range(2):
+                for f_ in ("out.sam", "out.j"):                      # (truncating a multi-GB tmpfs file at open is not part of the job)
+                    if os.path.exists(os.path.join(d, f_)):
+                        os.remove(os.path.join(d, f_))
                 t = time.perf_counter()
                 r = subprocess.run([dart_exe, "-i", cprefix, "-f", "1.fq", "-f2", "2.fq", "-o", "out.sam", "-j", "out.j", "-t", str(host_cores()), "-mis", str(args.mis)], cwd=d,
                                    env=dict(os.environ, DART_TIMING="1", DART_INFLIGHT="2"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)

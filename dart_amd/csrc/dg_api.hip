@@ -88,6 +88,7 @@ struct dg_ctx {
     int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
     int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
     size_t seedqf_lds_set = 0;
+    bool seed_qf_used = false;     // the last run's seeding kernel was k_seed_qf (its own-work counters are derived from its slot counts)
     int env_scan_budget = 0;      // DG_SCAN_POLL_BUDGET: poll budget of a look-back on the FIRST attempt of a batch (test hook: forces the DG_E_SCAN re-run path)
 };
 
@@ -772,6 +773,7 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     const int bail_trips = c->env_bail_trips, both_thr = c->env_both;
     unsigned int *tops = c->d_tops;
     // default: the queue kernel (dg_seedq.h).  DG_SEED_LEGACY=1 or reads too long for its LDS slots (> 496 bases): the lane-per-read kernel
+    c->seed_qf_used = false;
     if (!c->env_seed_legacy && !c->env_seed_phases && W <= 62 && c->pr.max_dup <= 30000) {      // (its slot state counts occurrences in 20 bits: 31 hits x max_dup)
         // the free-running queue kernel (dg_seedq.h, k_seed_qf): workgroups of `nw` waves around 2^lg read slots
         int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 11 ? c->env_seed_slots_lg : 9;
@@ -790,6 +792,7 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
         unsigned wgs = (unsigned)c->n_cu * per_cu;
         const unsigned need = (unsigned)(((size_t)n + ((size_t)1 << lg) - 1) >> lg);
         if (wgs > need) wgs = need;
+        c->seed_qf_used = true;
         k_seed_qf<<<wgs, nw * 64, lds, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, lg, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT,
                                                     c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, c->env_seed_partial, c->d_err);
     } else
@@ -1077,12 +1080,12 @@ static int finish_run(dg_ctx *c, size_t used[3])
     if (c->n_t < N_TIMERS) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_reseed0, c->ev_reseed1); c->tname[c->n_t] = "k_reseed(overlapped)"; c->tms[c->n_t] = ms; c->n_t++; }
     static_assert(CTR_N <= CTR_STRIDE, "the work counters fill one stripe");
     for (int k = 0; k < CTR_N; k++) c->counters[k] = c->h_tail->ctr[k];
-    if (c->counters[CTR_STEPS_ACT] == 0 && c->counters[CTR_SQ_LANES + SQ_STEP]) {
+    if (c->seed_qf_used) {
         // k_seed_qf keeps no per-lane tallies of its own work (they cost registers and moves in its loop): what it executed follows from the
         // slots its trips served -- one Occ step (one block; two when the interval straddles blocks, not counted) per slot of a step trip, one
-        // prefix-table entry per slot of a begin trip, one SA entry per slot of a locate trip
-        c->counters[CTR_STEPS_ACT] = c->counters[CTR_BLOCKS_ACT] = c->counters[CTR_SQ_LANES + SQ_STEP];
-        c->counters[CTR_KTAB] = c->counters[CTR_SQ_LANES + SQ_BEGIN]; c->counters[CTR_DIRECT] = c->counters[CTR_SQ_LANES + SQ_LOC];
+        // prefix-table entry per slot of a begin trip, one SA entry and one text window per slot of a locate trip (k_seed_heavy adds its own)
+        c->counters[CTR_STEPS_ACT] += c->counters[CTR_SQ_LANES + SQ_STEP]; c->counters[CTR_BLOCKS_ACT] += c->counters[CTR_SQ_LANES + SQ_STEP];
+        c->counters[CTR_KTAB] += c->counters[CTR_SQ_LANES + SQ_BEGIN]; c->counters[CTR_DIRECT] += c->counters[CTR_SQ_LANES + SQ_LOC] + c->counters[CTR_SQ_LANES + SQ_CMP];
     }
     const DSizes &sz = c->h_tail->sizes;
     c->counters[CTR_SEEDS] = sz.total_seeds;
