@@ -173,12 +173,21 @@ class Worker:
         import numpy as np
         from dart_amd import host
         self.gpu, self.mode, self.records, self.C = gpu, mode, records, C
-        self.caps = (C.c_size_t * 3)(int(n * 1.3) + 1024, 4 * n + 4096, n + 1024)
+        self.n_cap = n
         self.used = (C.c_size_t * 3)()
-        self.o_r = gpu.pinned((n,), host.READ_OUT); self.o_p = gpu.pinned((self.caps[0],), host.REPORT_OUT)          # (the compact types use the front of these)
+        self.alloc(int(n * 1.3) + 1024, 4 * n + 4096, n + 1024)
+        self.kern = {}; self.n_runs = 0; self.last_records = records
+
+    def alloc(self, reports, ops, tuples):
+        """the page-locked output arrays (the compact types use the front of the full ones'); grown when a batch needs more (a repeat-rich genome
+        has more reports per read)"""
+        import numpy as np
+        from dart_amd import host
+        gpu, n, C = self.gpu, self.n_cap, self.C
+        self.caps = (C.c_size_t * 3)(reports, ops, tuples)
+        self.o_r = gpu.pinned((n,), host.READ_OUT); self.o_p = gpu.pinned((self.caps[0],), host.REPORT_OUT)
         self.o_c = gpu.pinned((self.caps[1],), np.uint32); self.o_s = gpu.pinned((self.caps[2],), host.SJ_OUT)
         self.c_r = self.o_r.a.view(np.uint8)[:n * host.READ_C.itemsize].view(host.READ_C); self.c_p = self.o_p.a.view(np.uint8)[:self.caps[0] * host.REPORT_C.itemsize].view(host.REPORT_C)
-        self.kern = {}; self.n_runs = 0; self.last_records = records
 
     def map(self, b, mode=None, records=None):
         g, lib = self.gpu, self.gpu.lib
@@ -205,6 +214,14 @@ class Worker:
                                   self.o_r.a.ctypes.data, self.o_p.a.ctypes.data, self.o_c.a.ctypes.data, self.o_s.a.ctypes.data, self.caps, self.used)
         else:                                          # "resident": the batch uploaded last, records left in HBM
             rc = lib.dg_batch_run(g.ctx, self.used)
+        if rc == -4 and not getattr(self, "_grown", False):      # DG_ERR_CAPACITY: `used` holds the need; grow the arrays once and map the batch again
+            u = [int(x) for x in self.used]
+            self.alloc(max(int(self.caps[0]), int(u[0] * 1.25) + 1024), max(int(self.caps[1]), int(u[1] * 1.5) + 4096, 2 * int(self.caps[1])), max(int(self.caps[2]), int(u[2] * 1.5) + 1024))
+            self._grown = True
+            try:
+                return self.map(b, mode, records)
+            finally:
+                self._grown = False
         g._chk(rc, "dg_map_batch(%s)" % mode)
         g._n = b.n; g._used = [int(x) for x in self.used]
         self.last_rlen = b.rlen
@@ -365,7 +382,7 @@ def main():
     gather_dev = "cpu" if rehearse else "cuda"
     recv_bufs = None                                # rank 0: [source rank][array] byte buffers in HBM for what the other ranks send
     if gather_mode == "full" and rank == 0:
-        cap = workers[0].caps
+        cap = [max(int(workers[0].caps[0]), 3 * n_reads), max(int(workers[0].caps[1]), 8 * n_reads), max(int(workers[0].caps[2]), n_reads)]      # (room for a repeat-rich genome: HBM is not scarce)
         recv_bufs = [None] + [[torch.empty(n_reads * 12, dtype=torch.uint8, device=gather_dev), torch.empty(int(cap[0]) * 16, dtype=torch.uint8, device=gather_dev),
                                torch.empty(int(cap[1]) * 4, dtype=torch.uint8, device=gather_dev), torch.empty(int(cap[2]) * 24, dtype=torch.uint8, device=gather_dev)] for _ in range(1, world)]
     gathered = None                                 # --verify-gather: rank 0 keeps what arrived, per (source rank, batch)
