@@ -298,7 +298,18 @@ __device__ __forceinline__ void sqf_st16(uint16_t *p, uint32_t v) { __hip_atomic
 
 // what a trip adds to the wave's work counters (added to the accumulators at ONE place in the loop: accumulators that are
 // updated inside the four trip instances get a different register in each and a block of moves at every loop edge)
-struct SqfDelta { uint32_t steps, blocks, lf_ref, max_trips; };
+struct SqfDelta { uint32_t steps, blocks, lf_ref, max_trips;
+#ifdef DG_SQF_PROF
+    unsigned long long t, prof[12];
+#endif
+};
+#ifdef DG_SQF_PROF          // probe build only (profiles/probes/seed_phases.sh): where a wave's cycles go; the waits are forced, so the sum is a little above the product build's
+#define SQF_T(dl, i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (dl).prof[i] += n_ - (dl).t; (dl).t = n_; } while (0)
+#define SQF_TW(dl, i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); SQF_T(dl, i); } while (0)
+#else
+#define SQF_T(dl, i)
+#define SQF_TW(dl, i)
+#endif
 
 // sq_trip with the 32-byte state.  A trip whose search reaches the text comparison (a located prefix-table entry in a begin trip,
 // the SA entry in a locate trip) makes its first comparison at once, in the same trip: a second dependent load for those lanes,
@@ -342,7 +353,9 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
             } else { nsearch++; beginning = true; d_begin_issue(ix, e.K, rb, rm, pos, s, c, ta, t); }
         } else d_trip_issue<MODE == SQ_STEP ? TM_STEP : (MODE == SQ_CMP ? TM_CMP : TM_LOC)>(ix, rm, len, e.direct, s, c, ta, t);
     }
+    SQF_TW(dl, 2);
     d_trip_load(ta, t);
+    SQF_TW(dl, 3);
     // what a search does between two memory accesses: a one-row interval goes on to be located and compared with the text; a step whose next
     // base is an N or past the read's end is the end of the search (what its next trip would find, without the trip)
     auto between = [&]() {
@@ -354,6 +367,7 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
         else if (t.aux != T_NONE) d_trip_finish<MODE == SQ_STEP ? TM_STEP : (MODE == SQ_CMP ? TM_CMP : TM_LOC)>(ix, e.pr, rb, rm, len, s, c, t);
         between();
     }
+    SQF_TW(dl, 4);
     // A second access in the same trip where the first one has just produced its address: the first comparison of a search that has found its
     // text position (begin: a located table entry; locate: the SA entry).  One more dependent load for those lanes, but no push / pop / state
     // round trip in between: a fifth of all slot-trips were first comparisons.  (Chaining Occ steps the same way -- the first step behind a table
@@ -365,6 +379,7 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
         TripAddr ta2 = {nullptr, nullptr, nullptr, nullptr};
         if (go) d_trip_issue<M2>(ix, rm, len, e.direct, s, c, ta2, t2);
         d_trip_load(ta2, t2);
+        SQF_TW(dl, 5);
         if (go && t2.aux != T_NONE) { d_trip_finish<M2>(ix, e.pr, rb, rm, len, s, c, t2); between(); }
     }
     if (live) {
@@ -396,6 +411,7 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
         }
     }
     dl.lf_ref += (uint32_t)c.lf_ref; dl.max_trips = mt > dl.max_trips ? mt : dl.max_trips;
+    SQF_TW(dl, 6);
     return nq;
 }
 
@@ -431,6 +447,10 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
 
     uint32_t looks = 0, lazy = 0;
     bool running = true;
+#ifdef DG_SQF_PROF
+    SqfDelta pf; for (int i = 0; i < 12; i++) pf.prof[i] = 0; pf.t = __builtin_amdgcn_s_memtime();
+    const unsigned long long pf_t0 = pf.t;
+#endif
     while (running) {
         const uint32_t cw = sqf_ld32(&ctl[lane & 15]);            // all sixteen control words in one LDS instruction: a snapshot
         uint32_t hd[SQ_NQ], cn[SQ_NQ];
@@ -464,6 +484,7 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
         uint32_t got = 0;
         if (my_q >= 0 && lane == 0) got = atomicCAS(&ctl[my_q], hd[my_q], hd[my_q] + my_n) == hd[my_q] ? 1u : 0u;   // a failed swap: another wave took from this queue meanwhile, look again
         const bool go = my_q >= 0 && sq_rfl(got) != 0u;
+        SQF_TW(pf, 0);
         if (go) {
             lazy = 0;
             const uint32_t my_first = hd[my_q];
@@ -482,30 +503,47 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      // the slot's state and words were stored before its entry
             int nq = SQ_FREE;                                     // the queue this lane's slot goes to
             SqfDelta dl = {0u, 0u, 0u, 0u};
+#ifdef DG_SQF_PROF
+            SQF_TW(pf, 1);
+            for (int i = 0; i < 12; i++) dl.prof[i] = 0;
+            dl.t = pf.t;
+#endif
 
             if (my_q == SQ_FREE) {
                 // ---- refill: the next my_n reads of the batch move into the free slots ----
                 unsigned int base = 0;
                 if (lane == 0) base = atomicAdd(next_read, my_n);
                 base = sq_rfl(base);
+                SQF_TW(dl, 10);
                 const uint32_t avail = base < (unsigned int)n_reads ? (unsigned int)n_reads - base : 0u;
                 const uint32_t take = avail < my_n ? avail : my_n;
                 if (take < my_n && lane == 0) __hip_atomic_store(&ctl[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (act && (uint32_t)lane < take) {
-                    const uint32_t r = base + (uint32_t)lane;
-                    tab[wave * 64 + lane] = (uint16_t)slot;
-                    st[slot * 2] = make_uint4(r, (uint32_t)rlen[r], 0u, 0u);       // r | len, pos = 0, p = 0 | nothing yet | no occurrences
-                    nq = SQ_BEGIN;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tab is read by the other lanes of this wave
+                // One memory latency for the whole refill: the lengths and up to 16 x 64 words of the reads (all of them up to 128 bases) are
+                // requested before anything is stored.  (Four words per lane and pass cost a refill trip four latencies in a row:
+                // 14 % of a wave's cycles, profiles/r03/seed_phases.txt.)
+                const bool mine_r = act && (uint32_t)lane < take;
                 const uint32_t total = take * (uint32_t)W;            // the reads are consecutive: one contiguous run of enc
                 const uint32_t *src = enc + (size_t)base * W;
-                for (uint32_t i0 = 0; i0 < total; i0 += 256u) {
-                    uint32_t v[4];
+                uint32_t my_len = 0;
+                if (mine_r) { my_len = (uint32_t)rlen[base + (uint32_t)lane]; tab[wave * 64 + lane] = (uint16_t)slot; nq = SQ_BEGIN; }
+                for (uint32_t i0 = 0; i0 < total; i0 += 1024u) {
+                    uint32_t v[16];
+#ifdef DG_SQF_PROF
+                    { const uint32_t i = i0 + (uint32_t)lane; v[0] = i < total ? src[i] : 0u; }
+                    SQF_TW(dl, 11);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < total ? src[i] : 0u; }
+                    for (int k = 1; k < 16; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < total ? src[i] : 0u; }
+                    SQF_TW(dl, 9);
+#else
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < 16; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < total ? src[i] : 0u; }
+#endif
+                    if (i0 == 0u) {
+                        if (mine_r) st[slot * 2] = make_uint4(base + (uint32_t)lane, my_len, 0u, 0u);   // r | len, pos = 0, p = 0 | nothing yet | no occurrences
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tab is read by the other lanes of this wave
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
                         const uint32_t i = i0 + (uint32_t)(k * 64 + lane);
                         if (i < total) { const uint32_t rk = (i * w_magic) >> 20; rd[(size_t)(i - rk * (uint32_t)W) * NSLOT + tab[wave * 64 + rk]] = v[k]; }
                     }
@@ -514,6 +552,11 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
             else if (my_q == SQ_STEP) nq = sqf_trip<SQ_STEP>(env, act, slot, dl);
             else if (my_q == SQ_CMP) nq = sqf_trip<SQ_CMP>(env, act, slot, dl);
             else nq = sqf_trip<SQ_LOC>(env, act, slot, dl);
+#ifdef DG_SQF_PROF
+            if (my_q == SQ_FREE) SQF_TW(dl, 9);
+            for (int i = 0; i < 12; i++) pf.prof[i] += dl.prof[i];
+            pf.t = dl.t;
+#endif
             acc_steps += dl.steps; acc_blocks += dl.blocks; acc_lf += dl.lf_ref; max_trips = dl.max_trips > max_trips ? dl.max_trips : max_trips;
             // ---- every slot of this trip goes to the queue of its new state: lane k reserves queue k's entries, one round trip for all five ----
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // state and words first, entries after
@@ -534,15 +577,22 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
                 while (sqf_ld16(ep) != (lap ^ SQF_LAP)) __builtin_amdgcn_s_sleep(1);      // EMPTY of the previous lap (almost never waits)
                 sqf_st16(ep, SQF_FULL | lap | slot);
             }
+            SQF_TW(pf, 7);
         } else if (my_q < 0) {
             if (ex && cn[SQ_FREE] == (uint32_t)NSLOT) running = false;          // all slots free, nothing left to claim
             else {
                 if (lane == 0) atomicAdd(&ctl[21], 1u);
                 __builtin_amdgcn_s_sleep(32);                                   // ~1 us: a trip in flight lasts several
             }
+            SQF_T(pf, 8);
         }
         if (++looks > SQF_MAX_LOOKS) { if (lane == 0) atomicMax(err, DG_E_SEEDQ); running = false; }
     }
+#ifdef DG_SQF_PROF
+    if (lane == 0 && (blockIdx.x % 97u) == 0u && (wave & 3) == 0)
+        printf("sqf wg %u wave %d: total %llu trips %u looks %u | look %llu pop %llu issue %llu mem1 %llu fin1 %llu mem2 %llu fin2+store %llu push %llu idle %llu refill %llu refill_atomic %llu refill_loads %llu\n", blockIdx.x, wave,
+               __builtin_amdgcn_s_memtime() - pf_t0, wtrips, looks, pf.prof[0], pf.prof[1], pf.prof[2], pf.prof[3], pf.prof[4], pf.prof[5], pf.prof[6], pf.prof[7], pf.prof[8], pf.prof[9], pf.prof[10], pf.prof[11]);
+#endif
     atomicMax(d_ctr_stripe(ctr) + CTR_MAXTRIPS, (unsigned long long)max_trips);
     if (lane == 0) { atomicMax(d_ctr_stripe(ctr) + CTR_WTRIPS_MAX, (unsigned long long)wtrips); atomicAdd(d_ctr_stripe(ctr) + CTR_WTRIPS_SUM, (unsigned long long)wtrips); }
     d_wave_add(ctr + CTR_STEPS, acc_steps);
