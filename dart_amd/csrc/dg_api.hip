@@ -86,7 +86,7 @@ struct dg_ctx {
     int n_cu = 256, runs_of_last_batch = 0, attempt_no = 0;
     // environment switches, read once per context (not per batch)
     int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
-    int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
+    int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32, env_seed_multi = 4;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
     size_t seedqf_lds_set = 0;
     bool seed_qf_used = false;     // the last run's seeding kernel was k_seed_qf (its own-work counters are derived from its slot counts)
     int env_scan_budget = 0;      // DG_SCAN_POLL_BUDGET: poll budget of a look-back on the FIRST attempt of a batch (test hook: forces the DG_E_SCAN re-run path)
@@ -100,6 +100,7 @@ static void read_env(dg_ctx *c)
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
     c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0);
     c->env_seed_phases = geti("DG_SEED_PHASES", 0); c->env_seed_wg_waves = geti("DG_SEED_WG_WAVES", 4); c->env_seed_partial = geti("DG_SEED_PARTIAL_MIN", 32);
+    c->env_seed_multi = geti("DG_SEED_MULTI", 4); if (c->env_seed_multi < 0 || c->env_seed_multi > SQF_MULTI_MAX) c->env_seed_multi = SQF_MULTI_MAX;   // rows of an interval that are located and compared with the text at once (0: single rows only)
 }
 
 static int fail(dg_ctx *c, int code, const char *what, hipError_t e)
@@ -794,7 +795,7 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
         if (wgs > need) wgs = need;
         c->seed_qf_used = true;
         k_seed_qf<<<wgs, nw * 64, lds, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, lg, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT,
-                                                    c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, c->env_seed_partial, c->d_err);
+                                                    c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, c->env_seed_partial, c->env_seed_multi, c->d_err);
     } else
     if (!c->env_seed_legacy && W <= 62) {
         int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 10 ? c->env_seed_slots_lg : 9;

@@ -37,6 +37,7 @@ struct SqEnv {
     const DIndex &ix; const DParams &pr;
     uint4 *st; uint32_t *rd;
     int NSLOT, W2, K, H, bail_trips; bool direct;
+    int multi;                       // k_seed_qf with the full suffix array: intervals of up to `multi` rows are located and compared with the text (0: only single rows)
     DHit *hits; uint32_t *nhits, *nseeds; DHeavy *heavy; unsigned int *n_heavy;
 };
 
@@ -138,7 +139,7 @@ k_seed_q(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, co
     const uint32_t w_magic = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;       // i / W == (i * w_magic) >> 20 for i < 64 W <= 2^12
     SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_trips = 0, wtrips = 0;
-    const SqEnv env = { ix, pr, st, rd, NSLOT, W2, K, H, bail_trips, direct, hits, nhits, nseeds, heavy, n_heavy };
+    const SqEnv env = { ix, pr, st, rd, NSLOT, W2, K, H, bail_trips, direct, 0, hits, nhits, nseeds, heavy, n_heavy };
     uint32_t q_trips[SQ_NQ] = {0, 0, 0, 0, 0}, q_lanes[SQ_NQ] = {0, 0, 0, 0, 0};
 
     for (int i = tid; i < NSLOT; i += SQ_THREADS) q[(size_t)SQ_FREE * QCAP + i] = (uint16_t)i;
@@ -314,7 +315,8 @@ struct SqfDelta { uint32_t steps, blocks, lf_ref, max_trips;
 // sq_trip with the 32-byte state.  A trip whose search reaches the text comparison (a located prefix-table entry in a begin trip,
 // the SA entry in a locate trip) makes its first comparison at once, in the same trip: a second dependent load for those lanes,
 // but no push / pop / state round trip in between (a fifth of all slot-trips were first comparisons).
-template <int MODE>
+#define SQF_MULTI_MAX 4
+template <int MODE, bool MULTI = false>
 __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const uint32_t slot, SqfDelta &dl)
 {
     const DIndex &ix = e.ix;
@@ -334,6 +336,7 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
     if (MODE == SQ_STEP) { s.x0 = d_u64(B.x, B.w & 0xFFu); s.x1 = d_u64(B.y, (B.w >> 8) & 0xFFu); s.x2 = d_u64(B.z, (B.w >> 16) & 0xFFu); }
     else if (MODE == SQ_LOC) { s.lk = d_u64(B.x, B.y & 0xFFu); s.lsteps = B.y >> 8; }
     else if (MODE == SQ_CMP) { s.tpos = (int64_t)d_u64(B.x, B.y & 0xFFu); s.lsteps = B.y >> 8; s.lk = (uint64_t)B.z << 40; }
+    uint32_t nx = MODE == SQ_LOC ? B.z : 1u;              // rows of the interval a locate trip holds (1 unless MULTI)
     auto rb = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)wc * NSLOT + slot]; return w < W2 ? v : 0u; };
     auto rm = [&](int w) -> uint32_t { const int wc = w < W2 ? w : W2 - 1; const uint32_t v = rd[(size_t)(W2 + wc) * NSLOT + slot]; return w < W2 ? v : 0xFFFFFFFFu; };
     bool live = act, finished = false, beginning = false;
@@ -351,18 +354,108 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
                 mt = trips;
                 live = false;
             } else { nsearch++; beginning = true; d_begin_issue(ix, e.K, rb, rm, pos, s, c, ta, t); }
-        } else d_trip_issue<MODE == SQ_STEP ? TM_STEP : (MODE == SQ_CMP ? TM_CMP : TM_LOC)>(ix, rm, len, e.direct, s, c, ta, t);
+        } else if (!(MODE == SQ_LOC && MULTI)) d_trip_issue<MODE == SQ_STEP ? TM_STEP : (MODE == SQ_CMP ? TM_CMP : TM_LOC)>(ix, rm, len, e.direct, s, c, ta, t);
     }
     SQF_TW(dl, 2);
-    d_trip_load(ta, t);
+    if (!(MODE == SQ_LOC && MULTI)) d_trip_load(ta, t);
     SQF_TW(dl, 3);
     // what a search does between two memory accesses: a one-row interval goes on to be located and compared with the text; a step whose next
     // base is an N or past the read's end is the end of the search (what its next trip would find, without the trip)
     auto between = [&]() {
-        if (e.direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
+        if (e.direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; nx = 1u; }
         if (s.mode == 1 && (s.p >= len || d_at(rm, s.p))) d_search_end(e.pr, s);
+        // a few rows (full suffix array): their text positions are one load away and comparing the texts with the read finishes the search --
+        // no more Occ steps for this interval (a 16-mer of a human-sized text has 2-3 occurrences by chance alone: these steps were 45 % of all trips)
+        if (s.mode == 1 && s.x2 <= (uint64_t)e.multi) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; nx = (uint32_t)s.x2; }
     };
-    if (live) {
+    auto multi = [&](const bool go) {
+        // ---- locate the nx <= 4 rows of the interval and compare all their texts with the read, in this trip ----
+        // (a lane in mode 2 comes from a prefix-table entry that already holds its one text position: no suffix-array load for it)
+        // The interval's rows are suffixes in order, so the rows that match longest are neighbours: the search ends (bwt_search.cpp:152-170 run to
+        // its empty interval) with x0 = the first of them, x2 = how many, len = that match length.  Steps are counted as the reference's loop makes
+        // them (one per base + the failing one); Occ blocks as one per step, as in the single-row comparison (d_trip_finish).
+        uint2 sa[SQF_MULTI_MAX];
+#pragma unroll
+        for (int i = 0; i < SQF_MULTI_MAX; i++) sa[i] = make_uint2(0u, 0u);
+        const bool have_pos = s.mode == 2;
+        if (have_pos) { nx = 1u; sa[0] = make_uint2((uint32_t)s.lk, (uint32_t)(s.lk >> 32)); }
+        const uint2 *sap = (const uint2 *)ix.sa_dense + (have_pos ? 0ull : s.lk);
+#pragma unroll
+        for (int i = 0; i < SQF_MULTI_MAX; i++) if (go && !have_pos && (uint32_t)i < nx) sa[i] = sap[i];
+        SQF_TW(dl, 3);
+        const int64_t L = ix.l_pac;
+        const uint32_t *pw = (const uint32_t *)ix.pac;
+        uint4 s16[SQF_MULTI_MAX]; uint2 s8[SQF_MULTI_MAX]; uint32_t sh[SQF_MULTI_MAX]; int kind[SQF_MULTI_MAX];      // kind: 0 none, 1 forward, 2 reverse, 3 slow
+#pragma unroll
+        for (int i = 0; i < SQF_MULTI_MAX; i++) {
+            s16[i] = make_uint4(0u, 0u, 0u, 0u); s8[i] = make_uint2(0u, 0u); sh[i] = 0u; kind[i] = 0;
+            if (go && (uint32_t)i < nx) {
+                const int64_t tt = (int64_t)(d_u64(sa[i].x, sa[i].y & 0xFFu) - 1ull) + (s.p - s.start);
+                int64_t f0 = -1;
+                if (tt >= 0 && tt + 64 <= L) { f0 = tt; kind[i] = 1; }
+                else if (tt >= L && tt + 64 <= 2 * L) { f0 = 2 * L - 1 - tt - 63; kind[i] = 2; }
+                else kind[i] = 3;
+                if (f0 >= 0) { s16[i] = *(const uint4_a4 *)(pw + (f0 >> 4)); s8[i] = *(const uint2_a4 *)(pw + (f0 >> 4) + 4); sh[i] = (uint32_t)((f0 & 15) << 1); }
+            }
+        }
+        SQF_TW(dl, 5);
+        if (go) {
+            const int w = s.p >> 4;
+            const uint32_t o = (uint32_t)((s.p & 15) << 1);
+            const uint32_t b0 = rb(w), b1 = rb(w + 1), b2 = rb(w + 2), b3 = rb(w + 3), b4 = rb(w + 4);
+            const uint32_t m0 = rm(w), m1 = rm(w + 1), m2 = rm(w + 2), m3 = rm(w + 3), m4 = rm(w + 4);
+            const uint32_t R0 = __funnelshift_l(b1, b0, o), R1 = __funnelshift_l(b2, b1, o), R2 = __funnelshift_l(b3, b2, o), R3 = __funnelshift_l(b4, b3, o);
+            const uint32_t N0 = __funnelshift_l(m1, m0, o), N1 = __funnelshift_l(m2, m1, o), N2 = __funnelshift_l(m3, m2, o), N3 = __funnelshift_l(m4, m3, o);
+            bool slow = false;
+#pragma unroll
+            for (int i = 0; i < SQF_MULTI_MAX; i++) slow = slow || kind[i] == 3;
+            const int chunk = slow ? 16 : 64;                                          // a row near a strand boundary or the end of the text: everybody compares 16 symbols
+            const int in_read = len - s.p < chunk ? len - s.p : chunk;                 // bases left in the read
+            int jj[SQF_MULTI_MAX];
+#pragma unroll
+            for (int i = 0; i < SQF_MULTI_MAX; i++) {
+                jj[i] = -1;
+                if ((uint32_t)i < nx) {
+                    int nv = 64;
+                    uint32_t T0, T1 = 0, T2 = 0, T3 = 0;
+                    if (kind[i] != 3) {
+                        const uint32_t d0 = __builtin_bswap32(s16[i].x), d1 = __builtin_bswap32(s16[i].y), d2 = __builtin_bswap32(s16[i].z),
+                                       d3 = __builtin_bswap32(s16[i].w), d4 = __builtin_bswap32(s8[i].x);
+                        const uint32_t t0 = __funnelshift_l(d1, d0, sh[i]), t1 = __funnelshift_l(d2, d1, sh[i]), t2 = __funnelshift_l(d3, d2, sh[i]), t3 = __funnelshift_l(d4, d3, sh[i]);
+                        if (kind[i] == 2) { T0 = ~d_rev2(t3); T1 = ~d_rev2(t2); T2 = ~d_rev2(t1); T3 = ~d_rev2(t0); }   // T[t+j] = 3 - fwd[2L-1-t-j]
+                        else { T0 = t0; T1 = t1; T2 = t2; T3 = t3; }
+                    } else T0 = d_text16_slow(ix, (int64_t)(d_u64(sa[i].x, sa[i].y & 0xFFu) - 1ull) + (s.p - s.start), nv);
+                    const int lim = in_read < nv ? in_read : nv;
+                    auto tail = [&](int k) -> uint32_t { const int rem = lim - 16 * k; return rem >= 16 ? 0u : (rem <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu >> (2 * rem)); };
+                    const uint32_t e0 = (R0 ^ T0) | N0 | tail(0), e1 = (R1 ^ T1) | N1 | tail(1), e2 = (R2 ^ T2) | N2 | tail(2), e3 = (R3 ^ T3) | N3 | tail(3);
+                    jj[i] = e0 ? __clz((int)e0) >> 1 : e1 ? 16 + (__clz((int)e1) >> 1) : e2 ? 32 + (__clz((int)e2) >> 1) : e3 ? 48 + (__clz((int)e3) >> 1) : 64;
+                }
+            }
+            int j = -1, first = 0, cnt = 0;
+#pragma unroll
+            for (int i = 0; i < SQF_MULTI_MAX; i++) if (jj[i] > j) j = jj[i];
+#pragma unroll
+            for (int i = SQF_MULTI_MAX - 1; i >= 0; i--) if (jj[i] == j) { first = i; cnt++; }
+            uint2 se = sa[0];
+#pragma unroll
+            for (int i = 1; i < SQF_MULTI_MAX; i++) if (first == i) se = sa[i];
+            s.ref_steps += (uint32_t)j; s.ref_blocks += (uint32_t)j;
+            s.p += j;
+            c.n_direct++;
+            if (cnt == 1) {                                     // one row left: what a locate trip of that row would have found (T_SA)
+                const uint64_t en = d_u64(se.x, se.y);
+                s.tpos = (int64_t)((en & 0xFFFFFFFFFFull) - 1ull); s.lk = en; s.lsteps = 0; s.x2 = 1; s.mode = 2;
+            } else { s.x0 = s.lk + (uint64_t)first; s.x2 = (uint64_t)cnt; s.lk = s.x0; nx = (uint32_t)cnt; s.mode = j < chunk ? 1 : 3; }
+            if (j < chunk) {
+                // a mismatch or the end of the text costs the reference one more (failing) step; N / end of read do not
+                const uint32_t nsel = j < 16 ? N0 : j < 32 ? N1 : j < 48 ? N2 : N3;
+                if (j < in_read && !((nsel >> (30 - ((j & 15) << 1))) & 1u)) { s.ref_steps++; s.ref_blocks++; }
+                d_search_end(e.pr, s);
+            }
+        }
+    };
+    if (MODE == SQ_LOC && MULTI) multi(live);
+    else if (live) {
         if (MODE == SQ_BEGIN) { if (beginning) d_begin_finish(ix, e.K, rb, s, c, t); }
         else if (t.aux != T_NONE) d_trip_finish<MODE == SQ_STEP ? TM_STEP : (MODE == SQ_CMP ? TM_CMP : TM_LOC)>(ix, e.pr, rb, rm, len, s, c, t);
         between();
@@ -372,7 +465,8 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
     // text position (begin: a located table entry; locate: the SA entry).  One more dependent load for those lanes, but no push / pop / state
     // round trip in between: a fifth of all slot-trips were first comparisons.  (Chaining Occ steps the same way -- the first step behind a table
     // entry, two steps per step trip -- was measured too: 6 % fewer instructions, the same time with twelve batches in flight, 10 % longer alone.)
-    if (MODE == SQ_BEGIN || MODE == SQ_LOC) {
+    if (MODE == SQ_BEGIN && MULTI) multi(live && (s.mode == 2 || s.mode == 3));      // the table entry's position, or its few rows: located and compared at once
+    else if (MODE == SQ_BEGIN || MODE == SQ_LOC) {
         constexpr int M2 = TM_CMP;
         const bool go = live && ((M2 & TM_STEP) && s.mode == 1 || (M2 & TM_CMP) && s.mode == 2);
         TripData t2; t2.aux = T_NONE;
@@ -406,7 +500,7 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
             A.z = (uint32_t)nh | (nsearch << 5) | (trips << 10) | (s.ref_steps << 18); A.w = ns | (s.ref_blocks << 20);
             st[slot * 2] = A;
             if (s.mode == 1) st[slot * 2 + 1] = make_uint4((uint32_t)s.x0, (uint32_t)s.x1, (uint32_t)s.x2, (uint32_t)(s.x0 >> 32) | ((uint32_t)(s.x1 >> 32) << 8) | ((uint32_t)(s.x2 >> 32) << 16));
-            else if (s.mode == 3) st[slot * 2 + 1] = make_uint4((uint32_t)s.lk, (uint32_t)((s.lk >> 32) & 0xFFu) | (s.lsteps << 8), 0u, 0u);
+            else if (s.mode == 3) st[slot * 2 + 1] = make_uint4((uint32_t)s.lk, (uint32_t)((s.lk >> 32) & 0xFFu) | (s.lsteps << 8), nx, 0u);
             else if (s.mode == 2) st[slot * 2 + 1] = make_uint4((uint32_t)s.tpos, (uint32_t)(((uint64_t)s.tpos >> 32) & 0xFFu) | (s.lsteps << 8), (uint32_t)(s.lk >> 40), 0u);
         }
     }
@@ -418,7 +512,7 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
 __global__ void __launch_bounds__(512)
 k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H, int nslot_lg,
           DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
-          DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int partial_min, int *err)
+          DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int partial_min, int multi, int *err)
 {
     extern __shared__ uint4 sq_sh[];
     const int NSLOT = 1 << nslot_lg;
@@ -436,7 +530,7 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
     const int K = ix.ktab ? ix.ktab_k : 0;
     const bool direct = ix.sa_dense != nullptr;
     const uint32_t w_magic = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;       // i / W == (i * w_magic) >> 20 for i < 64 W <= 2^12
-    const SqEnv env = { ix, pr, st, rd, NSLOT, W2, K, H, bail_trips, direct, hits, nhits, nseeds, heavy, n_heavy };
+    const SqEnv env = { ix, pr, st, rd, NSLOT, W2, K, H, bail_trips, direct, (direct && ix.sa_dense_intv == 1) ? multi : 0, hits, nhits, nseeds, heavy, n_heavy };
     unsigned long long acc_steps = 0, acc_blocks = 0, acc_lf = 0;
     uint32_t max_trips = 0, wtrips = 0;
 
@@ -548,9 +642,10 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
                         if (i < total) { const uint32_t rk = (i * w_magic) >> 20; rd[(size_t)(i - rk * (uint32_t)W) * NSLOT + tab[wave * 64 + rk]] = v[k]; }
                     }
                 }
-            } else if (my_q == SQ_BEGIN) nq = sqf_trip<SQ_BEGIN>(env, act, slot, dl);
+            } else if (my_q == SQ_BEGIN) { if (env.multi) nq = sqf_trip<SQ_BEGIN, true>(env, act, slot, dl); else nq = sqf_trip<SQ_BEGIN>(env, act, slot, dl); }
             else if (my_q == SQ_STEP) nq = sqf_trip<SQ_STEP>(env, act, slot, dl);
             else if (my_q == SQ_CMP) nq = sqf_trip<SQ_CMP>(env, act, slot, dl);
+            else if (env.multi) nq = sqf_trip<SQ_LOC, true>(env, act, slot, dl);
             else nq = sqf_trip<SQ_LOC>(env, act, slot, dl);
 #ifdef DG_SQF_PROF
             if (my_q == SQ_FREE) SQF_TW(dl, 9);

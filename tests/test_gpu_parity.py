@@ -106,19 +106,20 @@ def test_gpu_seed_queue_configurations(ctxs, monkeypatch):
     monkeypatch.setenv("DG_SEED_LEGACY", "0")
     for phases in ("0", "1"):
         monkeypatch.setenv("DG_SEED_PHASES", phases)
-        for lg, wgs, bail, nw, part in ((9, 0, 128, 4, 32), (6, 1, 128, 4, 1), (7, 3, 128, 2, 64), (8, 2, 6, 8, 16), (9, 2, 1000, 1, 32), (10, 1, 128, 8, 48)):
+        for lg, wgs, bail, nw, part, multi in ((9, 0, 128, 4, 32, 4), (6, 1, 128, 4, 1, 2), (7, 3, 128, 2, 64, 3), (8, 2, 6, 8, 16, 4), (9, 2, 1000, 1, 32, 1), (10, 1, 128, 8, 48, 0)):
             if phases == "1" and lg > 9:
                 continue
             monkeypatch.setenv("DG_SEED_SLOTS_LG", str(lg)); monkeypatch.setenv("DG_SEED_WGS", str(wgs)); monkeypatch.setenv("DG_SEED_BAIL_TRIPS", str(bail))
             monkeypatch.setenv("DG_SEED_WG_WAVES", str(nw)); monkeypatch.setenv("DG_SEED_PARTIAL_MIN", str(part))
+            monkeypatch.setenv("DG_SEED_MULTI", str(multi))          # rows of an interval k_seed_qf locates and compares at once (0: Occ steps down to one row)
             gpu.set_params(host.default_params())
             got = gpu.probe_seeds(so, rl, flat)
             for a, b in zip(want, got):
-                assert np.array_equal(a, b), (phases, lg, wgs, bail, nw, part)
+                assert np.array_equal(a, b), (phases, lg, wgs, bail, nw, part, multi)
         monkeypatch.setenv("DG_SEED_SLOTS_LG", "6"); monkeypatch.setenv("DG_SEED_WGS", "2"); monkeypatch.delenv("DG_SEED_BAIL_TRIPS")
         gpu.set_params(host.default_params(paired=0, max_mismatch=4))
         assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=0, max_mismatch=4), so, rl, flat))
-    for k in ("DG_SEED_SLOTS_LG", "DG_SEED_WGS", "DG_SEED_LEGACY", "DG_SEED_PHASES", "DG_SEED_WG_WAVES", "DG_SEED_PARTIAL_MIN"):
+    for k in ("DG_SEED_SLOTS_LG", "DG_SEED_WGS", "DG_SEED_LEGACY", "DG_SEED_PHASES", "DG_SEED_WG_WAVES", "DG_SEED_PARTIAL_MIN", "DG_SEED_MULTI"):
         monkeypatch.delenv(k)
     gpu.set_params(host.default_params())
 
@@ -364,16 +365,28 @@ def test_gpu_both_seeding_kernels_match_oracle(workdir, monkeypatch):
     assert_same(gpu.map_batch(so, rl, flat), want)
     ctr = gpu.counters()
     assert ctr["seedq_trips_step"] > 0 and ctr["seedq_phases"] > 0
-    for k in ("steps", "lf_steps", "sa_lookups", "seeds", "occ_blocks"):
+    for k in ("steps", "lf_steps", "sa_lookups", "seeds"):
         assert ctr[k] == base_ctr[k], k
+    # Occ blocks: k_seed_qf finishes intervals of up to four rows by comparing their texts and counts those steps as one block each
+    # (the reference loads a second block when the interval's two rows lie in different blocks): a lower bound, within a percent
+    assert 0 <= ctr["occ_blocks"] - base_ctr["occ_blocks"] <= 0.01 * ctr["occ_blocks"]
+    phased_ctr = ctr
+    monkeypatch.setenv("DG_SEED_MULTI", "0")               # k_seed_qf with single-row comparisons only: block for block what the phased kernel counts
     monkeypatch.delenv("DG_SEED_PHASES")
+    gpu.set_params(gpu.params)
+    assert_same(gpu.map_batch(so, rl, flat), want)
+    ctr = gpu.counters()
+    for k in ("steps", "lf_steps", "sa_lookups", "seeds", "occ_blocks"):
+        assert ctr[k] == phased_ctr[k], k
+    assert ctr["seedq_trips_step"] > base_ctr["seedq_trips_step"]          # (the few-row intervals went through Occ steps again)
+    monkeypatch.delenv("DG_SEED_MULTI")
     monkeypatch.setenv("DG_SEED_LEGACY", "1")
     gpu.set_params(gpu.params)
     assert_same(gpu.map_batch(so, rl, flat), want)
     ctr = gpu.counters()
     assert ctr["seedq_trips_step"] == 0
     for k in ("steps", "lf_steps", "sa_lookups", "seeds", "occ_blocks"):
-        assert ctr[k] == base_ctr[k], k
+        assert ctr[k] == phased_ctr[k], k
     monkeypatch.delenv("DG_SEED_LEGACY")
     gpu.close(); orc.close()
 def test_gpu_packed_reads_and_pinned_buffers(workdir):
