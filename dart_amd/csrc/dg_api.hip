@@ -85,7 +85,7 @@ struct dg_ctx {
     bool want_compact = true, packed_valid = false;     // compact records: written by this run's kernels too / present for the batch that ran last
     int n_cu = 256, runs_of_last_batch = 0, attempt_no = 0;
     // environment switches, read once per context (not per batch)
-    int env_seed_waves = 4, env_bail_trips = 128, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
+    int env_seed_waves = 4, env_bail_trips = 0 /* 0: 64 trips in k_seed_qf (a trip there is up to three dependent accesses), 128 in the other two */, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
     int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32, env_seed_multi = 4;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
     size_t seedqf_lds_set = 0;
     bool seed_qf_used = false;     // the last run's seeding kernel was k_seed_qf (its own-work counters are derived from its slot counts)
@@ -95,7 +95,7 @@ struct dg_ctx {
 static void read_env(dg_ctx *c)
 {
     auto geti = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
-    c->env_seed_waves = geti("DG_SEED_WAVES", 4); c->env_bail_trips = geti("DG_SEED_BAIL_TRIPS", 128); c->env_both = geti("DG_SEED_BOTH", 0);
+    c->env_seed_waves = geti("DG_SEED_WAVES", 4); c->env_bail_trips = geti("DG_SEED_BAIL_TRIPS", 0); c->env_both = geti("DG_SEED_BOTH", 0);
     c->env_seed_legacy = geti("DG_SEED_LEGACY", 0); c->env_seed_slots_lg = geti("DG_SEED_SLOTS_LG", 0); c->env_seed_wgs = geti("DG_SEED_WGS", 0); c->env_blocking_sync = geti("DG_BLOCKING_SYNC", 0);
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
     c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0);
@@ -771,11 +771,12 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     unsigned blocks = (unsigned)c->n_cu * (unsigned)c->env_seed_waves;   // one wave per SIMD: the kernel is instruction-fetch bound, more waves add ~10 % alone but cost more than
                                                                          // that to the other batches in flight (measured 5.4 vs 6.0 ms per step with four batches)
     if ((size_t)blocks * 64 > (size_t)n) blocks = (unsigned)((n + 63) / 64);
-    const int bail_trips = c->env_bail_trips, both_thr = c->env_both;
+    const bool use_qf = !c->env_seed_legacy && !c->env_seed_phases && W <= 62 && c->pr.max_dup <= 30000;      // (k_seed_qf's slot state counts occurrences in 20 bits: 31 hits x max_dup)
+    const int bail_trips = c->env_bail_trips > 0 ? c->env_bail_trips : (use_qf ? 64 : 128), both_thr = c->env_both;
     unsigned int *tops = c->d_tops;
     // default: the queue kernel (dg_seedq.h).  DG_SEED_LEGACY=1 or reads too long for its LDS slots (> 496 bases): the lane-per-read kernel
     c->seed_qf_used = false;
-    if (!c->env_seed_legacy && !c->env_seed_phases && W <= 62 && c->pr.max_dup <= 30000) {      // (its slot state counts occurrences in 20 bits: 31 hits x max_dup)
+    if (use_qf) {
         // the free-running queue kernel (dg_seedq.h, k_seed_qf): workgroups of `nw` waves around 2^lg read slots
         int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 11 ? c->env_seed_slots_lg : 9;
         int nw = c->env_seed_wg_waves >= 1 && c->env_seed_wg_waves <= 8 ? c->env_seed_wg_waves : 4;
@@ -788,6 +789,10 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
         }
         unsigned per_cu = (unsigned)(((size_t)160 * 1024) / lds);
         if (per_cu * (unsigned)nw > 16u) per_cu = 16u / (unsigned)nw;
+        // Two workgroups per CU although three fit: the launch lasts as long as its slowest reads' chains of trips whatever the number of waves
+        // (alone 0.98 ms with two or three), and the third workgroup's 50 KB of LDS is what another batch's k_pair (72 KB) needs to start on
+        // the same CU: 840 against 806 M reads/s with twelve batches in flight (profiles/r03/d_variants_wgs_per_cu.txt).  DG_SEED_WGS overrides.
+        if (per_cu > 2u) per_cu = 2u;
         if (per_cu < 1u) per_cu = 1u;
         if (c->env_seed_wgs > 0) per_cu = (unsigned)c->env_seed_wgs;
         unsigned wgs = (unsigned)c->n_cu * per_cu;
