@@ -579,25 +579,34 @@ def main():
             d_["k_reseed"] = d_.pop("k_reseed(overlapped)")
     alg["k_reseed"] = counters["reseed_window"] // 4 + 64 * counters["reseed_calls"]      # window bases at 2 bit/base, streamed once (B_ref)
     stage_kernels = [k for k in ("k_seed", "k_locate", "k_pair", "k_report", "k_chain_heavy", "k_reseed") if k in kern]
-    dom = max(stage_kernels, key=lambda k: iso.get(k, kern.get(k, 0.0)))
     per_read_B = (alg["k_seed"] + alg["k_locate"]) / n_reads
-    dom_bytes = alg.get(dom)
-    if dom_bytes is None:      # pair / report kernels: their own input and output (seeds in, records out, read bases compared)
-        dom_bytes = 8 * counters["seeds"] + 90 * n_reads
-    # PMC traffic of the dominant kernel: only from passes taken with THESE kernel sources on THIS workload (profiles/run_profile.sh stores the
+    # PMC traffic: only from passes taken with THESE kernel sources on THIS workload (profiles/run_profile.sh stores the
     # fingerprint of the bench line it profiled in profiles/traffic.json); anything else says nothing about this run
     fingerprint = {"csrc_sha256": kernel_sources_sha256(),
                    "workload": "genome=%s model=%s pairs=%d rlen=%d spliced=%g introns=%d repeat_scale=%g mis=%d sub=%g indel=%g" %
                                (args.genome, args.genome_model, args.pairs, args.rlen, args.spliced, args.introns, args.repeat_scale, args.mis, args.sub_rate, args.indel_frac)}
-    traffic = None
+    tj = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("_fingerprint") == fingerprint:
-                traffic = tj.get(dom)
+            if tj.get("_fingerprint") != fingerprint:
+                tj = {}
         except Exception:
-            traffic = None
+            tj = {}
+    # The dominant kernel of an HBM roofline: the one that moves the most bytes through the memory side (PMC; the seeding stage: half of a
+    # batch's traffic) -- without a matching PMC profile, the one that runs longest alone.  (The longest stand-alone stage alone is a coin
+    # flip by now: seeding and the general-path report are both ~1.0 ms.)  `stages` carries the same figures for every stage either way.
+    ms_of = lambda k: iso.get(k) or kern[k]
+    dom = max(stage_kernels, key=(lambda k: tj.get(k, 0)) if any(tj.get(k) for k in stage_kernels) else ms_of)
+    traffic = tj.get(dom)
+    stages = {k: {"ms_standalone": round(ms_of(k), 4), "ms_in_timed_region": round(kern[k], 4), "traffic": tj.get(k),
+                  "GBps": round(tj[k] / (ms_of(k) * 1e-3) / 1e9, 1) if tj.get(k) else None,
+                  "frac": round(tj[k] / (ms_of(k) * 1e-3) / 8e12, 5) if tj.get(k) else None,
+                  "frac_of_random_line_ceiling": round(tj[k] / (ms_of(k) * 1e-3) / 3.1e12, 4) if tj.get(k) else None} for k in stage_kernels}
+    dom_bytes = alg.get(dom)
+    if dom_bytes is None:      # pair / report kernels: their own input and output (seeds in, records out, read bases compared)
+        dom_bytes = 8 * counters["seeds"] + 90 * n_reads
     own = {
         # Occ blocks + 16-byte table entries + per located search one 8-byte SA entry and ~2 text windows of 20 bytes
         # + the read's 2-bit/mask words in + 16-byte hits out
@@ -606,7 +615,7 @@ def main():
         "k_locate": 64 * counters.get("lf_steps_executed", 0) + 8 * counters["sa_lookups"] + 8 * counters["seeds"],
     }
     own_bytes = int(own.get(dom, dom_bytes))
-    ms_alone = iso.get(dom) or kern[dom]
+    ms_alone = ms_of(dom)
     # `achieved` is a HARDWARE statement: the bytes the dominant kernel really moves through the memory side (PMC FETCH_SIZE + WRITE_SIZE of one
     # launch; without a matching profile: the bytes it requests, from the live counters -- a lower bound) over the launch's stand-alone
     # duration, against 8 TB/s.  The rate on the REFERENCE algorithm's bytes stays beside it as `algorithmic_*`: the prefix
@@ -633,6 +642,7 @@ def main():
                 # SURVEY 8d's whole-job form: reads/s x algorithmic bytes per read (this GPU's share of `value`)
                 "whole_job_algorithmic_GBps_per_gpu": round(value / world * 1e6 * per_read_B / 1e9, 1),
                 "fingerprint": fingerprint,
+                "stages": stages,
                 "note": "one launch = one batch of %d reads.  achieved / frac = real bytes over the stand-alone duration (see achieved_basis); algorithmic_* = what the "
                         "reference's algorithm and layout would fetch for the same reads (SURVEY 8d: 64 B per Occ block of bwt_2occ4, per LF step, 8 B per SA entry), "
                         "kept as a work-elimination factor" % n_reads}
