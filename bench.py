@@ -751,7 +751,7 @@ def main():
                    "input": ("packed reads (2 bit/base + N list, dg_map_batch_packed): %.1f MB per batch" if args.input == "packed" else "ASCII reads (dg_map_batch): %.1f MB per batch") % (in_bytes / 1e6),
                    "output": ("%s + CIGAR ops + junction tuples into page-locked host arrays: %%.1f MB per batch" %
                               ("compact records (dg_read_c 12 B + dg_report_c 16 B, no CIGAR for plain full-length matches, lossless)" if args.records == "compact" else "dg_read_out 36 B + dg_report_out 40 B")) % (workers[0].out_bytes(n_reads) / 1e6),
-                   "host_link": "57 GB/s in total, both directions together (profiles/probes/pcie_probe.py): bytes in + bytes out per read bound this rate",
+                   "host_link": "57 GB/s per direction, full duplex for the copy engines (profiles/probes/duplex_probe.hip, profiles/r03/f_duplex_probe_and_download_cost.txt)",
                    "timed_region": "first batch handed over in host memory -> last record back in host memory (H2D + all kernels + D2H, %d batches in flight)" % len(workers),
                    "pairs_per_gpu_per_step": nb * args.pairs, "read_len": args.rlen, "spliced_fraction": args.spliced, "batches_in_flight_per_gpu": len(workers),
                    "synthetic_genome_repeat_content": ("planted repeat families cover ~18 %% of the genome at --repeat-scale 1 (real human DNA: ~50 %%; `--genome-model human` runs that: "
