@@ -389,6 +389,40 @@ def test_gpu_both_seeding_kernels_match_oracle(workdir, monkeypatch):
         assert ctr[k] == phased_ctr[k], k
     monkeypatch.delenv("DG_SEED_LEGACY")
     gpu.close(); orc.close()
+def test_gpu_index_aids_off_or_sampled(workdir, monkeypatch):
+    """dg_init's index aids are chosen by text size (dg_api.hip: full suffix array up to 12 G symbols, every 2nd / 4th row beyond; prefix table
+    K = 8..16): here they are forced to what a much larger genome would get -- no dense SA at all (LF walks to the reference's every-32nd-row
+    samples), every 2nd / 4th row (LF steps, then the sample), no prefix table, a short one -- and every combination gives the oracle's records
+    and the same reference-equivalent counters, through the queue kernel and the lane-per-read kernel"""
+    g = synth.make_genome([1200000, 600000], seed=71, repeat_scale=40.0, n_introns=100)
+    prefix = os.path.join(workdir, "aids")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    m1, m2 = synth.make_reads(g, 12000, rlen=101, seed=72, sub_rate=0.02, indel_frac=0.05, spliced_frac=0.1, n_frac=0.02)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    want = orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=16)
+    base = None
+    for dense, K, legacy in (("1", "", "0"), ("0", "", "0"), ("2", "", "0"), ("4", "10", "0"), ("1", "0", "0"), ("0", "0", "1"), ("4", "", "1")):
+        monkeypatch.setenv("DG_SA_DENSE", dense); monkeypatch.setenv("DG_SEED_LEGACY", legacy)
+        if K: monkeypatch.setenv("DG_KTAB_K", K)
+        else: monkeypatch.delenv("DG_KTAB_K", raising=False)
+        gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
+        assert_same(gpu.map_batch(so, rl, flat), want)
+        c = gpu.counters()
+        if base is None: base = c
+        for k in ("steps", "lf_steps", "sa_lookups", "seeds"):
+            assert c[k] == base[k], (k, dense, K, legacy)
+        gpu.close()
+    for k in ("DG_SA_DENSE", "DG_SEED_LEGACY"): monkeypatch.delenv(k)
+    monkeypatch.delenv("DG_KTAB_K", raising=False)
+    # -max_dup beyond what k_seed_qf's slot state counts (31 hits x max_dup in 20 bits): the phased queue kernel takes the batch
+    gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5, max_dup=40000))
+    assert_same(gpu.map_batch(so[:6000], rl[:6000], flat), orc.map_batch(orc.params(paired=1, max_mismatch=5, max_dup=40000), so[:6000], rl[:6000], flat, threads=16))
+    c = gpu.counters()
+    assert c["seedq_trips_step"] > 0 and c["seedq_phases"] > 0
+    gpu.close(); orc.close()
+
+
 def test_gpu_packed_reads_and_pinned_buffers(workdir):
     """dg_map_batch_packed (2 bit/base + N list) gives the records of dg_map_batch on the same reads, with fixed and with
     per-read lengths; page-locked caller buffers (dg_host_alloc) through the raw ABI; a read with a lower-case base is refused
