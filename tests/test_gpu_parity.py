@@ -389,6 +389,51 @@ def test_gpu_both_seeding_kernels_match_oracle(workdir, monkeypatch):
         assert ctr[k] == phased_ctr[k], k
     monkeypatch.delenv("DG_SEED_LEGACY")
     gpu.close(); orc.close()
+def test_gpu_seeds_at_the_ends_of_the_text(workdir):
+    """reads from the first and last bases of the genome, both strands -- their matches end at the strand boundary (position l_pac of the
+    text = forward strand + reverse complement) or at the end of the text, where the text comparisons of the seeding kernels take their
+    slow path (d_text16_slow) -- and the same stretches planted a second and third time inside the genome, so that the few-row comparison of
+    k_seed_qf holds rows next to a boundary together with ordinary ones"""
+    g = synth.make_genome([400000, 300000], seed=91, repeat_scale=5.0, n_introns=0)
+    L = g.total
+    g.codes[150000:150300] = g.codes[:300]                  # the genome's first 300 bases again ...
+    g.codes[500000:500300] = g.codes[L - 300:]              # ... and its last 300
+    g.codes[250000:250300] = g.codes[:300]
+    g.codes[399700:400000] = g.codes[L - 300:]              # the end of chromosome 1 = the end of the genome
+    prefix = os.path.join(workdir, "ends")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    asc = g.ascii()
+    comp = np.zeros(256, np.uint8); comp[list(b"ACGT")] = list(b"TGCA")
+    rng = np.random.default_rng(5)
+    seqs = []
+    for k in range(0, 120, 3):
+        for p, ln in ((k, 101), (L - 101 - k, 101), (k, 60), (L - 60 - k, 60), (150000 + k, 101), (500000 + 199 - k, 101), (399700 + 199 - k, 101), (L - 150 - k, 150)):
+            r = asc[p:p + ln].copy()
+            if k % 2: r[int(rng.integers(20, ln - 20))] = ord("ACGT"[int(rng.integers(0, 4))])
+            seqs.append(bytes(r.tobytes()))
+            seqs.append(bytes(comp[r[::-1]].tobytes()))
+    so, rl, flat = host.pack_reads(seqs)
+    gpu = host.DartGPU(ix, host.default_params(paired=0, max_mismatch=5, multi_hit=1))
+    # (-max_dup 1 / 2: the planted stretches occur three times, so an interval passes or fails the limit depending on how far the comparison narrows it)
+    for kw in (dict(paired=0, max_mismatch=5, multi_hit=1), dict(paired=1, max_mismatch=3), dict(paired=0, max_mismatch=5, max_dup=2), dict(paired=0, max_mismatch=5, max_dup=1, multi_hit=1)):
+        gpu.set_params(host.default_params(**kw))
+        assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(**kw), so, rl, flat))
+    gpu.set_params(host.default_params(paired=0, max_mismatch=5, multi_hit=1))
+    want = gpu.probe_seeds(so, rl, flat)
+    import os as _os
+    for env in ({"DG_SEED_MULTI": "0"}, {"DG_SEED_LEGACY": "1"}, {"DG_SEED_PHASES": "1"}):
+        for k_, v_ in env.items(): _os.environ[k_] = v_
+        try:
+            gpu.set_params(host.default_params(paired=0, max_mismatch=5, multi_hit=1))
+            got = gpu.probe_seeds(so, rl, flat)
+        finally:
+            for k_ in env: del _os.environ[k_]
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), env
+    gpu.close(); orc.close()
+
+
 def test_gpu_index_aids_off_or_sampled(workdir, monkeypatch):
     """dg_init's index aids are chosen by text size (dg_api.hip: full suffix array up to 12 G symbols, every 2nd / 4th row beyond; prefix table
     K = 8..16): here they are forced to what a much larger genome would get -- no dense SA at all (LF walks to the reference's every-32nd-row
