@@ -462,7 +462,7 @@ int main(int argc, char *argv[])
     // page-locked batch slots for the parallel FASTQ pipeline: allocated in the background while the index loads
     setenv("DG_BLOCKING_SYNC", "1", 0);      // the mapping threads sleep while their batch is on the GPU instead of spinning: the CPU share belongs to the parser, the formatter and the writer
     int n_gpu = getenv("DART_GPUS") ? atoi(getenv("DART_GPUS")) : 1; if (n_gpu < 1) n_gpu = 1;
-    size_t batch_reads = getenv("DART_BATCH") ? (size_t)atoll(getenv("DART_BATCH")) : 1000000; batch_reads = std::max<size_t>(4000, batch_reads & ~(size_t)1);
+    size_t batch_reads = getenv("DART_BATCH") ? (size_t)atoll(getenv("DART_BATCH")) : 500000; batch_reads = std::max<size_t>(4000, batch_reads & ~(size_t)1);
     const int inflight_cfg = std::max(1, getenv("DART_INFLIGHT") ? atoi(getenv("DART_INFLIGHT")) : 2);
     SlotPool pool;
     {

@@ -161,7 +161,9 @@ __attribute__((target("avx2"))) static void comp2_copy_avx2(char *d, const char 
 static const bool g_avx2 = __builtin_cpu_supports("avx2");
 static const char g_digits2[201] = "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
 
-struct TextBuf {
+// (one per formatter thread, side by side in a vector: each on cache lines of its own -- `n` is written with every field, and neighbours that
+//  shared a line made thirteen threads format slower than one: 890 ns per read and thread against 50, profiles/r03/g_formatter_false_sharing.txt)
+struct alignas(128) TextBuf {
     char *b = nullptr; size_t n = 0, cap = 0;
     ~TextBuf() { free(b); }
     inline void need(size_t more) { if (n + more > cap) { cap = std::max(cap * 2, n + more + (1 << 16)); b = (char *)realloc(b, cap); } }
@@ -192,7 +194,7 @@ struct TextBuf {
     }
 };
 
-struct Counters { long long total = 0, unique = 0, unmapped = 0, paired = 0; };
+struct alignas(128) Counters { long long total = 0, unique = 0, unmapped = 0, paired = 0; };
 
 // OutputPairedAlignments / OutputSingledAlignments (Mapping.cpp:208-369) for reads [lo,hi) of a batch.
 // names/name_len: chromosome names; n_pair_mode: reads below this index are mates of pairs (2i, 2i+1).
@@ -317,7 +319,9 @@ static int run_fast_library(const char *f1, const char *f2, bool pair_end, int t
     const int T = std::max(1, threads);
     // T is the budget of ALL stages (the GPU boxes grant a CPU quota, not cores: more runnable threads than the quota means the whole process is
     // throttled): the formatter takes what the writer (TWR threads), the assembler and the mapping threads leave.  DART_FMT_THREADS / DART_WRITE_THREADS override.
-    const int TWR = getenv("DART_WRITE_THREADS") ? std::max(1, atoi(getenv("DART_WRITE_THREADS"))) : 2;
+    // (ONE writer: pwrites to one file serialise on its inode lock, and two threads taking turns at it are slower than one that keeps it --
+    //  write 0.78 s against 1.4-1.6 s per 16 M reads on tmpfs, profiles/r03/g_formatter_false_sharing.txt)
+    const int TWR = getenv("DART_WRITE_THREADS") ? std::max(1, atoi(getenv("DART_WRITE_THREADS"))) : 1;
     const int TF = getenv("DART_FMT_THREADS") ? std::max(1, atoi(getenv("DART_FMT_THREADS"))) : std::max(1, T - TWR - 1);
     const char *wm = getenv("DART_WRITE");
     const bool use_mmap = wm && strcmp(wm, "mmap") == 0;          // default pwrite (measured on tmpfs: 5.1 GB/s against 3.2 GB/s through a shared mapping)
