@@ -465,10 +465,14 @@ int main(int argc, char *argv[])
     size_t batch_reads = getenv("DART_BATCH") ? (size_t)atoll(getenv("DART_BATCH")) : 500000; batch_reads = std::max<size_t>(4000, batch_reads & ~(size_t)1);
     const int inflight_cfg = std::max(1, getenv("DART_INFLIGHT") ? atoi(getenv("DART_INFLIGHT")) : 2);
     SlotPool pool;
+    FastqIndex pre;                         // the first library's read files are mapped and indexed while the genome index loads and dg_init runs
     {
         const std::string &fn0 = o.f1[0];
-        if (!o.bam && !getenv("DART_STREAMING") && fn0.substr(fn0.find_last_of('.') + 1) != "gz" && check_read_format(fn0.c_str()))
+        if (!o.bam && !getenv("DART_STREAMING") && fn0.substr(fn0.find_last_of('.') + 1) != "gz" && check_read_format(fn0.c_str())) {
             pool.start((size_t)n_gpu * inflight_cfg + 2, batch_reads, 160);
+            const bool two = o.f1.size() == o.f2.size();
+            if (!two || o.f2[0].substr(o.f2[0].find_last_of('.') + 1) != "gz") pre.start(fn0.c_str(), two ? o.f2[0].c_str() : nullptr, o.threads);
+        }
     }
     HostIndex ix;
     if (!o.index || !file_exists(std::string(o.index) + ".ann") || !file_exists(std::string(o.index) + ".amb") || !file_exists(std::string(o.index) + ".pac")) {
@@ -536,7 +540,7 @@ int main(int argc, char *argv[])
             uint64_t off = (uint64_t)ftello(sam);
             std::string ferr; FastStats fst;
             const int frc = run_fast_library(fn.c_str(), sep ? o.f2[lib].c_str() : nullptr, pair_end, o.threads, batch_reads, ctx, o.p, ix.names, o.unique, o.multi, o.silent,
-                                             fileno(sam), &off, total, sjmap, t0, ferr, fst, pool);
+                                             fileno(sam), &off, total, sjmap, t0, ferr, fst, pool, lib == 0 ? &pre : nullptr);
             fseeko(sam, (off_t)off, SEEK_SET);
             if (frc) { fprintf(stderr, "\nError! GPU mapping failed (%d): %s\n", frc, ferr.c_str()); return 1; }
             if (getenv("DART_TIMING")) fprintf(stderr, "[dart timing] index %.3f s, assemble %.3f s (of which page-locked allocation %.3f s), map (sum over workers) %.3f s, format %.3f s, write %.3f s\n", fst.t_index, fst.t_asm, fst.t_alloc, fst.t_map, fst.t_fmt, fst.t_write);
