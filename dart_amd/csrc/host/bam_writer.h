@@ -82,16 +82,19 @@ public:
             std::vector<uint8_t> one;
             for (size_t c = (size_t)t; c < n; c += (size_t)T) {
                 const char *p = chunks[c].first, *end = p + chunks[c].second;
-                recs[c].reserve(chunks[c].second);
+                // (a chunk's records and counts are gathered in locals: recs[c] / good[c] of neighbouring chunks share cache lines and belong to other threads)
+                std::vector<uint8_t> acc; acc.reserve(chunks[c].second);
+                long long g = 0, rf = 0;
                 while (p < end) {
                     const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
                     const char *le = nl ? nl : end;
                     if (le > p && *p != '@') {
                         one.clear();
-                        if (sam_line_to_bam(p, (size_t)(le - p), one)) { recs[c].insert(recs[c].end(), one.begin(), one.end()); good[c]++; } else refused[c]++;
+                        if (sam_line_to_bam(p, (size_t)(le - p), one)) { acc.insert(acc.end(), one.begin(), one.end()); g++; } else rf++;
                     }
                     p = nl ? nl + 1 : end;
                 }
+                recs[c] = std::move(acc); good[c] = g; refused[c] = rf;
             }
         };
         if (T <= 1) work(0);
