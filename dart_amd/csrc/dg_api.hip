@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <vector>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 
 static char g_init_error[512] = "";
@@ -45,6 +46,9 @@ struct dg_ctx {
     bool owns_index = true;       // false for dg_clone()d contexts: the index arrays belong to the parent
     size_t seedq_lds_set = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_dl = nullptr, ev_dl_block = nullptr;      // this context's place in the device's copy stream (copy_stream below); _block: the host thread sleeps (DG_BLOCKING_SYNC)
+    bool dl_on_copy_stream = false;
+    int env_copy_stream = 1;                           // DG_COPY_STREAM: 0 = the downloads on the context's own stream, 1 = on the device's copy stream
     hipEvent_t ev_prep = nullptr, ev_reseed0 = nullptr, ev_reseed1 = nullptr, ev_wait = nullptr;
     float reseed_ms = 0;
     char err[512] = "";
@@ -100,6 +104,7 @@ static void read_env(dg_ctx *c)
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
     c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0);
     c->env_seed_phases = geti("DG_SEED_PHASES", 0); c->env_seed_wg_waves = geti("DG_SEED_WG_WAVES", 4); c->env_seed_partial = geti("DG_SEED_PARTIAL_MIN", 32);
+    c->env_copy_stream = geti("DG_COPY_STREAM", 1);
     c->env_seed_multi = geti("DG_SEED_MULTI", 4); if (c->env_seed_multi < 0 || c->env_seed_multi > SQF_MULTI_MAX) c->env_seed_multi = SQF_MULTI_MAX;   // rows of an interval that are located and compared with the text at once (0: single rows only)
 }
 
@@ -231,6 +236,28 @@ static void caps_publish(std::atomic<size_t> &a, size_t v) { size_t cur = a.load
 static void caps_adopt(size_t &mine, const std::atomic<size_t> &a) { const size_t v = a.load(); if (v > mine) mine = v; }
 // waiting for a context's stream on the per-batch path.  DG_BLOCKING_SYNC=1: through an event created with hipEventBlockingSync, so the
 // host thread sleeps instead of spinning (one thread per context: a dozen spinning threads per GPU is a dozen busy cores)
+// One copy stream per device, with the highest priority, shared by all contexts of the device (dg_clone), for the downloads.  A context's
+// download is four copies; on its own stream each of them is a blit launch that queues among a dozen batches' kernels (a third of a
+// context's cycle was spent there).  On the device's copy stream they run ahead of the kernels and one batch after the other: 853
+// against 797-838 M reads/s (profiles/r03/h_copy_stream.txt).  One such stream PER CONTEXT is far worse (621): too many queues; the
+// uploads on a stream of the same kind (the context's stream waiting for an event): 827 against 850.
+// The host has waited for the run before it downloads, so the copy stream needs no dependency on the context's stream; the context waits
+// for its own event behind its copies.  The streams live as long as the process.
+static std::mutex g_copy_mu[16];
+static hipStream_t g_copy_stream[16][2];
+static hipError_t copy_stream(int device, int dir, hipStream_t *out)
+{
+    hipStream_t &sl = g_copy_stream[device & 15][dir];
+    if (!sl) {
+        int lo = 0, hi = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&sl, hipStreamNonBlocking, hi);
+        if (e != hipSuccess) { sl = nullptr; return e; }
+    }
+    *out = sl;
+    return hipSuccess;
+}
+
 static hipError_t wait_stream(dg_ctx *c)
 {
     if (!c->env_blocking_sync || !c->ev_wait) return hipStreamSynchronize(c->stream);
@@ -470,6 +497,8 @@ extern "C" void dg_destroy(dg_ctx *c)
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
+    if (c->ev_dl) (void)hipEventDestroy(c->ev_dl);
+    if (c->ev_dl_block) (void)hipEventDestroy(c->ev_dl_block);
     if (c->ev_reseed0) (void)hipEventDestroy(c->ev_reseed0);
     if (c->ev_reseed1) (void)hipEventDestroy(c->ev_reseed1);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -485,7 +514,8 @@ static hipError_t make_ctx_objects(dg_ctx *c)
     for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) return e;
     if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return e;
+        (e = hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_dl, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_dl_block, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return e;
     for (int i = 0; i <= N_TIMERS; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&c->d_ctr, CTR_STRIPES * CTR_STRIDE * 8)) != hipSuccess || (e = hipMalloc((void **)&c->d_tops, N_TOPS * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_err, 4)) != hipSuccess || (e = hipMalloc((void **)&c->d_sizes, sizeof(DSizes))) != hipSuccess ||
@@ -1125,11 +1155,30 @@ static int enqueue_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint3
         snprintf(c->err, 512, "output capacity too small: reports %zu of %zu, cigar ops %zu of %zu, junction tuples %zu of %zu", c->used[0], caps[0], c->used[1], caps[1], c->used[2], caps[2]);
         return DG_ERR_CAPACITY;
     }
+    c->dl_on_copy_stream = false;
+    if (c->env_copy_stream >= 1 && c->ev_dl) {                           // (as in dg_batch_download_compact)
+        std::lock_guard<std::mutex> lk(g_copy_mu[c->device & 15]);
+        hipStream_t cs = nullptr;
+        HIPCHK(copy_stream(c->device, 0, &cs));
+        if (c->n_reads && ro) HIPCHK(hipMemcpyAsync(ro, c->reads_out.p, (size_t)c->n_reads * sizeof(dg_read_out), hipMemcpyDeviceToHost, cs));
+        if (c->used[0] && po) HIPCHK(hipMemcpyAsync(po, c->reports.p, c->used[0] * sizeof(dg_report_out), hipMemcpyDeviceToHost, cs));
+        if (c->used[1] && cig) HIPCHK(hipMemcpyAsync(cig, c->cigfinal.p, c->used[1] * 4, hipMemcpyDeviceToHost, cs));
+        if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipEventRecord(c->env_blocking_sync ? c->ev_dl_block : c->ev_dl, cs));
+        c->dl_on_copy_stream = true;
+        return DG_OK;
+    }
     if (c->n_reads && ro) HIPCHK(hipMemcpyAsync(ro, c->reads_out.p, (size_t)c->n_reads * sizeof(dg_read_out), hipMemcpyDeviceToHost, c->stream));
     if (c->used[0] && po) HIPCHK(hipMemcpyAsync(po, c->reports.p, c->used[0] * sizeof(dg_report_out), hipMemcpyDeviceToHost, c->stream));
     if (c->used[1] && cig) HIPCHK(hipMemcpyAsync(cig, c->cigfinal.p, c->used[1] * 4, hipMemcpyDeviceToHost, c->stream));
     if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, c->stream));
     return DG_OK;
+}
+// waits for what enqueue_download enqueued
+static hipError_t wait_download(dg_ctx *c)
+{
+    if (c->dl_on_copy_stream) { c->dl_on_copy_stream = false; return hipEventSynchronize(c->env_blocking_sync ? c->ev_dl_block : c->ev_dl); }
+    return wait_stream(c);
 }
 
 extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3], size_t *n_ops_out)
@@ -1151,6 +1200,20 @@ extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *
     const size_t n_ops = (size_t)c->h_tail->sizes.pad[0];
     if (n_ops_out) *n_ops_out = n_ops;
     if (caps[1] < n_ops) { snprintf(c->err, 512, "output capacity too small: cigar ops %zu of %zu", n_ops, caps[1]); return DG_ERR_CAPACITY; }
+    if (c->env_copy_stream >= 1 && c->ev_dl) {
+        {
+            std::lock_guard<std::mutex> lk(g_copy_mu[c->device & 15]);        // (a context's copies and its event stay together in the shared stream)
+            hipStream_t cs = nullptr;
+            HIPCHK(copy_stream(c->device, 0, &cs));
+            if (ro) HIPCHK(hipMemcpyAsync(ro, c->reads_c.p, n * sizeof(dg_read_c), hipMemcpyDeviceToHost, cs));
+            if (nr && po) HIPCHK(hipMemcpyAsync(po, c->reports_c.p, nr * sizeof(dg_report_c), hipMemcpyDeviceToHost, cs));
+            if (n_ops && cig) HIPCHK(hipMemcpyAsync(cig, c->cig_c.p, n_ops * 4, hipMemcpyDeviceToHost, cs));
+            if (c->used[2] && so) HIPCHK(hipMemcpyAsync(so, c->sjfinal.p, c->used[2] * sizeof(dg_sj_out), hipMemcpyDeviceToHost, cs));
+            HIPCHK(hipEventRecord(c->env_blocking_sync ? c->ev_dl_block : c->ev_dl, cs));
+        }
+        HIPCHK(hipEventSynchronize(c->env_blocking_sync ? c->ev_dl_block : c->ev_dl));
+        return DG_OK;
+    }
     if (ro) HIPCHK(hipMemcpyAsync(ro, c->reads_c.p, n * sizeof(dg_read_c), hipMemcpyDeviceToHost, c->stream));
     if (nr && po) HIPCHK(hipMemcpyAsync(po, c->reports_c.p, nr * sizeof(dg_report_c), hipMemcpyDeviceToHost, c->stream));
     if (n_ops && cig) HIPCHK(hipMemcpyAsync(cig, c->cig_c.p, n_ops * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1191,7 +1254,7 @@ extern "C" int dg_batch_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, 
     HIPCHK(hipSetDevice(c->device));
     const int rc = enqueue_download(c, ro, po, cig, so, caps);
     if (rc) return rc;
-    HIPCHK(wait_stream(c));
+    HIPCHK(wait_download(c));
     return DG_OK;
 }
 
