@@ -18,6 +18,11 @@
 #include <atomic>
 #include <mutex>
 #include <chrono>
+#include <thread>
+#include <condition_variable>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
 
 static char g_init_error[512] = "";
 
@@ -41,8 +46,26 @@ enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAV
        TOP_WORK = 16, TOP_TICKET_PAIR = 17, TOP_TICKET_EMIT = 18, TOP_RESEED_COUNT = 19 /* 19..21 */, TOP_RESEED_TICKET = 22 /* 22..24 */, TOP_TICKET_SEED = 25,
        TOP_ORDER_INFO = 28 /* 28..30 */, TOP_CLASS_HIST = 32 /* 32..63 */, TOP_CLASS_FILL = 64 /* 64..95 */ };        // (explicit values: every index names its own word)
 
+// The index of a device as its contexts see it: the root context owns it, dg_clone()d contexts point to it.  The look-up aids may still be
+// under construction when the first batches run (DG_INIT_ASYNC_AIDS): the aids thread publishes a new DIndex (gen + 1) whenever one is
+// complete, and every context compares its generation at the start of a run.
+struct IndexShared {
+    std::mutex mu;
+    std::condition_variable cv;
+    DIndex ix{};
+    std::atomic<uint32_t> gen{1};
+    std::thread aids;
+    std::atomic<int> aids_state{0};          // 0 = no aids thread, 1 = allocating / building, 2 = complete, -1 = failed (the index works without)
+    char aids_msg[256] = "";
+    bool upload_done = false, upload_ok = false;
+    void *d_ktab = nullptr, *d_sa_dense = nullptr;
+    std::string report, report_out;
+    int device = 0;
+};
+
 struct dg_ctx {
     int device = 0;
+    IndexShared *shared_ix = nullptr; uint32_t ix_gen = 0;
     bool owns_index = true;       // false for dg_clone()d contexts: the index arrays belong to the parent
     size_t seedq_lds_set = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
@@ -54,8 +77,7 @@ struct dg_ctx {
     char err[512] = "";
     DIndex ix{};
     DParams pr{};
-    // index storage
-    void *d_ktab = nullptr, *d_sa_dense = nullptr;
+    // index storage (the aids belong to shared_ix)
     void *d_bwt = nullptr, *d_sa = nullptr, *d_pac = nullptr, *d_lockey = nullptr, *d_locchr = nullptr, *d_chroff = nullptr;
     // batch inputs
     int n_reads = 0, max_rlen = 0;
@@ -71,7 +93,8 @@ struct dg_ctx {
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c; DBuf<uint32_t> cig_c;     // compact records and their stored CIGAR ops (written by k_pair / k_emit_slow)
     DBuf<unsigned char> ws;
-    DBuf<unsigned long long> scan_state;
+    DBuf<unsigned long long> scan_state, scan_trace;      // look-back state words / what every tile's workgroup last said about itself (dg_scan.h)
+    int wall_khz = 100000;                                // rate of wall_clock64() on this device
     uint32_t scan_epoch = 0;      // number of the enqueued run, carried by every state word of its single-pass scans (dg_scan.h); never 0
     size_t cap_seeds = 0, cap_rep = 0, cap_work = 0, cap_cig = 0;
     // what any context of this index has learned about capacities (the root owns it, clones point to it): a clone does not have to overflow
@@ -93,6 +116,7 @@ struct dg_ctx {
     int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32, env_seed_multi = 4;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
     size_t seedqf_lds_set = 0;
     bool seed_qf_used = false;     // the last run's seeding kernel was k_seed_qf (its own-work counters are derived from its slot counts)
+    int env_scan_mask = 7;
     int env_scan_budget = 0;      // DG_SCAN_POLL_BUDGET: poll budget of a look-back on the FIRST attempt of a batch (test hook: forces the DG_E_SCAN re-run path)
 };
 
@@ -102,10 +126,17 @@ static void read_env(dg_ctx *c)
     c->env_seed_waves = geti("DG_SEED_WAVES", 4); c->env_bail_trips = geti("DG_SEED_BAIL_TRIPS", 0); c->env_both = geti("DG_SEED_BOTH", 0);
     c->env_seed_legacy = geti("DG_SEED_LEGACY", 0); c->env_seed_slots_lg = geti("DG_SEED_SLOTS_LG", 0); c->env_seed_wgs = geti("DG_SEED_WGS", 0); c->env_blocking_sync = geti("DG_BLOCKING_SYNC", 0);
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
-    c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0);
+    c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0); c->env_scan_mask = geti("DG_SCAN_POLL_SCANS", 7);
     c->env_seed_phases = geti("DG_SEED_PHASES", 0); c->env_seed_wg_waves = geti("DG_SEED_WG_WAVES", 4); c->env_seed_partial = geti("DG_SEED_PARTIAL_MIN", 32);
     c->env_copy_stream = geti("DG_COPY_STREAM", 1);
     c->env_seed_multi = geti("DG_SEED_MULTI", 4); if (c->env_seed_multi < 0 || c->env_seed_multi > SQF_MULTI_MAX) c->env_seed_multi = SQF_MULTI_MAX;   // rows of an interval that are located and compared with the text at once (0: single rows only)
+}
+
+// a context adopts the aids that were completed since its last run
+static inline void refresh_index(dg_ctx *c)
+{
+    IndexShared *sh = c->shared_ix;
+    if (sh && c->ix_gen != sh->gen.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> lk(sh->mu); c->ix = sh->ix; c->ix_gen = sh->gen.load(); }
 }
 
 static int fail(dg_ctx *c, int code, const char *what, hipError_t e)
@@ -476,6 +507,12 @@ extern "C" int dg_set_params(dg_ctx *c, const dg_params *p)
     return DG_OK;
 }
 
+extern "C" int dg_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 extern "C" const char *dg_last_error(const dg_ctx *c) { return c ? c->err : g_init_error; }
 
 extern "C" void dg_destroy(dg_ctx *c)
@@ -484,7 +521,16 @@ extern "C" void dg_destroy(dg_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-    void *ptrs[] = { c->d_ktab, c->d_sa_dense, c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff };
+    if (c->owns_index && c->shared_ix) {          // the aids thread may still be allocating or building: it ends by itself (a failed upload tells it so)
+        IndexShared *sh = c->shared_ix;
+        { std::lock_guard<std::mutex> lk(sh->mu); if (!sh->upload_done) { sh->upload_done = true; sh->upload_ok = false; } }
+        sh->cv.notify_all();
+        if (sh->aids.joinable()) sh->aids.join();
+        if (sh->d_ktab) (void)hipFree(sh->d_ktab);
+        if (sh->d_sa_dense) (void)hipFree(sh->d_sa_dense);
+        delete sh; c->shared_ix = nullptr;
+    }
+    void *ptrs[] = { c->d_bwt, c->d_sa, c->d_pac, c->d_lockey, c->d_locchr, c->d_chroff };
     if (c->owns_index) for (void *p : ptrs) if (p) (void)hipFree(p);
     void *own[] = { c->d_ctr, c->d_tops, c->d_err, c->d_sizes, c->d_input_bad };
     for (void *p : own) if (p) (void)hipFree(p);
@@ -493,7 +539,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
     c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_lists.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
-    c->ws.release(); c->scan_state.release(); c->reads_c.release(); c->reports_c.release(); c->cig_c.release();
+    c->ws.release(); c->scan_state.release(); c->scan_trace.release(); c->reads_c.release(); c->reports_c.release(); c->cig_c.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
@@ -522,13 +568,167 @@ static hipError_t make_ctx_objects(dg_ctx *c)
         (e = hipMalloc((void **)&c->d_input_bad, 4)) != hipSuccess) return e;
     if ((e = hipHostMalloc((void **)&c->h_tail, sizeof(dg_ctx::HostTail), hipHostMallocDefault)) != hipSuccess) return e;
     memset(c->h_tail, 0, sizeof(dg_ctx::HostTail));
+    { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) c->wall_khz = khz; }
     read_env(c);
     return hipSuccess;
 }
 
-extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int device, int *status)
+// ------------------------------------------------------------------------------------------
+// start-up: index bytes -> HBM through page-locked staging chunks, look-up aids built beside (or behind) it
+// ------------------------------------------------------------------------------------------
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// where a chunk's bytes come from: a file (pread: page cache -> staging chunk) or the caller's host array (memcpy)
+struct UpSrc { int fd = -1; const uint8_t *mem = nullptr; };
+struct UpChunk { UpSrc src; uint64_t src_off; uint8_t *dst; size_t bytes; uint64_t relayout_blocks; };
+
+// Reader threads take chunks in order; each owns a copy stream and two page-locked staging buffers, so a chunk's read from the page
+// cache overlaps the previous chunk's DMA, and the threads' reads overlap each other (one thread copies ~4 GB/s out of the page cache;
+// the link takes 50).  The Occ blocks of a .bwt chunk are re-laid in place on the same stream, behind the chunk's copy.
+static hipError_t upload_chunks(int device, const std::vector<UpChunk> &chunks, size_t chunk_cap, int n_threads, std::string &what)
 {
-    int st = DG_OK, ndev = 0;
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    std::mutex mu;
+    hipError_t first = hipSuccess;
+    auto fail_with = [&](hipError_t e, const char *w) { std::lock_guard<std::mutex> lk(mu); if (!failed.exchange(1)) { first = e == hipSuccess ? hipErrorUnknown : e; what = w; } };
+    auto work = [&]() {
+        hipError_t e;
+        if ((e = hipSetDevice(device)) != hipSuccess) { fail_with(e, "hipSetDevice (index upload)"); return; }
+        hipStream_t s = nullptr; uint8_t *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false};
+        if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) { fail_with(e, "hipStreamCreate (index upload)"); return; }
+        for (int b = 0; b < 2 && e == hipSuccess; b++) {
+            if ((e = hipHostMalloc((void **)&pin[b], chunk_cap, hipHostMallocDefault)) == hipSuccess) e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) fail_with(e, "page-locked staging buffers (index upload)");
+        int b = 0;
+        while (e == hipSuccess && !failed.load()) {
+            const size_t i = next.fetch_add(1);
+            if (i >= chunks.size()) break;
+            const UpChunk &ch = chunks[i];
+            if (used[b] && (e = hipEventSynchronize(ev[b])) != hipSuccess) { fail_with(e, "hipEventSynchronize (index upload)"); break; }
+            if (ch.src.mem) memcpy(pin[b], ch.src.mem + ch.src_off, ch.bytes);
+            else {
+                size_t got = 0;
+                while (got < ch.bytes) {
+                    const ssize_t r = pread(ch.src.fd, pin[b] + got, ch.bytes - got, (off_t)(ch.src_off + got));
+                    if (r <= 0) break;
+                    got += (size_t)r;
+                }
+                if (got < ch.bytes) { fail_with(hipErrorUnknown, "an index file is shorter than its header says"); break; }
+            }
+            if (ch.bytes && (e = hipMemcpyAsync(ch.dst, pin[b], ch.bytes, hipMemcpyHostToDevice, s)) != hipSuccess) { fail_with(e, "hipMemcpyAsync (index upload)"); break; }
+            if (ch.relayout_blocks) {
+                k_relayout_bwt<<<(unsigned)((ch.relayout_blocks + 255) / 256), 256, 0, s>>>((uint4 *)ch.dst, ch.relayout_blocks);
+                if ((e = hipGetLastError()) != hipSuccess) { fail_with(e, "k_relayout_bwt"); break; }
+            }
+            if ((e = hipEventRecord(ev[b], s)) != hipSuccess) { fail_with(e, "hipEventRecord (index upload)"); break; }
+            used[b] = true; b ^= 1;
+        }
+        if (s && (e = hipStreamSynchronize(s)) != hipSuccess) fail_with(e, "index upload");
+        for (int k = 0; k < 2; k++) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (pin[k]) (void)hipHostFree(pin[k]); }
+        if (s) (void)hipStreamDestroy(s);
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) th.emplace_back(work);
+    for (auto &t : th) t.join();
+    return failed.load() ? first : hipSuccess;
+}
+
+static void add_chunks(std::vector<UpChunk> &out, UpSrc src, uint64_t src_off, uint8_t *dst, size_t bytes, size_t chunk, bool relayout, uint64_t total_blocks)
+{
+    for (size_t o = 0; o < bytes || (relayout && o / 64 < total_blocks); o += chunk) {
+        const size_t nb = o < bytes ? std::min(chunk, bytes - o) : 0;
+        uint64_t rb = 0;
+        if (relayout) { const uint64_t first = o / 64; rb = std::min<uint64_t>(chunk / 64, total_blocks > first ? total_blocks - first : 0); }
+        out.push_back(UpChunk{src, src_off + o, dst + o, nb, rb});
+    }
+}
+
+// the look-up aids (full suffix array, K-mer prefix table): allocated while the index loads, built once it is in HBM, on a stream of the
+// lowest priority so that batches already being mapped (DG_INIT_ASYNC_AIDS) keep the GPU.  Each aid is published when complete.
+static void aids_thread(IndexShared *sh, int sa_file_intv, uint64_t n_sa)
+{
+    auto failed = [&](const char *w, hipError_t e) {
+        std::lock_guard<std::mutex> lk(sh->mu);
+        snprintf(sh->aids_msg, sizeof sh->aids_msg, "%s: %s", w, hipGetErrorString(e));
+        sh->aids_state.store(-1); sh->cv.notify_all();
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(sh->device)) != hipSuccess) return failed("hipSetDevice (aids)", e);
+    DIndex ix;
+    { std::lock_guard<std::mutex> lk(sh->mu); ix = sh->ix; }
+    const uint64_t seq_len = ix.seq_len;
+    double t0 = now_s();
+    // full suffix array (8 bytes per text symbol: 1 GB for chr20, 50 GB for a human genome -- this is what 288 GB are for): locating a row is
+    // one load instead of a walk of up to 31 LF steps.  Texts too large for that fall back to every 2nd / 4th row; DG_SA_DENSE=0 turns it
+    // off, =2/4/8/16 forces an interval
+    int intv = seq_len <= (12ull << 30) ? 1 : (seq_len <= (24ull << 30) ? 2 : 4);
+    if (const char *v = getenv("DG_SA_DENSE")) intv = atoi(v);
+    const bool want_dense = intv >= 1 && intv < sa_file_intv && (intv & (intv - 1)) == 0 && seq_len < (1ull << 39);
+    const uint64_t n_entries = want_dense ? seq_len / (uint64_t)intv + 1 : 0;
+    if (want_dense && (e = hipMalloc(&sh->d_sa_dense, n_entries * 8)) != hipSuccess) return failed("hipMalloc dense SA", e);
+    // K-mer prefix table: the smallest K with 4^K >= text length (so that most K-mers are unique or absent and a search needs the table plus
+    // a step or two), 8 <= K <= 16: 16 bytes per entry = 4.3 GB at K = 14 (chr20), 69 GB at K = 16 (human; K = 15, 17 GB: k_seed 2.47 instead
+    // of 2.18 ms).  DG_KTAB_K=0 turns it off, =2..16 forces K.
+    int K = 8;
+    while (K < 16 && (1ull << (2 * K)) < seq_len) K++;
+    {   // the table must leave room for the batches in flight: step down while it would not leave 48 GB free
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (K > 8 && ((size_t)16 << (2 * K)) + ((size_t)48 << 30) > free_b) K--;
+    }
+    if (const char *v = getenv("DG_KTAB_K")) K = atoi(v);
+    if (K > 16) K = 16;
+    if (K >= 2 && (e = hipMalloc(&sh->d_ktab, ((size_t)16) << (2 * K))) != hipSuccess) return failed("hipMalloc k-mer table", e);
+    const double t_alloc = now_s() - t0;
+    int lo = 0, hi = 0;
+    hipStream_t s = nullptr;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                    // (lo = the least priority)
+    if ((e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo)) != hipSuccess) return failed("hipStreamCreate (aids)", e);
+    {   // wait for the index bytes
+        std::unique_lock<std::mutex> lk(sh->mu);
+        sh->cv.wait(lk, [&]() { return sh->upload_done; });
+        if (!sh->upload_ok) { lk.unlock(); (void)hipStreamDestroy(s); sh->aids_state.store(-1); sh->cv.notify_all(); return; }
+    }
+    double t_dense = 0, t_ktab = 0;
+    if (want_dense) {
+        t0 = now_s();
+        k_build_sa_dense<<<(unsigned)std::min<uint64_t>((n_sa + 255) / 256, 1u << 22), 256, 0, s>>>(ix, intv, n_entries, (uint64_t *)sh->d_sa_dense);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipStreamDestroy(s); return failed("k_build_sa_dense", e); }
+        ix.sa_dense = (const uint64_t *)sh->d_sa_dense; ix.sa_dense_intv = intv; ix.sa_dense_shift = 0;
+        for (int b = 0; (1 << b) < intv; b++) ix.sa_dense_shift = b + 1;
+        { std::lock_guard<std::mutex> lk(sh->mu); sh->ix = ix; sh->gen.fetch_add(1, std::memory_order_release); }
+        t_dense = now_s() - t0;
+    }
+    if (K >= 2) {
+        t0 = now_s();
+        const size_t entries = (size_t)1 << (2 * K);
+        k_build_ktab<<<(unsigned)std::min<size_t>((entries + 255) / 256, (size_t)1 << 22), 256, 0, s>>>(ix, K, (uint64_t *)sh->d_ktab);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipStreamDestroy(s); return failed("k_build_ktab", e); }
+        ix.ktab = (const uint64_t *)sh->d_ktab; ix.ktab_k = K;
+        { std::lock_guard<std::mutex> lk(sh->mu); sh->ix = ix; sh->gen.fetch_add(1, std::memory_order_release); }
+        t_ktab = now_s() - t0;
+    }
+    (void)hipStreamDestroy(s);
+    {
+        std::lock_guard<std::mutex> lk(sh->mu);
+        char b[256];
+        snprintf(b, sizeof b, "; aids: hipMalloc %.3f s (full SA every %d row(s) %.1f GB, K=%d table %.1f GB), k_build_sa_dense %.3f s, k_build_ktab %.3f s",
+                 t_alloc, want_dense ? intv : 0, n_entries * 8 / 1e9, K >= 2 ? K : 0, K >= 2 ? (double)((size_t)16 << (2 * K)) / 1e9 : 0.0, t_dense, t_ktab);
+        sh->report += b;
+        sh->aids_state.store(2);
+    }
+    sh->cv.notify_all();
+}
+
+struct IndexMeta { uint64_t bwt_words, primary, L2[5], seq_len, n_sa; int sa_intv; int64_t l_pac; int n_chr; const int64_t *chr_off, *chr_len; };
+
+// everything of dg_init / dg_init_files behind the argument checks: contexts objects, index arrays, the upload, the aids
+static dg_ctx *init_index(const IndexMeta &m, UpSrc bwt, uint64_t bwt_off, UpSrc sa, uint64_t sa_off, uint64_t sa_first, uint64_t sa_count, UpSrc pac, size_t pac_copy,
+                          const dg_params *p, int device, int flags, int *status)
+{
+    int ndev = 0;
     dg_ctx *c = nullptr;
     auto bail = [&](int code, const char *what, hipError_t e) -> dg_ctx * {
         snprintf(g_init_error, sizeof g_init_error, "%s: %s", what, e == hipSuccess ? "invalid" : hipGetErrorString(e));
@@ -536,7 +736,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
         if (status) *status = code;
         return nullptr;
     };
-    if (!v || !p || !v->bwt || !v->sa || !v->pac || v->n_chr <= 0) return bail(DG_ERR_ARG, "dg_init arguments", hipSuccess);
+    const double t_start = now_s();
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return bail(DG_ERR_NO_DEVICE, "no HIP device (libdartgpu has no CPU fallback)", e);
     if (device < 0 || device >= ndev) return bail(DG_ERR_NO_DEVICE, "device ordinal out of range", hipSuccess);
@@ -544,86 +744,149 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     c = new dg_ctx();
     c->device = device;
     c->shared_caps = new dg_ctx::SharedCaps(); c->owns_shared_caps = true;
+    c->shared_ix = new IndexShared(); c->shared_ix->device = device;
     if ((e = make_ctx_objects(c)) != hipSuccess) return bail(DG_ERR_HIP, "stream / event / counter allocation", e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
     set_params(c, p);
+    const double t_ctx = now_s();
 
-    // ---- index upload: the .bwt blocks at a 64-byte aligned base (+ one block of padding so the
-    //      last, possibly partial, block can be fetched whole), sampled SA, pac, chromosome keys
-    const size_t bwt_bytes = (size_t)v->bwt_words * 4, sa_bytes = (size_t)v->n_sa * 8, pac_bytes = (size_t)(v->l_pac / 4 + 1);
+    // ---- index arrays: the .bwt blocks at a 64-byte aligned base (+ two blocks of padding so the last, possibly partial, block can be
+    //      fetched whole), sampled SA, pac, chromosome keys
+    const size_t bwt_bytes = (size_t)m.bwt_words * 4, sa_bytes = (size_t)m.n_sa * 8, pac_bytes = (size_t)(m.l_pac / 4 + 1);
+    const uint64_t n_blocks = (m.seq_len + 127) / 128;
+    if (bwt_bytes > (n_blocks + 1) * 64) return bail(DG_ERR_ARG, "the .bwt data is larger than its header's text length allows", hipSuccess);
+    if ((e = hipMalloc(&c->d_bwt, (n_blocks + 2) * 64)) != hipSuccess || (e = hipMemsetAsync(c->d_bwt, 0, (n_blocks + 2) * 64, c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc bwt", e);
+    if ((e = hipMalloc(&c->d_sa, sa_bytes + 8)) != hipSuccess || (e = hipMemsetAsync(c->d_sa, 0, sa_bytes + 8, c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc sa", e);
+    if ((e = hipMalloc(&c->d_pac, pac_bytes + 4096)) != hipSuccess || (e = hipMemsetAsync(c->d_pac, 0, pac_bytes + 4096, c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc pac", e);
     {
-        const uint64_t n_blocks = (v->seq_len + 127) / 128;
-        void *raw = nullptr;
-        if ((e = hipMalloc(&raw, bwt_bytes + 128)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc bwt staging", e);
-        if ((e = hipMemcpy(raw, v->bwt, bwt_bytes, hipMemcpyHostToDevice)) != hipSuccess) { (void)hipFree(raw); return bail(DG_ERR_HIP, "upload bwt", e); }
-        if ((e = hipMalloc(&c->d_bwt, (n_blocks + 2) * 64)) != hipSuccess) { (void)hipFree(raw); return bail(DG_ERR_HIP, "hipMalloc bwt", e); }
-        if ((e = hipMemset(c->d_bwt, 0, (n_blocks + 2) * 64)) != hipSuccess) { (void)hipFree(raw); return bail(DG_ERR_HIP, "hipMemset", e); }
-        k_relayout_bwt<<<(unsigned)((n_blocks + 255) / 256), 256, 0, c->stream>>>((const uint32_t *)raw, v->bwt_words, (uint4 *)c->d_bwt, n_blocks);
-        e = hipStreamSynchronize(c->stream);
-        (void)hipFree(raw);
-        if (e != hipSuccess) return bail(DG_ERR_HIP, "k_relayout_bwt", e);
-    }
-    if ((e = hipMalloc(&c->d_sa, sa_bytes)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc sa", e);
-    if ((e = hipMemcpy(c->d_sa, v->sa, sa_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload sa", e);
-    if ((e = hipMalloc(&c->d_pac, pac_bytes + 4096)) != hipSuccess || (e = hipMemset(c->d_pac, 0, pac_bytes + 4096)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc pac", e);
-    if ((e = hipMemcpy(c->d_pac, v->pac, pac_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload pac", e);
-    {
-        const int n = v->n_chr;
+        const int n = m.n_chr;
         std::vector<int64_t> key(2 * n), off(n);
         std::vector<int32_t> chr(2 * n);
         for (int i = 0; i < n; i++) {       // ChrLocMap, bwt_index.cpp:246-250
-            off[i] = v->chr_off[i];
-            key[i] = v->chr_off[i] + v->chr_len[i] - 1; chr[i] = i;
-            key[2 * n - 1 - i] = 2 * v->l_pac - v->chr_off[i] - 1; chr[2 * n - 1 - i] = i;
+            off[i] = m.chr_off[i];
+            key[i] = m.chr_off[i] + m.chr_len[i] - 1; chr[i] = i;
+            key[2 * n - 1 - i] = 2 * m.l_pac - m.chr_off[i] - 1; chr[2 * n - 1 - i] = i;
         }
         if ((e = hipMalloc(&c->d_lockey, 16 * (size_t)n)) != hipSuccess || (e = hipMalloc(&c->d_locchr, 8 * (size_t)n)) != hipSuccess ||
             (e = hipMalloc(&c->d_chroff, 8 * (size_t)n)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc chr tables", e);
         if ((e = hipMemcpy(c->d_lockey, key.data(), 16 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_locchr, chr.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_chroff, off.data(), 8 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(DG_ERR_HIP, "upload chr tables", e);
+        if (sa_first) {                    // (from the file: sa[0] = -1 is not stored, bwt.c:185-196)
+            const uint64_t minus1 = ~0ull;
+            if ((e = hipMemcpyAsync(c->d_sa, &minus1, 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "upload sa[0]", e);
+        }
     }
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "index array fills", e);
     c->ix.bwt = (const uint4 *)c->d_bwt; c->ix.sa = (const uint64_t *)c->d_sa; c->ix.pac = (const uint8_t *)c->d_pac;
     c->ix.loc_key = (const int64_t *)c->d_lockey; c->ix.loc_chr = (const int32_t *)c->d_locchr; c->ix.chr_off = (const int64_t *)c->d_chroff;
-    c->ix.primary = v->primary; for (int i = 0; i < 5; i++) c->ix.L2[i] = v->L2[i]; c->ix.seq_len = v->seq_len;
-    c->ix.l_pac = v->l_pac; c->ix.n_chr = v->n_chr; c->ix.sa_intv = v->sa_intv;
+    c->ix.primary = m.primary; for (int i = 0; i < 5; i++) c->ix.L2[i] = m.L2[i]; c->ix.seq_len = m.seq_len;
+    c->ix.l_pac = m.l_pac; c->ix.n_chr = m.n_chr; c->ix.sa_intv = m.sa_intv;
     c->ix.ktab = nullptr; c->ix.ktab_k = 0; c->ix.sa_dense = nullptr; c->ix.sa_dense_intv = 0; c->ix.sa_dense_shift = 0;
-    {   // full suffix array in HBM (8 bytes per text symbol: 1 GB for chr20, 50 GB for a human genome -- this is what
-        // 288 GB are for): locating a row is one load instead of a walk of up to 31 LF steps.  Texts too large for
-        // that fall back to every 2nd / 4th row; DG_SA_DENSE=0 turns it off, =2/4/8/16 forces an interval
-        int intv = v->seq_len <= (12ull << 30) ? 1 : (v->seq_len <= (24ull << 30) ? 2 : 4);
-        if (const char *v = getenv("DG_SA_DENSE")) intv = atoi(v);
-        if (intv >= 1 && intv < v->sa_intv && (intv & (intv - 1)) == 0 && v->seq_len < (1ull << 39)) {
-            const uint64_t n_entries = v->seq_len / (uint64_t)intv + 1;
-            if ((e = hipMalloc(&c->d_sa_dense, n_entries * 8)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc dense SA", e);
-            k_build_sa_dense<<<(unsigned)std::min<uint64_t>(((uint64_t)v->n_sa + 255) / 256, 1u << 22), 256, 0, c->stream>>>(c->ix, intv, n_entries, (uint64_t *)c->d_sa_dense);
-            if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_sa_dense", e);
-            c->ix.sa_dense = (const uint64_t *)c->d_sa_dense; c->ix.sa_dense_intv = intv;
-            for (int sh = 0; (1 << sh) < intv; sh++) c->ix.sa_dense_shift = sh + 1;
-        }
+    IndexShared *sh = c->shared_ix;
+    sh->ix = c->ix; c->ix_gen = sh->gen.load();
+    const double t_alloc = now_s();
+    sh->aids_state.store(1);
+    sh->aids = std::thread(aids_thread, sh, m.sa_intv, m.n_sa);           // allocates the aids while the index bytes travel
+
+    const size_t chunk = (size_t)32 << 20;
+    std::vector<UpChunk> chunks;
+    add_chunks(chunks, bwt, bwt_off, (uint8_t *)c->d_bwt, bwt_bytes, chunk, true, n_blocks);
+    add_chunks(chunks, sa, sa_off, (uint8_t *)c->d_sa + 8 * sa_first, (size_t)sa_count * 8, chunk, false, 0);
+    add_chunks(chunks, pac, 0, (uint8_t *)c->d_pac, pac_copy, chunk, false, 0);
+    int n_threads = 6;
+    if (const char *v = getenv("DG_INIT_THREADS")) n_threads = std::max(1, std::min(32, atoi(v)));
+    n_threads = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, chunks.size()));
+    std::string what;
+    e = upload_chunks(device, chunks, chunk, n_threads, what);
+    { std::lock_guard<std::mutex> lk(sh->mu); sh->upload_done = true; sh->upload_ok = e == hipSuccess; }
+    sh->cv.notify_all();
+    if (e != hipSuccess) return bail(what.find("shorter") != std::string::npos ? DG_ERR_ARG : DG_ERR_HIP, what.c_str(), what.find("shorter") != std::string::npos ? hipSuccess : e);
+    const double t_up = now_s();
+    {
+        std::lock_guard<std::mutex> lk(sh->mu);
+        char b[320];
+        snprintf(b, sizeof b, "context %.3f s, index arrays (hipMalloc + fill) %.3f s, %s -> HBM + Occ re-layout %.3f s (%.2f GB, %d reader threads)",
+                 t_ctx - t_start, t_alloc - t_ctx, bwt.mem ? "host arrays" : "index files", t_up - t_alloc, (bwt_bytes + sa_count * 8 + pac_copy) / 1e9, n_threads);
+        sh->report = std::string(b) + sh->report;
     }
-    {   // K-mer prefix table: the smallest K with 4^K >= text length (so that most K-mers are unique or absent and a
-        // search needs the table plus a step or two), 8 <= K <= 16: 16 bytes per entry = 4.3 GB at K = 14 (chr20),
-        // 69 GB at K = 16 (human; K = 15, 17 GB: k_seed 2.47 instead of 2.18 ms).  DG_KTAB_K=0 turns it off, =2..16 forces K.
-        int K = 8;
-        while (K < 16 && (1ull << (2 * K)) < v->seq_len) K++;
-        {   // the table must leave room for the batches in flight: step down while it would not leave 48 GB free
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                while (K > 8 && ((size_t)16 << (2 * K)) + ((size_t)48 << 30) > free_b) K--;
-        }
-        if (const char *v = getenv("DG_KTAB_K")) K = atoi(v);
-        if (K > 16) K = 16;
-        if (K >= 2) {
-            const size_t entries = (size_t)1 << (2 * K);
-            if ((e = hipMalloc(&c->d_ktab, entries * 16)) != hipSuccess) return bail(DG_ERR_HIP, "hipMalloc k-mer table", e);
-            k_build_ktab<<<(unsigned)std::min<size_t>((entries + 255) / 256, (size_t)1 << 22), 256, 0, c->stream>>>(c->ix, K, (uint64_t *)c->d_ktab);
-            if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(DG_ERR_HIP, "k_build_ktab", e);
-            c->ix.ktab = (const uint64_t *)c->d_ktab; c->ix.ktab_k = K;
-        }
+    if (!(flags & DG_INIT_ASYNC_AIDS)) {
+        const int rc = dg_index_wait(c);
+        if (rc != DG_OK) { char msg[256]; { std::lock_guard<std::mutex> lk(sh->mu); snprintf(msg, sizeof msg, "%s", sh->aids_msg); } snprintf(g_init_error, sizeof g_init_error, "%s", msg); dg_destroy(c); if (status) *status = rc; return nullptr; }
     }
-    if (status) *status = st;
+    if (getenv("DG_INIT_TIMING")) fprintf(stderr, "[libdartgpu init] %s%s (total %.3f s)\n", dg_init_report(c), (flags & DG_INIT_ASYNC_AIDS) ? "; aids: building in the background" : "", now_s() - t_start);
+    if (status) *status = DG_OK;
     return c;
+}
+
+extern "C" int dg_index_wait(dg_ctx *c)
+{
+    if (!c || !c->shared_ix) return DG_ERR_ARG;
+    IndexShared *sh = c->shared_ix;
+    {
+        std::unique_lock<std::mutex> lk(sh->mu);
+        sh->cv.wait(lk, [&]() { const int s = sh->aids_state.load(); return s != 1; });
+    }
+    refresh_index(c);
+    if (sh->aids_state.load() < 0) { std::lock_guard<std::mutex> lk(sh->mu); snprintf(c->err, 512, "look-up aids not built: %s", sh->aids_msg); return DG_ERR_HIP; }
+    return DG_OK;
+}
+
+extern "C" const char *dg_init_report(const dg_ctx *c)
+{
+    if (!c || !c->shared_ix) return "";
+    IndexShared *sh = c->shared_ix;
+    std::lock_guard<std::mutex> lk(sh->mu);
+    sh->report_out = sh->report;           // (a copy the caller may keep reading while the aids thread appends)
+    return sh->report_out.c_str();
+}
+
+extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int device, int *status)
+{
+    if (!v || !p || !v->bwt || !v->sa || !v->pac || v->n_chr <= 0 || v->n_sa == 0) {
+        snprintf(g_init_error, sizeof g_init_error, "dg_init arguments: invalid");
+        if (status) *status = DG_ERR_ARG;
+        return nullptr;
+    }
+    IndexMeta m;
+    m.bwt_words = v->bwt_words; m.primary = v->primary; for (int i = 0; i < 5; i++) m.L2[i] = v->L2[i]; m.seq_len = v->seq_len; m.n_sa = v->n_sa; m.sa_intv = v->sa_intv;
+    m.l_pac = v->l_pac; m.n_chr = v->n_chr; m.chr_off = v->chr_off; m.chr_len = v->chr_len;
+    UpSrc b, s, q;
+    b.mem = (const uint8_t *)v->bwt; s.mem = (const uint8_t *)v->sa; q.mem = v->pac;
+    return init_index(m, b, 0, s, 0, 0, v->n_sa, q, (size_t)(v->l_pac / 4 + 1), p, device, 0, status);
+}
+
+extern "C" dg_ctx *dg_init_files(const dg_index_files *f, const dg_params *p, int device, int flags, int *status)
+{
+    auto bad = [&](int code, const char *fmt, const char *arg) -> dg_ctx * {
+        snprintf(g_init_error, sizeof g_init_error, fmt, arg);
+        if (status) *status = code;
+        return nullptr;
+    };
+    if (!f || !p || !f->bwt_path || !f->sa_path || !f->pac_path || f->n_chr <= 0 || !f->chr_off || !f->chr_len || f->l_pac <= 0) return bad(DG_ERR_ARG, "dg_init_files arguments: %s", "invalid");
+    struct Fd { int fd = -1; ~Fd() { if (fd >= 0) close(fd); } } fb, fs, fp;
+    struct stat st;
+    IndexMeta m;
+    // .bwt: primary, L2[1..4], then the Occ-interleaved words (bwt_index.cpp:102-121)
+    if ((fb.fd = open(f->bwt_path, O_RDONLY)) < 0 || fstat(fb.fd, &st) != 0 || st.st_size < 40) return bad(DG_ERR_ARG, "cannot read %s", f->bwt_path);
+    uint64_t hdr[7];
+    if (pread(fb.fd, hdr, 40, 0) != 40) return bad(DG_ERR_ARG, "cannot read %s", f->bwt_path);
+    m.primary = hdr[0]; m.L2[0] = 0; for (int i = 1; i < 5; i++) m.L2[i] = hdr[i]; m.seq_len = m.L2[4];
+    m.bwt_words = ((uint64_t)st.st_size - 40) / 4;
+    // .sa: primary, L2[1..4], sa_intv, seq_len, then sa[1 .. n_sa) (bwt_index.cpp:15-35)
+    if ((fs.fd = open(f->sa_path, O_RDONLY)) < 0 || fstat(fs.fd, &st) != 0 || st.st_size < 56) return bad(DG_ERR_ARG, "cannot read %s", f->sa_path);
+    if (pread(fs.fd, hdr, 56, 0) != 56) return bad(DG_ERR_ARG, "cannot read %s", f->sa_path);
+    m.sa_intv = (int)hdr[5];
+    if (m.sa_intv <= 0 || m.seq_len == 0) return bad(DG_ERR_ARG, "%s: bad header", f->sa_path);
+    m.n_sa = (m.seq_len + (uint64_t)m.sa_intv) / (uint64_t)m.sa_intv;
+    const uint64_t sa_count = std::min<uint64_t>(m.n_sa - 1, ((uint64_t)st.st_size - 56) / 8);
+    if ((fp.fd = open(f->pac_path, O_RDONLY)) < 0 || fstat(fp.fd, &st) != 0) return bad(DG_ERR_ARG, "cannot read %s", f->pac_path);
+    const size_t pac_copy = std::min<size_t>((size_t)st.st_size, (size_t)(f->l_pac / 4 + 1));
+    m.l_pac = f->l_pac; m.n_chr = f->n_chr; m.chr_off = f->chr_off; m.chr_len = f->chr_len;
+    UpSrc b, s, q;
+    b.fd = fb.fd; s.fd = fs.fd; q.fd = fp.fd;
+    return init_index(m, b, 40, s, 56, 1, sa_count, q, pac_copy, p, device, flags, status);
 }
 
 // A second context on the same device that shares the parent's index (no copy): its own streams, batch buffers
@@ -642,7 +905,9 @@ extern "C" dg_ctx *dg_clone(dg_ctx *parent, int *status)
     if ((e = hipSetDevice(parent->device)) != hipSuccess) { if (status) *status = DG_ERR_HIP; return nullptr; }
     dg_ctx *c = new dg_ctx();
     c->device = parent->device; c->owns_index = false; c->n_cu = parent->n_cu;
-    c->ix = parent->ix; c->pr = parent->pr;
+    c->shared_ix = parent->shared_ix;
+    c->ix = parent->ix; c->ix_gen = parent->ix_gen; c->pr = parent->pr;
+    refresh_index(c);
     c->shared_caps = parent->shared_caps;
     if ((e = make_ctx_objects(c)) != hipSuccess) {
         snprintf(g_init_error, sizeof g_init_error, "dg_clone: %s", hipGetErrorString(e)); dg_destroy(c); if (status) *status = DG_ERR_HIP; return nullptr;
@@ -855,6 +1120,19 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     return hipGetLastError();
 }
 
+// A look-back may wait ~2 s of wall clock for a predecessor (DG_SCAN_POLL_BUDGET, the tests' hook: a poll count on a batch's FIRST attempt instead).
+// `first_tile`: where this scan's tiles start in the context's state / trace arrays.
+static TileScan make_tile_scan(dg_ctx *c, size_t first_tile, unsigned int *ticket, int which /* 1 = seed offsets, 2 = k_pair, 4 = k_emit_slow: DG_SCAN_POLL_SCANS picks the hooked ones */)
+{
+    TileScan ts;
+    ts.w = c->scan_state.p + SCAN_WORDS * first_tile; ts.ticket = ticket; ts.epoch = c->scan_epoch;
+    ts.budget = (c->env_scan_budget > 0 && c->attempt_no == 0 && (c->env_scan_mask & which)) ? (uint32_t)c->env_scan_budget : 0u;
+    ts.dbg = c->d_sizes->scan_dbg;
+    ts.ticks = (unsigned long long)c->wall_khz * 2000ull;
+    ts.trace = c->scan_trace.p ? c->scan_trace.p + SCAN_TRACE_WORDS * first_tile : nullptr;
+    return ts;
+}
+
 #define TICK(name) do { if (c->n_t < N_TIMERS) { c->tname[c->n_t] = name; HIPCHK(hipEventRecord(c->ev[c->n_t + 1], c->stream)); c->n_t++; } } while (0)
 
 // the kernels of the seeding + locate stage up to the located, unsorted seeds (shared by dg_batch_run and dg_probe_seeds)
@@ -870,7 +1148,7 @@ static int enqueue_seeding(dg_ctx *c, int n, int H, bool timed, bool paired_unit
     {
         const int paired = (paired_units && (n % 2 == 0)) ? 1 : 0;
         HIPCHK(c->heavy.ensure((size_t)n + 16));
-        const TileScan ts_seed{c->scan_state.p, c->d_tops + TOP_TICKET_SEED, c->scan_epoch, 1u << 20, c->d_sizes->scan_dbg};
+        const TileScan ts_seed = make_tile_scan(c, 0, c->d_tops + TOP_TICKET_SEED, 1);
         k_seed_offsets<<<(unsigned)((n + 256 * SO_PER - 1) / (256 * SO_PER)), 256, 0, c->stream>>>(n, paired, c->nseeds.p, c->seed_off.p, c->tile_read.p, (uint32_t)c->tile_read.cap,
                                                                                                  c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, &c->d_sizes->total_seeds, (uint32_t)c->cap_seeds, ts_seed, c->d_err);
         HIPCHK(hipGetLastError());
@@ -925,6 +1203,9 @@ static int zero_batch_state(dg_ctx *c, int n_reads, int n_units)
     if (words > c->scan_state.cap) {
         HIPCHK(c->scan_state.ensure(words));
         HIPCHK(hipMemsetAsync(c->scan_state.p, 0, c->scan_state.cap * 8, c->stream));
+        static_assert(SCAN_TRACE_WORDS == SCAN_WORDS, "the trace array is sized like the state array");
+        HIPCHK(c->scan_trace.ensure(c->scan_state.cap));
+        HIPCHK(hipMemsetAsync(c->scan_trace.p, 0, c->scan_trace.cap * 8, c->stream));
     }
     c->scan_epoch = (c->scan_epoch + 1u) & 0x3FFFFFFFu;
     if (c->scan_epoch == 0) c->scan_epoch = 1;
@@ -939,6 +1220,7 @@ static int enqueue_run(dg_ctx *c)
     const int n = c->n_reads;
     const int paired = (c->pr.paired && (n % 2 == 0)) ? 1 : 0;      // Mapping.cpp:598
     const int n_units = paired ? n / 2 : n;
+    refresh_index(c);
     c->n_t = 0;
     const int H = c->max_rlen / 16 + 1;
     const uint32_t nb = (uint32_t)((n + 255) / 256);
@@ -975,9 +1257,7 @@ static int enqueue_run(dg_ctx *c)
 #endif
     TICK("k_chain_heavy");
     const size_t tiles_s = scan_tiles_seed(n), tiles = scan_tiles_pair(n_units);
-    const uint32_t budget = (c->env_scan_budget > 0 && c->attempt_no == 0) ? (uint32_t)c->env_scan_budget : (1u << 20);   // ~2 s of polling
-    TileScan ts_pair{c->scan_state.p + SCAN_WORDS * tiles_s, tops + TOP_TICKET_PAIR, c->scan_epoch, budget, c->d_sizes->scan_dbg};
-    TileScan ts_emit{c->scan_state.p + SCAN_WORDS * (tiles_s + tiles), tops + TOP_TICKET_EMIT, c->scan_epoch, budget, c->d_sizes->scan_dbg};
+    const TileScan ts_pair = make_tile_scan(c, tiles_s, tops + TOP_TICKET_PAIR, 2), ts_emit = make_tile_scan(c, tiles_s + tiles, tops + TOP_TICKET_EMIT, 4);
     const int try_fast = (c->env_no_fast || c->ix.n_chr > 0xFFFF) ? 0 : 1;
     // the compact record types are written by the kernels that write the full ones (unless the caller is known to take the full ones: dg_map_batch)
     CompactOut co{nullptr, nullptr, nullptr, nullptr};
@@ -1095,13 +1375,19 @@ static int finish_run(dg_ctx *c, size_t used[3])
         else if (derr == DG_E_CIGFINAL) c->cap_cig = grow(sz.total_cig > 2 * c->cap_cig ? sz.total_cig : 2 * c->cap_cig);
         if (c->shared_caps) { caps_publish(c->shared_caps->seeds, c->cap_seeds); caps_publish(c->shared_caps->rep, c->cap_rep); caps_publish(c->shared_caps->work, c->cap_work); caps_publish(c->shared_caps->cig, c->cap_cig); }
         if (derr == DG_E_SEEDS || derr == DG_E_REPORTS || derr == DG_E_WORK || derr == DG_E_CIGFINAL) { /* grown above */ }
-        else if ((derr == DG_E_SCAN || derr == DG_E_SEEDQ) && attempt < 2) {
-            // a look-back that ran out of its poll budget (dg_scan.h) or the seeding kernel's safety net: nothing to grow, the batch runs again --
-            // but never silently: what the poller saw goes to stderr and into the context's error text, the count into dg_last_counters [35]
+        else if ((derr == DG_E_SCAN || derr == DG_E_SEEDQ) && attempt < 5) {
+            // a look-back that ran out of its time budget (dg_scan.h) or the seeding kernel's safety net: nothing to grow, the batch runs again (up to
+            // five times: an event is rare -- three in 600 000 batches -- and independent of the batch) -- but never silently: what the poller saw and
+            // what the stuck tile's workgroup last said about itself go to stderr and into the context's error text, the count into dg_last_counters [35]
             c->reruns_scan++;
             const unsigned long long *d = sz.scan_dbg;
-            snprintf(c->err, 512, "batch run again (device status %d): look-back of tile %llu gave up on tile %lld after %llu polls (lane %llu, epoch %llu): words %016llx %016llx %016llx",
-                     derr, d[0] ? d[0] - 1 : 0ull, (long long)d[1], d[6], d[7], d[5], d[2], d[3], d[4]);
+            const double tick_ms = 1.0 / (double)c->wall_khz;
+            const bool same_epoch = (d[8] >> 32) == d[5];
+            snprintf(c->err, 512, "batch run again (device status %d): look-back of tile %llu gave up on tile %lld after %llu polls / %.1f ms (lane %llu, epoch %llu): words %016llx %016llx %016llx; "
+                     "stuck tile's trace: epoch %llu%s HW_ID %08llx (wave %llu simd %llu cu %llu sh %llu se %llu) XCC %llu, ticket %.3f ms before the give-up, own totals %s, prefix %s",
+                     derr, d[0] ? d[0] - 1 : 0ull, (long long)d[1], d[6], (double)(d[12] - d[13]) * tick_ms, d[7], d[5], d[2], d[3], d[4],
+                     d[8] >> 32, same_epoch ? "" : " (NOT this run's: it never took its ticket here)", d[8] & 0xFFFFFFFFull, d[8] & 15, (d[8] >> 4) & 3, (d[8] >> 8) & 15, (d[8] >> 12) & 1, (d[8] >> 13) & 7, d[11] >> 56,
+                     (double)(d[12] - d[9]) * tick_ms, d[10] ? "published" : "NOT published", (d[11] & 0x00FFFFFFFFFFFFFFull) ? "published" : "NOT published");
             if (!c->env_scan_budget) fprintf(stderr, "[libdartgpu] %s\n", c->err);
         }
         else { snprintf(c->err, 512, "device-side scan did not complete (status %d)", derr); return DG_ERR_INTERNAL; }
@@ -1455,7 +1741,7 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
         HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n)); HIPCHK(c->done.ensure((size_t)n + 16));
         HIPCHK(c->heavy.ensure((size_t)n + 16)); HIPCHK(c->slow_units.ensure((size_t)n + 16)); HIPCHK(c->reports.ensure(16)); HIPCHK(c->cigfinal.ensure(16));
         k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
-        TileScan ts{c->scan_state.p + SCAN_WORDS * scan_tiles_seed(n), c->d_tops + TOP_TICKET_PAIR, c->scan_epoch, 1u << 20, c->d_sizes->scan_dbg};
+        const TileScan ts = make_tile_scan(c, scan_tiles_seed(n), c->d_tops + TOP_TICKET_PAIR, 2);
         k_pair<<<(unsigned)((n + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
             c->ix, c->pr, n, 0, 0, 1, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
             c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, 0xFFFFFFFFu, 0xFFFFFFFFu, ts, c->d_sizes, c->d_tops + TOP_CIG, c->d_ctr, c->d_err, CompactOut{nullptr, nullptr, nullptr, nullptr});

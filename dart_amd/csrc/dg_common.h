@@ -103,7 +103,7 @@ struct DParams {
 #define DG_COST_CLASSES 32       // k_report's work order: cost classes of the reads on the general path's list (k_prep, dg_reseed.h)
 // sizes the device reports at the end of a batch (one small D2H copy)
 struct DSizes { uint32_t total_seeds, total_rep, total_work, total_cig, total_sj, n_jobs, n_slow_units, n_heavy_units, cig_fast, pad[3];
-                unsigned long long scan_dbg[8]; };      // scan_dbg: what a look-back that ran out of budget saw (dg_scan.h, SCAN_DBG_WORDS)
+                unsigned long long scan_dbg[16]; };     // scan_dbg: what a look-back that ran out of budget saw (dg_scan.h, SCAN_DBG_WORDS)
 
 // work counters (dg_last_counters)
 enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, CTR_NWCELLS, CTR_RESEED, CTR_RESEEDW,

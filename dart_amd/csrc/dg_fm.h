@@ -92,23 +92,31 @@ __device__ __forceinline__ uint64_t d_lf(const DIndex &ix, uint64_t k)
 // ---------------------------------------------------------------------------------------------
 // k_relayout_bwt: reference .bwt blocks -> device blocks (once per dg_init)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_relayout_bwt(const uint32_t *__restrict__ src, uint64_t src_words, uint4 *__restrict__ dst, uint64_t n_blocks)
+// IN PLACE: a block is 64 bytes in both forms, a thread reads its whole block before it writes it, and the counts stay where they are --
+// so the start-up can copy the file's bytes to their final place chunk by chunk and re-lay each chunk behind its copy (the bytes past
+// the end of the file are the zeros the array was filled with).
+__global__ void __launch_bounds__(256) k_relayout_bwt(uint4 *blk, uint64_t n_blocks)
 {
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
-    const uint32_t *s = src + b * 16;
-    uint32_t w[16];
-    for (int i = 0; i < 16; i++) w[i] = (b * 16 + i) < src_words ? s[i] : 0u;
+    const uint4 s2 = blk[b * 4 + 2], s3 = blk[b * 4 + 3];
+    const uint32_t w[8] = { s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w };
     uint32_t H[4] = {0, 0, 0, 0}, L[4] = {0, 0, 0, 0};
-    for (int j = 0; j < 128; j++) {
-        const uint32_t sym = (w[8 + (j >> 4)] >> ((~j & 15) << 1)) & 3u;     // bwt_B0, bwt_search.cpp:30-32
-        H[j >> 5] |= (sym >> 1) << (j & 31);
-        L[j >> 5] |= (sym & 1u) << (j & 31);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        // 16 symbols of word q, first symbol in the top two bits (bwt_B0, bwt_search.cpp:30-32) -> bits 16 (q & 1) ... + 15 of plane word q >> 1
+        uint32_t h = 0, l = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t sym = (w[q] >> ((15 - j) << 1)) & 3u;
+            h |= (sym >> 1) << j;
+            l |= (sym & 1u) << j;
+        }
+        H[q >> 1] |= h << (16 * (q & 1));
+        L[q >> 1] |= l << (16 * (q & 1));
     }
-    dst[b * 4 + 0] = make_uint4(w[0], w[1], w[2], w[3]);
-    dst[b * 4 + 1] = make_uint4(w[4], w[5], w[6], w[7]);
-    dst[b * 4 + 2] = make_uint4(H[0], H[1], H[2], H[3]);
-    dst[b * 4 + 3] = make_uint4(L[0], L[1], L[2], L[3]);
+    blk[b * 4 + 2] = make_uint4(H[0], H[1], H[2], H[3]);
+    blk[b * 4 + 3] = make_uint4(L[0], L[1], L[2], L[3]);
 }
 
 // ---------------------------------------------------------------------------------------------

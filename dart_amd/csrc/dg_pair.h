@@ -444,9 +444,12 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
     __shared__ uint64_t s_rw[2 * PU_SLOTS * PU_THREADS];
     __shared__ unsigned long long s_scan[20];
     __shared__ unsigned int s_tile;
-    { const int e0 = *err; if (e0 == DG_E_SEEDS || e0 == DG_E_SEEDQ) return; }   // both are raised before this launch (the only earlier aborts: seeds that
-                                                       // do not fit, the seeding kernel's safety net: seed_off / nseeds cannot be trusted); errors
-                                                       // raised INSIDE this launch never make a workgroup leave: its successors wait for its totals
+    { const int e0 = *err; if (e0 == DG_E_SEEDS || e0 == DG_E_SEEDQ || e0 == DG_E_SCAN) return; }
+                                                       // SEEDS / SEEDQ are raised before this launch (seeds that do not fit, the seeding kernel's safety net), SCAN by
+                                                       // k_seed_offsets before it or by a look-back inside it: seed_off / nseeds cannot be trusted, the host runs the batch
+                                                       // again.  Leaving BEFORE the ticket is safe: no tile exists that a successor could wait for, and pollers of a
+                                                       // DG_E_SCAN run give up by themselves.  Capacity errors raised INSIDE this launch never make a workgroup leave:
+                                                       // its successors wait for its totals
     const unsigned int tile = d_tile_ticket(ts, &s_tile);
     const int u = (int)(tile * PU_THREADS + threadIdx.x);
     const bool valid = u < n_units;

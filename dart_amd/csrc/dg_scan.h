@@ -17,15 +17,21 @@
 // zeroed once, when allocated) and no stale word can be taken for a result -- round 2 zeroed them with a fill launch per batch and
 // trusted that no cached copy of a previous batch's word survived it.  The first wave of the workgroup looks back 64 tiles at a
 // time: it adds totals until it meets an inclusive prefix.
-// A poll budget turns a protocol failure into an error code instead of a hung GPU and records what the poller saw (ScanDebug);
-// the host logs that and runs the batch again (finish_run in dg_api.hip).
+// A time budget (wall-clock ticks, ~2 s; the tests' hook is a poll count) turns a predecessor that does not publish into an error code instead
+// of a hung GPU and records what the poller saw AND what the stuck tile's workgroup last said about itself (its trace words: where it runs --
+// HW_ID, XCC_ID -- and when it took its ticket, published its totals, published its prefix); the host logs that and runs the batch again
+// (finish_run in dg_api.hip).
 #pragma once
 #include "dg_common.h"
 
-struct TileScan { unsigned long long *w; unsigned int *ticket; uint32_t epoch, budget; unsigned long long *dbg; };
+struct TileScan { unsigned long long *w; unsigned int *ticket; uint32_t epoch, budget /* polls; 0 = none (the time budget alone) */; unsigned long long *dbg;
+                  unsigned long long ticks /* wall_clock64 ticks a look-back may wait; 0 = no limit */; unsigned long long *trace /* SCAN_TRACE_WORDS per tile, or null */; };
 struct Triple { uint32_t x, y; uint64_t z; uint32_t w; };   // four counters (the name is older than the fourth); z stays 64-bit for the callers' arithmetic, a published z is < 2^32: it counts CIGAR ops of one batch
 #define SCAN_WORDS 4            // state words per tile
-#define SCAN_DBG_WORDS 8        // what a poller that ran out of budget saw: tile, stuck predecessor, its words, epoch, polls, lane
+#define SCAN_DBG_WORDS 16       // what a poller that ran out of budget saw: [0] its tile + 1, [1] the stuck predecessor, [2..4] that tile's state words, [5] epoch, [6] polls, [7] lane,
+                                // [8..11] the stuck tile's trace words, [12] the time the poller gave up, [13] the time it started to wait
+#define SCAN_TRACE_WORDS 4      // per tile, written by thread 0 of its workgroup: [0] epoch << 32 | HW_ID (wave, SIMD, CU, SH, SE), [1] wall clock at the ticket,
+                                // [2] at the publication of its own totals (0: not yet), [3] XCC_ID << 56 | wall clock at the publication of its prefix (low bits 0: not yet)
 
 // RELAXED on purpose: a state word carries its whole message (tag + value in one 64-bit access that goes to the device-coherent
 // level, `sc1`), nothing else is published through it.  Acquire / release at agent scope cost a `buffer_inv sc1` per poll and a
@@ -44,7 +50,15 @@ __device__ __forceinline__ void ts_publish(const TileScan &ts, unsigned int tile
 // ticket of this workgroup (call once, by every thread; sh = one u32 of LDS)
 __device__ __forceinline__ unsigned int d_tile_ticket(const TileScan &ts, unsigned int *sh)
 {
-    if (threadIdx.x == 0) *sh = atomicAdd(ts.ticket, 1u);
+    if (threadIdx.x == 0) {
+        const unsigned int t = atomicAdd(ts.ticket, 1u);
+        *sh = t;
+        if (ts.trace) {
+            unsigned long long *p = ts.trace + (size_t)t * SCAN_TRACE_WORDS;
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_HW_ID, HW_REG_XCC_ID
+            p[0] = ((unsigned long long)ts.epoch << 32) | hw; p[1] = wall_clock64(); p[2] = 0ull; p[3] = (unsigned long long)(xcc & 0xFFu) << 56;
+        }
+    }
     __syncthreads();
     return *sh;
 }
@@ -59,16 +73,20 @@ __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile,
         const int lane = (int)threadIdx.x;
         uint64_t sx = 0, sy = 0, sz = 0, sw = 0;
         if (tile > 0) {
-            if (lane == 0) ts_publish(ts, tile, 1, own.x, own.y, (uint32_t)own.z, own.w);
+            if (lane == 0) { ts_publish(ts, tile, 1, own.x, own.y, (uint32_t)own.z, own.w); if (ts.trace) ts.trace[(size_t)tile * SCAN_TRACE_WORDS + 2] = wall_clock64(); }
             long long base = (long long)tile - 1;
             unsigned int polls = 0;
+            const unsigned long long t_wait0 = wall_clock64();
+            bool late = false;
             const uint32_t want1 = ts_tag(ts.epoch, 1), want2 = ts_tag(ts.epoch, 2);
             while (true) {
                 const long long t = base - lane;
                 unsigned long long va = ts_pack(want2, 0), vb = va, vc = va, vd = va;    // before tile 0: an inclusive prefix of nothing
                 if (t >= 0) { const unsigned long long *p = ts.w + (size_t)t * SCAN_WORDS; va = ts_load(p); vb = ts_load(p + 1); vc = ts_load(p + 2); vd = ts_load(p + 3); }
                 const uint32_t ta = (uint32_t)(va >> 32), tb = (uint32_t)(vb >> 32), tc = (uint32_t)(vc >> 32), td = (uint32_t)(vd >> 32);
-                const bool ready = ta == tb && tb == tc && tc == td && (ta == want1 || ta == want2);   // (a torn state shows different tags and is polled again)
+                // (a torn state shows different tags and is polled again; the tests' hook -- a poll budget of 1 -- makes tile 1 see nothing at all, so
+                //  that one tile of every hooked scan gives up whatever the timing: elsewhere a predecessor has usually published already)
+                const bool ready = !(ts.budget == 1u && tile == 1u) && ta == tb && tb == tc && tc == td && (ta == want1 || ta == want2);
                 const unsigned long long m_incl = __ballot(ready && ta == want2), m_wait = __ballot(!ready);
                 int upto = -1;                                                          // lanes 0..upto are summed; -1 = poll again
                 bool done = false;
@@ -91,13 +109,16 @@ __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile,
                         // a state word is read with a device-coherent load; should a copy ever sit in this CU's vector cache, this drops it
                         // (one invalidate per thousand polls costs nothing; one per poll tripled k_pair's time)
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        late = ts.ticks && wall_clock64() - t_wait0 > ts.ticks;
                     }
-                    if (polls > ts.budget) {
+                    if (late || (ts.budget && polls > ts.budget)) {
                         // the nearest predecessor this wave still waits for, and what its words look like from here
                         const int stuck = __ffsll((long long)m_wait) - 1;
                         if (lane == stuck && ts.dbg && atomicCAS(ts.dbg, 0ull, (unsigned long long)tile + 1ull) == 0ull) {
                             ts.dbg[1] = (unsigned long long)t; ts.dbg[2] = va; ts.dbg[3] = vb; ts.dbg[4] = vc ^ (vd & 0xFFFFFFFFull);      // (the fourth word's value folded in: it carries the same tag)
                             ts.dbg[5] = ts.epoch; ts.dbg[6] = polls; ts.dbg[7] = (unsigned long long)lane;
+                            if (ts.trace && t >= 0) for (int k = 0; k < SCAN_TRACE_WORDS; k++) ts.dbg[8 + k] = __hip_atomic_load(ts.trace + (size_t)t * SCAN_TRACE_WORDS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ts.dbg[12] = wall_clock64(); ts.dbg[13] = t_wait0;
                         }
                         if (lane == 0) atomicMax(err, DG_E_SCAN);
                         break;
@@ -108,6 +129,7 @@ __device__ inline Triple d_tile_exclusive(const TileScan &ts, unsigned int tile,
         }
         if (lane == 0) {
             ts_publish(ts, tile, 2, (uint32_t)sx + own.x, (uint32_t)sy + own.y, (uint32_t)(sz + own.z), (uint32_t)sw + own.w);
+            if (ts.trace) { unsigned long long *q = ts.trace + (size_t)tile * SCAN_TRACE_WORDS + 3; *q = (*q & 0xFF00000000000000ull) | (wall_clock64() & 0x00FFFFFFFFFFFFFFull); }
             sh[0] = sx; sh[1] = sy; sh[2] = sz; sh[3] = sw;
         }
     }

@@ -70,45 +70,17 @@ static void usage(const char *prog, const Options &o)   // ShowProgramUsage, mai
 // ---------------------------------------------------------------------------------------------
 // index files
 // ---------------------------------------------------------------------------------------------
+// What the host keeps of the index: the chromosome table of PREFIX.ann (names for the SAM header and the records, offsets for
+// junctions.tab).  The three big files (.bwt, .sa, .pac) go from the page cache to HBM inside dg_init_files; the host never holds them.
 struct HostIndex {
-    std::vector<uint32_t> bwt; std::vector<uint64_t> sa; std::vector<uint8_t> pac;
     std::vector<std::string> names; std::vector<int64_t> off, len;
-    uint64_t primary = 0, L2[5] = {0, 0, 0, 0, 0}, seq_len = 0; int sa_intv = 32; int64_t l_pac = 0;
-    dg_index_view view() const {
-        dg_index_view v;
-        v.bwt = bwt.data(); v.bwt_words = bwt.size(); v.primary = primary; for (int i = 0; i < 5; i++) v.L2[i] = L2[i]; v.seq_len = seq_len;
-        v.sa = sa.data(); v.n_sa = sa.size(); v.sa_intv = sa_intv; v.pac = pac.data(); v.l_pac = l_pac;
-        v.n_chr = (int32_t)names.size(); v.chr_off = off.data(); v.chr_len = len.data();
-        return v;
-    }
+    int64_t l_pac = 0;
 };
-
-static bool slurp(const std::string &fn, std::vector<uint8_t> &out)
-{
-    FILE *f = fopen(fn.c_str(), "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
-    out.resize((size_t)n);
-    bool ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
-    fclose(f);
-    return ok;
-}
 
 static bool file_exists(const std::string &fn) { FILE *f = fopen(fn.c_str(), "r"); if (!f) return false; fclose(f); return true; }
 
-static bool load_index(const std::string &prefix, HostIndex &ix)
+static bool load_ann(const std::string &prefix, HostIndex &ix)      // bwt_index.cpp:37-89 (bns_restore_core)
 {
-    std::vector<uint8_t> raw;
-    if (!slurp(prefix + ".bwt", raw) || raw.size() < 40) return false;
-    memcpy(&ix.primary, raw.data(), 8); memcpy(&ix.L2[1], raw.data() + 8, 32); ix.seq_len = ix.L2[4];
-    ix.bwt.resize((raw.size() - 40) / 4); memcpy(ix.bwt.data(), raw.data() + 40, ix.bwt.size() * 4);
-    if (!slurp(prefix + ".sa", raw) || raw.size() < 56) return false;
-    uint64_t intv; memcpy(&intv, raw.data() + 40, 8); ix.sa_intv = (int)intv;
-    const uint64_t n_sa = (ix.seq_len + (uint64_t)ix.sa_intv) / (uint64_t)ix.sa_intv;
-    ix.sa.assign(n_sa, 0); ix.sa[0] = (uint64_t)-1;
-    memcpy(ix.sa.data() + 1, raw.data() + 56, std::min<size_t>((n_sa - 1) * 8, raw.size() - 56));
-    if (!slurp(prefix + ".pac", ix.pac)) return false;
-    ix.pac.resize(ix.pac.size() + 16, 0);
     FILE *f = fopen((prefix + ".ann").c_str(), "r");
     if (!f) return false;
     long long xx; int n; unsigned seed;
@@ -123,7 +95,7 @@ static bool load_index(const std::string &prefix, HostIndex &ix)
         ix.names.push_back(name); ix.off.push_back(total); ix.len.push_back(l); total += l;
     }
     fclose(f);
-    return true;
+    return n > 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -459,31 +431,65 @@ int main(int argc, char *argv[])
         }
         if (!ok) return 0;
     }
-    // page-locked batch slots for the parallel FASTQ pipeline: allocated in the background while the index loads
     setenv("DG_BLOCKING_SYNC", "1", 0);      // the mapping threads sleep while their batch is on the GPU instead of spinning: the CPU share belongs to the parser, the formatter and the writer
-    int n_gpu = getenv("DART_GPUS") ? atoi(getenv("DART_GPUS")) : 1; if (n_gpu < 1) n_gpu = 1;
+    const double t_proc0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     size_t batch_reads = getenv("DART_BATCH") ? (size_t)atoll(getenv("DART_BATCH")) : 500000; batch_reads = std::max<size_t>(4000, batch_reads & ~(size_t)1);
     const int inflight_cfg = std::max(1, getenv("DART_INFLIGHT") ? atoi(getenv("DART_INFLIGHT")) : 2);
-    SlotPool pool;
-    FastqIndex pre;                         // the first library's read files are mapped and indexed while the genome index loads and dg_init runs
+    FastqIndex pre;                         // the first library's read files are mapped and indexed while the HIP runtime starts, the genome index loads and dg_init_files runs
+    bool fast_first = false;
     {
         const std::string &fn0 = o.f1[0];
         if (!o.bam && !getenv("DART_STREAMING") && fn0.substr(fn0.find_last_of('.') + 1) != "gz" && check_read_format(fn0.c_str())) {
-            pool.start((size_t)n_gpu * inflight_cfg + 2, batch_reads, 160);
+            fast_first = true;
             const bool two = o.f1.size() == o.f2.size();
             if (!two || o.f2[0].substr(o.f2[0].find_last_of('.') + 1) != "gz") pre.start(fn0.c_str(), two ? o.f2[0].c_str() : nullptr, o.threads);
         }
     }
+    // every device of the node maps batches (reads shard, the index is replicated; the reference's -t threads over one shared index,
+    // Mapping.cpp:792-793); DART_GPUS=n restricts it to the first n
+    int n_gpu = dg_device_count();
+    if (getenv("DART_GPUS")) n_gpu = std::min(std::max(1, atoi(getenv("DART_GPUS"))), std::max(1, n_gpu));
+    if (n_gpu < 1) { fprintf(stderr, "Error! No HIP device (this build of dart has no CPU path)\n"); return 1; }
+    SlotPool pool;                          // batch slots of the parallel FASTQ pipeline (page-locked in the background with DART_PINNED=1)
+    if (fast_first) pool.start((size_t)n_gpu * inflight_cfg + 2, batch_reads, 160);
     HostIndex ix;
     if (!o.index || !file_exists(std::string(o.index) + ".ann") || !file_exists(std::string(o.index) + ".amb") || !file_exists(std::string(o.index) + ".pac")) {
         fprintf(stderr, "Error! Please specify a valid reference index!\n"); usage(argv[0], o); return 1;
     }
     fprintf(stdout, "Load the genome index files...");
-    if (!load_index(o.index, ix)) { fprintf(stderr, "\n\nError! Index files are corrupt!\n"); return 0; }
-    fprintf(stdout, "\nLoad the reference sequences...\n");
+    if (!load_ann(o.index, ix)) { fprintf(stderr, "\n\nError! Index files are corrupt!\n"); return 0; }
 
+    // The contexts: one root per device (the index files go to its HBM inside dg_init_files, main.cpp:231-235 / bwt_index.cpp:147-159), clones
+    // for the batches in flight.  The look-up aids are built in the background while the first batches are mapped (DART_SYNC_AIDS=1: before).
     std::vector<dg_ctx *> ctx, roots, clones;
-    dg_index_view view = ix.view();
+    {
+        const std::string pb = std::string(o.index) + ".bwt", ps = std::string(o.index) + ".sa", pp = std::string(o.index) + ".pac";
+        dg_index_files files;
+        files.bwt_path = pb.c_str(); files.sa_path = ps.c_str(); files.pac_path = pp.c_str();
+        files.l_pac = ix.l_pac; files.n_chr = (int32_t)ix.names.size(); files.chr_off = ix.off.data(); files.chr_len = ix.len.data();
+        o.p.paired = (o.pair_end || o.f1.size() == o.f2.size()) ? 1 : 0;
+        const int init_flags = (getenv("DART_SYNC_AIDS") && atoi(getenv("DART_SYNC_AIDS"))) ? 0 : DG_INIT_ASYNC_AIDS;
+        roots.assign(n_gpu, nullptr);
+        std::vector<int> st(n_gpu, 0); std::vector<std::string> msg(n_gpu);
+        std::vector<std::thread> th;
+        for (int d = 0; d < n_gpu; d++) th.emplace_back([&, d]() { roots[d] = dg_init_files(&files, &o.p, d, init_flags, &st[d]); if (!roots[d]) msg[d] = dg_last_error(nullptr); });
+        for (auto &t : th) t.join();
+        for (int d = 0; d < n_gpu; d++) if (!roots[d]) {
+            if (st[d] == DG_ERR_ARG) fprintf(stderr, "\n\nError! Index files are corrupt!\n"); else fprintf(stderr, "\nError! GPU %d: %s\n", d, msg[d].c_str());
+            for (auto c : roots) if (c) dg_destroy(c);
+            return st[d] == DG_ERR_ARG ? 0 : 1;
+        }
+        for (int d = 0; d < n_gpu; d++) {
+            ctx.push_back(roots[d]);
+            for (int k = 1; k < inflight_cfg; k++) {
+                int st2 = 0; dg_ctx *cl = dg_clone(roots[d], &st2);
+                if (!cl) { fprintf(stderr, "Error! GPU %d: %s\n", d, dg_last_error(nullptr)); return 1; }
+                ctx.push_back(cl); clones.push_back(cl);
+            }
+        }
+    }
+    const double t_init1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    fprintf(stdout, "\nLoad the reference sequences...\n");
 
     std::string hdr_text = std::string("@PG\tID:Dart\tPN:Dart\tVN:") + VersionStr + "\n";      // Mapping.cpp:741-751
     for (size_t i = 0; i < ix.names.size(); i++) hdr_text += "@SQ\tSN:" + ix.names[i] + "\tLN:" + std::to_string((long long)ix.len[i]) + "\n";
@@ -521,20 +527,6 @@ int main(int argc, char *argv[])
         // the mate files start being parsed now, i.e. also while dg_init uploads the index and builds its tables
         Prefetch pf1, pf2;
         if (sep && !fast_host) { pf1.start(&s1, false); pf2.start(&s2, pair_end); }
-        if (ctx.empty()) {   // contexts are created once the first library opens (so flag errors never touch the GPU)
-            o.p.paired = pair_end ? 1 : 0;
-            const int inflight = inflight_cfg;
-            for (int d = 0; d < n_gpu; d++) {
-                int st = 0; dg_ctx *c = dg_init(&view, &o.p, d, &st);
-                if (!c) { fprintf(stderr, "Error! GPU %d: %s\n", d, dg_last_error(nullptr)); return 1; }
-                ctx.push_back(c); roots.push_back(c);
-                for (int k = 1; k < inflight; k++) {
-                    dg_ctx *cl = dg_clone(c, &st);
-                    if (!cl) { fprintf(stderr, "Error! GPU %d: %s\n", d, dg_last_error(nullptr)); return 1; }
-                    ctx.push_back(cl); clones.push_back(cl);
-                }
-            }
-        }
         if (fast_host) {
             fflush(sam);
             uint64_t off = (uint64_t)ftello(sam);
@@ -543,7 +535,7 @@ int main(int argc, char *argv[])
                                              fileno(sam), &off, total, sjmap, t0, ferr, fst, pool, lib == 0 ? &pre : nullptr);
             fseeko(sam, (off_t)off, SEEK_SET);
             if (frc) { fprintf(stderr, "\nError! GPU mapping failed (%d): %s\n", frc, ferr.c_str()); return 1; }
-            if (getenv("DART_TIMING")) fprintf(stderr, "[dart timing] index %.3f s, assemble %.3f s (of which page-locked allocation %.3f s), map (sum over workers) %.3f s, format %.3f s, write %.3f s\n", fst.t_index, fst.t_asm, fst.t_alloc, fst.t_map, fst.t_fmt, fst.t_write);
+            if (getenv("DART_TIMING")) fprintf(stderr, "[dart timing] start-up %.3f s (%s), index %.3f s, assemble %.3f s (of which page-locked allocation %.3f s), map (sum over workers) %.3f s, format %.3f s, write %.3f s\n", t_init1 - t_proc0, dg_init_report(roots[0]), fst.t_index, fst.t_asm, fst.t_alloc, fst.t_map, fst.t_fmt, fst.t_write);
             if (s1.fp) fclose(s1.fp);
             if (s2.fp) fclose(s2.fp);
             continue;

@@ -80,25 +80,29 @@ def expand_compact(reads_c, reports_c, cigar_c, rlen):
     return r, p, cig
 
 
+class IndexFiles(C.Structure):
+    _fields_ = [("bwt_path", C.c_char_p), ("sa_path", C.c_char_p), ("pac_path", C.c_char_p), ("l_pac", C.c_int64), ("n_chr", C.c_int32),
+                ("chr_off", C.c_void_p), ("chr_len", C.c_void_p)]
+
+
+INIT_ASYNC_AIDS = 1
+
+
 class Index:
-    """The BWA-format index files as the reference loads them (bwt_index.cpp:15-35,102-121,229-251)."""
+    """The BWA-format index files as the reference loads them (bwt_index.cpp:15-35,102-121,229-251).  The headers and the chromosome
+    table are read at once; the three big arrays only when something asks for them (dg_init's host-array view, tests): dg_init_files
+    takes them from the files straight to HBM."""
 
     def __init__(self, prefix: str):
         self.prefix = prefix
-        raw = np.fromfile(prefix + ".bwt", dtype=np.uint8)
-        hdr = raw[:40].view(np.uint64)
+        hdr = np.fromfile(prefix + ".bwt", dtype=np.uint64, count=5)
         self.primary = int(hdr[0])
         self.L2 = [0] + [int(x) for x in hdr[1:5]]
         self.seq_len = self.L2[4]
-        self.bwt = np.ascontiguousarray(raw[40:]).view(np.uint32)
-        sa_raw = np.fromfile(prefix + ".sa", dtype=np.uint64)
-        self.sa_intv = int(sa_raw[5])
+        sa_hdr = np.fromfile(prefix + ".sa", dtype=np.uint64, count=7)
+        self.sa_intv = int(sa_hdr[5])
         self.n_sa = (self.seq_len + self.sa_intv) // self.sa_intv
-        sa = np.empty(self.n_sa, dtype=np.uint64)
-        sa[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
-        sa[1:] = sa_raw[7:7 + self.n_sa - 1]
-        self.sa = sa
-        self.pac = np.fromfile(prefix + ".pac", dtype=np.uint8)
+        self._bwt = self._sa = self._pac = None
         with open(prefix + ".ann") as f:
             first = f.readline().split()
             self.l_pac, n = int(first[0]), int(first[1])
@@ -108,6 +112,36 @@ class Index:
                 lens.append(int(f.readline().split()[1]))
         self.chr_len = np.asarray(lens, dtype=np.int64)
         self.chr_off = np.concatenate([[0], np.cumsum(self.chr_len)[:-1]]).astype(np.int64)
+
+    @property
+    def bwt(self):
+        if self._bwt is None:
+            self._bwt = np.fromfile(self.prefix + ".bwt", dtype=np.uint32, offset=40)
+        return self._bwt
+
+    @property
+    def sa(self):
+        if self._sa is None:
+            sa = np.zeros(self.n_sa, dtype=np.uint64)
+            sa[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            body = np.fromfile(self.prefix + ".sa", dtype=np.uint64, offset=56, count=self.n_sa - 1)
+            sa[1:1 + len(body)] = body
+            self._sa = sa
+        return self._sa
+
+    @property
+    def pac(self):
+        if self._pac is None:
+            self._pac = np.fromfile(self.prefix + ".pac", dtype=np.uint8)
+        return self._pac
+
+    def files(self) -> IndexFiles:
+        f = IndexFiles()
+        self._paths = [(self.prefix + e).encode() for e in (".bwt", ".sa", ".pac")]
+        f.bwt_path, f.sa_path, f.pac_path = self._paths
+        f.l_pac = self.l_pac; f.n_chr = len(self.names)
+        f.chr_off = self.chr_off.ctypes.data; f.chr_len = self.chr_len.ctypes.data
+        return f
 
     def view(self) -> IndexView:
         v = IndexView()
@@ -150,6 +184,12 @@ def _load_lib():
     lib = C.CDLL(LIB_PATH)
     lib.dg_init.restype = C.c_void_p
     lib.dg_init.argtypes = [C.POINTER(IndexView), C.POINTER(Params), C.c_int, C.POINTER(C.c_int)]
+    lib.dg_init_files.restype = C.c_void_p
+    lib.dg_init_files.argtypes = [C.POINTER(IndexFiles), C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_int)]
+    lib.dg_index_wait.argtypes = [C.c_void_p]
+    lib.dg_init_report.restype = C.c_char_p
+    lib.dg_init_report.argtypes = [C.c_void_p]
+    lib.dg_device_count.restype = C.c_int
     lib.dg_last_error.restype = C.c_char_p
     lib.dg_last_error.argtypes = [C.c_void_p]
     lib.dg_destroy.argtypes = [C.c_void_p]
@@ -241,15 +281,29 @@ class BatchResult:
 class DartGPU:
     """dg_ctx wrapper: DART's per-read mapping path on one MI355X."""
 
-    def __init__(self, index: Index, params: Params | None = None, device: int = 0):
+    def __init__(self, index: Index, params: Params | None = None, device: int = 0, from_files: bool | None = None, async_aids: bool = False):
+        """from_files (default: unless DART_INIT_VIEW=1): dg_init_files -- the index files go straight to HBM; False: dg_init with the
+        host-array view.  async_aids: the look-up aids are built in the background (dg_index_wait / wait_index joins them)."""
         self.lib = _load_lib()
         self.index = index
         self.params = params or default_params()
         st = C.c_int(0)
-        v = index.view()
-        self.ctx = self.lib.dg_init(C.byref(v), C.byref(self.params), device, C.byref(st))
+        if from_files is None:
+            from_files = os.environ.get("DART_INIT_VIEW") != "1"
+        if from_files:
+            f = index.files()
+            self.ctx = self.lib.dg_init_files(C.byref(f), C.byref(self.params), device, INIT_ASYNC_AIDS if async_aids else 0, C.byref(st))
+        else:
+            v = index.view()
+            self.ctx = self.lib.dg_init(C.byref(v), C.byref(self.params), device, C.byref(st))
         if not self.ctx:
             raise RuntimeError("dg_init failed (%d): %s" % (st.value, (self.lib.dg_last_error(None) or b"").decode()))
+
+    def wait_index(self):
+        self._chk(self.lib.dg_index_wait(self.ctx), "dg_index_wait")
+
+    def init_report(self) -> str:
+        return (self.lib.dg_init_report(self.ctx) or b"").decode()
 
     def clone(self):
         """A second context sharing this one's index on the same device (dg_clone): for a second batch in flight."""

@@ -68,8 +68,31 @@ typedef struct { int32_t aln_score, sj_type, flag, paired_idx, chr, bdir; int64_
 typedef struct { int64_t g1, g2; int32_t type, read_idx; } dg_sj_out;
 
 void        dg_params_default(dg_params *);
+/* HIP devices this process can use (0: none, or the runtime failed): a multi-GPU host creates one root context per device and shards its
+ * batches over them -- the reference's `-t` threads over one shared index (Mapping.cpp:792-793) */
+int         dg_device_count(void);
 /* uploads the index to device `device` (0-based HIP ordinal) and builds the device-side layout */
 dg_ctx     *dg_init(const dg_index_view *, const dg_params *, int device, int *status);
+/* ---- start-up from the index FILES (replaces RestoreReferenceInfo / bwa_idx_load, bwt_index.cpp:147-159,229-253, and main.cpp:231-235) ----
+ * The reference reads PREFIX.bwt / .sa / .pac into host arrays and expands RefSequence before the first read is mapped.  Here the
+ * three files go from the page cache through page-locked staging chunks straight to HBM (several reader threads, each with its own
+ * copy stream; the Occ blocks are re-laid in place chunk by chunk behind their copy), so the host never holds the index.  The host
+ * program parses the small text file PREFIX.ann itself (it needs the names for the SAM header) and passes the chromosome table.
+ * The look-up aids the kernels build on top of the reference's index -- the full suffix array and the K-mer prefix table, which
+ * change no result -- are allocated while the files load and
+ *   flags = 0                   built before the call returns (what dg_init does)
+ *   flags & DG_INIT_ASYNC_AIDS  built by a library thread on a low-priority stream while the caller already maps batches: a context
+ *                               picks up each aid at its next batch.  A short job never waits for a 69 GB table it cannot amortise.
+ * dg_index_wait blocks until the aids are complete (DG_OK) or failed (the mapping still works without them; text in dg_last_error).
+ * dg_init_report: one line of text with the start-up split in seconds (allocation, file -> HBM, each build kernel).              */
+typedef struct {
+    const char *bwt_path, *sa_path, *pac_path;
+    int64_t l_pac; int32_t n_chr; const int64_t *chr_off; const int64_t *chr_len;
+} dg_index_files;
+#define DG_INIT_ASYNC_AIDS 1
+dg_ctx     *dg_init_files(const dg_index_files *, const dg_params *, int device, int flags, int *status);
+int         dg_index_wait(dg_ctx *);
+const char *dg_init_report(const dg_ctx *);
 void        dg_destroy(dg_ctx *);
 /* a second context on the same device sharing the parent's index (no copy): own streams and batch buffers, so two
  * batches can be in flight at once, one host thread per context -- what the reference gets from running
@@ -110,9 +133,9 @@ int dg_map_batch_packed(dg_ctx *, int n_reads, int rlen_all, const uint16_t *rle
                         const size_t caps[3], size_t used[3]);
 
 /* ---- compact records: the same information in 12 + 16 bytes instead of 36 + 40, and no CIGAR for a plain full-length match ----
- * The host link carries ~57 GB/s in total on an MI355X box (both directions together), so at several hundred million reads
- * per second the bytes of the records ARE the throughput: 85 -> 30 bytes per read.  Nothing is lost; what the layout already
- * says is not sent:
+ * The host link carries ~57 GB/s per direction on an MI355X box (full duplex for the copy engines: profiles/probes/duplex_probe.hip),
+ * so at several hundred million reads per second the bytes of the records load it: 85 -> 30 bytes per read (full records: 545 M
+ * reads/s, compact: 860).  Nothing is lost; what the layout already says is not sent:
  *   rep_off    reports lie in read order: a read's reports start at the sum of n_rep of the reads before it
  *   sj_off     likewise the junction tuples: the sum of n_sj of the reads before it
  *   cigar_off  the stored CIGAR ops lie in TWO regions, each in report order: first those of the reports whose `pad` bit 0 is clear (finished

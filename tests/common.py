@@ -69,6 +69,17 @@ def golden_sam(base):
     return gzip.open(os.path.join(GOLDEN, base + ".sam.gz"), "rb").read().decode()
 
 
+def golden_stats(base):
+    return open(os.path.join(GOLDEN, base + ".stats.txt")).read()
+
+
+def stats_block(stdout_bytes):
+    """the statistics block a run prints at its end (Mapping.cpp:812-822): the '\t# of ...' lines of its stdout, without the junction file's name -- what tests/golden/*.stats.txt hold of the reference's stdout"""
+    import re
+    lines = [l for l in stdout_bytes.decode("latin1").replace("\r", "\n").split("\n") if l.startswith("\t# of")]
+    return "".join(re.sub(r" \(file: .*\)$", "", l) + "\n" for l in lines)
+
+
 def golden_junctions(base):
     return open(os.path.join(GOLDEN, base + ".junctions.tab")).read()
 

@@ -30,6 +30,12 @@ BIG_INDEX = {
     "chr20_human": dict(lengths=[64444167], gseed=20, names=["chr20"], model="human"),           # = bench.py --genome chr20 --genome-model human
 }
 
+def stats_block(stdout_bytes):
+    """the '\t# of ...' lines of a run's stdout, with without the junction file's name (same helper as tests/common.py)"""
+    import re
+    lines = [l for l in stdout_bytes.decode("latin1").replace("\r", "\n").split("\n") if l.startswith("\t# of")]
+    return "".join(re.sub(r" \(file: .*\)$", "", l) + "\n" for l in lines)
+
 def case_inputs(spec, d):
     g = synth.make_genome(spec["lengths"], seed=spec["gseed"], repeat_scale=spec["rscale"], n_introns=spec["nintr"])
     m1, m2 = synth.make_reads(g, spec["npairs"], rlen=spec["rlen"], seed=spec["rseed"], spliced_frac=spec["spliced"],
@@ -59,8 +65,11 @@ def main():
             entry["index_sha256"][ext] = hashlib.sha256(open(os.path.join(d, name + "." + ext), "rb").read()).hexdigest()
         for k, fl in enumerate(spec["flags"]):
             sam = os.path.join(d, "o.sam"); junc = os.path.join(d, "o.junc"); dump = os.path.join(d, "o.dump")
-            subprocess.check_call([REF, "map", "-i", os.path.join(d, name)] + files + ["-o", sam, "-j", junc, "-dump", dump] + fl, stdout=subprocess.DEVNULL)
+            ref_stdout = subprocess.run([REF, "map", "-i", os.path.join(d, name)] + files + ["-o", sam, "-j", junc, "-dump", dump] + fl, stdout=subprocess.PIPE, check=True).stdout
             base = "%s.run%d" % (name, k)
+            # the statistics block the reference prints at the end of a run (Mapping.cpp:812-822; the harness prints it from the reference's
+            # own counters): the "# of" lines, without the junction file's name
+            with open(os.path.join(HERE, base + ".stats.txt"), "w") as f: f.write(stats_block(ref_stdout))
             with gzip.GzipFile(os.path.join(HERE, base + ".sam.gz"), "wb", mtime=0) as f: f.write(open(sam, "rb").read())
             with open(os.path.join(HERE, base + ".junctions.tab"), "wb") as f: f.write(open(junc, "rb").read())
             if k == 0:   # per-stage dump (seeds, candidates, final seeds) of the first run

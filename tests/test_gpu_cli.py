@@ -20,10 +20,12 @@ def test_dart_cli_reproduces_golden_sam(workdir):
         if c["spec"]["paired"]:
             synth.write_fastq(os.path.join(d, "2.fq"), c["m2"], 2); files += ["-f2", "2.fq"]
         for run in c["runs"]:
-            subprocess.run([DART, "-i", c["prefix"]] + files + ["-o", "o.sam", "-j", "o.j", "-t", "4"] + run["flags"], cwd=d, stdout=subprocess.DEVNULL, check=True)
+            r = subprocess.run([DART, "-i", c["prefix"]] + files + ["-o", "o.sam", "-j", "o.j", "-t", "4"] + run["flags"], cwd=d, stdout=subprocess.PIPE, check=True)
             got, want = open(os.path.join(d, "o.sam")).read(), common.golden_sam(run["base"])
             assert got == want, common.first_diff(got, want)
             assert open(os.path.join(d, "o.j")).read() == common.golden_junctions(run["base"])
+            # the statistics block of the run's stdout (Mapping.cpp:812-822) against the reference's own
+            assert common.stats_block(r.stdout) == common.golden_stats(run["base"]), (run["base"], r.stdout[-600:])
 
 
 def test_dart_cli_bam_output(workdir):
@@ -62,11 +64,12 @@ def test_dart_cli_matches_oracle_cli_on_input_variants(flags, label, host_path, 
     env = dict(os.environ, DART_BATCH="5000")      # several batches, so batch seams are exercised too
     if host_path == "streaming":
         env["DART_STREAMING"] = "1"
-    subprocess.run([DART, "-i", c["prefix"]] + flags + ["-o", "gpu.sam", "-j", "gpu.j", "-t", "3"], cwd=d, stdout=subprocess.DEVNULL, check=True, env=env)
-    subprocess.run([oracle_py.ORACLE_CLI, "-i", c["prefix"]] + flags + ["-o", "orc.sam", "-j", "orc.j"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    rg = subprocess.run([DART, "-i", c["prefix"]] + flags + ["-o", "gpu.sam", "-j", "gpu.j", "-t", "3"], cwd=d, stdout=subprocess.PIPE, check=True, env=env)
+    ro = subprocess.run([oracle_py.ORACLE_CLI, "-i", c["prefix"]] + flags + ["-o", "orc.sam", "-j", "orc.j"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
     a, b = open(os.path.join(d, "orc.sam")).read(), open(os.path.join(d, "gpu.sam")).read()
     assert a == b, common.first_diff(b, a)
     assert open(os.path.join(d, "orc.j")).read() == open(os.path.join(d, "gpu.j")).read()
+    assert common.stats_block(rg.stdout) == common.stats_block(ro.stdout) != "", (rg.stdout[-600:], ro.stdout[-600:])
 
 
 @pytest.mark.parametrize("host_path", ["parallel", "streaming"])

@@ -628,15 +628,20 @@ def test_gpu_scan_timeout_rerun_path(workdir, monkeypatch):
     want = orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=16)
     gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
     assert_same(gpu.map_batch(so, rl, flat), want)         # (sizes the context's buffers: a capacity re-run would hide the scan's)
-    monkeypatch.setenv("DG_SCAN_POLL_BUDGET", "1")
-    gpu.set_params(gpu.params)                             # the DG_* switches are read at init and at dg_set_params
-    res = gpu.map_batch(so, rl, flat)
-    c = gpu.counters()
-    monkeypatch.delenv("DG_SCAN_POLL_BUDGET")
-    gpu.set_params(gpu.params)
-    assert_same(res, want)
-    assert c["reruns_scan_total"] >= 1 and c["batch_runs"] == 2, c
-    assert b"look-back" in (gpu.lib.dg_last_error(gpu.ctx) or b"")
+    # each of the batch's three single-pass scans on its own (DG_SCAN_POLL_SCANS: 1 = k_seed_offsets, 2 = k_pair, 4 = k_emit_slow), then all three:
+    # a give-up in k_seed_offsets leaves seed_off[] unwritten for the tiles behind it -- k_pair must not touch them (it leaves at entry)
+    for mask in ("1", "2", "4", "7"):
+        monkeypatch.setenv("DG_SCAN_POLL_BUDGET", "1"); monkeypatch.setenv("DG_SCAN_POLL_SCANS", mask)
+        gpu.set_params(gpu.params)                         # the DG_* switches are read at init and at dg_set_params
+        before = gpu.counters()["reruns_scan_total"]
+        res = gpu.map_batch(so, rl, flat)
+        c = gpu.counters()
+        monkeypatch.delenv("DG_SCAN_POLL_BUDGET"); monkeypatch.delenv("DG_SCAN_POLL_SCANS")
+        gpu.set_params(gpu.params)
+        assert_same(res, want)
+        assert c["reruns_scan_total"] == before + 1 and c["batch_runs"] == 2, (mask, c)
+        msg = gpu.lib.dg_last_error(gpu.ctx) or b""
+        assert b"look-back" in msg and b"stuck tile's trace" in msg, msg
     gpu.close(); orc.close()
 
 

@@ -39,6 +39,25 @@ def test_oracle_sam_and_junctions_match_reference(name, oracles):
         assert junc == common.golden_junctions(run["base"])
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_cli_prints_the_reference_statistics(name, workdir):
+    """the statistics block at the end of a run's stdout (Mapping.cpp:812-822: mapped / paired / unique / multiple / unmapped / junctions):
+    the oracle's command line against what the reference's own counters printed for the same run (tests/golden/*.stats.txt)"""
+    import subprocess
+    from dart_amd import synth
+    oracle_py.build()
+    c = common.build_case(name, workdir)
+    d = os.path.join(workdir, "stats_" + name); os.makedirs(d, exist_ok=True)
+    synth.write_fastq(os.path.join(d, "1.fq"), c["m1"], 1)
+    files = ["-f", "1.fq"]
+    if c["spec"]["paired"]:
+        synth.write_fastq(os.path.join(d, "2.fq"), c["m2"], 2); files += ["-f2", "2.fq"]
+    for run in c["runs"]:
+        r = subprocess.run([oracle_py.ORACLE_CLI, "-i", c["prefix"]] + files + ["-o", "o.sam", "-j", "o.j", "-t", "2"] + run["flags"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+        assert common.stats_block(r.stdout) == common.golden_stats(run["base"]), (run["base"], r.stdout[-600:])
+        assert open(os.path.join(d, "o.sam")).read() == common.golden_sam(run["base"])
+
+
 def test_oracle_threads_do_not_change_results(oracles):
     c, orc, ix = oracles["pe101_spliced"]
     so, rl, flat = host.pack_reads(c["reads"])

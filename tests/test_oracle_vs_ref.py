@@ -9,8 +9,10 @@ pytestmark = pytest.mark.skipif(not os.path.exists(oracle_py.REF_HARNESS), reaso
 
 
 def run_both(d, prefix, flags):
-    subprocess.run([oracle_py.REF_HARNESS, "map", "-i", prefix] + flags + ["-o", "ref.sam", "-j", "ref.j"], cwd=d, stdout=subprocess.DEVNULL, check=True)
-    subprocess.run([oracle_py.ORACLE_CLI, "-i", prefix] + flags + ["-o", "orc.sam", "-j", "orc.j", "-t", "3"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    rr = subprocess.run([oracle_py.REF_HARNESS, "map", "-i", prefix] + flags + ["-o", "ref.sam", "-j", "ref.j"], cwd=d, stdout=subprocess.PIPE, check=True)
+    ro = subprocess.run([oracle_py.ORACLE_CLI, "-i", prefix] + flags + ["-o", "orc.sam", "-j", "orc.j", "-t", "3"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    # the statistics block of stdout (Mapping.cpp:812-822): the harness prints it from the reference's own counters
+    assert common.stats_block(rr.stdout) == common.stats_block(ro.stdout) != "", (rr.stdout[-600:], ro.stdout[-600:])
     a, b = open(os.path.join(d, "ref.sam")).read(), open(os.path.join(d, "orc.sam")).read()
     assert a == b, common.first_diff(b, a)
     assert open(os.path.join(d, "ref.j")).read() == open(os.path.join(d, "orc.j")).read()
