@@ -135,6 +135,100 @@ def self_launch(args, argv):
     return subprocess.call(cmd)
 
 
+def run_cli(dart_exe, prefix, g, label, seed_pairs, args, cpu_pairs=0, gz_pairs=0):
+    """`dart` as a child process: FASTQ files on tmpfs -> SAM + junctions on tmpfs, process start to exit (HIP start-up, index files -> HBM, FASTQ
+    parsing, mapping, SAM formatting, writing), best of two.  seed_pairs: [(seed, pairs)] -- the reads are synth.make_reads(g, pairs, seed) one
+    after the other.  cpu_pairs: the CPU command line (the oracle's, all host cores) on the head of the same files, end to end, and its wall
+    extrapolated to the whole job (index load + reads / its mapping rate).  gz_pairs: the head of the files gzipped, through `dart` again."""
+    import shutil, tempfile, re
+    import numpy as np
+    from dart_amd import synth
+    t = time.time()
+    total_pairs = sum(p_ for _, p_ in seed_pairs)
+    need = total_pairs * 2 * 560
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 1.3 * need else args.cache
+    d = tempfile.mkdtemp(prefix="dart_cli_", dir=base)
+    try:
+        first = 0
+        head = None
+        for seed, pairs in seed_pairs:
+            m1, m2 = synth.make_reads(g, pairs, rlen=101, seed=seed, sub_rate=args.sub_rate, indel_frac=args.indel_frac, n_frac=0.002)
+            synth.write_fastq_fast(os.path.join(d, "1.fq"), m1, 1, append=first > 0, first_id=first); synth.write_fastq_fast(os.path.join(d, "2.fq"), m2, 2, append=first > 0, first_id=first)
+            if head is None:
+                head = (m1[:max(cpu_pairs, gz_pairs)].copy(), m2[:max(cpu_pairs, gz_pairs)].copy())
+            first += pairs
+            del m1, m2
+        log("[bench] command-line run: %d pairs of FASTQ under %s prepared in %.1f s" % (total_pairs, d, time.time() - t))
+        cores = host_cores()
+        cmd = lambda f1, f2, out: [dart_exe, "-i", prefix, "-f", f1, "-f2", f2, "-o", out, "-j", out + ".j", "-t", str(cores), "-mis", str(args.mis)]
+
+        def timed_dart(f1, f2, out, reps):
+            best = None
+            for _ in range(reps):
+                for f_ in (out, out + ".j"):                            # (truncating a multi-GB tmpfs file at open is not part of the job)
+                    if os.path.exists(os.path.join(d, f_)):
+                        os.remove(os.path.join(d, f_))
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd(f1, f2, out), cwd=d, env=dict(os.environ, DART_TIMING="1", DART_INFLIGHT="2"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    raise RuntimeError("dart exited with %d: %s" % (r.returncode, r.stderr.decode()[-300:]))
+                tl = [l for l in r.stderr.decode().splitlines() if l.startswith("[dart timing]")]
+                if best is None or dt < best[0]:
+                    best = (dt, tl[-1] if tl else None, os.path.getsize(os.path.join(d, out)))
+            return best
+        best = timed_dart("1.fq", "2.fq", "out.sam", 2)
+        res = {"value": round(2 * total_pairs / best[0] / 1e6, 3), "unit": "M reads/s", "wall_s": round(best[0], 3), "sam_bytes": best[2],
+               "what": "`dart -i <%s> -f 1.fq -f2 2.fq -o out.sam -j out.j -t %d -mis %d` as a child process, %d pairs 2x101, files on %s: process start, HIP start-up, index files -> HBM, "
+                       "FASTQ parsing, mapping, SAM formatting and writing; best of 2" % (label.split(" (")[0], cores, args.mis, total_pairs, base),
+               "stages": best[1]}
+        m_ = re.search(r"start-up ([0-9.]+) s", best[1] or "")
+        if m_:
+            res["startup_s"] = float(m_.group(1))
+        if cpu_pairs > 0 and head is not None:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_py
+            oracle_py.build()
+            n_c = min(cpu_pairs, len(head[0]))
+            synth.write_fastq_fast(os.path.join(d, "c1.fq"), head[0][:n_c], 1); synth.write_fastq_fast(os.path.join(d, "c2.fq"), head[1][:n_c], 2)
+            t0 = time.perf_counter()
+            r = subprocess.run([oracle_py.ORACLE_CLI, "-i", prefix, "-f", "c1.fq", "-f2", "c2.fq", "-o", "cpu.sam", "-j", "cpu.j", "-t", str(cores), "-mis", str(args.mis)], cwd=d,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError("the CPU command line exited with %d: %s" % (r.returncode, r.stderr.decode()[-300:]))
+            m_ = re.search(r"index load ([0-9.]+) s, mapping phase ([0-9.]+) s", r.stderr.decode())
+            load_s, map_s = (float(m_.group(1)), float(m_.group(2))) if m_ else (0.0, dt)
+            other_s = max(0.0, dt - load_s - map_s)                      # parsing, formatting, writing: grows with the job like the mapping phase
+            whole = load_s + (map_s + other_s) * total_pairs / n_c
+            # the same reads through `dart`: the SAM must be the CPU command line's, byte for byte
+            timed_dart("c1.fq", "c2.fq", "gpu_head.sam", 1)
+            same = open(os.path.join(d, "cpu.sam"), "rb").read() == open(os.path.join(d, "gpu_head.sam"), "rb").read() and \
+                open(os.path.join(d, "cpu.j"), "rb").read() == open(os.path.join(d, "gpu_head.sam.j"), "rb").read()
+            res["cpu_command_line"] = {"kind": "port", "cores": cores, "pairs": n_c, "wall_s": round(dt, 3), "index_load_s": round(load_s, 3), "mapping_phase_s": round(map_s, 3),
+                                       "value": round(2 * n_c / dt / 1e6, 4), "unit": "M reads/s",
+                                       "wall_s_extrapolated_to_the_whole_job": round(whole, 1),
+                                       "what": "oracle/dart_oracle (the CPU restatement's command line) on the first %d pairs of the same files, %d threads, process start to exit; "
+                                               "extrapolation to %d pairs = index load + (the rest) x %d / %d" % (n_c, cores, total_pairs, total_pairs, n_c),
+                                       "sam_and_junctions_identical_to_dart_on_these_pairs": bool(same)}
+            res["speedup_vs_cpu_command_line_whole_job"] = round(whole / best[0], 1)
+        if gz_pairs > 0 and head is not None:
+            import gzip
+            n_z = min(gz_pairs, len(head[0]))
+            for k_, nm in ((0, "z1.fq"), (1, "z2.fq")):
+                synth.write_fastq_fast(os.path.join(d, nm), head[k_][:n_z], k_ + 1)
+                with open(os.path.join(d, nm), "rb") as fi, gzip.open(os.path.join(d, nm + ".gz"), "wb", compresslevel=1) as fo:
+                    shutil.copyfileobj(fi, fo, 1 << 24)
+            bz = timed_dart("z1.fq.gz", "z2.fq.gz", "gz.sam", 1)
+            bp = timed_dart("z1.fq", "z2.fq", "plain.sam", 1)
+            res["gz_input"] = {"pairs": n_z, "wall_s": round(bz[0], 3), "value": round(2 * n_z / bz[0] / 1e6, 3), "unit": "M reads/s", "stages": bz[1],
+                               "sam_identical_to_plain_fastq_input": open(os.path.join(d, "gz.sam"), "rb").read() == open(os.path.join(d, "plain.sam"), "rb").read(),
+                               "what": "the first %d pairs as 1.fq.gz / 2.fq.gz through the same command line (GetData.cpp:181-247)" % n_z}
+        return res
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 class Batch:
     """one distinct batch of pairs: ASCII and packed forms in page-locked host memory"""
 
@@ -278,6 +372,11 @@ def main():
                     help="N>1, after the timed region: rank 0 expands what it gathered from every rank for one step and compares it, batch by batch, with its own "
                          "single-rank mapping of the same reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cli-big-pairs", type=int, default=10000000,
+                    help="after the timed region: `dart` end to end on BASELINE configs[2] itself -- this many 2x101 pairs (the timed region's reads, as FASTQ files) against the "
+                         "GRCh38-sized index, process start to exit; 0 = skip (skipped too when the workload is not the default one)")
+    ap.add_argument("--cli-cpu-pairs", type=int, default=400000, help="pairs of the same files the CPU command line (oracle/dart_oracle, all host cores) maps beside it, end to end")
+    ap.add_argument("--cli-gz-pairs", type=int, default=2000000, help="pairs of the same files, gzipped, through `dart` (what users feed DART: GetData.cpp:181-247); 0 = skip")
     ap.add_argument("--cli-pairs", type=int, default=4000000,
                     help="after the timed region: the product's `dart` command line end to end (FASTQ files -> SAM file, process start, index load and dg_init included) on "
                          "this many 2x101 pairs against the chr20-sized genome; 0 = skip")
@@ -329,15 +428,9 @@ def main():
         label, gnames, glens = genome_spec("chr20")
         label = "FALLBACK (GRCh38-sized index build failed) " + label
         prefix, g = prepare_index(args.cache, (gnames, glens), rank, barrier, args.introns, args.repeat_scale, args.genome_model)
-    ix = host.Index(prefix)
-    params = host.default_params(paired=1, max_mismatch=args.mis, max_intron=args.max_intron)
-    t = time.time()
-    gpu = host.DartGPU(ix, params, device=local)
-    torch.cuda.synchronize()
-    if rank == 0:
-        log("[bench] dg_init (upload + Occ relayout + prefix table + full SA) %.2f s" % (time.time() - t))
-
-    # ---- the step's distinct batches, in page-locked host memory ----
+    # ---- the step's distinct batches, in page-locked host memory (before the library context is created: the index builder has just released
+    #      > 100 GB of HBM, which the driver clears in the background; allocations that need those pages wait for it -- seconds of hipMalloc) ----
+    lib = host._load_lib()
     t = time.time()
     strong = args.total_pairs > 0
     if not strong:
@@ -360,12 +453,22 @@ def main():
             specs += [(0, (0, 0))] * (int(tt.item()) - n_local)
     nb = len(specs)
     with ThreadPoolExecutor(max_workers=min(4, nb)) as ex:
-        batches = list(ex.map(lambda js: Batch(gpu.lib, g, args.pairs if js[1] is None else min(args.pairs, args.total_pairs - (js[0] - 1000) * args.pairs) if js[1][1] else 1,
+        batches = list(ex.map(lambda js: Batch(lib, g, args.pairs if js[1] is None else min(args.pairs, args.total_pairs - (js[0] - 1000) * args.pairs) if js[1][1] else 1,
                                                args.rlen, js[0], args.sub_rate, args.indel_frac, args.spliced, want_truth=(js is specs[0]), rows=js[1]), specs))
     n_reads = max(b.n for b in batches)
     reads_per_step = 2 * args.total_pairs if strong else 2 * args.pairs * nb * world          # whole job, all ranks
     if rank == 0:
         log("[bench] %d distinct batches of %d pairs generated in %.1f s" % (nb, args.pairs, time.time() - t))
+
+    ix = host.Index(prefix)
+    params = host.default_params(paired=1, max_mismatch=args.mis, max_intron=args.max_intron)
+    t = time.time()
+    gpu = host.DartGPU(ix, params, device=local)           # dg_init_files: the index files straight to HBM, full look-up aids (the job size is not given)
+    init_s = time.time() - t
+    torch.cuda.synchronize()
+    init_report = gpu.init_report()
+    if rank == 0:
+        log("[bench] dg_init_files %.2f s: %s" % (time.time() - t, gpu.init_report()))
 
     # `inflight` contexts share the index; each is driven by its own host thread, the way the reference runs ReadMapping in -t
     # threads.  Work item i = batch i % nb on context i % inflight; a step = nb items.
@@ -387,6 +490,13 @@ def main():
                                torch.empty(int(cap[1]) * 4, dtype=torch.uint8, device=gather_dev), torch.empty(int(cap[2]) * 24, dtype=torch.uint8, device=gather_dev)] for _ in range(1, world)]
     gathered = None                                 # --verify-gather: rank 0 keeps what arrived, per (source rank, batch)
     gather_bytes = [0]
+    # the writer's next step (Mapping.cpp:644-664: ONE ordered writer): rank 0 brings what it gathered from HBM to page-locked host memory, batch by
+    # batch in input order -- switched on for a second timed pass after the contract's (`value_with_writer_download`): it is the host link of ONE GPU
+    # that carries all ranks' records then
+    writer_dl = [False]
+    host_bufs = None
+    if recv_bufs is not None:
+        host_bufs = [None] + [[torch.empty(b_.numel(), dtype=torch.uint8, pin_memory=not rehearse) for b_ in recv_bufs[r]] for r in range(1, world)]
 
     def gather(w, item=None):
         nonlocal gather_buf
@@ -400,6 +510,14 @@ def main():
                 torch.cuda.current_stream().synchronize()   # the context's next run overwrites these records
             if rank == 0:
                 gather_bytes[0] += int(counts[1:].sum())
+                if writer_dl[0]:
+                    for r in range(1, world):
+                        for k in range(4):
+                            nb_ = int(counts[r, k])
+                            if nb_:
+                                host_bufs[r][k][:nb_].copy_(recv_bufs[r][k][:nb_], non_blocking=True)
+                    if not rehearse:
+                        torch.cuda.current_stream().synchronize()
                 if gathered is not None and item is not None:
                     for r in range(world):
                         src = parts if r == 0 else [recv_bufs[r][k][:int(counts[r, k])] for k in range(4)]
@@ -499,6 +617,11 @@ def main():
 
     # ---- secondary rates, outside the timed region (fewer items) ----
     secondary = {}
+    if gather_mode == "full" and not args.no_secondary:
+        writer_dl[0] = True
+        e_dl = timed(args.steps * nb, args.input)
+        writer_dl[0] = False
+        secondary["value_with_writer_download"] = round(reads_per_step * args.steps / e_dl / 1e6, 3)
     gather_timed = do_gather
     do_gather = False                                      # (the secondary rates are per-GPU diagnostics of other entry points: no gather)
     if not args.no_secondary:
@@ -702,40 +825,27 @@ def main():
         log("[bench] accuracy not computed:", repr(e))
 
     # ---- the drop-in product end to end (SURVEY 8d "plus end-to-end wall"): `dart -i IDX -f 1.fq -f2 2.fq -o out.sam` as a child process ----
-    cli = None
+    cli = cli_big = None
     dart_exe = os.path.join(ROOT, "dart_amd", "dart")
-    if args.cli_pairs > 0 and not args.no_cpu_baseline and os.path.exists(dart_exe):
+    if not args.no_cpu_baseline and os.path.exists(dart_exe):
+        # the library context of the timed region is closed first: `dart` is measured as a user runs it, alone on the GPU
         try:
-            import shutil, tempfile
-            t = time.time()
-            cprefix, cg = prepare_index(args.cache, (["chr20"], [CHR20_LEN]), 0, lambda: None)
-            cm1, cm2 = synth.make_reads(cg, args.cli_pairs, rlen=101, seed=1000, sub_rate=0.01, indel_frac=0.02, n_frac=0.002)
-            need = args.cli_pairs * 2 * 520
-            base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 1.3 * need else args.cache
-            d = tempfile.mkdtemp(prefix="dart_cli_", dir=base)
-            synth.write_fastq_fast(os.path.join(d, "1.fq"), cm1, 1); synth.write_fastq_fast(os.path.join(d, "2.fq"), cm2, 2)
-            del cm1, cm2
-            log("[bench] command-line run: %d pairs of FASTQ under %s prepared in %.1f s" % (args.cli_pairs, d, time.time() - t))
-            best = None
-            for _ in range(2):
-                for f_ in ("out.sam", "out.j"):                      # (truncating a multi-GB tmpfs file at open is not part of the job)
-                    if os.path.exists(os.path.join(d, f_)):
-                        os.remove(os.path.join(d, f_))
-                t = time.perf_counter()
-                r = subprocess.run([dart_exe, "-i", cprefix, "-f", "1.fq", "-f2", "2.fq", "-o", "out.sam", "-j", "out.j", "-t", str(host_cores()), "-mis", str(args.mis)], cwd=d,
-                                   env=dict(os.environ, DART_TIMING="1", DART_INFLIGHT="2"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-                dt = time.perf_counter() - t
-                if r.returncode != 0:
-                    raise RuntimeError("dart exited with %d: %s" % (r.returncode, r.stderr.decode()[-300:]))
-                if best is None or dt < best[0]:
-                    best = (dt, r.stderr.decode().strip().splitlines()[-1:], os.path.getsize(os.path.join(d, "out.sam")))
-            cli = {"value": round(2 * args.cli_pairs / best[0] / 1e6, 3), "unit": "M reads/s", "wall_s": round(best[0], 3), "sam_bytes": best[2],
-                   "what": "`dart -i <chr20-sized index> -f 1.fq -f2 2.fq -o out.sam -j out.j -t %d -mis %d` as a child process, %d pairs 2x101, files on %s: process start, index load, dg_init, "
-                           "FASTQ parsing, mapping, SAM formatting and writing; best of 2" % (host_cores(), args.mis, args.cli_pairs, base),
-                   "stages": best[1][0] if best[1] else None}
-            shutil.rmtree(d, ignore_errors=True)
+            gpu.close()                                    # (closes its clones too)
         except Exception as e:
-            log("[bench] command-line run failed:", repr(e))
+            log("[bench] closing the timed region's contexts:", repr(e))
+        if args.cli_big_pairs > 0 and args.genome == "grch38" and args.genome_model == "planted" and not args.spliced and args.rlen == 101:
+            try:
+                # BASELINE configs[2] through the command line: the SAME reads as the timed region's batches (seeds 1000 ...), 1 M pairs per seed
+                cli_big = run_cli(dart_exe, prefix, g, label, [(1000 + j, min(1000000, args.cli_big_pairs - j * 1000000)) for j in range((args.cli_big_pairs + 999999) // 1000000)],
+                                  args, cpu_pairs=args.cli_cpu_pairs, gz_pairs=args.cli_gz_pairs)
+            except Exception as e:
+                log("[bench] command-line run (GRCh38-sized) failed:", repr(e))
+        if args.cli_pairs > 0:
+            try:
+                cprefix, cg = prepare_index(args.cache, (["chr20"], [CHR20_LEN]), 0, lambda: None)
+                cli = run_cli(dart_exe, cprefix, cg, "chr20-sized synthetic genome", [(1000, args.cli_pairs)], args, cpu_pairs=0, gz_pairs=0)
+            except Exception as e:
+                log("[bench] command-line run failed:", repr(e))
 
     in_bytes = b0.bytes_packed if args.input == "packed" else b0.bytes_ascii
     line = {
@@ -764,10 +874,14 @@ def main():
         "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
         "kernels_ms_one_batch_in_flight": {k: round(v, 4) for k, v in iso.items()},
         "counters_per_launch": counters,
+        "library_start_up": {"dg_init_files_s": round(init_s, 3), "split": init_report},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "accuracy": accuracy,
     }
+    if cli_big:
+        line["value_cli_end_to_end_grch38"] = cli_big["value"]
+        line["cli_end_to_end_grch38"] = cli_big
     if cli:
         line["value_cli_end_to_end"] = cli["value"]
         line["cli_end_to_end"] = cli

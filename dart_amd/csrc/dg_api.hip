@@ -647,7 +647,7 @@ static void add_chunks(std::vector<UpChunk> &out, UpSrc src, uint64_t src_off, u
 
 // the look-up aids (full suffix array, K-mer prefix table): allocated while the index loads, built once it is in HBM, on a stream of the
 // lowest priority so that batches already being mapped (DG_INIT_ASYNC_AIDS) keep the GPU.  Each aid is published when complete.
-static void aids_thread(IndexShared *sh, int sa_file_intv, uint64_t n_sa)
+static void aids_thread(IndexShared *sh, int sa_file_intv, uint64_t n_sa, bool async, uint64_t expected_reads)
 {
     auto failed = [&](const char *w, hipError_t e) {
         std::lock_guard<std::mutex> lk(sh->mu);
@@ -663,16 +663,30 @@ static void aids_thread(IndexShared *sh, int sa_file_intv, uint64_t n_sa)
     // full suffix array (8 bytes per text symbol: 1 GB for chr20, 50 GB for a human genome -- this is what 288 GB are for): locating a row is
     // one load instead of a walk of up to 31 LF steps.  Texts too large for that fall back to every 2nd / 4th row; DG_SA_DENSE=0 turns it
     // off, =2/4/8/16 forces an interval
+    // A job known to be short (dg_index_files::expected_reads) gets LEAN aids -- every 4th row of the SA and K <= 14: 17 GB instead of 118 GB for
+    // a human genome, the seeding stage twice as long (1.85 + 0.25 against 0.97 + 0.10 ms per 2 M reads, profiles/r04/b_init_probe_aids_vs_startup.txt)
+    // -- because the full ones cost more than they save below some hundred million reads: 0.7 s of build kernels, and up to 3-4 s of hipMalloc
+    // when the device's memory was in use a moment ago (the driver clears VRAM behind a release; an allocation that needs those pages waits).
+    const bool lean = expected_reads != 0 && expected_reads < 400000000ull;
     int intv = seq_len <= (12ull << 30) ? 1 : (seq_len <= (24ull << 30) ? 2 : 4);
+    if (lean && intv < 4) intv = 4;
     if (const char *v = getenv("DG_SA_DENSE")) intv = atoi(v);
     const bool want_dense = intv >= 1 && intv < sa_file_intv && (intv & (intv - 1)) == 0 && seq_len < (1ull << 39);
     const uint64_t n_entries = want_dense ? seq_len / (uint64_t)intv + 1 : 0;
-    if (want_dense && (e = hipMalloc(&sh->d_sa_dense, n_entries * 8)) != hipSuccess) return failed("hipMalloc dense SA", e);
-    // K-mer prefix table: the smallest K with 4^K >= text length (so that most K-mers are unique or absent and a search needs the table plus
-    // a step or two), 8 <= K <= 16: 16 bytes per entry = 4.3 GB at K = 14 (chr20), 69 GB at K = 16 (human; K = 15, 17 GB: k_seed 2.47 instead
-    // of 2.18 ms).  DG_KTAB_K=0 turns it off, =2..16 forces K.
     int K = 8;
     while (K < 16 && (1ull << (2 * K)) < seq_len) K++;
+    if (lean && K > 14) K = 14;
+    if (async) {
+        // the caller maps batches meanwhile: the device allocations below take a lock every other allocation of the process needs (a context's
+        // first batch sizes its buffers) and, on recently used memory, seconds -- so they start only when the index itself is in HBM
+        std::unique_lock<std::mutex> lk(sh->mu);
+        sh->cv.wait(lk, [&]() { return sh->upload_done; });
+        if (!sh->upload_ok) { lk.unlock(); sh->aids_state.store(-1); sh->cv.notify_all(); return; }
+    }
+    if (want_dense && (e = hipMalloc(&sh->d_sa_dense, n_entries * 8)) != hipSuccess) return failed("hipMalloc dense SA", e);
+    // K-mer prefix table: the smallest K with 4^K >= text length (so that most K-mers are unique or absent and a search needs the table plus
+    // a step or two), 8 <= K <= 16: 16 bytes per entry = 4.3 GB at K = 14 (chr20), 69 GB at K = 16 (human; K = 14: k_seed 1.31 instead of
+    // 0.97 ms).  DG_KTAB_K=0 turns it off, =2..16 forces K.
     {   // the table must leave room for the batches in flight: step down while it would not leave 48 GB free
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
@@ -692,9 +706,16 @@ static void aids_thread(IndexShared *sh, int sa_file_intv, uint64_t n_sa)
         if (!sh->upload_ok) { lk.unlock(); (void)hipStreamDestroy(s); sh->aids_state.store(-1); sh->cv.notify_all(); return; }
     }
     double t_dense = 0, t_ktab = 0;
+    // Built beside running batches (async), the two kernels take a quarter of the wave slots (4 workgroups of 256 per CU, grid-stride): the
+    // stream's low priority alone did not keep them from crowding the batches out (a batch waited for the whole build, profiles/r04/a_*).
+    int n_cu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, sh->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+    int per_cu = 4;
+    if (const char *v = getenv("DG_AIDS_WGS_PER_CU")) per_cu = std::max(1, atoi(v));
+    const uint64_t grid_cap = async ? (uint64_t)n_cu * (uint64_t)per_cu : (uint64_t)1 << 22;
     if (want_dense) {
         t0 = now_s();
-        k_build_sa_dense<<<(unsigned)std::min<uint64_t>((n_sa + 255) / 256, 1u << 22), 256, 0, s>>>(ix, intv, n_entries, (uint64_t *)sh->d_sa_dense);
+        k_build_sa_dense<<<(unsigned)std::min<uint64_t>((n_sa + 255) / 256, grid_cap), 256, 0, s>>>(ix, intv, n_entries, (uint64_t *)sh->d_sa_dense);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipStreamDestroy(s); return failed("k_build_sa_dense", e); }
         ix.sa_dense = (const uint64_t *)sh->d_sa_dense; ix.sa_dense_intv = intv; ix.sa_dense_shift = 0;
         for (int b = 0; (1 << b) < intv; b++) ix.sa_dense_shift = b + 1;
@@ -704,7 +725,7 @@ static void aids_thread(IndexShared *sh, int sa_file_intv, uint64_t n_sa)
     if (K >= 2) {
         t0 = now_s();
         const size_t entries = (size_t)1 << (2 * K);
-        k_build_ktab<<<(unsigned)std::min<size_t>((entries + 255) / 256, (size_t)1 << 22), 256, 0, s>>>(ix, K, (uint64_t *)sh->d_ktab);
+        k_build_ktab<<<(unsigned)std::min<uint64_t>((entries + 255) / 256, grid_cap), 256, 0, s>>>(ix, K, (uint64_t *)sh->d_ktab);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipStreamDestroy(s); return failed("k_build_ktab", e); }
         ix.ktab = (const uint64_t *)sh->d_ktab; ix.ktab_k = K;
         { std::lock_guard<std::mutex> lk(sh->mu); sh->ix = ix; sh->gen.fetch_add(1, std::memory_order_release); }
@@ -714,15 +735,15 @@ static void aids_thread(IndexShared *sh, int sa_file_intv, uint64_t n_sa)
     {
         std::lock_guard<std::mutex> lk(sh->mu);
         char b[256];
-        snprintf(b, sizeof b, "; aids: hipMalloc %.3f s (full SA every %d row(s) %.1f GB, K=%d table %.1f GB), k_build_sa_dense %.3f s, k_build_ktab %.3f s",
-                 t_alloc, want_dense ? intv : 0, n_entries * 8 / 1e9, K >= 2 ? K : 0, K >= 2 ? (double)((size_t)16 << (2 * K)) / 1e9 : 0.0, t_dense, t_ktab);
+        snprintf(b, sizeof b, "; %saids%s: hipMalloc %.3f s (full SA every %d row(s) %.1f GB, K=%d table %.1f GB), k_build_sa_dense %.3f s, k_build_ktab %.3f s",
+                 lean ? "lean " : "", async ? " (built beside the first batches)" : "", t_alloc, want_dense ? intv : 0, n_entries * 8 / 1e9, K >= 2 ? K : 0, K >= 2 ? (double)((size_t)16 << (2 * K)) / 1e9 : 0.0, t_dense, t_ktab);
         sh->report += b;
         sh->aids_state.store(2);
     }
     sh->cv.notify_all();
 }
 
-struct IndexMeta { uint64_t bwt_words, primary, L2[5], seq_len, n_sa; int sa_intv; int64_t l_pac; int n_chr; const int64_t *chr_off, *chr_len; };
+struct IndexMeta { uint64_t bwt_words, primary, L2[5], seq_len, n_sa; int sa_intv; int64_t l_pac; int n_chr; const int64_t *chr_off, *chr_len; uint64_t expected_reads; };
 
 // everything of dg_init / dg_init_files behind the argument checks: contexts objects, index arrays, the upload, the aids
 static dg_ctx *init_index(const IndexMeta &m, UpSrc bwt, uint64_t bwt_off, UpSrc sa, uint64_t sa_off, uint64_t sa_first, uint64_t sa_count, UpSrc pac, size_t pac_copy,
@@ -788,7 +809,7 @@ static dg_ctx *init_index(const IndexMeta &m, UpSrc bwt, uint64_t bwt_off, UpSrc
     sh->ix = c->ix; c->ix_gen = sh->gen.load();
     const double t_alloc = now_s();
     sh->aids_state.store(1);
-    sh->aids = std::thread(aids_thread, sh, m.sa_intv, m.n_sa);           // allocates the aids while the index bytes travel
+    sh->aids = std::thread(aids_thread, sh, m.sa_intv, m.n_sa, (flags & DG_INIT_ASYNC_AIDS) != 0, m.expected_reads);   // (sync: allocates the aids while the index bytes travel)
 
     const size_t chunk = (size_t)32 << 20;
     std::vector<UpChunk> chunks;
@@ -851,7 +872,7 @@ extern "C" dg_ctx *dg_init(const dg_index_view *v, const dg_params *p, int devic
     }
     IndexMeta m;
     m.bwt_words = v->bwt_words; m.primary = v->primary; for (int i = 0; i < 5; i++) m.L2[i] = v->L2[i]; m.seq_len = v->seq_len; m.n_sa = v->n_sa; m.sa_intv = v->sa_intv;
-    m.l_pac = v->l_pac; m.n_chr = v->n_chr; m.chr_off = v->chr_off; m.chr_len = v->chr_len;
+    m.l_pac = v->l_pac; m.n_chr = v->n_chr; m.chr_off = v->chr_off; m.chr_len = v->chr_len; m.expected_reads = 0;
     UpSrc b, s, q;
     b.mem = (const uint8_t *)v->bwt; s.mem = (const uint8_t *)v->sa; q.mem = v->pac;
     return init_index(m, b, 0, s, 0, 0, v->n_sa, q, (size_t)(v->l_pac / 4 + 1), p, device, 0, status);
@@ -883,7 +904,7 @@ extern "C" dg_ctx *dg_init_files(const dg_index_files *f, const dg_params *p, in
     const uint64_t sa_count = std::min<uint64_t>(m.n_sa - 1, ((uint64_t)st.st_size - 56) / 8);
     if ((fp.fd = open(f->pac_path, O_RDONLY)) < 0 || fstat(fp.fd, &st) != 0) return bad(DG_ERR_ARG, "cannot read %s", f->pac_path);
     const size_t pac_copy = std::min<size_t>((size_t)st.st_size, (size_t)(f->l_pac / 4 + 1));
-    m.l_pac = f->l_pac; m.n_chr = f->n_chr; m.chr_off = f->chr_off; m.chr_len = f->chr_len;
+    m.l_pac = f->l_pac; m.n_chr = f->n_chr; m.chr_off = f->chr_off; m.chr_len = f->chr_len; m.expected_reads = f->expected_reads;
     UpSrc b, s, q;
     b.fd = fb.fd; s.fd = fs.fd; q.fd = fp.fd;
     return init_index(m, b, 40, s, 56, 1, sa_count, q, pac_copy, p, device, flags, status);

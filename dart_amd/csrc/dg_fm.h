@@ -707,10 +707,63 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
         auto rm = [&](int w) -> uint32_t { const uint32_t v = sh[W2 + (w < W2 ? w : W2 - 1)]; return w < W2 ? v : 0xFFFFFFFFu; };
         int pos = hv.pos, nh = hv.nh;
         uint32_t ns = hv.ns;
+        // The tail of a read inside a high-copy repeat (satellites, microsatellites, young interspersed copies): the reference restarts its search at
+        // every base (a failed search advances by one, AlignmentCandidates.cpp:209) and each of those searches runs to the end of the read --
+        // O(rlen^2) Occ steps, two thirds of this kernel's work on a human-like genome.  A search from s that matches through to the read's end e
+        // stops there with the interval of read[s, e) (bwt_search.cpp:152-171), and that interval only grows as s moves right.  So ONE backward
+        // walk from e (prepending a base = extending the reverse complement on the right: the text holds both strands) finds the leftmost s_f
+        // whose read[s_f, e) occurs more than max_dup times -- and at least 128 times, so that every step of those searches fetched two Occ
+        // blocks, which keeps the reference-equivalent block count exact: every start in [s_f, e) fails (bwt_search.cpp:173) after e - s - 1 steps.
+        // (The whole wave computes the walk redundantly: the values are uniform, the loads broadcast.)
+        int sfail = len;
+        {
+            const uint64_t thr = (uint64_t)(pr.max_dup + 1 > 128 ? pr.max_dup + 1 : 128);
+            int q = len - 1;
+            if (q >= pos && d_at(rm, q) == 0) {
+                uint64_t x0 = 0, x1 = 0, x2 = 0;
+                bool have = false;
+                if (K && len - K >= pos) {
+                    const uint32_t sft = 32u - 2u * (uint32_t)K;
+                    if ((d_win16(rm, len - K) >> sft) == 0) {           // the read's last K bases, none of them N
+                        const uint4 e4 = *(const uint4_a4 *)(ix.ktab + (size_t)(d_win16(rb, len - K) >> sft) * 2);
+                        const uint64_t w0 = d_u64(e4.x, e4.y), w1 = d_u64(e4.z, e4.w);
+                        if (lane == 0) c.ktab++;
+                        if (!(w1 >> 63)) {                               // (an overflowing entry: start from the last base instead)
+                            have = true;
+                            if ((w1 >> 62) & 1ull) x2 = 1;               // a located (unique) K-mer
+                            else { x2 = (w1 >> 16) & 0x7FFFFFFFull; x0 = w0 & 0xFFFFFFFFFFull; x1 = (w0 >> 40) | ((w1 & 0xFFFFull) << 24); q = len - K; }
+                        }
+                    }
+                }
+                if (!have) { const int cc = (int)d_at(rb, q); x0 = d_L2(ix, cc) + 1; x1 = d_L2(ix, 3 - cc) + 1; x2 = d_L2(ix, cc + 1) - d_L2(ix, cc); }
+                if (x2 >= thr) {
+                    sfail = q;
+                    while (q > pos) {
+                        const int qq = q - 1;
+                        if (d_at(rm, qq)) break;
+                        uint64_t y0 = x1, y1 = x0, y2 = x2;              // the bi-interval of the reverse complement
+                        uint32_t nb;
+                        const bool ok = d_extend(ix, 3 - (int)d_at(rb, qq), y0, y1, y2, nb);
+                        if (lane == 0) { c.steps_act++; c.blocks_act += nb; }
+                        if (!ok || y2 < thr) break;
+                        x1 = y0; x0 = y1; x2 = y2; q = qq; sfail = q;
+                    }
+                }
+            }
+        }
         while (pos < end_pos) {                      // uniform
+            if (pos >= sfail) {                      // every remaining start fails after len - s - 1 steps: the sum over s = pos .. end_pos - 1
+                if (lane == 0) {
+                    const unsigned long long n = (unsigned long long)(end_pos - pos), st2 = n * (unsigned long long)((len - pos - 1) + (len - end_pos));
+                    c.steps += st2 / 2; c.blocks += st2;
+                }
+                pos = end_pos;
+                break;
+            }
             Search s; s.mode = 0; s.hit_len = 0; s.located = false; s.ref_steps = s.ref_blocks = 0; s.start = pos + lane; s.x2 = 0; s.x0 = 0; s.tpos = 0; s.lsteps = 0; s.lk = 0;
             const int st = pos + lane;
-            const bool acgt = st < end_pos && d_at(rm, st) == 0;
+            const bool doomed = st >= sfail && st < end_pos;             // (fails without being searched)
+            const bool acgt = st < end_pos && st < sfail && d_at(rm, st) == 0;
             {   // the 64 searches advance in lock step: one issue phase, one finish phase per trip
                 TripData t; t.aux = T_NONE;
                 TripAddr ta = {nullptr, nullptr, nullptr, nullptr};
@@ -735,6 +788,7 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
                 const int src = cur - pos;
                 const int is_acgt = __shfl((int)acgt, src, 64);
                 const int hl = __shfl(s.hit_len, src, 64);
+                if (lane == src && doomed) { c.steps += (unsigned long long)(len - st - 1); c.blocks += 2ull * (unsigned long long)(len - st - 1); }
                 if (lane == src && acgt) {           // this search is one the reference performs
                     c.steps += s.ref_steps; c.blocks += s.ref_blocks;
                     if (s.hit_len) {

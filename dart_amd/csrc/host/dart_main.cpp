@@ -129,7 +129,33 @@ struct Source {
             if (!blk) { blk_cap = (size_t)8 << 20; blk = (char *)malloc(blk_cap + 1); }
             if (blk_beg > 0) { memmove(blk, blk + blk_beg, blk_end - blk_beg); blk_end -= blk_beg; blk_beg = 0; }
             if (blk_end == blk_cap) { blk_cap *= 2; blk = (char *)realloc(blk, blk_cap + 1); }
-            const size_t got = fread(blk + blk_end, 1, blk_cap - blk_end, fp);
+            const size_t got = fill(blk_cap - blk_end);
+            if (got == 0) blk_eof = true;
+            blk_end += got;
+        }
+    }
+    size_t fill(size_t room) {                       // the next bytes of the (inflated) stream behind blk_end
+        if (!gz) return fread(blk + blk_end, 1, room, fp);
+        const int got = gzread(gz, blk + blk_end, (unsigned)std::min<size_t>(room, (size_t)1 << 30));
+        return got > 0 ? (size_t)got : 0;
+    }
+    // gzgets(file, buffer, 1024) as a view into the block (GetData.cpp:181-210 reads every line that way): up to 1023 bytes, ending behind
+    // the first newline among them; 0 = end of the stream.  (zlib inflates in large blocks here instead of once per line.)
+    size_t gets_view(char **line) {
+        while (true) {
+            const size_t avail = blk_end - blk_beg, want = std::min<size_t>(avail, 1023);
+            char *nl = want ? (char *)memchr(blk + blk_beg, '\n', want) : nullptr;
+            if (nl || want == 1023 || (blk_eof && avail)) {
+                *line = blk + blk_beg;
+                const size_t len = nl ? (size_t)(nl - (blk + blk_beg)) + 1 : want;
+                blk_beg += len;
+                return len;
+            }
+            if (blk_eof) return 0;
+            if (!blk) { blk_cap = (size_t)8 << 20; blk = (char *)malloc(blk_cap + 1); }
+            if (blk_beg > 0) { memmove(blk, blk + blk_beg, blk_end - blk_beg); blk_end -= blk_beg; blk_beg = 0; }
+            if (blk_end == blk_cap) { blk_cap *= 2; blk = (char *)realloc(blk, blk_cap + 1); }
+            const size_t got = fill(blk_cap - blk_end);
             if (got == 0) blk_eof = true;
             blk_end += got;
         }
@@ -161,25 +187,7 @@ struct Source {
         }
         return e;
     }
-    // gzGetNextEntry, GetData.cpp:181-210
-    Entry next_gz() {
-        Entry e; char b[1024];
-        if (gzgets(gz, b, 1024) != NULL) {
-            int len = (int)strlen(b), p1 = hdr_beg(b, len), p2 = hdr_end(b, len);
-            len = p2 - p1;
-            if (len > 0 && (b[0] == '@' || b[0] == '>')) {
-                e.header.assign(b + p1, b + p2);
-                if (gzgets(gz, b, 1024) == NULL) { b[0] = '\n'; b[1] = 0; }
-                e.rlen = (int)strlen(b) - 1; e.seq.assign(b, b + e.rlen);
-                if (fastq) {
-                    if (gzgets(gz, b, 1024) == NULL || gzgets(gz, b, 1024) == NULL) b[0] = 0;
-                    e.qual.assign(b, b + std::min<size_t>((size_t)e.rlen, strlen(b)));
-                }
-            }
-        }
-        return e;
-    }
-    Entry next() { return gz ? next_gz() : next_plain(); }
+    Entry next() { return next_plain(); }
 };
 
 // A run of reads in flat buffers (no per-read allocation: with one std::string per field the allocator, not the
@@ -208,9 +216,40 @@ struct Reads {
 // one read from a Source appended to R (mate 2 of a pair: reverse-complemented, qualities reversed, GetData.cpp:160-166);
 // false = end of the stream (an entry of length 0, as in the reference).  Plain FASTQ is parsed straight into the flat
 // buffers; FASTA and gz go through the Entry readers above.
+// gzGetNextEntry, GetData.cpp:181-210, parsed straight into the flat buffers: every line is a gzgets of at most 1023 bytes; a header line
+// must start with '@' or '>' and name something; the sequence is the next line without its last byte; FASTQ: two more lines, the second
+// holds the qualities (cut to the read length).  FASTA through this reader has ONE sequence line per record, as in the reference.
+static bool read_into_gz(Source &s, Reads &R, bool rc)
+{
+    char *ln; size_t len = s.gets_view(&ln);
+    if (len == 0) return false;
+    len = strnlen(ln, len);                               // (the reference measures its buffer with strlen)
+    const int p1 = hdr_beg(ln, (int)len), p2 = hdr_end(ln, (int)len);
+    if (!(p2 - p1 > 0 && (ln[0] == '@' || ln[0] == '>'))) return false;      // an entry of length 0 ends the stream
+    const size_t h0 = R.hdr.size(), s0 = R.seq.size();
+    R.hdr.append(ln + p1, (size_t)(p2 - p1));
+    size_t sl = s.gets_view(&ln);
+    sl = sl ? strnlen(ln, sl) : 1;                        // (end of the stream behind a header: an empty line)
+    const int rlen = (int)sl - 1;
+    if (rlen <= 0) { R.hdr.resize(h0); return false; }
+    if (rc) { R.seq.resize(s0 + (size_t)rlen); for (int i = 0; i < rlen; i++) R.seq[s0 + i] = comp_base(ln[rlen - 1 - i]); }
+    else R.seq.append(ln, (size_t)rlen);
+    if (s.fastq) {
+        char *q = nullptr; size_t ql = 0;
+        if (s.gets_view(&q) != 0) ql = s.gets_view(&q);
+        if (ql == 0) q = nullptr;
+        const size_t take = std::min<size_t>((size_t)rlen, q ? strnlen(q, ql) : 0), q0 = R.qual.size();
+        if (rc) { R.qual.resize(q0 + take); for (size_t i = 0; i < take; i++) R.qual[q0 + i] = q[take - 1 - i]; }
+        else if (take) R.qual.append(q, take);
+    }
+    R.hoff.push_back((uint32_t)R.hdr.size()); R.soff.push_back((uint32_t)R.seq.size()); R.qoff.push_back((uint32_t)R.qual.size());
+    return true;
+}
+
 static bool read_into(Source &s, Reads &R, bool rc)
 {
-    if (s.gz || !s.fastq) {
+    if (s.gz) return read_into_gz(s, R, rc);
+    if (!s.fastq) {
         Entry e = s.next();
         if (e.rlen == 0) return false;
         R.add(e.header.data(), e.header.size(), e.seq.data(), e.seq.size(), e.qual.data(), e.qual.size(), rc, s.fastq);
@@ -452,6 +491,34 @@ int main(int argc, char *argv[])
     if (n_gpu < 1) { fprintf(stderr, "Error! No HIP device (this build of dart has no CPU path)\n"); return 1; }
     SlotPool pool;                          // batch slots of the parallel FASTQ pipeline (page-locked in the background with DART_PINNED=1)
     if (fast_first) pool.start((size_t)n_gpu * inflight_cfg + 2, batch_reads, 160);
+    // The read files of a library.  Plain FASTQ goes through the parallel host pipeline (fast_fastq.h); FASTA, .gz, -bo and DART_STREAMING=1 through the
+    // streaming one: one thread per mate file inflates (zlib, 1 MB at a time) and parses into flat buffers.  Library 0 is opened HERE, before the
+    // index goes to the GPU, so that its files are read while the HIP runtime starts and dg_init_files runs.
+    struct LibIO { Source s1, s2; Prefetch pf1, pf2; bool sep = false, gz = false, fastq = false, fast_host = false; int state = -1; };
+    std::vector<std::unique_ptr<LibIO>> libs(o.f1.size());
+    auto open_lib = [&](size_t lib) -> int {        // 0 = opened, 1 = a file cannot be opened (the library is skipped, Mapping.cpp:765-779), 2 = mates in different formats
+        if (libs[lib]) return libs[lib]->state;
+        libs[lib].reset(new LibIO());
+        LibIO &L = *libs[lib];
+        const std::string &fn = o.f1[lib];
+        L.gz = fn.substr(fn.find_last_of('.') + 1) == "gz";
+        L.fastq = check_read_format(fn.c_str());
+        L.s1.fastq = L.s2.fastq = L.fastq;
+        if (L.gz) L.s1.gz = gzopen(fn.c_str(), "rb"); else L.s1.fp = fopen(fn.c_str(), "r");
+        if (o.f1.size() == o.f2.size()) {
+            L.sep = true;
+            if (L.fastq != check_read_format(o.f2[lib].c_str())) { fprintf(stderr, "Error! %s and %s are with different format...\n", fn.c_str(), o.f2[lib].c_str()); return L.state = 2; }
+            if (L.gz) L.s2.gz = gzopen(o.f2[lib].c_str(), "rb"); else L.s2.fp = fopen(o.f2[lib].c_str(), "r");
+        }
+        if (!L.s1.fp && !L.s1.gz) return L.state = 1;
+        if (L.sep && !L.s2.fp && !L.s2.gz) return L.state = 1;
+        if (L.s1.gz) gzbuffer(L.s1.gz, 1u << 20);
+        if (L.s2.gz) gzbuffer(L.s2.gz, 1u << 20);
+        L.fast_host = L.fastq && !L.gz && !o.bam && !getenv("DART_STREAMING") && (!L.sep || o.f2[lib].substr(o.f2[lib].find_last_of('.') + 1) != "gz");
+        if (L.sep && !L.fast_host) { L.pf1.start(&L.s1, false); L.pf2.start(&L.s2, true); }      // (separate mate files: paired, mate 2 reverse-complemented)
+        return L.state = 0;
+    };
+    if (!fast_first && o.index && file_exists(std::string(o.index) + ".ann")) open_lib(0);
     HostIndex ix;
     if (!o.index || !file_exists(std::string(o.index) + ".ann") || !file_exists(std::string(o.index) + ".amb") || !file_exists(std::string(o.index) + ".pac")) {
         fprintf(stderr, "Error! Please specify a valid reference index!\n"); usage(argv[0], o); return 1;
@@ -467,6 +534,13 @@ int main(int argc, char *argv[])
         dg_index_files files;
         files.bwt_path = pb.c_str(); files.sa_path = ps.c_str(); files.pac_path = pp.c_str();
         files.l_pac = ix.l_pac; files.n_chr = (int32_t)ix.names.size(); files.chr_off = ix.off.data(); files.chr_len = ix.len.data();
+        {   // the size of the job, from the sizes of its input files: ~250 bytes per FASTQ read of 2x101 (a quarter of that gzipped; FASTA: half).
+            // A coarse figure is all the library needs: it decides between lean and full look-up aids at some hundred million reads.
+            uint64_t bytes = 0; struct stat st;
+            for (auto &v : {&o.f1, &o.f2}) for (auto &fn : *v) if (stat(fn.c_str(), &st) == 0) bytes += (uint64_t)st.st_size * (fn.size() > 3 && fn.substr(fn.size() - 3) == ".gz" ? 4u : 1u);
+            files.expected_reads = std::max<uint64_t>(1, bytes / 250);
+            if (getenv("DART_EXPECTED_READS")) files.expected_reads = (uint64_t)atoll(getenv("DART_EXPECTED_READS"));
+        }
         o.p.paired = (o.pair_end || o.f1.size() == o.f2.size()) ? 1 : 0;
         const int init_flags = (getenv("DART_SYNC_AIDS") && atoi(getenv("DART_SYNC_AIDS"))) ? 0 : DG_INIT_ASYNC_AIDS;
         roots.assign(n_gpu, nullptr);
@@ -509,24 +583,14 @@ int main(int argc, char *argv[])
     if (o.silent) fprintf(stdout, "Start read mapping...\n");
     bool pair_end = o.pair_end;
     for (size_t lib = 0; lib < o.f1.size(); lib++) {
-        Source s1, s2; bool sep = false;
+        const int orc = open_lib(lib);              // (library 0 was opened before the index went to the GPU: its files are being inflated and parsed since)
+        if (orc == 2) return 1;
+        if (orc == 1) continue;
+        LibIO &L = *libs[lib];
+        Source &s1 = L.s1, &s2 = L.s2; Prefetch &pf1 = L.pf1, &pf2 = L.pf2;
+        const bool sep = L.sep, gz = L.gz, fastq = L.fastq, fast_host = L.fast_host;
         const std::string &fn = o.f1[lib];
-        const bool gz = fn.substr(fn.find_last_of('.') + 1) == "gz";
-        const bool fastq = check_read_format(fn.c_str());
-        s1.fastq = s2.fastq = fastq;
-        if (gz) s1.gz = gzopen(fn.c_str(), "rb"); else s1.fp = fopen(fn.c_str(), "r");
-        if (o.f1.size() == o.f2.size()) {
-            sep = pair_end = true;
-            if (fastq != check_read_format(o.f2[lib].c_str())) { fprintf(stderr, "Error! %s and %s are with different format...\n", fn.c_str(), o.f2[lib].c_str()); return 1; }
-            if (gz) s2.gz = gzopen(o.f2[lib].c_str(), "rb"); else s2.fp = fopen(o.f2[lib].c_str(), "r");
-        }
-        if (!s1.fp && !s1.gz) continue;
-        if (sep && !s2.fp && !s2.gz) continue;
-        // plain FASTQ goes through the parallel host pipeline (fast_fastq.h); FASTA, .gz, -bo and DART_STREAMING=1 through the streaming one below
-        const bool fast_host = fastq && !gz && !o.bam && !getenv("DART_STREAMING") && (!sep || o.f2[lib].substr(o.f2[lib].find_last_of('.') + 1) != "gz");
-        // the mate files start being parsed now, i.e. also while dg_init uploads the index and builds its tables
-        Prefetch pf1, pf2;
-        if (sep && !fast_host) { pf1.start(&s1, false); pf2.start(&s2, pair_end); }
+        if (sep) pair_end = true;
         if (fast_host) {
             fflush(sam);
             uint64_t off = (uint64_t)ftello(sam);

@@ -2,11 +2,13 @@
 
   eva      sensitivity + average sequence identity of a SAM file against the genome  (GeneralEvaluation.cpp:28-140)
   SJ_Eva   how many predicted junctions lie within 5 bp of a true one                (SJ_Evaluation.cpp:94-116)
-  FluxEva  how many alignments start where the read was simulated from               (FluxEvaluation.cpp; here: the synthetic
-           generator's own truth instead of Flux read names, MAPQ 0 alignments left out as the reference does)
+  FluxEva  how many alignments start where the read was simulated from               (FluxEvaluation.cpp:26-80: `flux_eva`, on
+           Flux-style read names "chr:left-rightW..."; `mapping_accuracy` asks the same question of a batch's record arrays
+           with the synthetic generator's own truth)
 
     python -m dart_amd.evaluate eva OUT.sam GENOME.fa
     python -m dart_amd.evaluate sj  junctions.tab TRUE_JUNCTIONS.txt
+    python -m dart_amd.evaluate flux OUT.sam
 
 `mapping_accuracy` scores the record arrays of a batch directly (bench.py's `accuracy`).  Host-side tools: no GPU involved.
 """
@@ -101,6 +103,53 @@ def sj_eva(predicted, truth, slack: int = 5):
             "true_junctions": n_true, "recall": (sum(int(f.sum()) for f in found.values()) / n_true) if n_true else 0.0}
 
 
+def _atoi(t: str) -> int:
+    """C atoi: leading blanks, an optional sign, then digits; anything else ends the number (no digits: 0)"""
+    m = re.match(r"\s*([+-]?\d+)", t)
+    return int(m.group(1)) if m else 0
+
+
+def flux_eva(sam_lines):
+    """FluxEva (FluxEvaluation.cpp:26-80).  A read's name says where the Flux simulator took it from: "<chr>:<left>-<right>W..." (the text
+    between the first ':' and the first '-' and from there to the first 'W', read with atoi).  Per name only the first two records
+    count; a record without CIGAR is "empty", one with MAPQ 0 is left out, the rest are right when the chromosome is the name's and POS
+    lies in [left, right].  Returns the program's three numbers: right, scored (= total - empty - MAPQ 0) and the accuracy in per cent,
+    rounded as it prints it ((int)(1000 * (right / scored + 0.0005)) / 10)."""
+    total = right = low = empty = 0
+    prev, hits = None, 0
+    for line in sam_lines:
+        line = line.rstrip("\n")
+        if line == "":
+            break                                       # (the program stops at the first empty line)
+        if line[0] == "@":
+            continue
+        f = line.split()
+        header, p_chr, gpos, mapq, cigar = f[0], f[2], _atoi(f[3]), _atoi(f[4]), f[5]
+        # IdentifyGenomicRegion, FluxEvaluation.cpp:10-24: std::string::substr(pos, len) with int arithmetic -- a character that is not
+        # there gives -1, and a negative length wraps to "the rest of the string"
+        sub = lambda t, pos, n: t[pos:] if n < 0 else t[pos:pos + n]
+        p1, p2, p3 = header.find(":"), header.find("-"), header.find("W")
+        r_chr = sub(header, 0, p1)
+        left = _atoi(sub(header, p1 + 1, p2 - p1 - 1))
+        right_pos = _atoi(sub(header, p2 + 1, p3 - p2 + 1))
+        if header != prev:
+            prev, hits = header, 1
+        else:
+            hits += 1
+        if hits > 2:
+            continue
+        total += 1
+        if cigar == "*":
+            empty += 1
+        elif mapq == 0:
+            low += 1
+        elif p_chr == r_chr and left <= gpos <= right_pos:
+            right += 1
+    scored = total - empty - low
+    acc = int(1000 * (right / scored + 0.0005)) / 10.0 if total > 0 and scored > 0 else 0.0
+    return {"right": right, "scored": scored, "accuracy_percent": acc, "records": total, "empty": empty, "mapq0": low}
+
+
 def mapping_accuracy(res, truth, tolerance: int = 10):
     """FluxEva's question on a batch's records: of the plain fragments (no planted indel or intron: their truth is exact), how
     many reads are mapped, and how many best alignments start within `tolerance` bp of where the read was sampled from
@@ -145,6 +194,10 @@ def main(argv):
         tab = lambda p: [tuple(l.split()[:3]) for l in open(p) if l.strip()]
         r = sj_eva(tab(argv[1]), tab(argv[2]))
         print("%d of %d predicted junctions annotated (%.3f); %d true junctions, recall %.3f" % (r["annotated"], r["predicted"], r["precision"], r["true_junctions"], r["recall"]))
+        return 0
+    if len(argv) == 2 and argv[0] == "flux":
+        r = flux_eva(open(argv[1]))
+        print("Acc = %d / %d = %.2f" % (r["right"], r["scored"], r["accuracy_percent"]))
         return 0
     print(__doc__)
     return 2

@@ -82,7 +82,7 @@ def expand_compact(reads_c, reports_c, cigar_c, rlen):
 
 class IndexFiles(C.Structure):
     _fields_ = [("bwt_path", C.c_char_p), ("sa_path", C.c_char_p), ("pac_path", C.c_char_p), ("l_pac", C.c_int64), ("n_chr", C.c_int32),
-                ("chr_off", C.c_void_p), ("chr_len", C.c_void_p)]
+                ("chr_off", C.c_void_p), ("chr_len", C.c_void_p), ("expected_reads", C.c_uint64)]
 
 
 INIT_ASYNC_AIDS = 1
@@ -135,8 +135,9 @@ class Index:
             self._pac = np.fromfile(self.prefix + ".pac", dtype=np.uint8)
         return self._pac
 
-    def files(self) -> IndexFiles:
+    def files(self, expected_reads: int = 0) -> IndexFiles:
         f = IndexFiles()
+        f.expected_reads = int(expected_reads)
         self._paths = [(self.prefix + e).encode() for e in (".bwt", ".sa", ".pac")]
         f.bwt_path, f.sa_path, f.pac_path = self._paths
         f.l_pac = self.l_pac; f.n_chr = len(self.names)
@@ -281,7 +282,7 @@ class BatchResult:
 class DartGPU:
     """dg_ctx wrapper: DART's per-read mapping path on one MI355X."""
 
-    def __init__(self, index: Index, params: Params | None = None, device: int = 0, from_files: bool | None = None, async_aids: bool = False):
+    def __init__(self, index: Index, params: Params | None = None, device: int = 0, from_files: bool | None = None, async_aids: bool = False, expected_reads: int = 0):
         """from_files (default: unless DART_INIT_VIEW=1): dg_init_files -- the index files go straight to HBM; False: dg_init with the
         host-array view.  async_aids: the look-up aids are built in the background (dg_index_wait / wait_index joins them)."""
         self.lib = _load_lib()
@@ -291,7 +292,7 @@ class DartGPU:
         if from_files is None:
             from_files = os.environ.get("DART_INIT_VIEW") != "1"
         if from_files:
-            f = index.files()
+            f = index.files(expected_reads)      # (expected_reads: 0 = unknown -> full aids; a short job gets lean ones)
             self.ctx = self.lib.dg_init_files(C.byref(f), C.byref(self.params), device, INIT_ASYNC_AIDS if async_aids else 0, C.byref(st))
         else:
             v = index.view()

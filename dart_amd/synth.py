@@ -349,7 +349,7 @@ def write_fastq(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I")) ->
         f.write(b"".join(chunk))
 
 
-def write_fastq_fast(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I"), chunk: int = 500000) -> None:
+def write_fastq_fast(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I"), chunk: int = 500000, append: bool = False, first_id: int = 0) -> None:
     """FASTQ with fixed-width names "@r<9 digits>/<mate>": every record has the same length, so the file is assembled as a byte matrix
     (a few million reads per second; write_fastq's per-read loop needs more than a minute for 16 M reads).  For throughput measurements."""
     n, rlen = seqs.shape
@@ -360,10 +360,10 @@ def write_fastq_fast(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I"
     tmpl[hdr + rlen] = 10; tmpl[hdr + rlen + 1] = ord("+"); tmpl[hdr + rlen + 2] = 10; tmpl[rec - 1] = 10
     d3 = np.array([[ord("0") + k // 100, ord("0") + k // 10 % 10, ord("0") + k % 10] for k in range(1000)], dtype=np.uint8)
     out = np.tile(tmpl, (min(chunk, max(n, 1)), 1))                       # allocated (and paged in) once
-    with open(path, "wb") as f:
+    with open(path, "ab" if append else "wb") as f:
         for c0 in range(0, n, chunk):
             m = min(chunk, n - c0)
-            ids = np.arange(c0, c0 + m, dtype=np.int64)
+            ids = np.arange(first_id + c0, first_id + c0 + m, dtype=np.int64)
             out[:m, 2:5] = d3[ids // 1000000 % 1000]; out[:m, 5:8] = d3[ids // 1000 % 1000]; out[:m, 8:11] = d3[ids % 1000]
             out[:m, hdr:hdr + rlen] = seqs[c0:c0 + m]
             f.write(out[:m].tobytes())

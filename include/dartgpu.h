@@ -81,13 +81,16 @@ dg_ctx     *dg_init(const dg_index_view *, const dg_params *, int device, int *s
  * The look-up aids the kernels build on top of the reference's index -- the full suffix array and the K-mer prefix table, which
  * change no result -- are allocated while the files load and
  *   flags = 0                   built before the call returns (what dg_init does)
- *   flags & DG_INIT_ASYNC_AIDS  built by a library thread on a low-priority stream while the caller already maps batches: a context
- *                               picks up each aid at its next batch.  A short job never waits for a 69 GB table it cannot amortise.
+ *   flags & DG_INIT_ASYNC_AIDS  allocated and built by a library thread (a quarter of the GPU's wave slots, lowest stream priority) while the
+ *                               caller already maps batches: a context picks up each aid at its next batch.
  * dg_index_wait blocks until the aids are complete (DG_OK) or failed (the mapping still works without them; text in dg_last_error).
  * dg_init_report: one line of text with the start-up split in seconds (allocation, file -> HBM, each build kernel).              */
 typedef struct {
     const char *bwt_path, *sa_path, *pac_path;
     int64_t l_pac; int32_t n_chr; const int64_t *chr_off; const int64_t *chr_len;
+    uint64_t expected_reads;   /* size of the job if the host knows it (file sizes), 0 = unknown: below 400 M reads the aids are LEAN -- every 4th
+                                  SA row, K <= 14: 17 GB instead of 118 GB for a human genome, seeding twice as long -- because the full ones
+                                  cost 0.7 s of build kernels and, on memory that was in use a moment ago, seconds of allocation */
 } dg_index_files;
 #define DG_INIT_ASYNC_AIDS 1
 dg_ctx     *dg_init_files(const dg_index_files *, const dg_params *, int device, int flags, int *status);

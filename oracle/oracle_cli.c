@@ -152,7 +152,7 @@ int main(int argc, char **argv)
     int64_t total = 0, n_unique = 0, n_unmapped = 0, n_paired = 0;
     sj_t *sj = NULL; size_t nsj = 0, msj = 0;
     FILE *sam;
-    double t_map = 0;
+    double t_map = 0, t_load = 0;
     struct timeval tv0, tv1;
 
     orc_params_default(&pr);
@@ -180,7 +180,10 @@ int main(int argc, char **argv)
     (void)silent;
     if (nf1 == 0) { fprintf(stderr, "Error! Please specify a valid read input!\n"); return 1; }
     if (nf2 > 0 && nf1 != nf2) { fprintf(stderr, "Error! Paired-end reads input numbers do not match!\n"); return 1; }
+    gettimeofday(&tv0, 0);
     if (!index || !(ix = orc_index_load(index))) { fprintf(stderr, "Error! Please specify a valid reference index!\n"); return 1; }
+    gettimeofday(&tv1, 0);
+    t_load = (double)(tv1.tv_sec - tv0.tv_sec) + 1e-6 * (double)(tv1.tv_usec - tv0.tv_usec);
 
     sam = fopen(out_name, "w");
     fprintf(sam, "@PG\tID:Dart\tPN:Dart\tVN:1.4.6\n");
@@ -343,7 +346,7 @@ int main(int argc, char **argv)
         fclose(jf);
         fprintf(stdout, "\t# of splice junctions = %d (file: %s)\n", nj, sj_name);
         fprintf(stdout, "\tAlignment output: %s\n\n", out_name);
-        fprintf(stderr, "[dart_oracle] mapping phase %.3f s, %lld reads, %d threads -> %.1f reads/s\n", t_map, (long long)total, threads, total / (t_map > 0 ? t_map : 1e-9));
+        fprintf(stderr, "[dart_oracle] index load %.3f s, mapping phase %.3f s, %lld reads, %d threads -> %.1f reads/s\n", t_load, t_map, (long long)total, threads, total / (t_map > 0 ? t_map : 1e-9));
     }
     orc_index_free(ix);
     return 0;

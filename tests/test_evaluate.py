@@ -9,6 +9,7 @@ from dart_amd import evaluate
 
 REF_EVA = os.path.join(oracle_py.ORACLE_DIR, "_ref", "eva")
 REF_SJ = os.path.join(oracle_py.ORACLE_DIR, "_ref", "SJ_Eva")
+REF_FLUX = os.path.join(oracle_py.ORACLE_DIR, "_ref", "FluxEva")
 
 
 def test_eva_known_answers():
@@ -74,3 +75,59 @@ def test_scorers_match_reference_programs(workdir):
     pred = [tuple(l.split()[:3]) for l in junc.split("\n") if l.strip()]
     j = evaluate.sj_eva(pred, truth)
     assert (j["annotated"], j["predicted"]) == (acc, n_rep)
+
+
+def _flux_sam(workdir, n_keep=4000, seed=5):
+    """the golden SAM of the spliced case with Flux-simulator read names ("<chr>:<left>-<right>W:..."): the region is the record's own POS
+    shifted by a random amount, so that some records fall inside it and some outside; plus the cases the program treats specially --
+    records without CIGAR, MAPQ 0, more than two records per name, a name on another chromosome, names without 'W' or '-'"""
+    c, g, chroms, sam, junc = _spliced_case(workdir)
+    rng = np.random.default_rng(seed)
+    out = []
+    body = [l for l in sam.split("\n") if l and l[0] != "@"][:n_keep]
+    out += [l for l in sam.split("\n") if l.startswith("@")]
+    for i in range(0, len(body) - 1, 2):
+        f1, f2 = body[i].split("\t"), body[i + 1].split("\t")
+        pos = int(f1[3])
+        left = max(0, pos - int(rng.integers(0, 300)) + (400 if rng.random() < 0.15 else 0))
+        right = left + int(rng.integers(100, 600))
+        chr_ = f1[2] if (f1[2] != "*" and rng.random() < 0.9) else g.names[int(rng.integers(0, len(g.names)))]
+        style = i // 2 % 11
+        name = "%s:%d-%dW:%d:%d" % (chr_, left, right, i, 7)
+        if style == 9: name = "%s:%d-%d" % (chr_, left, right)                 # no 'W'
+        if style == 10: name = "%s:%d" % (chr_, left)                           # no '-'
+        for f in (f1, f2):
+            f[0] = name
+            if style == 7: f[4] = "0"
+            out.append("\t".join(f))
+        if style == 8:                                                          # a third and a fourth record of the same name: not counted
+            out.append("\t".join(f1)); out.append("\t".join(f2))
+    return "\n".join(out) + "\n"
+
+
+def test_flux_eva_known_answers():
+    sam = ["@SQ\tSN:c1\tLN:1000",
+           "c1:100-200W:x\t0\tc1\t150\t50\t8M\t*\t0\t0\tACGTACGT\tIIIIIIII",      # right
+           "c1:100-200W:x\t0\tc1\t201\t50\t8M\t*\t0\t0\tACGTACGT\tIIIIIIII",      # outside
+           "c1:100-200W:x\t0\tc1\t150\t50\t8M\t*\t0\t0\tACGTACGT\tIIIIIIII",      # third record of the name: not counted
+           "c1:300-400W:y\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII",                   # empty
+           "c1:300-400W:y\t0\tc1\t300\t0\t4M\t*\t0\t0\tACGT\tIIII",               # MAPQ 0: left out
+           "c2:5-9W:z\t0\tc1\t7\t50\t4M\t*\t0\t0\tACGT\tIIII",                    # another chromosome
+           "c1:5-9W:z\t0\tc1\t9\t50\t4M\t*\t0\t0\tACGT\tIIII"]                    # right (inclusive bound)
+    r = evaluate.flux_eva(sam)
+    assert (r["right"], r["scored"], r["records"], r["empty"], r["mapq0"]) == (2, 4, 6, 1, 1) and r["accuracy_percent"] == 50.0
+
+
+@pytest.mark.skipif(not os.path.exists(REF_FLUX), reason="oracle/_ref/FluxEva not built (no /root/reference here)")
+def test_flux_eva_matches_reference_program(workdir):
+    d = os.path.join(workdir, "flux_ref"); os.makedirs(d, exist_ok=True)
+    for seed in (5, 6):
+        sam = _flux_sam(workdir, seed=seed)
+        open(os.path.join(d, "flux.sam"), "w").write(sam)
+        out = subprocess.run([REF_FLUX, "flux.sam"], cwd=d, capture_output=True, text=True).stdout
+        m = re.search(r"Acc = (\d+) / (\d+) = ([0-9.]+)\s*$", out.split("\r")[-1])
+        assert m, out
+        r = evaluate.flux_eva(sam.split("\n"))
+        assert (r["right"], r["scored"]) == (int(m.group(1)), int(m.group(2))), (r, out[-200:])
+        assert "%.2f" % r["accuracy_percent"] == m.group(3)
+        assert r["right"] > 200 and r["scored"] - r["right"] > 100 and r["mapq0"] > 100 and r["empty"] > 0

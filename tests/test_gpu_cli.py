@@ -140,6 +140,18 @@ def test_dart_cli_error_behaviour(workdir):
     assert r.returncode == 0 and r.stdout.startswith(b"DART v1.4.6")
 
 
+def test_rccl_single_rank_carries_the_record_arrays(workdir):
+    """backend "nccl" (= RCCL) with ONE rank -- all a one-GPU box allows: the library's HBM record arrays go through the all_gather and the
+    batched point-to-point calls of the multi-GPU gather (dart_amd/dist.py) and arrive intact (tests/rccl_smoke.py, a child process with its
+    own process group)."""
+    import subprocess, sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(common.HERE, "rccl_smoke.py"), workdir], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0 and "rccl smoke ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_bench_two_ranks_through_the_self_launcher(workdir):
     """`python bench.py --gpus 2` with no launcher around it: bench.py starts two ranks itself (torch.distributed.run), each maps
     its own distinct batches host to host, the per-read records are gathered to rank 0 inside the timed region, and ONE JSON line
@@ -158,6 +170,7 @@ def test_bench_two_ranks_through_the_self_launcher(workdir):
     assert line["n_gpus"] == 2 and line["value"] > 0 and "gather" in line["config"]["parallelism"] and "host-to-host" in line["config"]["workload"]
     assert line["scaling"] == "weak" and line["gather"]["mode"] == "full" and line["gather"]["bytes_received_by_rank0_total"] > 0
     assert line["gather"]["verified_against_single_rank_mapping"] is True          # rank 0's gathered record set == its own mapping of the same reads
+    assert line["value_with_writer_download"] > 0                                  # the second pass: rank 0 also brings the gathered records to host memory
     assert line["cpu_baseline"]["gpu_records_identical_on_sample"] is True and line["cpu_baseline"]["value_t1"] > 0
     assert line["roofline"]["frac"] > 0 and line["accuracy"]["correct_frac"] > 0.9
 
