@@ -810,7 +810,12 @@ def main():
         cpu = {"value": round(ns / dt / 1e6, 5), "unit": "M reads/s", "cores": cores, "kind": "port",
                "sample": "first %d pairs of batch 0, oracle/dart_oracle.c with %d threads, %.1f s wall" % (ns // 2, cores, dt),
                "value_t1": round(n1t / dt1 / 1e6, 5), "sample_t1": "first %d pairs of batch 0, 1 thread, %.1f s wall" % (n1t // 2, dt1),
-               "gpu_records_identical_on_sample": same}
+               "gpu_records_identical_on_sample": same,
+               # the CPU baseline is the PORT (the reference cannot travel to the GPU box).  How its speed relates to the reference's own object code
+               # was measured where both exist, the builder's container: oracle/dart_oracle -t 1 against oracle/_ref/ref_harness, mapping phase taken
+               # from the difference of a 4 k-pair and a 24 k-pair run of 2x101 -mis 5 on a 40 Mbp human-like genome: 18.6 k against 28.7 k reads/s
+               # per core (round 1, 500 kb genome: 0.7).  value / port_vs_reference = what reference `dart` would show on these cores.
+               "port_vs_reference": 0.65, "value_reference_equivalent": round(ns / dt / 1e6 / 0.65, 5)}
         log("[bench] oracle counters on sample:", orc.counters)
 
     # accuracy beside parity (the reference's Evaluation/eva idea): of the plain fragments (no planted indel or

@@ -1707,6 +1707,23 @@ extern "C" int dg_last_counters(dg_ctx *c, uint64_t *out, int cap)
     return k;
 }
 
+// diagnostic: the per-tile trace of one of the last run's single-pass scans (dg_scan.h, SCAN_TRACE_WORDS u64 per tile: epoch << 32 | HW_ID, wall clock at the
+// ticket, at the publication of the tile's own totals, XCC_ID << 56 | wall clock at the publication of its prefix), for tests/probes/kpair_wait.py:
+// how long does a workgroup of k_pair work before its look-back, and how long does the look-back wait?  which: 0 = k_seed_offsets, 1 = k_pair, 2 = k_emit_slow
+extern "C" int dg_debug_scan_trace(dg_ctx *c, int which, uint64_t *out, size_t cap_tiles, size_t *n_tiles, double *ticks_per_ms)
+{
+    if (!c || !out || !n_tiles || which < 0 || which > 2) return DG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const int n = c->n_reads, paired = (c->pr.paired && (n % 2 == 0)) ? 1 : 0, n_units = paired ? n / 2 : n;
+    const size_t ts = scan_tiles_seed(n), tp = scan_tiles_pair(n_units), te = (size_t)(2 * n_units + 255) / 256 + 1;
+    const size_t first = which == 0 ? 0 : (which == 1 ? ts : ts + tp), cnt = (which == 0 ? ts : (which == 1 ? tp : te)) - 1;
+    *n_tiles = cnt;
+    if (ticks_per_ms) *ticks_per_ms = (double)c->wall_khz;
+    if (!c->scan_trace.p || cnt > cap_tiles) return cnt > cap_tiles ? DG_ERR_CAPACITY : DG_ERR_ARG;
+    HIPCHK(hipMemcpy(out, c->scan_trace.p + SCAN_TRACE_WORDS * first, cnt * SCAN_TRACE_WORDS * 8, hipMemcpyDeviceToHost));
+    return DG_OK;
+}
+
 // ---- the index builder's sorter (dg_sort.h): stable radix sort of n (key, value) pairs in device memory, ascending by the low
 // key_bits bits of the key.  keys/vals hold the input and the result; *_tmp are scratch of the same size.  Runs on the NULL
 // stream of `device` (so it is ordered with a caller that uses the default stream, e.g. torch) and returns when it is done.

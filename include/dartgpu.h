@@ -199,6 +199,11 @@ int dg_last_timings(dg_ctx *, const char **names, float *ms, int cap);
  * [34] / [35] how often this context has run a batch again since it was created: capacity grown / a scan that did not complete   */
 int dg_last_counters(dg_ctx *, uint64_t *out, int cap);
 
+/* diagnostic (tests/probes/kpair_wait.py): the per-tile trace of one of the last run's single-pass scans -- 4 u64 per tile: epoch << 32 | HW_ID,
+ * wall clock at the ticket, at the publication of the tile's own totals, XCC_ID << 56 | wall clock at the publication of its prefix.
+ * which: 0 = seed offsets, 1 = the fused pair kernel, 2 = the general path's emit kernel.  DG_ERR_CAPACITY: *n_tiles holds the need. */
+int dg_debug_scan_trace(dg_ctx *, int which, uint64_t *out, size_t cap_tiles, size_t *n_tiles, double *ticks_per_ms);
+
 /* ---- the index builder's sorter (replaces the suffix sorting inside BWT_Index/bwtindex.c:77-148) ----
  * Stable radix sort of n < 2^32 (key, value) pairs in DEVICE memory, ascending by the low key_bits bits of the key; keys/vals hold the
  * input and the result, *_tmp are scratch of the same size.  Runs on the device's NULL stream and returns when done.
