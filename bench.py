@@ -726,7 +726,7 @@ def main():
     stages = {k: {"ms_standalone": round(ms_of(k), 4), "ms_in_timed_region": round(kern[k], 4), "traffic": tj.get(k),
                   "GBps": round(tj[k] / (ms_of(k) * 1e-3) / 1e9, 1) if tj.get(k) else None,
                   "frac": round(tj[k] / (ms_of(k) * 1e-3) / 8e12, 5) if tj.get(k) else None,
-                  "frac_of_random_line_ceiling": round(tj[k] / (ms_of(k) * 1e-3) / 3.1e12, 4) if tj.get(k) else None} for k in stage_kernels}
+                  "frac_of_random_line_ceiling": round(tj[k] / (ms_of(k) * 1e-3) / 2.58e12, 4) if tj.get(k) else None} for k in stage_kernels}
     dom_bytes = alg.get(dom)
     if dom_bytes is None:      # pair / report kernels: their own input and output (seeds in, records out, read bases compared)
         dom_bytes = 8 * counters["seeds"] + 90 * n_reads
@@ -753,10 +753,15 @@ def main():
                                   + " / the launch's stand-alone HIP-event duration measured in this run",
                 "kernel_ms_standalone": round(ms_alone, 4), "kernel_ms_in_timed_region": round(kern[dom], 4),
                 "own_requested_bytes_per_launch": own_bytes,
-                # what the memory system allows for THIS access pattern: random 64-byte lines over 8 ... 119 GB run at 48 G lines/s = 3.1 TB/s from
-                # 4 waves per CU on, ~1 us per dependent line (profiles/r02/tlb_probe_big_footprints.txt)
-                "random_64B_line_ceiling_GBps": 3100.0,
-                "frac_of_random_line_ceiling": round(achieved / 3100.0, 4),
+                # what the memory system allows for THIS access pattern, measured with known bytes (profiles/probes/fetch_calib.hip,
+                # profiles/r04/e_fetch_size_calibration_random_accesses.txt): random 64-byte accesses over the 3.1 GB Occ array run at 40.3 G lines/s
+                # = 2.58 TB/s from 4 waves per CU on (16-byte accesses, which round 2's probe used: 49 G/s); a random 128-byte access is ONE fabric
+                # request but runs at half that rate (21-22 G/s): the bytes, not the requests, are what the memory side limits.  The same probe
+                # calibrates the counter: FETCH_SIZE is exact for random accesses of up to 64 bytes (one 64-byte request each, also for 16 bytes)
+                # and reports half the bytes of 128-byte and wider ones (MI355X_MICROARCH.md's note on wide streams) -- the seeding kernels' accesses
+                # are 8 to 64 bytes wide, so their FETCH_SIZE needs no correction
+                "random_64B_line_ceiling_GBps": 2580.0,
+                "frac_of_random_line_ceiling": round(achieved / 2580.0, 4),
                 "algorithmic_bytes_per_launch": int(dom_bytes),
                 "algorithmic_GBps_standalone": round(dom_bytes / (ms_alone * 1e-3) / 1e9, 1),
                 "algorithmic_GBps_in_timed_region": round(dom_bytes / (kern[dom] * 1e-3) / 1e9, 1),

@@ -117,6 +117,7 @@ struct dg_ctx {
     size_t seedqf_lds_set = 0;
     bool seed_qf_used = false;     // the last run's seeding kernel was k_seed_qf (its own-work counters are derived from its slot counts)
     int env_scan_mask = 7;
+    int env_chain_bpc = 8, env_seedh_bpc = 8, env_reseed_pct = 100;      // persistent one-wave workgroups per CU of k_chain_heavy / k_seed_heavy; k_reseed's grids in per cent (sweeps: DG_CHAIN_BPC, DG_SEEDH_BPC, DG_RESEED_PCT)
     int env_scan_budget = 0;      // DG_SCAN_POLL_BUDGET: poll budget of a look-back on the FIRST attempt of a batch (test hook: forces the DG_E_SCAN re-run path)
 };
 
@@ -129,6 +130,7 @@ static void read_env(dg_ctx *c)
     c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0); c->env_scan_mask = geti("DG_SCAN_POLL_SCANS", 7);
     c->env_seed_phases = geti("DG_SEED_PHASES", 0); c->env_seed_wg_waves = geti("DG_SEED_WG_WAVES", 4); c->env_seed_partial = geti("DG_SEED_PARTIAL_MIN", 32);
     c->env_copy_stream = geti("DG_COPY_STREAM", 1);
+    c->env_chain_bpc = std::max(1, geti("DG_CHAIN_BPC", 8)); c->env_seedh_bpc = std::max(1, geti("DG_SEEDH_BPC", 8)); c->env_reseed_pct = std::max(10, geti("DG_RESEED_PCT", 100));
     c->env_seed_multi = geti("DG_SEED_MULTI", 4); if (c->env_seed_multi < 0 || c->env_seed_multi > SQF_MULTI_MAX) c->env_seed_multi = SQF_MULTI_MAX;   // rows of an interval that are located and compared with the text at once (0: single rows only)
 }
 
@@ -984,16 +986,8 @@ k_unpack(const uint32_t *__restrict__ words, uint32_t n_words, int W2, double in
     const int ww = (int)(t - r * (uint32_t)W2);
     const int len = rlen_in ? rlen_in[r] : rlen_all, left = len - 16 * ww;
     const uint32_t w = words[t];
-    uint32_t out[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        // four codes (one byte of w, first base on top) -> one selector byte each (copies of the byte at shifts 0, 10, 20, 30 put the
-        // k-th pair at bit 8 k + 6), then "ACGT"[code] for all four with one byte permute
-        const uint32_t a = (w >> (24 - 8 * q)) & 0xFFu;
-        const uint32_t sel = ((a * 0x40100401u) >> 6) & 0x03030303u;
-        out[q] = __builtin_amdgcn_perm(0u, 0x54474341u, sel);
-    }
-    *(uint4 *)(seq + (size_t)r * 16 * W2 + 16 * ww) = make_uint4(out[0], out[1], out[2], out[3]);       // (bases past the end: never read)
+    // (no ASCII copy of the batch: the seeding stage and the fused pair kernel read the words; k_unpack_listed rebuilds the characters of the
+    //  units that take the general path -- a twentieth of a DNA batch)
     const uint32_t past = left >= 16 ? 0u : (left <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu >> (2 * left));          // mask 0b11 past the end, as k_encode
     enc[(size_t)r * 2 * W2 + ww] = w & ~past;
     enc[(size_t)r * 2 * W2 + W2 + ww] = past;
@@ -1006,10 +1000,36 @@ k_unpack_n(const uint32_t *__restrict__ nlist, uint32_t n_n, int W2, uint32_t n_
     if (i >= n_n) return;
     const uint32_t flat = nlist[i], per = 16u * (uint32_t)W2, r = flat / per, pos = flat - r * per;
     if (flat >= n_bases) { atomicMax(bad, 1u); return; }       // a list entry outside the batch (a buggy packer) must not write outside it: dg_batch_run reports DG_ERR_ARG
-    seq[flat] = 'N';
     const uint32_t bit = 3u << (30 - 2 * (pos & 15u));
     atomicAnd(&enc[(size_t)r * 2 * W2 + (pos >> 4)], ~bit);
     atomicOr(&enc[(size_t)r * 2 * W2 + W2 + (pos >> 4)], bit);
+}
+
+// the ASCII bytes of the reads of the units on the general path's list (k_pair's slow_units), from the batch's 2-bit + mask words: A/C/G/T by code,
+// 'N' where the mask says so.  One thread = 16 bases of one read; grid-stride over (listed unit, mate, word).
+__global__ void __launch_bounds__(256)
+k_unpack_listed(const uint32_t *__restrict__ slow_units, const uint32_t *__restrict__ n_slow_p, int paired, int W2, const uint32_t *__restrict__ enc,
+                unsigned char *__restrict__ seq, const int *__restrict__ err)
+{
+    if (*err >= DG_ABORT) return;
+    const uint32_t per_unit = (uint32_t)(paired ? 2 : 1) * (uint32_t)W2;
+    const uint64_t total = (uint64_t)*n_slow_p * per_unit;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)(t / per_unit), rem = (uint32_t)(t - (uint64_t)k * per_unit), mate = rem / (uint32_t)W2, ww = rem - mate * (uint32_t)W2;
+        const uint32_t r = (paired ? 2u * slow_units[k] : slow_units[k]) + mate;
+        const uint32_t w = enc[(size_t)r * 2 * W2 + ww], m = enc[(size_t)r * 2 * W2 + W2 + ww];
+        uint32_t out[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            // four codes (one byte of w, first base on top) -> one selector byte each (copies of the byte at shifts 0, 10, 20, 30 put the
+            // k-th pair at bit 8 k + 6), then "ACGT"[code] for all four with one byte permute; the mask's pairs the same way -> 'N'
+            const uint32_t a = (w >> (24 - 8 * q)) & 0xFFu, b = (m >> (24 - 8 * q)) & 0xFFu;
+            const uint32_t sel = ((a * 0x40100401u) >> 6) & 0x03030303u, nb = ((b * 0x40100401u) >> 6) & 0x03030303u;
+            const uint32_t isn = ((nb | (nb >> 1)) & 0x01010101u) * 0xFFu;
+            out[q] = (__builtin_amdgcn_perm(0u, 0x54474341u, sel) & ~isn) | (0x4E4E4E4Eu & isn);
+        }
+        *(uint4 *)(seq + (size_t)r * 16 * W2 + 16 * ww) = make_uint4(out[0], out[1], out[2], out[3]);       // (bases past the end: 'N', never read)
+    }
 }
 
 static int enqueue_upload_packed(dg_ctx *c, int n_reads, int rlen_all, const uint16_t *rlen, int words_per_read, const uint32_t *words, const uint32_t *nlist, size_t n_n)
@@ -1137,7 +1157,7 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     } else
     if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr);
     else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr);
-    k_seed_heavy<<<(unsigned)c->n_cu * 8u, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr);
+    k_seed_heavy<<<(unsigned)c->n_cu * (unsigned)c->env_seedh_bpc, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr);
     return hipGetLastError();
 }
 
@@ -1263,7 +1283,7 @@ static int enqueue_run(dg_ctx *c)
     unsigned int *tops = c->d_tops;
 
     // units with more seeds than a lane of k_pair holds: a wave each, before k_pair (which needs their candidate counts)
-    k_chain_heavy<<<c->n_cu * 8, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p,
+    k_chain_heavy<<<c->n_cu * c->env_chain_bpc, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p,
                                                      c->heavy.p, tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
 #ifdef DG_PROFILE_CLASSES
@@ -1286,10 +1306,20 @@ static int enqueue_run(dg_ctx *c)
         HIPCHK(c->reads_c.ensure((size_t)n + 1)); HIPCHK(c->reports_c.ensure(c->cap_rep + 1)); HIPCHK(c->cig_c.ensure(c->cap_cig + 16));
         co = CompactOut{c->reads_c.p, c->reports_c.p, c->cig_c.p, &c->d_sizes->pad[1]};
     }
-    k_pair<<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
-        c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
-        c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err, co);
+    const int W2p = (c->max_rlen + 15) / 16 > 0 ? (c->max_rlen + 15) / 16 : 1;
+    if (c->enc_ready)       // a packed batch: the characters follow from its words; only the general path's units get an ASCII copy (below)
+        k_pair<true><<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
+            c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->enc.p, W2p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
+            c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err, co);
+    else
+        k_pair<false><<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
+            c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->enc.p, W2p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
+            c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err, co);
     HIPCHK(hipGetLastError());
+    if (c->enc_ready) {
+        k_unpack_listed<<<(unsigned)c->n_cu * 8u, 256, 0, c->stream>>>(c->slow_units.p, &c->d_sizes->n_slow_units, paired, W2p, c->enc.p, c->seq.p, c->d_err);
+        HIPCHK(hipGetLastError());
+    }
     TICK("k_pair");
 
     // ---- the general path, on the units k_pair listed ----
@@ -1316,9 +1346,9 @@ static int enqueue_run(dg_ctx *c)
     k_order_jobs<<<1, 1024, 0, c->stream2>>>(c->jobs.p, tops + TOP_JOBS, jobcap, c->job_lists.p, tops + TOP_RESEED_COUNT, c->d_err);
     // (one stream for the three ring sizes: side by side on streams of their own they finish sooner alone -- the wide ones have few jobs, but a
     //  single 500 kb window keeps one wave busy for ~1 ms -- and cost the step 8 % with eight batches in flight: streams share 4 hardware queues)
-    k_reseed<1><<<c->n_cu * 10, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p, tops + TOP_RESEED_COUNT, tops + TOP_RESEED_TICKET, c->d_ctr, c->d_err);
-    k_reseed<2><<<c->n_cu * 6, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + jobcap, tops + TOP_RESEED_COUNT + 1, tops + TOP_RESEED_TICKET + 1, c->d_ctr, c->d_err);
-    k_reseed<4><<<c->n_cu * 4, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + 2 * (size_t)jobcap, tops + TOP_RESEED_COUNT + 2, tops + TOP_RESEED_TICKET + 2, c->d_ctr, c->d_err);
+    k_reseed<1><<<c->n_cu * 10 * c->env_reseed_pct / 100, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p, tops + TOP_RESEED_COUNT, tops + TOP_RESEED_TICKET, c->d_ctr, c->d_err);
+    k_reseed<2><<<c->n_cu * 6 * c->env_reseed_pct / 100, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + jobcap, tops + TOP_RESEED_COUNT + 1, tops + TOP_RESEED_TICKET + 1, c->d_ctr, c->d_err);
+    k_reseed<4><<<c->n_cu * 4 * c->env_reseed_pct / 100, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + 2 * (size_t)jobcap, tops + TOP_RESEED_COUNT + 2, tops + TOP_RESEED_TICKET + 2, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_reseed1, c->stream2));
     k_order_reads<<<slow_grid, 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->done.p, tops + TOP_CLASS_HIST, tops + TOP_CLASS_FILL, c->perm.p, tops + TOP_ORDER_INFO, c->d_err);
@@ -1780,8 +1810,8 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
         HIPCHK(c->heavy.ensure((size_t)n + 16)); HIPCHK(c->slow_units.ensure((size_t)n + 16)); HIPCHK(c->reports.ensure(16)); HIPCHK(c->cigfinal.ensure(16));
         k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
         const TileScan ts = make_tile_scan(c, scan_tiles_seed(n), c->d_tops + TOP_TICKET_PAIR, 2);
-        k_pair<<<(unsigned)((n + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
-            c->ix, c->pr, n, 0, 0, 1, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
+        k_pair<false><<<(unsigned)((n + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
+            c->ix, c->pr, n, 0, 0, 1, c->seq.p, c->seq_off.p, c->enc.p, 1, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
             c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, 0xFFFFFFFFu, 0xFFFFFFFFu, ts, c->d_sizes, c->d_tops + TOP_CIG, c->d_ctr, c->d_err, CompactOut{nullptr, nullptr, nullptr, nullptr});
         HIPCHK(hipGetLastError());
         k_batch_end<<<1, 256, 0, c->stream>>>(c->d_sizes, c->d_err, c->d_tops, c->d_ctr, c->h_tail);

@@ -196,9 +196,9 @@ __host__ __device__ __forceinline__ void d_unit_sort(SKey *key, int n)
 // nw_alignment (nw_alignment.cpp:18-82, integers x2 as d_nw in dg_report.h) of two strings of the same length g <= 8, asked one
 // question: is the traceback the plain diagonal (g columns of M, no gap)?  The DP runs row by row with the previous row in
 // registers (one strip of 8 columns, as d_nw's strips); only the cells (i,i) decide: the walk from (g,g) stays on the diagonal
-// exactly when none of them equals its r or t value.  a = read bases, b8 = genome bases (byte k = base k).
+// exactly when none of them equals its r or t value.  a8 = read bases, b8 = genome bases (byte k = base k).
 #define SMALL_NW 8
-__host__ __device__ inline bool d_small_nw_is_diagonal(const unsigned char *a, uint64_t b8, int g)
+__host__ __device__ inline bool d_small_nw_is_diagonal(uint64_t a8, uint64_t b8, int g)
 {
     int sp[SMALL_NW], tp[SMALL_NW];
     uint8_t cb[SMALL_NW];
@@ -208,7 +208,7 @@ __host__ __device__ inline bool d_small_nw_is_diagonal(const unsigned char *a, u
     bool leaves = false;
     for (int i = 1; i <= g; i++) {
         int left_s = -2 - i, left_r = -131072;
-        const uint8_t ca = d_nt4(a[i - 1]);
+        const uint8_t ca = d_nt4((unsigned char)(a8 >> (8 * (i - 1))));
         int diag = diag0;
         diag0 = left_s;
 #pragma unroll
@@ -229,14 +229,27 @@ __host__ __device__ inline bool d_small_nw_is_diagonal(const unsigned char *a, u
     return !leaves;
 }
 
+// A read as the fused kernel looks at it: the ASCII bytes of dg_map_batch (case, '-' and IUPAC letters matter to the reference: tools.cpp:40-104), or the
+// 2-bit + mask words of a packed batch (dg_map_batch_packed: A/C/G/T/N by contract, so the characters follow from the words and the ASCII copy of the
+// batch -- 202 MB per million pairs, written by k_unpack and read back here -- is only made for the units of the general path: k_unpack_listed).
+struct ReadAscii { const unsigned char *p; __host__ __device__ __forceinline__ unsigned char at(int i) const { return p[i]; } };
+struct ReadWords {
+    const uint32_t *w; int W2;           // k_encode's format: W2 words of 2-bit codes (first base on top), then W2 words with 0b11 where the base is no A/C/G/T
+    __host__ __device__ __forceinline__ unsigned char at(int i) const {
+        const int sh = 30 - ((i & 15) << 1);
+        const uint32_t m = (w[W2 + (i >> 4)] >> sh) & 3u, c = (w[i >> 4] >> sh) & 3u;
+        return m ? (unsigned char)'N' : (unsigned char)(0x54474341u >> (8u * c));
+    }
+};
+
 // GenMappingReport for the live candidates of one mate, where it reduces to "[S] M [S]": every seed of the candidate exact and on
 // one diagonal, at least one read base between neighbours, and the bases between them either equal-length with <= 2 and <= 20 %
 // mismatches (ProcessNormalSequencePair's M shortcut, tools.cpp:137-141) or a single substituted base (a 1 x 1 nw_alignment).
 // Then the clean-up passes, re-seeding, gap filling, splice detection and overlap trimming are all the identity
 // (they act on repeated rPos, order inversions and diagonal changes).  Returns false when some live candidate is outside
 // the pattern (nothing of this unit is then kept: the general path redoes it).
-template <int S>
-__host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &pr, bool first, const unsigned char *seq, int len,
+template <int S, class RD>
+__host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &pr, bool first, const RD seq, int len,
                                                const SKey *key, uint32_t *cw, int nc, uint64_t *rw, int &n_slot, DRead &rd, uint32_t &n_cig, uint32_t &n_nw, uint32_t &n_cells)
 {
     const int64_t L = ix.l_pac;
@@ -262,11 +275,11 @@ __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &
             for (int q = 0; q < g; q += 8) {
                 const uint64_t ref = d_ref8(ix, gp + q);
                 const int e = g - q < 8 ? g - q : 8;
-                for (int t = 0; t < e; t++) { const unsigned char ch = seq[from + q + t]; dash = dash || ch == '-'; nm += ch != (unsigned char)(ref >> (8 * t)); }
+                for (int t = 0; t < e; t++) { const unsigned char ch = seq.at(from + q + t); dash = dash || ch == '-'; nm += ch != (unsigned char)(ref >> (8 * t)); }
             }
             if (nm <= 2 && nm <= (int)(g * 0.2)) { aln += g - nm; mis += nm; }
             else if (g == 1 && !dash) { calls++; cells++; mis += 1; }
-            else if (g <= SMALL_NW && !dash && d_small_nw_is_diagonal(seq + from, d_ref8(ix, gp), g)) {
+            else if (g <= SMALL_NW && !dash && d_small_nw_is_diagonal([&]() { uint64_t a8 = 0; for (int t = 0; t < g; t++) a8 |= (uint64_t)seq.at(from + t) << (8 * t); return a8; }(), d_ref8(ix, gp), g)) {
                 // two substitutions a few bases apart: ProcessNormalSequencePair calls nw_alignment (tools.cpp:142-163), the
                 // alignment is g columns of M, AddNewCigarElements scores the identical characters
                 calls++; cells += (uint32_t)(g * g); aln += g - nm; mis += nm;
@@ -304,9 +317,9 @@ __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &
 
 // One unit from sorted-or-not seeds in key[0 .. n1+n2) to either finished records in LDS (st.fast) or candidate words for the
 // general path.  try_fast = false: the candidate stage only (dg_probe_seeds, chr tables too wide for the slots).
-template <int S>
-__host__ __device__ inline void d_unit_process(const DIndex &ix, const DParams &pr, bool paired, int n1, int n2, int len1, int len2,
-                                               const unsigned char *seq1, const unsigned char *seq2, SKey *key, uint32_t *cw, uint64_t *rw,
+template <int S, class RD>
+__host__ __device__ inline void d_unit_process_rd(const DIndex &ix, const DParams &pr, bool paired, int n1, int n2, int len1, int len2,
+                                               const RD seq1, const RD seq2, SKey *key, uint32_t *cw, uint64_t *rw,
                                                bool try_fast, UnitState &st)
 {
     d_unit_sort<S>(key, n1);
@@ -336,6 +349,13 @@ __host__ __device__ inline void d_unit_process(const DIndex &ix, const DParams &
     d_mapq(st.rd[0], p1);
     st.flag0[0] = p1.flag0; st.flag0[1] = p2.flag0;
     st.fast = true; st.n_cig = n_cig; st.n_nw = n_nw; st.n_cells = n_cells;
+}
+template <int S>
+__host__ __device__ inline void d_unit_process(const DIndex &ix, const DParams &pr, bool paired, int n1, int n2, int len1, int len2,
+                                               const unsigned char *seq1, const unsigned char *seq2, SKey *key, uint32_t *cw, uint64_t *rw,
+                                               bool try_fast, UnitState &st)
+{
+    d_unit_process_rd<S, ReadAscii>(ix, pr, paired, n1, n2, len1, len2, ReadAscii{seq1}, ReadAscii{seq2}, key, cw, rw, try_fast, st);
 }
 
 // ---- the compact record types (include/dartgpu.h: dg_read_c 12 bytes, dg_report_c 16 bytes), written by the kernels that write the full
@@ -431,9 +451,10 @@ __host__ __device__ inline uint32_t d_unit_emit_read(bool first, const DRead &rd
 // ---------------------------------------------------------------------------------------------
 #include "dg_scan.h"
 
+template <bool PACKED>      // the reads of the batch: their 2-bit + mask words (a packed batch: enc, W2) or their ASCII bytes (seq, seq_off)
 __global__ void __launch_bounds__(PU_THREADS)
 k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast, int write_all_sorted,
-       const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen,
+       const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off, const uint32_t *__restrict__ enc, int W2, const uint16_t *__restrict__ rlen,
        const uint32_t *__restrict__ seed_off, SKey *__restrict__ seeds, DCand *__restrict__ cands, uint32_t *__restrict__ ncand,
        uint32_t *__restrict__ rep_off, uint32_t *__restrict__ slow_units,
        dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *__restrict__ cigar,
@@ -478,7 +499,10 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
                 if (i0 + 3 < nt) key[(i0 + 3) * PU_THREADS] = k3;
             }
             len1 = rlen[r1]; len2 = paired ? rlen[r1 + 1] : 0;
-            d_unit_process<PU_THREADS>(ix, pr, paired != 0, n1, n2, len1, len2, seq + seq_off[r1], seq + seq_off[r1 + (paired ? 1 : 0)], key, cw, rw, try_fast != 0, st);
+            if (PACKED) {
+                const ReadWords a{enc + (size_t)r1 * 2 * W2, W2}, b{enc + (size_t)(r1 + (paired ? 1 : 0)) * 2 * W2, W2};
+                d_unit_process_rd<PU_THREADS, ReadWords>(ix, pr, paired != 0, n1, n2, len1, len2, a, b, key, cw, rw, try_fast != 0, st);
+            } else d_unit_process<PU_THREADS>(ix, pr, paired != 0, n1, n2, len1, len2, seq + seq_off[r1], seq + seq_off[r1 + (paired ? 1 : 0)], key, cw, rw, try_fast != 0, st);
         } else { st.nc[0] = (int)ncand[r1]; st.nc[1] = paired ? (int)ncand[r1 + 1] : 0; }
     }
     const uint32_t nrep1 = valid ? (uint32_t)(st.nc[0] > 0 ? st.nc[0] : 1) : 0u, nrep2 = (valid && paired) ? (uint32_t)(st.nc[1] > 0 ? st.nc[1] : 1) : 0u;

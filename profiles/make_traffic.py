@@ -21,9 +21,11 @@ for k, c in acc.items():
     out[name] += b * 1024.0
 doc = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes), profiles/run_profile.sh %s, "
                       "default bench workload, one batch in flight (2 M reads per launch), mean per launch; bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; k_seed = k_seed_qf (or k_seed_q / k_seed) + "
-                      "k_seed_heavy, k_report = mean of its two passes. For these 64-byte random reads "
-                      "FETCH_SIZE*1024/64 equals TCC_MISS_sum, i.e. one 64-B fabric request per line; the 2x correction of MI355X_MICROARCH.md "
-                      "applies to wide coalesced streams and is NOT applied here (uncalibrated for this access width)." % tag}
+                      "k_seed_heavy, k_report = mean of its two passes. Calibrated with known bytes (profiles/probes/fetch_calib.hip, "
+                      "profiles/r04/e_fetch_size_calibration_random_accesses.txt): FETCH_SIZE is exact for random accesses of up to 64 bytes (one 64-byte fabric "
+                      "request each) and reports half the bytes of 128-byte and wider accesses; the seeding, locate, pair and report kernels read 8 to 64 bytes per access, so the 2x "
+                      "correction of MI355X_MICROARCH.md (wide coalesced streams) is NOT applied to them; the two streaming kernels (k_unpack, k_encode: 16 B per lane, coalesced) "
+                      "are under-reported by their read half -- they are not the dominant kernel." % tag}
 # the bench line of the profiled command says which kernel sources and which workload these passes belong to; bench.py reports
 # `roofline.traffic` only when its own fingerprint equals this one
 try:

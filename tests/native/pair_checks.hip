@@ -39,7 +39,7 @@ int main(int argc, char **argv)
     DIndex ix; memset(&ix, 0, sizeof ix);
     ix.pac = pac.data(); ix.l_pac = l_pac; ix.n_chr = n_chr; ix.loc_key = key.data(); ix.loc_chr = chr.data(); ix.chr_off = chr_off.data();
     const int nm = paired ? 2 : 1, n_units = n_reads / nm;
-    long n_fast = 0, n_slow = 0, n_big = 0, bad = 0, n_multi = 0;
+    long n_fast = 0, n_slow = 0, n_big = 0, bad = 0, n_multi = 0, n_packed = 0;
     uint64_t rng = 88172645463325252ull;
     for (int u = 0; u < n_units; u++) {
         const int r1 = u * nm;
@@ -52,7 +52,37 @@ int main(int argc, char **argv)
             for (int i = n - 1; i > 0; i--) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; const int j = (int)(rng % (uint64_t)(i + 1)); const SKey t = seg[i]; seg[i] = seg[j]; seg[j] = t; }
         }
         UnitState st;
+        SKey lk2[PU_SEEDS]; uint32_t lcw2[PU_SEEDS]; uint64_t lrw2[2 * PU_SLOTS];
+        for (int i = 0; i < n1 + n2; i++) lk2[i] = lk[i];
         d_unit_process<1>(ix, pr, paired != 0, n1, n2, rlen[r1], paired ? rlen[r1 + 1] : 0, seq.data() + seq_off[r1], seq.data() + seq_off[r1 + (paired ? 1 : 0)], lk, lcw, lrw, true, st);
+        {   // the same unit with its reads as 2-bit + mask words (a packed batch, dg_map_batch_packed: reads of A/C/G/T/N only): the same state, word for word
+            bool plain = true;
+            std::vector<uint32_t> words[2];
+            int W2m[2] = {1, 1};
+            for (int m = 0; m < nm; m++) {
+                const int len = rlen[r1 + m], W2 = (len + 15) / 16 > 0 ? (len + 15) / 16 : 1;
+                W2m[m] = W2; words[m].assign(2 * (size_t)W2, 0u);
+                for (int i = 0; i < 16 * W2; i++) {
+                    const unsigned char ch = i < len ? seq[seq_off[r1 + m] + i] : (unsigned char)'N';
+                    const char *f = ch ? strchr("ACGT", ch) : nullptr;
+                    if (!f && ch != 'N') plain = false;
+                    if (f) words[m][i >> 4] |= (uint32_t)(f - "ACGT") << (30 - 2 * (i & 15));
+                    else words[m][W2 + (i >> 4)] |= 3u << (30 - 2 * (i & 15));
+                }
+            }
+            if (plain) {
+                UnitState s2;
+                const ReadWords a{words[0].data(), W2m[0]}, b{words[paired ? 1 : 0].data(), W2m[paired ? 1 : 0]};
+                d_unit_process_rd<1, ReadWords>(ix, pr, paired != 0, n1, n2, rlen[r1], paired ? rlen[r1 + 1] : 0, a, b, lk2, lcw2, lrw2, true, s2);
+                bool same = s2.fast == st.fast && s2.nc[0] == st.nc[0] && s2.nc[1] == st.nc[1];
+                if (same && st.fast) {
+                    same = s2.n_cig == st.n_cig && s2.n_nw == st.n_nw && s2.n_cells == st.n_cells && memcmp(&s2.rd[0], &st.rd[0], sizeof st.rd[0]) == 0 && (!paired || memcmp(&s2.rd[1], &st.rd[1], sizeof st.rd[1]) == 0);
+                    for (int i = 0; same && i < st.nc[0] + st.nc[1]; i++) same = lcw2[i] == lcw[i];
+                }
+                if (!same) { if (bad < 5) printf("unit %d: the packed-read form of the unit code differs from the ASCII form\n", u); bad++; }
+                n_packed++;
+            }
+        }
         if (!st.fast) { n_slow++; continue; }
         n_fast++;
         dg_read_out o[2]; std::vector<dg_report_out> rep(64); std::vector<uint32_t> cig(256);
@@ -74,6 +104,6 @@ int main(int argc, char **argv)
             if (!ok) { if (bad < 5) printf("unit %d mate %d differs: score %d/%d sub %d/%d mis %d/%d mapq %d/%d n_rep %d/%d best %d/%d\n", u, m, e.score, g.score, e.sub_score, g.sub_score, e.mis_num, g.mis_num, e.mapq, g.mapq, e.n_rep, g.n_rep, e.best, g.best); bad++; }
         }
     }
-    printf("units %d: finished here %ld, to the general path %ld, more than %d seeds %ld; reads with several reports %ld; bad=%ld\n", n_units, n_fast, n_slow, PU_SEEDS, n_big, n_multi, bad);
+    printf("units %d: finished here %ld, to the general path %ld, more than %d seeds %ld; reads with several reports %ld; units also run from 2-bit words %ld; bad=%ld\n", n_units, n_fast, n_slow, PU_SEEDS, n_big, n_multi, n_packed, bad);
     return bad ? 1 : 0;
 }

@@ -117,7 +117,7 @@ def test_pair_kernel_unit_code_on_host_against_oracle(workdir):
         p, _ = common.parse_flags(flags)
         runs.append((prefix, p, 1, arr))
     runs.append((prefix, common.parse_flags(["-mis", "4"])[0], 0, m1))
-    fast = total = multi = 0
+    fast = total = multi = packed = 0
     for k, (pf, p, paired, reads_arr) in enumerate(runs):
         path = os.path.join(workdir, "pairchk_%d.bin" % k)
         orc = oracle_py.Oracle(pf)
@@ -127,4 +127,6 @@ def test_pair_kernel_unit_code_on_host_against_oracle(workdir):
         assert out.returncode == 0 and out.stdout.strip().endswith("bad=0"), (k, p, out.stdout + out.stderr)
         f = out.stdout.split()
         total += int(f[1].rstrip(":")); fast += int(f[4].rstrip(",")); multi += int(f[f.index("reports") + 1].rstrip(";"))
-    assert total > 20000 and fast > 0.5 * total and multi > 200, (total, fast, multi)
+        packed += int(f[f.index("words") + 1].rstrip(";"))
+    # (packed: units whose reads hold A/C/G/T/N only were run a second time from 2-bit + mask words -- what k_pair does for a packed batch -- and gave the same state)
+    assert total > 20000 and fast > 0.5 * total and multi > 200 and packed > 0.5 * total, (total, fast, multi, packed)
