@@ -615,6 +615,25 @@ def main():
         if os.environ.get("DART_BENCH_STRICT") == "1":
             sys.exit(3)
 
+    # ---- which resource do the batches in flight fill?  The kernels' waves report the time they were resident (summed over the waves, last batch of
+    #      context 0 inside the timed region); against the batch period that gives the share of the GPU's wave slots, of its vector register file
+    #      (registers as the hardware allocates them: next_free_vgpr rounded up to 8) and of its LDS that each kernel holds on average ----
+    period_ms = elapsed / (args.steps * nb) * 1e3
+    tick_ms = 1e-5
+    res = {"k_seed_qf": (136, 51200 / 4), "k_seed_heavy": (232, 0), "k_chain_heavy": (56, 39440), "k_pair": (128, 73896 / 4), "k_report": (256, 16128), "k_reseed": (48, 14720)}
+    n_cu_ = torch.cuda.get_device_properties(local).multi_processor_count
+    occupancy = {"batch_period_ms": round(period_ms, 3), "kernels": {}}
+    tot = [0.0, 0.0, 0.0]
+    for k_, (vg, lds_per_wave) in res.items():
+        ticks = counters.get("wave_ticks_" + k_, counters.get("k_reseed_wave_ticks_100mhz", 0) if k_ == "k_reseed" else 0)
+        wave_ms = ticks * tick_ms
+        sh = [wave_ms / (n_cu_ * 32 * period_ms), wave_ms * vg / (n_cu_ * 4 * 512 * period_ms), wave_ms * lds_per_wave / (n_cu_ * 163840 * period_ms)]
+        occupancy["kernels"][k_] = {"wave_ms_per_batch": round(wave_ms, 1), "share_of_wave_slots": round(sh[0], 4), "share_of_vector_registers": round(sh[1], 4), "share_of_lds": round(sh[2], 4)}
+        tot = [a + b for a, b in zip(tot, sh)]
+    occupancy["sum_over_these_kernels"] = {"share_of_wave_slots": round(tot[0], 4), "share_of_vector_registers": round(tot[1], 4), "share_of_lds": round(tot[2], 4)}
+    occupancy["note"] = ("wave-resident time per batch / (CUs x 32 wave slots | 4 SIMDs x 512 registers | 160 KB LDS) x the batch period; the batch is the last one context 0 mapped "
+                         "inside the timed region (%d batches in flight)" % len(workers))
+
     # ---- secondary rates, outside the timed region (fewer items) ----
     secondary = {}
     if gather_mode == "full" and not args.no_secondary:
@@ -885,6 +904,7 @@ def main():
         "kernels_ms_one_batch_in_flight": {k: round(v, 4) for k, v in iso.items()},
         "counters_per_launch": counters,
         "library_start_up": {"dg_init_files_s": round(init_s, 3), "split": init_report},
+        "gpu_occupancy_in_flight": occupancy,
         "roofline": roofline,
         "cpu_baseline": cpu,
         "accuracy": accuracy,

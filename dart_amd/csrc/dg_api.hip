@@ -116,7 +116,7 @@ struct dg_ctx {
     int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32, env_seed_multi = 4;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
     size_t seedqf_lds_set = 0;
     bool seed_qf_used = false;     // the last run's seeding kernel was k_seed_qf (its own-work counters are derived from its slot counts)
-    int env_scan_mask = 7;
+    int env_scan_mask = 7, env_one_stream = 0;
     int env_chain_bpc = 8, env_seedh_bpc = 8, env_reseed_pct = 100;      // persistent one-wave workgroups per CU of k_chain_heavy / k_seed_heavy; k_reseed's grids in per cent (sweeps: DG_CHAIN_BPC, DG_SEEDH_BPC, DG_RESEED_PCT)
     int env_scan_budget = 0;      // DG_SCAN_POLL_BUDGET: poll budget of a look-back on the FIRST attempt of a batch (test hook: forces the DG_E_SCAN re-run path)
 };
@@ -129,7 +129,7 @@ static void read_env(dg_ctx *c)
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
     c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0); c->env_scan_mask = geti("DG_SCAN_POLL_SCANS", 7);
     c->env_seed_phases = geti("DG_SEED_PHASES", 0); c->env_seed_wg_waves = geti("DG_SEED_WG_WAVES", 4); c->env_seed_partial = geti("DG_SEED_PARTIAL_MIN", 32);
-    c->env_copy_stream = geti("DG_COPY_STREAM", 1);
+    c->env_copy_stream = geti("DG_COPY_STREAM", 1); c->env_one_stream = geti("DG_ONE_STREAM", 0);
     c->env_chain_bpc = std::max(1, geti("DG_CHAIN_BPC", 8)); c->env_seedh_bpc = std::max(1, geti("DG_SEEDH_BPC", 8)); c->env_reseed_pct = std::max(10, geti("DG_RESEED_PCT", 100));
     c->env_seed_multi = geti("DG_SEED_MULTI", 4); if (c->env_seed_multi < 0 || c->env_seed_multi > SQF_MULTI_MAX) c->env_seed_multi = SQF_MULTI_MAX;   // rows of an interval that are located and compared with the text at once (0: single rows only)
 }
@@ -315,6 +315,7 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
          const uint32_t *__restrict__ n_jobreads_p, const uint32_t *__restrict__ heavy_end_p, const uint32_t *__restrict__ single_first_p, int job_part, dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
          unsigned int *tops, unsigned char *ws, const WSLayout L, unsigned long long *ctr, int *err)
 {
+    const unsigned long long t_wave0 = wall_clock64();
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t lds_pm[64 * PM_LDS_WORDS];
     if (*err >= DG_ABORT) return;
@@ -383,6 +384,7 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
     d_wave_add(ctr + CTR_NWCELLS, cx.nw_cells);
     d_wave_add(ctr + CTR_RESEED, cx.n_reseed);
     d_wave_add(ctr + CTR_RESEEDW, cx.reseed_w);
+    d_wave_resident(ctr, CTR_WT_REPORT, t_wave0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1340,17 +1342,21 @@ static int enqueue_run(dg_ctx *c)
     TICK("k_prep");
     // k_reseed runs on a second stream, concurrently with the report of every read that has no re-seeding job; only the job reads wait for it
     HIPCHK(hipEventRecord(c->ev_prep, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_prep, 0));
-    HIPCHK(hipEventRecord(c->ev_reseed0, c->stream2));
+    // DG_ONE_STREAM=1: the re-seeding kernels on the context's main stream (in order before the report kernel, no overlap with it) -- a context then
+    // owns ONE hardware queue instead of two: with a dozen contexts the runtime multiplexes 25 streams onto 16 queues, and two contexts that share
+    // a queue wait for each other's kernels
+    const hipStream_t s2 = c->env_one_stream ? c->stream : c->stream2;
+    if (!c->env_one_stream) HIPCHK(hipStreamWaitEvent(s2, c->ev_prep, 0));
+    HIPCHK(hipEventRecord(c->ev_reseed0, s2));
     const uint32_t jobcap = (uint32_t)c->jobs.cap;
-    k_order_jobs<<<1, 1024, 0, c->stream2>>>(c->jobs.p, tops + TOP_JOBS, jobcap, c->job_lists.p, tops + TOP_RESEED_COUNT, c->d_err);
+    k_order_jobs<<<1, 1024, 0, s2>>>(c->jobs.p, tops + TOP_JOBS, jobcap, c->job_lists.p, tops + TOP_RESEED_COUNT, c->d_err);
     // (one stream for the three ring sizes: side by side on streams of their own they finish sooner alone -- the wide ones have few jobs, but a
     //  single 500 kb window keeps one wave busy for ~1 ms -- and cost the step 8 % with eight batches in flight: streams share 4 hardware queues)
-    k_reseed<1><<<c->n_cu * 10 * c->env_reseed_pct / 100, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p, tops + TOP_RESEED_COUNT, tops + TOP_RESEED_TICKET, c->d_ctr, c->d_err);
-    k_reseed<2><<<c->n_cu * 6 * c->env_reseed_pct / 100, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + jobcap, tops + TOP_RESEED_COUNT + 1, tops + TOP_RESEED_TICKET + 1, c->d_ctr, c->d_err);
-    k_reseed<4><<<c->n_cu * 4 * c->env_reseed_pct / 100, 64, 0, c->stream2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + 2 * (size_t)jobcap, tops + TOP_RESEED_COUNT + 2, tops + TOP_RESEED_TICKET + 2, c->d_ctr, c->d_err);
+    k_reseed<1><<<c->n_cu * 10 * c->env_reseed_pct / 100, 64, 0, s2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p, tops + TOP_RESEED_COUNT, tops + TOP_RESEED_TICKET, c->d_ctr, c->d_err);
+    k_reseed<2><<<c->n_cu * 6 * c->env_reseed_pct / 100, 64, 0, s2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + jobcap, tops + TOP_RESEED_COUNT + 1, tops + TOP_RESEED_TICKET + 1, c->d_ctr, c->d_err);
+    k_reseed<4><<<c->n_cu * 4 * c->env_reseed_pct / 100, 64, 0, s2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + 2 * (size_t)jobcap, tops + TOP_RESEED_COUNT + 2, tops + TOP_RESEED_TICKET + 2, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_reseed1, c->stream2));
+    HIPCHK(hipEventRecord(c->ev_reseed1, s2));
     k_order_reads<<<slow_grid, 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->done.p, tops + TOP_CLASS_HIST, tops + TOP_CLASS_FILL, c->perm.p, tops + TOP_ORDER_INFO, c->d_err);
     HIPCHK(hipGetLastError());
     const uint32_t *n_jobreads_p = tops + TOP_ORDER_INFO;             // reads of class 0 (they wait for k_reseed)
@@ -1429,7 +1435,7 @@ static int finish_run(dg_ctx *c, size_t used[3])
         else if ((derr == DG_E_SCAN || derr == DG_E_SEEDQ) && attempt < 5) {
             // a look-back that ran out of its time budget (dg_scan.h) or the seeding kernel's safety net: nothing to grow, the batch runs again (up to
             // five times: an event is rare -- three in 600 000 batches -- and independent of the batch) -- but never silently: what the poller saw and
-            // what the stuck tile's workgroup last said about itself go to stderr and into the context's error text, the count into dg_last_counters [35]
+            // what the stuck tile's workgroup last said about itself go to stderr and into the context's error text, the count into dg_last_counters [40]
             c->reruns_scan++;
             const unsigned long long *d = sz.scan_dbg;
             const double tick_ms = 1.0 / (double)c->wall_khz;
@@ -1730,7 +1736,7 @@ extern "C" int dg_last_counters(dg_ctx *c, uint64_t *out, int cap)
     if (!c) return 0;
     int k = CTR_N < cap ? CTR_N : cap;
     for (int i = 0; i < k; i++) out[i] = c->counters[i];
-    // [31] units that took the general path, [32] units chained by a wave each, [33] times the batch was enqueued, [34] / [35] re-runs of this context so far: capacity grown / scan not completed (> 1: a buffer grew)
+    // [36] units that took the general path, [37] units chained by a wave each, [38] times the batch was enqueued, [39] / [40] re-runs of this context so far: capacity grown / scan not completed (> 1: a buffer grew)
     const uint64_t extra[5] = { c->h_tail ? c->h_tail->sizes.n_slow_units : 0u, c->h_tail ? c->h_tail->tops[TOP_HEAVY_UNITS] : 0u, (uint64_t)c->runs_of_last_batch,
                                 c->reruns_capacity, c->reruns_scan };
     for (int i = 0; i < 5 && k < cap; i++) out[k++] = extra[i];

@@ -295,6 +295,7 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
               uint32_t *__restrict__ ncand, const uint32_t *__restrict__ heavy_list, const unsigned int *__restrict__ n_heavy_p,
               unsigned long long *ctr, const int *__restrict__ abort_p)
 {
+    const unsigned long long t_wave0 = wall_clock64();
     __shared__ SKey ls[2][CH_MAXS];
     __shared__ DCand lc[2][CH_MAXC];
     __shared__ int s_n[2], s_pairing;
@@ -400,4 +401,5 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
         }
     }
     if (lane == 0 && nc_total) atomicAdd(d_ctr_stripe(ctr) + CTR_CANDS, nc_total);
+    d_wave_resident(ctr, CTR_WT_CHAIN, t_wave0);
 }

@@ -109,7 +109,8 @@ struct DSizes { uint32_t total_seeds, total_rep, total_work, total_cig, total_sj
 enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, CTR_NWCELLS, CTR_RESEED, CTR_RESEEDW,
        CTR_STEPS_ACT, CTR_BLOCKS_ACT, CTR_KTAB, CTR_LF_ACT, CTR_DIRECT, CTR_MAXTRIPS, CTR_WTRIPS_MAX, CTR_WTRIPS_SUM,
        CTR_RESEED_TRIPS, CTR_RESEED_TICKS,
-       CTR_SQ_TRIPS, CTR_SQ_LANES = CTR_SQ_TRIPS + 5, CTR_SQ_PHASES = CTR_SQ_LANES + 5, CTR_N };   // k_seed_q: wave-trips and slots served per queue (begin, step, compare, locate, refill)   // *_ACT: steps/blocks this implementation really executed
+       CTR_SQ_TRIPS, CTR_SQ_LANES = CTR_SQ_TRIPS + 5, CTR_SQ_PHASES = CTR_SQ_LANES + 5,
+       CTR_WT_SEEDQF, CTR_WT_SEEDH, CTR_WT_CHAIN, CTR_WT_PAIR, CTR_WT_REPORT, CTR_N };             // CTR_WT_*: time the kernel's waves were resident, summed over its waves, in wall-clock ticks (10 ns): which resource do a dozen batches in flight fill?   // k_seed_q: wave-trips and slots served per queue (begin, step, compare, locate, refill)   // *_ACT: steps/blocks this implementation really executed
 
 __host__ __device__ __forceinline__ uint8_t d_nt4(unsigned char c)   // nst_nt4_table, BWT_Index/bntseq.c:40: ACGT/acgt -> 0..3, '-' -> 5, else 4
 {
@@ -180,12 +181,17 @@ __host__ __device__ __forceinline__ bool d_seed_less(const DSeed &a, const DSeed
     return a.gPos == b.gPos ? a.rPos < b.rPos : a.gPos < b.gPos;
 }
 
-// The work counters live in CTR_STRIPES copies, 256 bytes apart, chosen by workgroup: atomics on ONE address
+// The work counters live in CTR_STRIPES copies, 384 bytes apart, chosen by workgroup: atomics on ONE address
 // serialise at ~6 ns each on this chip (three counters updated by each of k_locate's 56 k waves cost 1 ms,
 // more than the kernel's work).  dg_batch_run sums (or, for the two maxima, maximises) the stripes.
 #define CTR_STRIPES 64
-#define CTR_STRIDE  32
+#define CTR_STRIDE  48
 __device__ __forceinline__ unsigned long long *d_ctr_stripe(unsigned long long *ctr) { return ctr + (blockIdx.x & (CTR_STRIPES - 1)) * CTR_STRIDE; }
+// the time this wave was resident, added to a striped counter by its first lane (the last statement of a kernel)
+__device__ __forceinline__ void d_wave_resident(unsigned long long *ctr, int which, unsigned long long t_begin)
+{
+    if ((threadIdx.x & 63) == 0) atomicAdd(d_ctr_stripe(ctr) + which, (unsigned long long)(wall_clock64() - t_begin));
+}
 // wave-level sum of a per-lane counter, one atomic per wave
 __device__ __forceinline__ void d_wave_add(unsigned long long *dst, unsigned long long v)
 {

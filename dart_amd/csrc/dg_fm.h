@@ -690,6 +690,7 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
              DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds,
              const DHeavy *__restrict__ heavy, const unsigned int *__restrict__ n_heavy_p, unsigned long long *ctr)
 {
+    const unsigned long long t_wave0 = wall_clock64();
     extern __shared__ uint32_t sh[];                 // the read's words (k_encode format), shared by the wave
     const int W2 = W >> 1;
     const int lane = threadIdx.x;
@@ -817,6 +818,7 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
     d_wave_add(ctr + CTR_LF, c.lf_ref);
     d_wave_add(ctr + CTR_LF_ACT, c.lf_act);
     d_wave_add(ctr + CTR_DIRECT, c.n_direct);
+    d_wave_resident(ctr, CTR_WT_SEEDH, t_wave0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -460,6 +460,11 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
        dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *__restrict__ cigar,
        uint32_t cap_rep, uint32_t cap_cig, TileScan ts, DSizes *sizes, unsigned int *pool_top, unsigned long long *ctr, int *err, const CompactOut co)
 {
+    const unsigned long long t_wave0 = wall_clock64();
+    // (static LDS on purpose.  The compiler derives the kernel's occupancy from it and pads the register allocation to match -- 122 used, 169 claimed;
+    //  k_chain_heavy 56 -> 257, k_reseed 44 -> 129 / 169 / 257 --; with dynamic LDS the padding goes away, which changed nothing measurable with twelve
+    //  batches in flight (profiles/r04/g_variants_dynamic_lds_and_hw_queues.txt), and this kernel then faulted -- a global access at an LDS-sized
+    //  address -- whenever the compact-record pointers were null (dg_map_batch); static LDS it stays)
     __shared__ SKey s_key[PU_SEEDS * PU_THREADS];
     __shared__ uint32_t s_cw[PU_SEEDS * PU_THREADS];
     __shared__ uint64_t s_rw[2 * PU_SLOTS * PU_THREADS];
@@ -564,4 +569,5 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
     d_wave_add(ctr + CTR_CANDS, n_cands);
     d_wave_add(ctr + CTR_NW, n_nw);
     d_wave_add(ctr + CTR_NWCELLS, n_cells);
+    d_wave_resident(ctr, CTR_WT_PAIR, t_wave0);
 }

@@ -514,6 +514,7 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
           DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
           DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int partial_min, int multi, int *err)
 {
+    const unsigned long long t_wave0 = wall_clock64();
     extern __shared__ uint4 sq_sh[];
     const int NSLOT = 1 << nslot_lg;
     const int QCAP = NSLOT, QLG = nslot_lg;
@@ -693,6 +694,7 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
     d_wave_add(ctr + CTR_STEPS, acc_steps);
     d_wave_add(ctr + CTR_BLOCKS, acc_blocks);
     d_wave_add(ctr + CTR_LF, acc_lf);
+    d_wave_resident(ctr, CTR_WT_SEEDQF, t_wave0);
     __syncthreads();                                              // every wave has left the loop: the workgroup's statistics are final
     if (tid < SQ_NQ) {
         atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_TRIPS + tid, (unsigned long long)ctl[16 + tid]); atomicAdd(d_ctr_stripe(ctr) + CTR_SQ_LANES + tid, (unsigned long long)ctl[24 + tid]);

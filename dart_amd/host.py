@@ -463,12 +463,13 @@ class DartGPU:
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
     def counters(self):
-        out = (C.c_uint64 * 48)()
-        n = self.lib.dg_last_counters(self.ctx, out, 48)
+        out = (C.c_uint64 * 64)()
+        n = self.lib.dg_last_counters(self.ctx, out, 64)
         keys = ["steps", "occ_blocks", "lf_steps", "sa_lookups", "seeds", "candidates", "nw_calls", "nw_cells", "reseed_calls", "reseed_window",
                 "steps_executed", "occ_blocks_executed", "ktab_lookups", "lf_steps_executed", "direct_extensions", "k_seed_max_trips_per_read", "k_seed_wave_trips_max", "k_seed_wave_trips_sum", "k_reseed_trips", "k_reseed_wave_ticks_100mhz",
                 "seedq_trips_begin", "seedq_trips_step", "seedq_trips_compare", "seedq_trips_locate", "seedq_trips_refill",
-                "seedq_slots_begin", "seedq_slots_step", "seedq_slots_compare", "seedq_slots_locate", "seedq_slots_refill", "seedq_phases", "general_path_units", "wave_chained_units", "batch_runs", "reruns_capacity_total", "reruns_scan_total"]
+                "seedq_slots_begin", "seedq_slots_step", "seedq_slots_compare", "seedq_slots_locate", "seedq_slots_refill", "seedq_phases",
+                "wave_ticks_k_seed_qf", "wave_ticks_k_seed_heavy", "wave_ticks_k_chain_heavy", "wave_ticks_k_pair", "wave_ticks_k_report", "general_path_units", "wave_chained_units", "batch_runs", "reruns_capacity_total", "reruns_scan_total"]
         return {keys[i]: int(out[i]) for i in range(min(n, len(keys)))}
 
     def probe_seeds(self, seq_off, rlen, flat):

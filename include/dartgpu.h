@@ -194,9 +194,10 @@ int dg_last_timings(dg_ctx *, const char **names, float *ms, int cap);
  * [18] 512-position trips of k_reseed's waves, [19] the time its waves were resident, summed, in 10 ns ticks,
  * [20..24] wave-trips of the seeding kernel per queue (begin, Occ step, text comparison, locate, refill), [25..29] the slots they served,
  * [30] its phases, summed over the workgroups (a phase can serve four wave-trips),
- * [31] units (pairs / single reads) that took the general report path, [32] units chained by a wave each (> 16 seeds),
- * [33] how many times the batch was enqueued (> 1: a capacity estimate was too small and the batch ran again),
- * [34] / [35] how often this context has run a batch again since it was created: capacity grown / a scan that did not complete   */
+ * [31..35] the time the waves of k_seed_qf, k_seed_heavy, k_chain_heavy, k_pair, k_report were resident, summed over the waves, in 10 ns ticks,
+ * [36] units (pairs / single reads) that took the general report path, [37] units chained by a wave each (> 16 seeds),
+ * [38] how many times the batch was enqueued (> 1: a capacity estimate was too small and the batch ran again),
+ * [39] / [40] how often this context has run a batch again since it was created: capacity grown / a scan that did not complete   */
 int dg_last_counters(dg_ctx *, uint64_t *out, int cap);
 
 /* diagnostic (tests/probes/kpair_wait.py): the per-tile trace of one of the last run's single-pass scans -- 4 u64 per tile: epoch << 32 | HW_ID,

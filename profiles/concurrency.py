@@ -48,3 +48,28 @@ for n, (c, t, r) in sorted(busy.items(), key=lambda kv: -kv[1][1]):
     g = lambda k: r.get(k, "?")
     print("%-48s %6d %10.2f %9.3f %5.1f%%  %s / %s / %s / %s / %s / %s" % (n, c, t / 1e6, t / c / 1e6, 100.0 * t / tot, g("VGPR_Count"), g("Accum_VGPR_Count"), g("SGPR_Count"), g("LDS_Block_Size"),
                                                                        g("Workgroup_Size_X") if "Workgroup_Size_X" in r else g("Workgroup_Size"), g("Grid_Size_X") if "Grid_Size_X" in r else g("Grid_Size")))
+
+# ---- per hardware queue: how busy is it, and where are the gaps?  (a context's stream runs on one hardware queue; several streams can share one:
+#      a kernel then waits for another context's kernel ahead of it in the same queue)
+byq = defaultdict(list)
+for s_, e_, n_, r_ in ev:
+    byq[r_.get("Queue_Id", "?")].append((s_, e_, n_))
+print("hardware queues seen: %d" % len(byq))
+gap_by = defaultdict(lambda: [0, 0])
+tot_gap = tot_busy = 0
+for q, lst in sorted(byq.items()):
+    lst.sort()
+    busy_q = sum(e_ - max(s_, t0) for s_, e_, _ in lst)
+    gaps = 0
+    overl = 0
+    for (s0, e0, n0), (s1, e1, n1) in zip(lst, lst[1:]):
+        g_ = s1 - e0
+        if g_ > 0:
+            gaps += g_; gap_by[(n0, n1)][0] += 1; gap_by[(n0, n1)][1] += g_
+        else:
+            overl += 1
+    tot_gap += gaps; tot_busy += busy_q
+    print("  queue %-6s dispatches %5d  busy %5.1f %%  idle between its dispatches %5.1f %%  (overlapping successors: %d)" % (q, len(lst), 100.0 * busy_q / wall, 100.0 * gaps / wall, overl))
+print("largest idle time between consecutive dispatches of one queue, by (previous kernel -> next kernel):")
+for (a, b), (c, g_) in sorted(gap_by.items(), key=lambda kv: -kv[1][1])[:16]:
+    print("  %-28s -> %-28s  %5d times, mean %7.3f ms, total %8.2f ms" % (a[:28], b[:28], c, g_ / c / 1e6, g_ / 1e6))

@@ -468,6 +468,47 @@ def test_gpu_index_aids_off_or_sampled(workdir, monkeypatch):
     gpu.close(); orc.close()
 
 
+def test_gpu_start_up_paths_give_the_same_records(workdir):
+    """dg_init (the index as host arrays) and dg_init_files (the index files straight to HBM, in-place Occ re-layout chunk by chunk), the look-up
+    aids built before the call returns or by the library thread while batches already map (DG_INIT_ASYNC_AIDS: a context adopts each aid at
+    its next batch, so the first batches run without them), full aids or the lean ones a short job gets (dg_index_files::expected_reads):
+    every combination gives the oracle's records -- the aids change no result -- and clones created before the aids exist pick them up too."""
+    g = synth.make_genome([1500000, 700000], seed=171, repeat_scale=30.0, n_introns=120)
+    prefix = os.path.join(workdir, "startup")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    m1, m2 = synth.make_reads(g, 15000, rlen=101, seed=172, sub_rate=0.02, indel_frac=0.05, spliced_frac=0.1, n_frac=0.01)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    want = orc.map_batch(orc.params(paired=1, max_mismatch=5), so, rl, flat, threads=16)
+    p = host.default_params(paired=1, max_mismatch=5)
+    for kw in (dict(from_files=False), dict(from_files=True), dict(from_files=True, expected_reads=30000),
+               dict(from_files=True, async_aids=True), dict(from_files=True, async_aids=True, expected_reads=30000)):
+        gpu = host.DartGPU(ix, p, **kw)
+        cl = gpu.clone()                                        # (created while the aids may still be missing)
+        for k in range(3):                                      # the first of these run beside the aid build
+            assert_same(gpu.map_batch(so, rl, flat), want)
+            assert_same(cl.map_batch(so, rl, flat), want)
+        gpu.wait_index()
+        assert_same(gpu.map_batch(so, rl, flat), want); assert_same(cl.map_batch(so, rl, flat), want)
+        rep = gpu.init_report()
+        assert ("lean aids" in rep) == ("expected_reads" in kw) and ("beside the first batches" in rep) == bool(kw.get("async_aids")), (kw, rep)
+        assert "k_build_ktab" in rep and ("host arrays" in rep) == (not kw["from_files"]), rep
+        gpu.close()
+    # index files that are missing or shorter than a header: an argument error with a message (the host program prints the reference's
+    # "Index files are corrupt"), not a crash
+    import ctypes as C
+    lib = host._load_lib()
+    f = ix.files()
+    for bad in (prefix + ".nothere", None):
+        if bad is None:
+            bad = prefix + "_short.sa"
+            open(bad, "wb").write(b"x" * 20)
+        f.sa_path = bad.encode()
+        st = C.c_int(0)
+        assert not lib.dg_init_files(C.byref(f), C.byref(p), 0, 0, C.byref(st)) and st.value == -3 and b"cannot read" in lib.dg_last_error(None)
+    orc.close()
+
+
 def test_gpu_packed_reads_and_pinned_buffers(workdir):
     """dg_map_batch_packed (2 bit/base + N list) gives the records of dg_map_batch on the same reads, with fixed and with
     per-read lengths; page-locked caller buffers (dg_host_alloc) through the raw ABI; a read with a lower-case base is refused
