@@ -67,7 +67,6 @@ struct dg_ctx {
     int device = 0;
     IndexShared *shared_ix = nullptr; uint32_t ix_gen = 0;
     bool owns_index = true;       // false for dg_clone()d contexts: the index arrays belong to the parent
-    size_t seedq_lds_set = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_dl = nullptr, ev_dl_block = nullptr;      // this context's place in the device's copy stream (copy_stream below); _block: the host thread sleeps (DG_BLOCKING_SYNC)
     bool dl_on_copy_stream = false;
@@ -114,7 +113,6 @@ struct dg_ctx {
     // environment switches, read once per context (not per batch)
     int env_seed_waves = 4, env_bail_trips = 0 /* 0: 64 trips in k_seed_qf (a trip there is up to three dependent accesses), 128 in the other two */, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
     int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32, env_seed_multi = 4;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
-    size_t seedqf_lds_set = 0;
     bool seed_qf_used = false;     // the last run's seeding kernel was k_seed_qf (its own-work counters are derived from its slot counts)
     int env_scan_mask = 7, env_one_stream = 0;
     int env_chain_bpc = 8, env_seedh_bpc = 8, env_reseed_pct = 100;      // persistent one-wave workgroups per CU of k_chain_heavy / k_seed_heavy; k_reseed's grids in per cent (sweeps: DG_CHAIN_BPC, DG_SEEDH_BPC, DG_RESEED_PCT)
@@ -276,11 +274,11 @@ static void caps_adopt(size_t &mine, const std::atomic<size_t> &a) { const size_
 // uploads on a stream of the same kind (the context's stream waiting for an event): 827 against 850.
 // The host has waited for the run before it downloads, so the copy stream needs no dependency on the context's stream; the context waits
 // for its own event behind its copies.  The streams live as long as the process.
-static std::mutex g_copy_mu[16];
-static hipStream_t g_copy_stream[16][2];
+static std::mutex g_copy_mu[64];
+static hipStream_t g_copy_stream[64][2];
 static hipError_t copy_stream(int device, int dir, hipStream_t *out)
 {
-    hipStream_t &sl = g_copy_stream[device & 15][dir];
+    hipStream_t &sl = g_copy_stream[device & 63][dir];
     if (!sl) {
         int lo = 0, hi = 0;
         hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -289,6 +287,17 @@ static hipError_t copy_stream(int device, int dir, hipStream_t *out)
     }
     *out = sl;
     return hipSuccess;
+}
+
+// The shared copy stream pays off for page-locked destinations (true asynchronous DMA).  A copy into ordinary memory is staged and blocks its caller --
+// under the device-wide mutex every other context's download would wait behind it (`dart`'s streaming path passes ordinary arrays): those go
+// through the context's own stream.
+static bool host_page_locked(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
 }
 
 static hipError_t wait_stream(dg_ctx *c)
@@ -1094,6 +1103,21 @@ static WSLayout make_ws_layout(int R)
     return L;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function on a device, not to a context: it only ever grows here (a
+// context with shorter reads used to lower what a sibling with longer reads had set, whose next launch then asked for more than allowed)
+#define DG_MAX_DEVICES 64
+static std::mutex g_lds_mu;
+static size_t g_lds_set[2][DG_MAX_DEVICES];
+static hipError_t raise_dynamic_lds(const void *fn, int which, int device, size_t lds)
+{
+    std::lock_guard<std::mutex> lk(g_lds_mu);
+    size_t &cur = g_lds_set[which][device & (DG_MAX_DEVICES - 1)];
+    if (lds <= cur) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) cur = lds;
+    return e;
+}
+
 // k_encode + k_seed (reads staged in LDS when 256 lanes x W words fit comfortably)
 static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode = nullptr)
 {
@@ -1121,10 +1145,7 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
         while (lg > 6 && sqf_lds_bytes(lg, W, nw) > (size_t)156 * 1024) lg--;
         if (c->env_seed_slots_lg == 0) while (lg > 6 && sqf_lds_bytes(lg, W, nw) > (size_t)80 * 1024) lg--;      // default: two workgroups per CU
         const size_t lds = sqf_lds_bytes(lg, W, nw);
-        if (lds > c->seedqf_lds_set) {
-            if ((e = hipFuncSetAttribute((const void *)k_seed_qf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-            c->seedqf_lds_set = lds;
-        }
+        if ((e = raise_dynamic_lds((const void *)k_seed_qf, 0, c->device, lds)) != hipSuccess) return e;
         unsigned per_cu = (unsigned)(((size_t)160 * 1024) / lds);
         if (per_cu * (unsigned)nw > 16u) per_cu = 16u / (unsigned)nw;
         // Two workgroups per CU although three fit: the launch lasts as long as its slowest reads' chains of trips whatever the number of waves
@@ -1144,10 +1165,7 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
         int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 10 ? c->env_seed_slots_lg : 9;
         while (lg > 6 && sq_lds_bytes(lg, W) > (size_t)80 * 1024) lg--;
         const size_t lds = sq_lds_bytes(lg, W);
-        if (lds > c->seedq_lds_set) {
-            if ((e = hipFuncSetAttribute((const void *)k_seed_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-            c->seedq_lds_set = lds;
-        }
+        if ((e = raise_dynamic_lds((const void *)k_seed_q, 1, c->device, lds)) != hipSuccess) return e;
         unsigned per_cu = (unsigned)(((size_t)160 * 1024) / lds);
         if (per_cu > 4u) per_cu = 4u;
         if (c->env_seed_wgs > 0) per_cu = (unsigned)c->env_seed_wgs;
@@ -1499,8 +1517,8 @@ static int enqueue_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint3
         return DG_ERR_CAPACITY;
     }
     c->dl_on_copy_stream = false;
-    if (c->env_copy_stream >= 1 && c->ev_dl) {                           // (as in dg_batch_download_compact)
-        std::lock_guard<std::mutex> lk(g_copy_mu[c->device & 15]);
+    if (c->env_copy_stream >= 1 && c->ev_dl && host_page_locked(ro)) {   // (as in dg_batch_download_compact)
+        std::lock_guard<std::mutex> lk(g_copy_mu[c->device & 63]);
         hipStream_t cs = nullptr;
         HIPCHK(copy_stream(c->device, 0, &cs));
         if (c->n_reads && ro) HIPCHK(hipMemcpyAsync(ro, c->reads_out.p, (size_t)c->n_reads * sizeof(dg_read_out), hipMemcpyDeviceToHost, cs));
@@ -1543,9 +1561,9 @@ extern "C" int dg_batch_download_compact(dg_ctx *c, dg_read_c *ro, dg_report_c *
     const size_t n_ops = (size_t)c->h_tail->sizes.pad[0];
     if (n_ops_out) *n_ops_out = n_ops;
     if (caps[1] < n_ops) { snprintf(c->err, 512, "output capacity too small: cigar ops %zu of %zu", n_ops, caps[1]); return DG_ERR_CAPACITY; }
-    if (c->env_copy_stream >= 1 && c->ev_dl) {
+    if (c->env_copy_stream >= 1 && c->ev_dl && host_page_locked(ro)) {
         {
-            std::lock_guard<std::mutex> lk(g_copy_mu[c->device & 15]);        // (a context's copies and its event stay together in the shared stream)
+            std::lock_guard<std::mutex> lk(g_copy_mu[c->device & 63]);        // (a context's copies and its event stay together in the shared stream)
             hipStream_t cs = nullptr;
             HIPCHK(copy_stream(c->device, 0, &cs));
             if (ro) HIPCHK(hipMemcpyAsync(ro, c->reads_c.p, n * sizeof(dg_read_c), hipMemcpyDeviceToHost, cs));

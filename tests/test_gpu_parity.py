@@ -558,6 +558,15 @@ def test_gpu_packed_reads_and_pinned_buffers(workdir):
     rc = gpu.lib.dg_map_batch(gpu.ctx, n, p_so.a.ctypes.data, p_rl.a.ctypes.data, p_seq.a.ctypes.data, o_r.a.ctypes.data, o_p.a.ctypes.data, o_c.a.ctypes.data, o_s.a.ctypes.data, caps, used)
     assert rc == 0, (rc, gpu.lib.dg_last_error(gpu.ctx), list(used), list(caps))
     assert_same(host.BatchResult(o_r.a.copy(), o_p.a[:used[0]].copy(), o_c.a[:used[1]].copy(), o_s.a[:used[2]].copy()), want)
+    # dg_map_batch writes the full records only: asking for the compact ones afterwards is an argument error with a message, not stale data
+    n_ops = C.c_size_t(0)
+    rc = gpu.lib.dg_batch_download_compact(gpu.ctx, o_r.a.ctypes.data, o_p.a.ctypes.data, o_c.a.ctypes.data, o_s.a.ctypes.data, caps, C.byref(n_ops))
+    assert rc == -3 and b"full records only" in gpu.lib.dg_last_error(gpu.ctx), (rc, gpu.lib.dg_last_error(gpu.ctx))
+    # the same call with ordinary (not page-locked) arrays: the download then goes through the context's own stream, same records
+    q_r = np.zeros(n, host.READ_OUT); q_p = np.zeros(caps[0], host.REPORT_OUT); q_c = np.zeros(caps[1], np.uint32); q_s = np.zeros(caps[2], host.SJ_OUT)
+    rc = gpu.lib.dg_map_batch(gpu.ctx, n, p_so.a.ctypes.data, p_rl.a.ctypes.data, p_seq.a.ctypes.data, q_r.ctypes.data, q_p.ctypes.data, q_c.ctypes.data, q_s.ctypes.data, caps, used)
+    assert rc == 0, (rc, gpu.lib.dg_last_error(gpu.ctx))
+    assert_same(host.BatchResult(q_r, q_p[:used[0]], q_c[:used[1]], q_s[:used[2]]), want)
     for p in (p_so, p_rl, p_seq, o_r, o_p, o_c, o_s):
         p.free()
     gpu.close(); orc.close()
