@@ -728,14 +728,16 @@ def main():
                    "workload": "genome=%s model=%s pairs=%d rlen=%d spliced=%g introns=%d repeat_scale=%g mis=%d sub=%g indel=%g" %
                                (args.genome, args.genome_model, args.pairs, args.rlen, args.spliced, args.introns, args.repeat_scale, args.mis, args.sub_rate, args.indel_frac)}
     tj = {}
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("_fingerprint") != fingerprint:
-                tj = {}
-        except Exception:
-            tj = {}
+    for tname in ("traffic.json", "traffic_human.json"):         # (the default workload's passes; the human-like genome's)
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            try:
+                cand = json.load(open(tpath))
+                if cand.get("_fingerprint") == fingerprint:
+                    tj = cand
+                    break
+            except Exception:
+                pass
     # The dominant kernel of an HBM roofline: the one that moves the most bytes through the memory side (PMC; the seeding stage: half of a
     # batch's traffic) -- without a matching PMC profile, the one that runs longest alone.  (The longest stand-alone stage alone is a coin
     # flip by now: seeding and the general-path report are both ~1.0 ms.)  `stages` carries the same figures for every stage either way.

@@ -134,10 +134,44 @@ struct Source {
             blk_end += got;
         }
     }
+    // gz: a thread of its own inflates 2 MB pieces ahead of the parser (zlib is the slower of the two: the parser then never waits for it to start)
+    struct Inflater {
+        std::thread th; std::mutex mu; std::condition_variable cv;
+        std::deque<std::vector<char>> q; bool done = false, stop = false; std::vector<char> cur; size_t cur_pos = 0;
+        void start(gzFile g) {
+            th = std::thread([this, g]() {
+                while (true) {
+                    std::vector<char> b((size_t)2 << 20);
+                    const int got = gzread(g, b.data(), (unsigned)b.size());
+                    std::unique_lock<std::mutex> lk(mu);
+                    if (got <= 0) { done = true; cv.notify_all(); return; }
+                    b.resize((size_t)got);
+                    cv.wait(lk, [this]() { return q.size() < 8 || stop; });
+                    if (stop) return;
+                    q.push_back(std::move(b));
+                    cv.notify_all();
+                }
+            });
+        }
+        size_t read(char *dst, size_t room) {
+            if (cur_pos == cur.size()) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this]() { return !q.empty() || done; });
+                if (q.empty()) return 0;
+                cur = std::move(q.front()); q.pop_front(); cur_pos = 0;
+                cv.notify_all();
+            }
+            const size_t n = std::min(room, cur.size() - cur_pos);
+            memcpy(dst, cur.data() + cur_pos, n); cur_pos += n;
+            return n;
+        }
+        ~Inflater() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+    };
+    std::unique_ptr<Inflater> inf;
     size_t fill(size_t room) {                       // the next bytes of the (inflated) stream behind blk_end
         if (!gz) return fread(blk + blk_end, 1, room, fp);
-        const int got = gzread(gz, blk + blk_end, (unsigned)std::min<size_t>(room, (size_t)1 << 30));
-        return got > 0 ? (size_t)got : 0;
+        if (!inf) { inf.reset(new Inflater()); inf->start(gz); }
+        return inf->read(blk + blk_end, room);
     }
     // gzgets(file, buffer, 1024) as a view into the block (GetData.cpp:181-210 reads every line that way): up to 1023 bytes, ending behind
     // the first newline among them; 0 = end of the stream.  (zlib inflates in large blocks here instead of once per line.)
@@ -752,6 +786,7 @@ int main(int argc, char *argv[])
         if (getenv("DART_TIMING")) fprintf(stderr, "[dart timing] read+parse %.3f s, map (sum over workers) %.3f s, format %.3f s, write %.3f s\n", t_read, t_map, t_fmt, t_write);
         if (s1.fp) fclose(s1.fp);
         if (s2.fp) fclose(s2.fp);
+        s1.inf.reset(); s2.inf.reset();              // (the inflater threads end before their files are closed)
         if (s1.gz) gzclose(s1.gz);
         if (s2.gz) gzclose(s2.gz);
     }
