@@ -114,7 +114,7 @@ struct dg_ctx {
     int env_seed_waves = 4, env_bail_trips = 0 /* 0: 64 trips in k_seed_qf (a trip there is up to three dependent accesses), 128 in the other two */, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
     int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32, env_seed_multi = 4;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
     bool seed_qf_used = false;     // the last run's seeding kernel was k_seed_qf (its own-work counters are derived from its slot counts)
-    int env_scan_mask = 7, env_one_stream = 0;
+    int env_scan_mask = 7, env_one_stream = 0, env_packed_pair = 1, env_drain_bail = 0;
     int env_chain_bpc = 8, env_seedh_bpc = 8, env_reseed_pct = 100;      // persistent one-wave workgroups per CU of k_chain_heavy / k_seed_heavy; k_reseed's grids in per cent (sweeps: DG_CHAIN_BPC, DG_SEEDH_BPC, DG_RESEED_PCT)
     int env_scan_budget = 0;      // DG_SCAN_POLL_BUDGET: poll budget of a look-back on the FIRST attempt of a batch (test hook: forces the DG_E_SCAN re-run path)
 };
@@ -127,7 +127,7 @@ static void read_env(dg_ctx *c)
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
     c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0); c->env_scan_mask = geti("DG_SCAN_POLL_SCANS", 7);
     c->env_seed_phases = geti("DG_SEED_PHASES", 0); c->env_seed_wg_waves = geti("DG_SEED_WG_WAVES", 4); c->env_seed_partial = geti("DG_SEED_PARTIAL_MIN", 32);
-    c->env_copy_stream = geti("DG_COPY_STREAM", 1); c->env_one_stream = geti("DG_ONE_STREAM", 0);
+    c->env_copy_stream = geti("DG_COPY_STREAM", 1); c->env_one_stream = geti("DG_ONE_STREAM", 0); c->env_packed_pair = geti("DG_PACKED_PAIR", 1); c->env_drain_bail = geti("DG_SEED_DRAIN_BAIL", 0);
     c->env_chain_bpc = std::max(1, geti("DG_CHAIN_BPC", 8)); c->env_seedh_bpc = std::max(1, geti("DG_SEEDH_BPC", 8)); c->env_reseed_pct = std::max(10, geti("DG_RESEED_PCT", 100));
     c->env_seed_multi = geti("DG_SEED_MULTI", 4); if (c->env_seed_multi < 0 || c->env_seed_multi > SQF_MULTI_MAX) c->env_seed_multi = SQF_MULTI_MAX;   // rows of an interval that are located and compared with the text at once (0: single rows only)
 }
@@ -1043,6 +1043,25 @@ k_unpack_listed(const uint32_t *__restrict__ slow_units, const uint32_t *__restr
     }
 }
 
+// DG_PACKED_PAIR=0 (a measurement switch): the ASCII copy of the WHOLE packed batch, as rounds 2-3 made it, for k_pair<false>
+__global__ void __launch_bounds__(256)
+k_unpack_all(uint32_t n_words, int W2, const uint32_t *__restrict__ enc, unsigned char *__restrict__ seq)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_words) return;
+    const uint32_t r = t / (uint32_t)W2, ww = t - r * (uint32_t)W2;
+    const uint32_t w = enc[(size_t)r * 2 * W2 + ww], m = enc[(size_t)r * 2 * W2 + W2 + ww];
+    uint32_t out[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t a = (w >> (24 - 8 * q)) & 0xFFu, b = (m >> (24 - 8 * q)) & 0xFFu;
+        const uint32_t sel = ((a * 0x40100401u) >> 6) & 0x03030303u, nb = ((b * 0x40100401u) >> 6) & 0x03030303u;
+        const uint32_t isn = ((nb | (nb >> 1)) & 0x01010101u) * 0xFFu;
+        out[q] = (__builtin_amdgcn_perm(0u, 0x54474341u, sel) & ~isn) | (0x4E4E4E4Eu & isn);
+    }
+    *(uint4 *)(seq + (size_t)r * 16 * W2 + 16 * ww) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
 static int enqueue_upload_packed(dg_ctx *c, int n_reads, int rlen_all, const uint16_t *rlen, int words_per_read, const uint32_t *words, const uint32_t *nlist, size_t n_n)
 {
     if (!c || n_reads < 0 || words_per_read < 1 || (n_reads > 0 && !words) || (n_n > 0 && !nlist)) return DG_ERR_ARG;
@@ -1066,6 +1085,7 @@ static int enqueue_upload_packed(dg_ctx *c, int n_reads, int rlen_all, const uin
         k_unpack_n<<<(unsigned)((n_n + 255) / 256), 256, 0, c->stream>>>(c->nlist_in.p, (uint32_t)n_n, W2, (uint32_t)(nw * 16), c->seq.p, c->enc.p, c->d_input_bad);
         HIPCHK(hipMemcpyAsync(&c->h_tail->input_bad, c->d_input_bad, 4, hipMemcpyDeviceToHost, c->stream));
     } else c->h_tail->input_bad = 0;
+    if (!c->env_packed_pair) k_unpack_all<<<(unsigned)((nw + 255) / 256), 256, 0, c->stream>>>((uint32_t)nw, W2, c->enc.p, c->seq.p);
     HIPCHK(hipGetLastError());
     return DG_OK;
 }
@@ -1159,7 +1179,8 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
         if (wgs > need) wgs = need;
         c->seed_qf_used = true;
         k_seed_qf<<<wgs, nw * 64, lds, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, lg, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT,
-                                                    c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, c->env_seed_partial, c->env_seed_multi, c->d_err);
+                                                    c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, c->env_seed_partial, c->env_seed_multi, c->d_err,
+                                                    c->env_drain_bail > 0 ? c->env_drain_bail : bail_trips);
     } else
     if (!c->env_seed_legacy && W <= 62) {
         int lg = c->env_seed_slots_lg >= 6 && c->env_seed_slots_lg <= 10 ? c->env_seed_slots_lg : 9;
@@ -1327,7 +1348,8 @@ static int enqueue_run(dg_ctx *c)
         co = CompactOut{c->reads_c.p, c->reports_c.p, c->cig_c.p, &c->d_sizes->pad[1]};
     }
     const int W2p = (c->max_rlen + 15) / 16 > 0 ? (c->max_rlen + 15) / 16 : 1;
-    if (c->enc_ready)       // a packed batch: the characters follow from its words; only the general path's units get an ASCII copy (below)
+    const bool packed_pair = c->enc_ready && c->env_packed_pair;
+    if (packed_pair)        // a packed batch: the characters follow from its words; only the general path's units get an ASCII copy (below)
         k_pair<true><<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
             c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->enc.p, W2p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
             c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err, co);
@@ -1336,7 +1358,7 @@ static int enqueue_run(dg_ctx *c)
             c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->enc.p, W2p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
             c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err, co);
     HIPCHK(hipGetLastError());
-    if (c->enc_ready) {
+    if (packed_pair) {
         k_unpack_listed<<<(unsigned)c->n_cu * 8u, 256, 0, c->stream>>>(c->slow_units.p, &c->d_sizes->n_slow_units, paired, W2p, c->enc.p, c->seq.p, c->d_err);
         HIPCHK(hipGetLastError());
     }

@@ -47,7 +47,7 @@ __host__ __device__ inline void d_sort_keys(SKey *a, int n)
 // key(i) -> SKey of seed i; emit(first, count, score, PosDiff) is called per candidate, in order.  Returns their number.
 // ---------------------------------------------------------------------------------------------
 template <class KeyAt, class Emit>
-__host__ __device__ inline int d_cluster_seeds(const DIndex &ix, const DParams &pr, int rlen, int num, KeyAt key, Emit emit)
+__host__ __device__ inline int d_cluster_seeds(const LocTab &lt, const DParams &pr, int rlen, int num, KeyAt key, Emit emit)
 {
     const int need = (int)(rlen * 0.3);
     int made = 0, head = 0;
@@ -62,7 +62,7 @@ __host__ __device__ inline int d_cluster_seeds(const DIndex &ix, const DParams &
             if (jump < 0) jump = -jump;
             bool joins = jump < pr.max_gaps;
             if (!joins && jump < pr.max_intron)
-                joins = sk_gpos(cand) < ix.loc_key[d_loc_lower_bound(ix, sk_gpos(tail))] && sk_rpos(cand) > sk_rpos(tail);
+                joins = sk_gpos(cand) < lt.key[d_loc_lower_bound(lt, sk_gpos(tail))] && sk_rpos(cand) > sk_rpos(tail);
             if (!joins) break;
             covered += sk_rlen(cand);
             tail = cand;
@@ -71,6 +71,11 @@ __host__ __device__ inline int d_cluster_seeds(const DIndex &ix, const DParams &
         head = next;
     }
     return made;
+}
+template <class KeyAt, class Emit>
+__host__ __device__ inline int d_cluster_seeds(const DIndex &ix, const DParams &pr, int rlen, int num, KeyAt key, Emit emit)
+{
+    return d_cluster_seeds(d_loc_tab(ix), pr, rlen, num, key, emit);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -200,12 +205,13 @@ __device__ __forceinline__ bool d_unit_is_heavy(const uint32_t *seed_off, int pa
 // ---------------------------------------------------------------------------------------------
 #define CH_MAXS 1024
 #define CH_MAXC 192
+#define CH_LOC_MAX 64         // ChrLocMap keys k_chain_heavy keeps in LDS
 
 // d_gen_candidates by one wave over sorted keys in LDS (num <= CH_MAXS).  Whether seed i starts a new candidate depends on its
 // predecessor only (the clustering walk compares every seed with the one it has just taken), so the starts, the covered-bases prefix
 // and every candidate's end come from ballots and one running sum; candidates are numbered in seed order as the serial walk does.
 // scratch: pref[CH_MAXS + 1] u32 and starts[CH_MAXS / 64] u64 (LDS).  Every lane returns the count.
-__device__ inline int d_gen_candidates_wave(const DIndex &ix, const DParams &pr, int rlen, const SKey *s, int num, uint32_t base, DCand *out,
+__device__ inline int d_gen_candidates_wave(const LocTab &lt, const DParams &pr, int rlen, const SKey *s, int num, uint32_t base, DCand *out,
                                             uint32_t *pref, unsigned long long *starts, int lane)
 {
     const int need = (int)(rlen * 0.3), rounds = (num + 63) >> 6;
@@ -232,7 +238,7 @@ __device__ inline int d_gen_candidates_wave(const DIndex &ix, const DParams &pr,
                 if (jump < 0) jump = -jump;
                 bool joins = jump < pr.max_gaps;
                 if (!joins && jump < pr.max_intron)
-                    joins = sk_gpos(cand) < ix.loc_key[d_loc_lower_bound(ix, sk_gpos(tail))] && sk_rpos(cand) > sk_rpos(tail);
+                    joins = sk_gpos(cand) < lt.key[d_loc_lower_bound(lt, sk_gpos(tail))] && sk_rpos(cand) > sk_rpos(tail);
                 start = !joins;
             }
         }
@@ -302,6 +308,13 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
     __shared__ int16_t s_pick[CH_MAXC];
     __shared__ uint32_t s_pref[CH_MAXS + 1];
     __shared__ unsigned long long s_starts[CH_MAXS / 64];
+    // the ChrLocMap keys in LDS when they fit (32 chromosomes: 512 bytes, four waves still share a CU): the clustering asks "does this seed lie
+    // before the end of its neighbour's chromosome half" through a binary search, six dependent loads from memory otherwise (dg_common.h, LocTab)
+    __shared__ int64_t s_lkey[CH_LOC_MAX];
+    const bool tab_in_lds = 2 * ix.n_chr <= CH_LOC_MAX;
+    if (tab_in_lds) for (int i = threadIdx.x; i < 2 * ix.n_chr; i += 64) s_lkey[i] = ix.loc_key[i];
+    __syncthreads();
+    const LocTab lt = tab_in_lds ? LocTab{s_lkey, ix.loc_chr, ix.chr_off, 2 * ix.n_chr} : d_loc_tab(ix);
     if (*abort_p >= DG_ABORT) return;
     const int lane = threadIdx.x;
     const unsigned int n_heavy = *n_heavy_p;
@@ -328,7 +341,7 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
         }
         if (fits) {
             for (int m = 0; m < nm; m++) {
-                const int made = d_gen_candidates_wave(ix, pr, rlen[r1 + m], ls[m], (int)n[m], b[m], cands + b[m], s_pref, s_starts, lane);
+                const int made = d_gen_candidates_wave(lt, pr, rlen[r1 + m], ls[m], (int)n[m], b[m], cands + b[m], s_pref, s_starts, lane);
                 if (lane == 0) s_n[m] = made;
             }
         } else if (lane == 0) {

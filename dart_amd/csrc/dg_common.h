@@ -175,6 +175,17 @@ __host__ __device__ __forceinline__ int d_loc_lower_bound(const DIndex &ix, int6
     while (lo < hi) { int mid = (lo + hi) >> 1; if (ix.loc_key[mid] < g) lo = mid + 1; else hi = mid; }
     return lo;
 }
+// The chromosome table (ChrLocMap keys, their chromosomes, the chromosomes' offsets) as three pointers: the index's arrays in memory, or a copy a
+// workgroup keeps in LDS -- a look-up is seven dependent loads (a binary search over 2 n keys, then the chromosome and its offset), and k_pair
+// makes one per seed-joining question and one per reported candidate: from memory they were half of a tile's processing time.
+struct LocTab { const int64_t *key; const int32_t *chr; const int64_t *off; int n2; };
+__host__ __device__ __forceinline__ LocTab d_loc_tab(const DIndex &ix) { return LocTab{ix.loc_key, ix.loc_chr, ix.chr_off, 2 * ix.n_chr}; }
+__host__ __device__ __forceinline__ int d_loc_lower_bound(const LocTab &t, int64_t g)
+{
+    int lo = 0, hi = t.n2;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (t.key[mid] < g) lo = mid + 1; else hi = mid; }
+    return lo;
+}
 
 __host__ __device__ __forceinline__ bool d_seed_less(const DSeed &a, const DSeed &b)   // CompByGenomePos, AlignmentCandidates.cpp:21-25
 {

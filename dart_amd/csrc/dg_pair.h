@@ -134,7 +134,8 @@ struct RepMem {
 #define PU_SEEDS UNIT_MAX_SEEDS
 #ifndef PU_SLOTS
 #define PU_SLOTS 6
-#endif                        // 2 workgroups of 256 lanes per CU: (16 x 8 + 16 x 4 + 2 x 6 x 8) bytes per lane = 72 KB each
+#endif
+#define PU_LOC_MAX 256        // ChrLocMap keys a workgroup keeps in LDS (two per chromosome)                        // 2 workgroups of 256 lanes per CU: (16 x 8 + 16 x 4 + 2 x 6 x 8) bytes per lane = 72 KB each
 
 __host__ __device__ __forceinline__ uint32_t cw_make(int first, int count, int score) { return (uint32_t)first | ((uint32_t)count << 5) | ((uint32_t)score << 10) | (31u << 22) | (15u << 27); }
 __host__ __device__ __forceinline__ int cw_first(uint32_t w) { return (int)(w & 31u); }
@@ -172,7 +173,16 @@ struct RepLds {                       // report view of one mate: report i = can
 };
 
 // what a unit looks like after d_unit_process
+// -DDG_PAIR_PROF (profiles/probes/pair_phases.sh): cycle stamps between the phases of k_pair, summed per wave and printed for a few tiles
+#if defined(DG_PAIR_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define PP_STAMP(pp, pt, i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); (pp)[i] += _n - (pt); (pt) = _n; } while (0)
+#else
+#define PP_STAMP(pp, pt, i) do { } while (0)
+#endif
 struct UnitState {
+#ifdef DG_PAIR_PROF
+    unsigned long long pp[10], pt;
+#endif
     DRead rd[2];
     int nc[2];            // candidates per mate
     int flag0[2];
@@ -232,13 +242,24 @@ __host__ __device__ inline bool d_small_nw_is_diagonal(uint64_t a8, uint64_t b8,
 // A read as the fused kernel looks at it: the ASCII bytes of dg_map_batch (case, '-' and IUPAC letters matter to the reference: tools.cpp:40-104), or the
 // 2-bit + mask words of a packed batch (dg_map_batch_packed: A/C/G/T/N by contract, so the characters follow from the words and the ASCII copy of the
 // batch -- 202 MB per million pairs, written by k_unpack and read back here -- is only made for the units of the general path: k_unpack_listed).
-struct ReadAscii { const unsigned char *p; __host__ __device__ __forceinline__ unsigned char at(int i) const { return p[i]; } };
+// get8(i, e): the characters i .. i + e - 1 (e <= 8) as the bytes of a word, character i in the low byte -- the form d_ref8 gives the genome in
+struct ReadAscii {
+    const unsigned char *p;
+    __host__ __device__ __forceinline__ uint64_t get8(int i, int e) const { uint64_t v = 0; for (int t = 0; t < e; t++) v |= (uint64_t)p[i + t] << (8 * t); return v; }
+};
 struct ReadWords {
     const uint32_t *w; int W2;           // k_encode's format: W2 words of 2-bit codes (first base on top), then W2 words with 0b11 where the base is no A/C/G/T
-    __host__ __device__ __forceinline__ unsigned char at(int i) const {
-        const int sh = 30 - ((i & 15) << 1);
-        const uint32_t m = (w[W2 + (i >> 4)] >> sh) & 3u, c = (w[i >> 4] >> sh) & 3u;
-        return m ? (unsigned char)'N' : (unsigned char)(0x54474341u >> (8u * c));
+    __host__ __device__ __forceinline__ uint64_t get8(int i, int e) const {
+        // eight codes and eight masks from two words each (the window may straddle a word), then 'A' 'C' 'G' 'T' by code, 'N' where masked
+        const int w0 = i >> 4, sh = (i & 15) << 1;
+        const uint32_t chi = w[w0], clo = w0 + 1 < W2 ? w[w0 + 1] : 0u, mhi = w[W2 + w0], mlo = w0 + 1 < W2 ? w[W2 + w0 + 1] : 0xFFFFFFFFu;
+        const uint32_t c16 = (sh ? (chi << sh) | (clo >> (32 - sh)) : chi) >> 16, m16 = (sh ? (mhi << sh) | (mlo >> (32 - sh)) : mhi) >> 16;
+        uint64_t v = 0;
+        for (int t = 0; t < e; t++) {
+            const uint32_t c = (c16 >> (14 - 2 * t)) & 3u, m = (m16 >> (14 - 2 * t)) & 3u;
+            v |= (uint64_t)(m ? 0x4Eu : ((0x54474341u >> (8u * c)) & 0xFFu)) << (8 * t);
+        }
+        return v;
     }
 };
 
@@ -249,7 +270,7 @@ struct ReadWords {
 // (they act on repeated rPos, order inversions and diagonal changes).  Returns false when some live candidate is outside
 // the pattern (nothing of this unit is then kept: the general path redoes it).
 template <int S, class RD>
-__host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &pr, bool first, const RD seq, int len,
+__host__ __device__ inline bool d_unit_reports(const DIndex &ix, const LocTab &lt, const DParams &pr, bool first, const RD seq, int len,
                                                const SKey *key, uint32_t *cw, int nc, uint64_t *rw, int &n_slot, DRead &rd, uint32_t &n_cig, uint32_t &n_nw, uint32_t &n_cells)
 {
     const int64_t L = ix.l_pac;
@@ -275,11 +296,15 @@ __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &
             for (int q = 0; q < g; q += 8) {
                 const uint64_t ref = d_ref8(ix, gp + q);
                 const int e = g - q < 8 ? g - q : 8;
-                for (int t = 0; t < e; t++) { const unsigned char ch = seq.at(from + q + t); dash = dash || ch == '-'; nm += ch != (unsigned char)(ref >> (8 * t)); }
+                // e characters at once: bytes that differ from the genome's, and whether one of them is a '-' (tools.cpp:130-164 compares characters)
+                const uint64_t a8 = seq.get8(from + q, e), keep = e == 8 ? ~0ull : (1ull << (8 * e)) - 1ull, lo7 = 0x7F7F7F7F7F7F7F7Full, hi1 = 0x8080808080808080ull;
+                const uint64_t x = (a8 ^ ref) & keep, y = (a8 ^ 0x2D2D2D2D2D2D2D2Dull) | ~keep;
+                nm += __builtin_popcountll((((x & lo7) + lo7) | x) & hi1);
+                dash = dash || ((~(((y & lo7) + lo7) | y)) & hi1) != 0ull;
             }
             if (nm <= 2 && nm <= (int)(g * 0.2)) { aln += g - nm; mis += nm; }
             else if (g == 1 && !dash) { calls++; cells++; mis += 1; }
-            else if (g <= SMALL_NW && !dash && d_small_nw_is_diagonal([&]() { uint64_t a8 = 0; for (int t = 0; t < g; t++) a8 |= (uint64_t)seq.at(from + t) << (8 * t); return a8; }(), d_ref8(ix, gp), g)) {
+            else if (g <= SMALL_NW && !dash && d_small_nw_is_diagonal(seq.get8(from, g), d_ref8(ix, gp), g)) {
                 // two substitutions a few bases apart: ProcessNormalSequencePair calls nw_alignment (tools.cpp:142-163), the
                 // alignment is g columns of M, AddNewCigarElements scores the identical characters
                 calls++; cells += (uint32_t)(g * g); aln += g - nm; mis += nm;
@@ -296,11 +321,11 @@ __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &
         const int slot = n_slot++;
         uint64_t w0 = 0;
         if (aln > 0) {                                                       // GenCoordinateInfo :83-116
-            const int lb = d_loc_lower_bound(ix, gPos);
-            const int chr = ix.loc_chr[lb];
+            const int lb = d_loc_lower_bound(lt, gPos);
+            const int chr = lt.chr[lb];
             int64_t pos; int bdir;
-            if (gPos < L) { bdir = first ? 1 : 0; pos = gPos + 1 - ix.chr_off[chr]; }
-            else { bdir = first ? 0 : 1; pos = ix.loc_key[lb] - end_gPos + 1; }
+            if (gPos < L) { bdir = first ? 1 : 0; pos = gPos + 1 - lt.off[chr]; }
+            else { bdir = first ? 0 : 1; pos = lt.key[lb] - end_gPos + 1; }
             if (pos <= 0 || pos > 0xFFFFFFFFll || chr > 0xFFFF) return false;   // (a report the reference zeroes late, or fields too wide for the slot)
             w0 = (uint64_t)pos | ((uint64_t)chr << 32) | ((uint64_t)aln << 48) | ((uint64_t)bdir << 60) | (1ull << 61);
             n_cig += 1u + (head > 0) + (tail > 0);
@@ -318,28 +343,31 @@ __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const DParams &
 // One unit from sorted-or-not seeds in key[0 .. n1+n2) to either finished records in LDS (st.fast) or candidate words for the
 // general path.  try_fast = false: the candidate stage only (dg_probe_seeds, chr tables too wide for the slots).
 template <int S, class RD>
-__host__ __device__ inline void d_unit_process_rd(const DIndex &ix, const DParams &pr, bool paired, int n1, int n2, int len1, int len2,
+__host__ __device__ inline void d_unit_process_rd(const DIndex &ix, const LocTab &lt, const DParams &pr, bool paired, int n1, int n2, int len1, int len2,
                                                const RD seq1, const RD seq2, SKey *key, uint32_t *cw, uint64_t *rw,
                                                bool try_fast, UnitState &st)
 {
     d_unit_sort<S>(key, n1);
     if (paired) d_unit_sort<S>(key + n1 * S, n2);
     int k = 0;
-    st.nc[0] = d_cluster_seeds(ix, pr, len1, n1, [&](int i) { return key[i * S]; },
+    st.nc[0] = d_cluster_seeds(lt, pr, len1, n1, [&](int i) { return key[i * S]; },
                                [&](int first, int count, int score, int64_t) { cw[(k++) * S] = cw_make(first, count, score); });
     st.nc[1] = 0;
     CandLds<S> a{key, cw, st.nc[0]}, b{key + n1 * S, cw + st.nc[0] * S, 0};
     if (paired) {
-        st.nc[1] = b.cnt = d_cluster_seeds(ix, pr, len2, n2, [&](int i) { return key[(n1 + i) * S]; },
+        st.nc[1] = b.cnt = d_cluster_seeds(lt, pr, len2, n2, [&](int i) { return key[(n1 + i) * S]; },
                                            [&](int first, int count, int score, int64_t) { cw[(k++) * S] = cw_make(first, count, score); });
     }
+    PP_STAMP(st.pp, st.pt, 1);       // sort + clustering
     d_candidate_rules(paired, a, b);
+    PP_STAMP(st.pp, st.pt, 2);       // candidate rules (pairing, redundancy)
     st.fast = false; st.n_cig = 0; st.n_nw = st.n_cells = 0; st.flag0[0] = st.flag0[1] = 0;
     if (!try_fast) return;
     int n_slot = 0;
     uint32_t n_cig = 0, n_nw = 0, n_cells = 0;
-    if (!d_unit_reports<S>(ix, pr, true, seq1, len1, key, cw, st.nc[0], rw, n_slot, st.rd[0], n_cig, n_nw, n_cells)) return;
-    if (paired && !d_unit_reports<S>(ix, pr, false, seq2, len2, key + n1 * S, cw + st.nc[0] * S, st.nc[1], rw, n_slot, st.rd[1], n_cig, n_nw, n_cells)) return;
+    if (!d_unit_reports<S>(ix, lt, pr, true, seq1, len1, key, cw, st.nc[0], rw, n_slot, st.rd[0], n_cig, n_nw, n_cells)) return;
+    if (paired && !d_unit_reports<S>(ix, lt, pr, false, seq2, len2, key + n1 * S, cw + st.nc[0] * S, st.nc[1], rw, n_slot, st.rd[1], n_cig, n_nw, n_cells)) return;
+    PP_STAMP(st.pp, st.pt, 3);       // the reports of the live candidates (read bases, genome words, chromosome table)
     RepLds<S> p1{cw, rw, st.nc[0], 0}, p2{cw + st.nc[0] * S, rw, st.nc[1], 0};
     if (paired) {
         d_settle_pair(pr, st.rd[0], p1, st.rd[1], p2);
@@ -349,13 +377,14 @@ __host__ __device__ inline void d_unit_process_rd(const DIndex &ix, const DParam
     d_mapq(st.rd[0], p1);
     st.flag0[0] = p1.flag0; st.flag0[1] = p2.flag0;
     st.fast = true; st.n_cig = n_cig; st.n_nw = n_nw; st.n_cells = n_cells;
+    PP_STAMP(st.pp, st.pt, 4);       // pair settling, FLAG, MAPQ
 }
 template <int S>
 __host__ __device__ inline void d_unit_process(const DIndex &ix, const DParams &pr, bool paired, int n1, int n2, int len1, int len2,
                                                const unsigned char *seq1, const unsigned char *seq2, SKey *key, uint32_t *cw, uint64_t *rw,
                                                bool try_fast, UnitState &st)
 {
-    d_unit_process_rd<S, ReadAscii>(ix, pr, paired, n1, n2, len1, len2, ReadAscii{seq1}, ReadAscii{seq2}, key, cw, rw, try_fast, st);
+    d_unit_process_rd<S, ReadAscii>(ix, d_loc_tab(ix), pr, paired, n1, n2, len1, len2, ReadAscii{seq1}, ReadAscii{seq2}, key, cw, rw, try_fast, st);
 }
 
 // ---- the compact record types (include/dartgpu.h: dg_read_c 12 bytes, dg_report_c 16 bytes), written by the kernels that write the full
@@ -470,6 +499,14 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
     __shared__ uint64_t s_rw[2 * PU_SLOTS * PU_THREADS];
     __shared__ unsigned long long s_scan[20];
     __shared__ unsigned int s_tile;
+    // the chromosome table in LDS when it fits (up to 128 chromosomes; 4 KB: two workgroups still share a CU): d_loc_tab's comment says why
+    __shared__ int64_t s_lkey[PU_LOC_MAX]; __shared__ int64_t s_coff[PU_LOC_MAX / 2]; __shared__ int32_t s_lchr[PU_LOC_MAX];
+    const bool tab_in_lds = 2 * ix.n_chr <= PU_LOC_MAX;
+    if (tab_in_lds) {
+        for (int i = threadIdx.x; i < 2 * ix.n_chr; i += PU_THREADS) { s_lkey[i] = ix.loc_key[i]; s_lchr[i] = ix.loc_chr[i]; }
+        for (int i = threadIdx.x; i < ix.n_chr; i += PU_THREADS) s_coff[i] = ix.chr_off[i];
+    }                                                  // (d_tile_ticket's barrier below orders these stores before every use)
+    const LocTab lt = tab_in_lds ? LocTab{s_lkey, s_lchr, s_coff, 2 * ix.n_chr} : d_loc_tab(ix);
     { const int e0 = *err; if (e0 == DG_E_SEEDS || e0 == DG_E_SEEDQ || e0 == DG_E_SCAN) return; }
                                                        // SEEDS / SEEDQ are raised before this launch (seeds that do not fit, the seeding kernel's safety net), SCAN by
                                                        // k_seed_offsets before it or by a look-back inside it: seed_off / nseeds cannot be trusted, the host runs the batch
@@ -484,6 +521,11 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
     uint64_t *rw = s_rw + threadIdx.x;
     UnitState st;
     st.fast = false; st.n_cig = 0; st.n_nw = st.n_cells = 0; st.nc[0] = st.nc[1] = 0; st.flag0[0] = st.flag0[1] = 0;
+#ifdef DG_PAIR_PROF
+    for (int i = 0; i < 10; i++) st.pp[i] = 0;
+    st.pt = __builtin_amdgcn_s_memtime();
+    const unsigned long long pp_t0 = st.pt;
+#endif
     int r1 = 0, n1 = 0, n2 = 0, len1 = 0, len2 = 0;
     uint32_t b1 = 0;
     bool heavy = false;
@@ -504,10 +546,11 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
                 if (i0 + 3 < nt) key[(i0 + 3) * PU_THREADS] = k3;
             }
             len1 = rlen[r1]; len2 = paired ? rlen[r1 + 1] : 0;
+            PP_STAMP(st.pp, st.pt, 0);       // ticket, seed offsets, seeds into LDS
             if (PACKED) {
                 const ReadWords a{enc + (size_t)r1 * 2 * W2, W2}, b{enc + (size_t)(r1 + (paired ? 1 : 0)) * 2 * W2, W2};
-                d_unit_process_rd<PU_THREADS, ReadWords>(ix, pr, paired != 0, n1, n2, len1, len2, a, b, key, cw, rw, try_fast != 0, st);
-            } else d_unit_process<PU_THREADS>(ix, pr, paired != 0, n1, n2, len1, len2, seq + seq_off[r1], seq + seq_off[r1 + (paired ? 1 : 0)], key, cw, rw, try_fast != 0, st);
+                d_unit_process_rd<PU_THREADS, ReadWords>(ix, lt, pr, paired != 0, n1, n2, len1, len2, a, b, key, cw, rw, try_fast != 0, st);
+            } else d_unit_process_rd<PU_THREADS, ReadAscii>(ix, lt, pr, paired != 0, n1, n2, len1, len2, ReadAscii{seq + seq_off[r1]}, ReadAscii{seq + seq_off[r1 + (paired ? 1 : 0)]}, key, cw, rw, try_fast != 0, st);
         } else { st.nc[0] = (int)ncand[r1]; st.nc[1] = paired ? (int)ncand[r1 + 1] : 0; }
     }
     const uint32_t nrep1 = valid ? (uint32_t)(st.nc[0] > 0 ? st.nc[0] : 1) : 0u, nrep2 = (valid && paired) ? (uint32_t)(st.nc[1] > 0 ? st.nc[1] : 1) : 0u;
@@ -520,8 +563,11 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
         cc1 = d_unit_compact_ops<PU_THREADS>(st.rd[0], q1);
         mine.w = cc1 + (paired ? d_unit_compact_ops<PU_THREADS>(st.rd[1], q2) : 0u);
     }
+    PP_STAMP(st.pp, st.pt, 5);               // (whatever the lane did since its last stamp: units that left d_unit_process early, the compact op count)
     const Triple inb = d_block_exclusive(mine, tot, s_scan);
+    PP_STAMP(st.pp, st.pt, 6);               // the scan inside the workgroup (two barriers: the workgroup's slowest wave)
     const Triple base = d_tile_exclusive(ts, tile, tot, s_scan + 16, err);
+    PP_STAMP(st.pp, st.pt, 7);               // the look-back
     const uint32_t rep0 = base.x + inb.x, slow_at = base.y + inb.y;
     const uint64_t cig0 = base.z + inb.z;
     unsigned long long n_cands = 0, n_nw = 0, n_cells = 0;
@@ -566,6 +612,12 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
         sizes->pad[2] = base.w + tot.w;                              // stored compact ops of the finished units: the general path's follow behind them
         *pool_top = (base.x + tot.x) * CIG_SLOT;                     // the report kernel's CIGAR pool: one slot group per report, overflow area behind
     }
+    PP_STAMP(st.pp, st.pt, 8);               // the records (or, for the general path, the sorted seeds and candidates) to memory
+#ifdef DG_PAIR_PROF
+    if ((threadIdx.x & 63) == 0 && (tile % 61u) == 0u)
+        printf("kpair tile %u wave %d: total %llu | load %llu sort+cluster %llu rules %llu reports %llu settle %llu rest %llu blockscan %llu lookback %llu emit %llu\n", tile, (int)(threadIdx.x >> 6),
+               __builtin_amdgcn_s_memtime() - pp_t0, st.pp[0], st.pp[1], st.pp[2], st.pp[3], st.pp[4], st.pp[5], st.pp[6], st.pp[7], st.pp[8]);
+#endif
     d_wave_add(ctr + CTR_CANDS, n_cands);
     d_wave_add(ctr + CTR_NW, n_nw);
     d_wave_add(ctr + CTR_NWCELLS, n_cells);

@@ -512,7 +512,7 @@ __device__ __forceinline__ int sqf_trip(const SqEnv &e, const bool act, const ui
 __global__ void __launch_bounds__(512)
 k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int n_reads, int W, int H, int nslot_lg,
           DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds, unsigned int *next_read,
-          DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int partial_min, int multi, int *err)
+          DHeavy *__restrict__ heavy, unsigned int *n_heavy, unsigned long long *ctr, int bail_trips, int partial_min, int multi, int *err, int drain_bail)
 {
     const unsigned long long t_wave0 = wall_clock64();
     extern __shared__ uint4 sq_sh[];
@@ -532,6 +532,9 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
     const bool direct = ix.sa_dense != nullptr;
     const uint32_t w_magic = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;       // i / W == (i * w_magic) >> 20 for i < 64 W <= 2^12
     const SqEnv env = { ix, pr, st, rd, NSLOT, W2, K, H, bail_trips, direct, (direct && ix.sa_dense_intv == 1) ? multi : 0, hits, nhits, nseeds, heavy, n_heavy };
+    // once the batch has no more reads to hand out, a workgroup only drains its slots: the launch then lasts as long as the longest chain of trips still
+    // ahead of one read, so reads give up for k_seed_heavy (a wave each) after fewer trips (DG_SEED_DRAIN_BAIL; = bail_trips: no difference)
+    SqEnv env_drain = env; env_drain.bail_trips = drain_bail;
     unsigned long long acc_steps = 0, acc_blocks = 0, acc_lf = 0;
     uint32_t max_trips = 0, wtrips = 0;
 
@@ -643,7 +646,7 @@ k_seed_qf(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, c
                         if (i < total) { const uint32_t rk = (i * w_magic) >> 20; rd[(size_t)(i - rk * (uint32_t)W) * NSLOT + tab[wave * 64 + rk]] = v[k]; }
                     }
                 }
-            } else if (my_q == SQ_BEGIN) { if (env.multi) nq = sqf_trip<SQ_BEGIN, true>(env, act, slot, dl); else nq = sqf_trip<SQ_BEGIN>(env, act, slot, dl); }
+            } else if (my_q == SQ_BEGIN) { const SqEnv &eb = ex ? env_drain : env; if (env.multi) nq = sqf_trip<SQ_BEGIN, true>(eb, act, slot, dl); else nq = sqf_trip<SQ_BEGIN>(eb, act, slot, dl); }
             else if (my_q == SQ_STEP) nq = sqf_trip<SQ_STEP>(env, act, slot, dl);
             else if (my_q == SQ_CMP) nq = sqf_trip<SQ_CMP>(env, act, slot, dl);
             else if (env.multi) nq = sqf_trip<SQ_LOC, true>(env, act, slot, dl);

@@ -73,7 +73,7 @@ int main(int argc, char **argv)
             if (plain) {
                 UnitState s2;
                 const ReadWords a{words[0].data(), W2m[0]}, b{words[paired ? 1 : 0].data(), W2m[paired ? 1 : 0]};
-                d_unit_process_rd<1, ReadWords>(ix, pr, paired != 0, n1, n2, rlen[r1], paired ? rlen[r1 + 1] : 0, a, b, lk2, lcw2, lrw2, true, s2);
+                d_unit_process_rd<1, ReadWords>(ix, d_loc_tab(ix), pr, paired != 0, n1, n2, rlen[r1], paired ? rlen[r1 + 1] : 0, a, b, lk2, lcw2, lrw2, true, s2);
                 bool same = s2.fast == st.fast && s2.nc[0] == st.nc[0] && s2.nc[1] == st.nc[1];
                 if (same && st.fast) {
                     same = s2.n_cig == st.n_cig && s2.n_nw == st.n_nw && s2.n_cells == st.n_cells && memcmp(&s2.rd[0], &st.rd[0], sizeof st.rd[0]) == 0 && (!paired || memcmp(&s2.rd[1], &st.rd[1], sizeof st.rd[1]) == 0);
