@@ -32,6 +32,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+T_PROCESS_START = time.time()
 sys.path.insert(0, ROOT)
 
 CHR20_LEN = 64444167
@@ -381,6 +382,9 @@ def main():
                     help="after the timed region: the product's `dart` command line end to end (FASTQ files -> SAM file, process start, index load and dg_init included) on "
                          "this many 2x101 pairs against the chr20-sized genome; 0 = skip")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (other entry point, device-resident)")
+    ap.add_argument("--human-like-budget", type=float, default=330.0,
+                    help="after everything else (default workload, one GPU, CPU legs on): the same timed region on the human-like genome (--genome-model human) as a child process, "
+                         "if this run has used fewer seconds than this so far (the leg costs ~110 s: genome, index, batches); 0 = never")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "12")),
                     help="batches in flight per GPU: contexts sharing one index, one host thread each (dg_clone)")
     ap.add_argument("--cache", default=os.environ.get("DART_BENCH_CACHE", "/tmp/dart_bench_cache"))
@@ -878,6 +882,31 @@ def main():
             except Exception as e:
                 log("[bench] command-line run failed:", repr(e))
 
+    # ---- the human-like genome beside the default one (about half of the genome in repeat classes: what a real human index looks like to the seeding stage) ----
+    human = None
+    human_skipped = None
+    if world == 1 and args.genome == "grch38" and args.genome_model == "planted" and not args.spliced and args.rlen == 101 and args.repeat_scale == 1:
+        used = time.time() - T_PROCESS_START
+        if args.no_cpu_baseline or args.no_secondary: human_skipped = "a reduced run (--no-cpu-baseline / --no-secondary)"
+        elif args.human_like_budget <= 0 or used > args.human_like_budget: human_skipped = "%.0f s used by the legs before it, budget %.0f s (--human-like-budget)" % (used, args.human_like_budget)
+        else:
+            try:
+                gpu.close()                                    # (idempotent: the child gets the GPU to itself)
+                t = time.time()
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--genome-model", "human", "--no-secondary", "--no-cpu-baseline", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                    "--pairs", str(args.pairs), "--batches", str(args.batches), "--inflight", str(args.inflight), "--mis", str(args.mis), "--cache", args.cache],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+                hl = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                human = {"value": hl["value"], "unit": hl["unit"], "ms_per_step": hl["ms_per_step"], "steps": hl["steps"], "warmup": hl["warmup"], "workload": hl["config"]["workload"],
+                         "kernels_ms": hl["kernels_ms"], "kernels_ms_one_batch_in_flight": hl["kernels_ms_one_batch_in_flight"],
+                         "roofline": {k: hl["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_standalone", "frac_of_random_line_ceiling", "fingerprint", "stages")},
+                         "counters_per_launch": {k: hl["counters_per_launch"].get(k) for k in ("steps", "steps_executed", "occ_blocks_executed", "seeds", "candidates", "nw_calls", "reseed_calls", "general_path_units", "wave_chained_units")},
+                         "what": "`bench.py --genome-model human --no-secondary --no-cpu-baseline` with this run's steps / warm-up / batches, as a child process after this run's contexts were closed "
+                                 "(its own genome, index and batches: %.0f s)" % (time.time() - t)}
+            except Exception as e:
+                human_skipped = "the child run failed: " + repr(e)
+                log("[bench] human-like leg failed:", repr(e))
+
     in_bytes = b0.bytes_packed if args.input == "packed" else b0.bytes_ascii
     line = {
         "metric": "M paired-end reads/sec (2x%d bp vs GRCh38-sized index), host to host; records bit-identical to CPU dart" % args.rlen,
@@ -917,6 +946,11 @@ def main():
     if cli:
         line["value_cli_end_to_end"] = cli["value"]
         line["cli_end_to_end"] = cli
+    if human:
+        line["value_human_like"] = human["value"]
+        line["human_like"] = human
+    elif human_skipped:
+        line["human_like"] = {"skipped": human_skipped}
     if gather_mode == "full":
         line["gather"] = {"mode": "full", "bytes_received_by_rank0_total": gather_bytes[0], "verified_against_single_rank_mapping": gather_verified}
     line.update(secondary)

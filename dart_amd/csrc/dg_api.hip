@@ -571,6 +571,17 @@ static hipError_t make_ctx_objects(dg_ctx *c)
 {
     hipError_t e;
     for (int i = 0; i <= N_TIMERS; i++) c->ev[i] = nullptr;
+    // DG_CU_PARTS=P (measurement switch, profiles/r04/y_*): context k's two streams only get the compute units of part k % P (DG_CU_LAYOUT 0: P contiguous
+    // ranges of the mask's bits, 1: bit i belongs to part (i % 8) % P) -- fewer different kernels share a CU's instruction cache and LDS at a time
+    static std::atomic<int> n_made{0};
+    const int parts = getenv("DG_CU_PARTS") ? atoi(getenv("DG_CU_PARTS")) : 0, layout = getenv("DG_CU_LAYOUT") ? atoi(getenv("DG_CU_LAYOUT")) : 0;
+    if (parts > 1) {
+        int n_cu = 0; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+        const int part = n_made.fetch_add(1) % parts;
+        std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+        for (int i = 0; i < n_cu; i++) { const int pi = layout == 1 ? (i % 8) % parts : (int)((long long)i * parts / n_cu); if (pi == part) mask[(size_t)i / 32] |= 1u << (i % 32); }
+        if ((e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data())) != hipSuccess || (e = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)mask.size(), mask.data())) != hipSuccess) return e;
+    } else
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) return e;
     if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess ||

@@ -581,6 +581,11 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
             else {
                 RepLds<PU_THREADS> p1{cw, rw, st.nc[0], st.flag0[0]}, p2{cw + st.nc[0] * PU_THREADS, rw, st.nc[1], st.flag0[1]};
                 const uint32_t cigc0 = base.w + inb.w;               // (stored ops never outnumber the full ones: the same capacity covers them)
+#ifdef DG_EXP_EMIT2      /* measurement only: the records written twice -- what the second time costs is what the stores cost */
+                d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar, co, co.reads ? co.reads + r1 : nullptr, cigc0);
+                if (paired) d_unit_emit_read<PU_THREADS>(false, st.rd[1], p2, rep0 + nrep1, (uint32_t)cig0 + d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar, co, co.reads ? co.reads + r1 : nullptr, cigc0), rout + r1 + 1, reports, cigar, co, co.reads ? co.reads + r1 + 1 : nullptr, cigc0 + cc1);
+                __asm__ volatile("" ::: "memory");
+#endif
                 const uint32_t c1 = d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar, co, co.reads ? co.reads + r1 : nullptr, cigc0);
                 if (paired) d_unit_emit_read<PU_THREADS>(false, st.rd[1], p2, rep0 + nrep1, (uint32_t)cig0 + c1, rout + r1 + 1, reports, cigar, co, co.reads ? co.reads + r1 + 1 : nullptr, cigc0 + cc1);
                 n_nw = st.n_nw; n_cells = st.n_cells;
