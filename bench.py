@@ -136,6 +136,44 @@ def self_launch(args, argv):
     return subprocess.call(cmd)
 
 
+def with_human_like_leg(args, argv):
+    """The default run on one GPU: this process stays off the GPU and runs two children one after the other, each alone on it -- the measurement
+    itself (`--as-child`: everything this file did before round 4) and, if the time budget allows, the same timed region on the human-like genome
+    (`--genome-model human`: about half of the genome in repeat classes, what a real human index looks like to the seeding stage).  A child that
+    ran inside the first one's process found that process's sixteen hardware queues still mapped and lost 8 %.  Prints the first child's line
+    with `value_human_like` / `human_like` added."""
+    me = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, me] + argv + ["--as-child"], stdout=subprocess.PIPE)
+    out = r.stdout.decode().strip().splitlines()
+    if r.returncode != 0 or not out:
+        sys.stdout.write(r.stdout.decode())
+        return r.returncode or 1
+    line = json.loads(out[-1])
+    used = time.time() - T_PROCESS_START
+    if used > args.human_like_budget:
+        line["human_like"] = {"skipped": "%.0f s used by the legs before it, budget %.0f s (--human-like-budget)" % (used, args.human_like_budget)}
+    else:
+        try:
+            t = time.time()
+            h = subprocess.run([sys.executable, me, "--as-child", "--genome-model", "human", "--no-secondary", "--no-cpu-baseline", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                "--pairs", str(args.pairs), "--batches", str(args.batches), "--inflight", str(args.inflight), "--mis", str(args.mis), "--cache", args.cache],
+                               stdout=subprocess.PIPE, timeout=400)
+            hl = json.loads(h.stdout.decode().strip().splitlines()[-1])
+            line["value_human_like"] = hl["value"]
+            line["human_like"] = {
+                "value": hl["value"], "unit": hl["unit"], "ms_per_step": hl["ms_per_step"], "steps": hl["steps"], "warmup": hl["warmup"], "workload": hl["config"]["workload"],
+                "kernels_ms": hl["kernels_ms"], "kernels_ms_one_batch_in_flight": hl["kernels_ms_one_batch_in_flight"],
+                "roofline": {k: hl["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_standalone", "frac_of_random_line_ceiling", "seeding_mixed_ceiling", "fingerprint", "stages")},
+                "counters_per_launch": {k: hl["counters_per_launch"].get(k) for k in ("steps", "steps_executed", "occ_blocks_executed", "seeds", "candidates", "nw_calls", "reseed_calls", "general_path_units", "wave_chained_units")},
+                "what": "`bench.py --genome-model human --no-secondary --no-cpu-baseline` with this run's steps / warm-up / batches, a second child process after the first one has left the GPU "
+                        "(its own genome, index and batches: %.0f s)" % (time.time() - t)}
+        except Exception as e:
+            line["human_like"] = {"skipped": "the child run failed: " + repr(e)}
+            log("[bench] human-like leg failed:", repr(e))
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def run_cli(dart_exe, prefix, g, label, seed_pairs, args, cpu_pairs=0, gz_pairs=0):
     """`dart` as a child process: FASTQ files on tmpfs -> SAM + junctions on tmpfs, process start to exit (HIP start-up, index files -> HBM, FASTQ
     parsing, mapping, SAM formatting, writing), best of two.  seed_pairs: [(seed, pairs)] -- the reads are synth.make_reads(g, pairs, seed) one
@@ -150,15 +188,21 @@ def run_cli(dart_exe, prefix, g, label, seed_pairs, args, cpu_pairs=0, gz_pairs=
     base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 1.3 * need else args.cache
     d = tempfile.mkdtemp(prefix="dart_cli_", dir=base)
     try:
-        first = 0
-        head = None
-        for seed, pairs in seed_pairs:
+        from concurrent.futures import ThreadPoolExecutor
+        firsts = [sum(p_ for _, p_ in seed_pairs[:j]) for j in range(len(seed_pairs))]
+        for nm in ("1.fq", "2.fq"):
+            open(os.path.join(d, nm), "wb").close()
+        heads = {}
+
+        def one_chunk(j):                                   # (records have a fixed length: every chunk goes to its own place of the two files)
+            seed, pairs = seed_pairs[j]
             m1, m2 = synth.make_reads(g, pairs, rlen=101, seed=seed, sub_rate=args.sub_rate, indel_frac=args.indel_frac, n_frac=0.002)
-            synth.write_fastq_fast(os.path.join(d, "1.fq"), m1, 1, append=first > 0, first_id=first); synth.write_fastq_fast(os.path.join(d, "2.fq"), m2, 2, append=first > 0, first_id=first)
-            if head is None:
-                head = (m1[:max(cpu_pairs, gz_pairs)].copy(), m2[:max(cpu_pairs, gz_pairs)].copy())
-            first += pairs
-            del m1, m2
+            synth.write_fastq_fast(os.path.join(d, "1.fq"), m1, 1, first_id=firsts[j], in_place=True); synth.write_fastq_fast(os.path.join(d, "2.fq"), m2, 2, first_id=firsts[j], in_place=True)
+            if j == 0:
+                heads[0] = (m1[:max(cpu_pairs, gz_pairs)].copy(), m2[:max(cpu_pairs, gz_pairs)].copy())
+        with ThreadPoolExecutor(max_workers=min(4, len(seed_pairs))) as ex:
+            list(ex.map(one_chunk, range(len(seed_pairs))))
+        head = heads.get(0)
         log("[bench] command-line run: %d pairs of FASTQ under %s prepared in %.1f s" % (total_pairs, d, time.time() - t))
         cores = host_cores()
         cmd = lambda f1, f2, out: [dart_exe, "-i", prefix, "-f", f1, "-f2", f2, "-o", out, "-j", out + ".j", "-t", str(cores), "-mis", str(args.mis)]
@@ -378,13 +422,15 @@ def main():
                          "GRCh38-sized index, process start to exit; 0 = skip (skipped too when the workload is not the default one)")
     ap.add_argument("--cli-cpu-pairs", type=int, default=400000, help="pairs of the same files the CPU command line (oracle/dart_oracle, all host cores) maps beside it, end to end")
     ap.add_argument("--cli-gz-pairs", type=int, default=2000000, help="pairs of the same files, gzipped, through `dart` (what users feed DART: GetData.cpp:181-247); 0 = skip")
-    ap.add_argument("--cli-pairs", type=int, default=4000000,
+    ap.add_argument("--cli-pairs", type=int, default=0,
                     help="after the timed region: the product's `dart` command line end to end (FASTQ files -> SAM file, process start, index load and dg_init included) on "
-                         "this many 2x101 pairs against the chr20-sized genome; 0 = skip")
+                         "this many 2x101 pairs against the chr20-sized genome; 0 = skip (the default since round 4: --cli-big-pairs measures the same on the headline index, "
+                         "and the run's time goes to the human-like leg instead)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (other entry point, device-resident)")
     ap.add_argument("--human-like-budget", type=float, default=330.0,
-                    help="after everything else (default workload, one GPU, CPU legs on): the same timed region on the human-like genome (--genome-model human) as a child process, "
-                         "if this run has used fewer seconds than this so far (the leg costs ~110 s: genome, index, batches); 0 = never")
+                    help="the default workload on one GPU with the CPU legs on: after the measurement, the same timed region on the human-like genome (--genome-model human) as a "
+                         "second child process, if the run has used fewer seconds than this so far (the leg costs ~110 s: genome, index, batches); 0 = never")
+    ap.add_argument("--as-child", action="store_true", help="(set by this file) the measurement itself, in a process of its own: see with_human_like_leg")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("DART_BENCH_INFLIGHT", "12")),
                     help="batches in flight per GPU: contexts sharing one index, one host thread each (dg_clone)")
     ap.add_argument("--cache", default=os.environ.get("DART_BENCH_CACHE", "/tmp/dart_bench_cache"))
@@ -393,6 +439,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
+    if (world == 1 and "RANK" not in os.environ and not args.as_child and args.human_like_budget > 0 and not args.no_cpu_baseline and not args.no_secondary and
+            args.genome == "grch38" and args.genome_model == "planted" and not args.spliced and args.rlen == 101 and args.repeat_scale == 1):
+        sys.exit(with_human_like_leg(args, sys.argv[1:]))
     if args.gpus != world:
         log("[bench] --gpus %d but WORLD_SIZE is %d: start it as `python bench.py --gpus N` or under a launcher with N ranks" % (args.gpus, world))
         sys.exit(2)
@@ -787,6 +836,17 @@ def main():
                 # are 8 to 64 bytes wide, so their FETCH_SIZE needs no correction
                 "random_64B_line_ceiling_GBps": 2580.0,
                 "frac_of_random_line_ceiling": round(achieved / 2580.0, 4),
+                # ... and that ceiling depends on the FOOTPRINT (profiles/probes/footprint_sweep.sh, profiles/r04/y_random_line_rate_vs_footprint.txt): the same random
+                # 64-byte reads run at 39 G lines/s over 3.1 GB and at 19 G lines/s over 16, 49, 118 and 200 GB alike (UTCL1 translation misses 31 % -> 99.5 %:
+                # address translation, 2 MB fragments).  The prefix table (69 GB) and the full suffix array (49 GB) are "far", the Occ blocks (3.1 GB) and the
+                # text (0.8 GB) "near": what the memory side allows the seeding kernels is the sum of the three terms below
+                "seeding_mixed_ceiling": (lambda far, near: (lambda ms_min: {
+                    "far_lines": int(far), "near_lines": int(near), "far_rate_G_lines_per_s": 19.0, "near_rate_G_lines_per_s": 39.3, "streamed_bytes": int(max(0, moved - 64 * (far + near))),
+                    "ms_min": round(ms_min, 4), "frac_of_mixed_ceiling": round(ms_min / ms_alone, 4),
+                    "what": "far = prefix-table look-ups + suffix-array look-ups of the seeding kernels, near = Occ blocks + text windows of the direct comparisons (1.5 lines each), "
+                            "the rest of the launch's PMC bytes streamed at 8 TB/s; ms_min = far / 19.0 G/s + near / 39.3 G/s + streamed / 8 TB/s"})(
+                        (far / 19.0e9 + near / 39.3e9 + max(0, moved - 64 * (far + near)) / 8e12) * 1e3))(
+                    counters.get("ktab_lookups", 0) + counters.get("seedq_slots_locate", 0), counters.get("occ_blocks_executed", 0) + 1.5 * counters.get("direct_extensions", 0)) if dom == "k_seed" else None,
                 "algorithmic_bytes_per_launch": int(dom_bytes),
                 "algorithmic_GBps_standalone": round(dom_bytes / (ms_alone * 1e-3) / 1e9, 1),
                 "algorithmic_GBps_in_timed_region": round(dom_bytes / (kern[dom] * 1e-3) / 1e9, 1),
@@ -882,31 +942,6 @@ def main():
             except Exception as e:
                 log("[bench] command-line run failed:", repr(e))
 
-    # ---- the human-like genome beside the default one (about half of the genome in repeat classes: what a real human index looks like to the seeding stage) ----
-    human = None
-    human_skipped = None
-    if world == 1 and args.genome == "grch38" and args.genome_model == "planted" and not args.spliced and args.rlen == 101 and args.repeat_scale == 1:
-        used = time.time() - T_PROCESS_START
-        if args.no_cpu_baseline or args.no_secondary: human_skipped = "a reduced run (--no-cpu-baseline / --no-secondary)"
-        elif args.human_like_budget <= 0 or used > args.human_like_budget: human_skipped = "%.0f s used by the legs before it, budget %.0f s (--human-like-budget)" % (used, args.human_like_budget)
-        else:
-            try:
-                gpu.close()                                    # (idempotent: the child gets the GPU to itself)
-                t = time.time()
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--genome-model", "human", "--no-secondary", "--no-cpu-baseline", "--steps", str(args.steps), "--warmup", str(args.warmup),
-                                    "--pairs", str(args.pairs), "--batches", str(args.batches), "--inflight", str(args.inflight), "--mis", str(args.mis), "--cache", args.cache],
-                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
-                hl = json.loads(r.stdout.decode().strip().splitlines()[-1])
-                human = {"value": hl["value"], "unit": hl["unit"], "ms_per_step": hl["ms_per_step"], "steps": hl["steps"], "warmup": hl["warmup"], "workload": hl["config"]["workload"],
-                         "kernels_ms": hl["kernels_ms"], "kernels_ms_one_batch_in_flight": hl["kernels_ms_one_batch_in_flight"],
-                         "roofline": {k: hl["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_standalone", "frac_of_random_line_ceiling", "fingerprint", "stages")},
-                         "counters_per_launch": {k: hl["counters_per_launch"].get(k) for k in ("steps", "steps_executed", "occ_blocks_executed", "seeds", "candidates", "nw_calls", "reseed_calls", "general_path_units", "wave_chained_units")},
-                         "what": "`bench.py --genome-model human --no-secondary --no-cpu-baseline` with this run's steps / warm-up / batches, as a child process after this run's contexts were closed "
-                                 "(its own genome, index and batches: %.0f s)" % (time.time() - t)}
-            except Exception as e:
-                human_skipped = "the child run failed: " + repr(e)
-                log("[bench] human-like leg failed:", repr(e))
-
     in_bytes = b0.bytes_packed if args.input == "packed" else b0.bytes_ascii
     line = {
         "metric": "M paired-end reads/sec (2x%d bp vs GRCh38-sized index), host to host; records bit-identical to CPU dart" % args.rlen,
@@ -946,11 +981,6 @@ def main():
     if cli:
         line["value_cli_end_to_end"] = cli["value"]
         line["cli_end_to_end"] = cli
-    if human:
-        line["value_human_like"] = human["value"]
-        line["human_like"] = human
-    elif human_skipped:
-        line["human_like"] = {"skipped": human_skipped}
     if gather_mode == "full":
         line["gather"] = {"mode": "full", "bytes_received_by_rank0_total": gather_bytes[0], "verified_against_single_rank_mapping": gather_verified}
     line.update(secondary)

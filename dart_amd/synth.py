@@ -349,9 +349,10 @@ def write_fastq(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I")) ->
         f.write(b"".join(chunk))
 
 
-def write_fastq_fast(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I"), chunk: int = 500000, append: bool = False, first_id: int = 0) -> None:
+def write_fastq_fast(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I"), chunk: int = 500000, append: bool = False, first_id: int = 0, in_place: bool = False) -> None:
     """FASTQ with fixed-width names "@r<9 digits>/<mate>": every record has the same length, so the file is assembled as a byte matrix
-    (a few million reads per second; write_fastq's per-read loop needs more than a minute for 16 M reads).  For throughput measurements."""
+    (a few million reads per second; write_fastq's per-read loop needs more than a minute for 16 M reads).  For throughput measurements.
+    in_place: the records go to their own place (first_id x record length) of an existing file -- several writers fill one file side by side."""
     n, rlen = seqs.shape
     hdr = 1 + 1 + 9 + 2 + 1                        # @ r ddddddddd / m \n
     rec = hdr + rlen + 3 + rlen + 1
@@ -360,7 +361,8 @@ def write_fastq_fast(path: str, seqs: np.ndarray, mate: int, qual: int = ord("I"
     tmpl[hdr + rlen] = 10; tmpl[hdr + rlen + 1] = ord("+"); tmpl[hdr + rlen + 2] = 10; tmpl[rec - 1] = 10
     d3 = np.array([[ord("0") + k // 100, ord("0") + k // 10 % 10, ord("0") + k % 10] for k in range(1000)], dtype=np.uint8)
     out = np.tile(tmpl, (min(chunk, max(n, 1)), 1))                       # allocated (and paged in) once
-    with open(path, "ab" if append else "wb") as f:
+    with open(path, "r+b" if in_place else ("ab" if append else "wb")) as f:
+        if in_place: f.seek(first_id * rec)
         for c0 in range(0, n, chunk):
             m = min(chunk, n - c0)
             ids = np.arange(first_id + c0, first_id + c0 + m, dtype=np.int64)
