@@ -836,16 +836,17 @@ def main():
                 # are 8 to 64 bytes wide, so their FETCH_SIZE needs no correction
                 "random_64B_line_ceiling_GBps": 2580.0,
                 "frac_of_random_line_ceiling": round(achieved / 2580.0, 4),
-                # ... and that ceiling depends on the FOOTPRINT (profiles/probes/footprint_sweep.sh, profiles/r04/y_random_line_rate_vs_footprint.txt): the same random
-                # 64-byte reads run at 39 G lines/s over 3.1 GB and at 19 G lines/s over 16, 49, 118 and 200 GB alike (UTCL1 translation misses 31 % -> 99.5 %:
-                # address translation, 2 MB fragments).  The prefix table (69 GB) and the full suffix array (49 GB) are "far", the Occ blocks (3.1 GB) and the
-                # text (0.8 GB) "near": what the memory side allows the seeding kernels is the sum of the three terms below
-                "seeding_mixed_ceiling": (lambda far, near: (lambda ms_min: {
-                    "far_lines": int(far), "near_lines": int(near), "far_rate_G_lines_per_s": 19.0, "near_rate_G_lines_per_s": 39.3, "streamed_bytes": int(max(0, moved - 64 * (far + near))),
+                # ... per class of access (profiles/probes/footprint_sweep.sh, profiles/r04/y_random_line_rate_vs_footprint.txt): a random look-up made with ONE load
+                # instruction (16 bytes of the prefix table, 8 of the suffix array) runs at 46-49 G/s whatever the footprint (3 to 118 GB); a random 64-byte
+                # access is FOUR 16-byte loads, each translated on its own once the footprint is beyond the translation caches' reach: 39 G/s over the 3.1 GB
+                # Occ array (UTCL1 misses 31 %), 21 G/s over 8 GB, 19 G/s over 16-200 GB (99.5 %) -- ~76 G load instructions/s is what the translation path
+                # takes.  The seeding kernels make their wide accesses only in the 3.1 GB Occ array and the 0.8 GB text, so what the memory side allows them is
+                "seeding_mixed_ceiling": (lambda one, wide: (lambda ms_min: {
+                    "single_load_lookups": int(one), "occ_blocks_and_text_windows": int(wide), "single_load_rate_G_per_s": 46.0, "wide_rate_G_per_s": 39.3, "streamed_bytes": int(max(0, moved - 64 * (one + wide))),
                     "ms_min": round(ms_min, 4), "frac_of_mixed_ceiling": round(ms_min / ms_alone, 4),
-                    "what": "far = prefix-table look-ups + suffix-array look-ups of the seeding kernels, near = Occ blocks + text windows of the direct comparisons (1.5 lines each), "
-                            "the rest of the launch's PMC bytes streamed at 8 TB/s; ms_min = far / 19.0 G/s + near / 39.3 G/s + streamed / 8 TB/s"})(
-                        (far / 19.0e9 + near / 39.3e9 + max(0, moved - 64 * (far + near)) / 8e12) * 1e3))(
+                    "what": "single-load look-ups = prefix-table entries + suffix-array entries read by the seeding kernels, wide = Occ blocks + text windows of the direct comparisons "
+                            "(1.5 lines each), the rest of the launch's PMC bytes streamed at 8 TB/s; ms_min = single / 46 G/s + wide / 39.3 G/s + streamed / 8 TB/s"})(
+                        (one / 46.0e9 + wide / 39.3e9 + max(0, moved - 64 * (one + wide)) / 8e12) * 1e3))(
                     counters.get("ktab_lookups", 0) + counters.get("seedq_slots_locate", 0), counters.get("occ_blocks_executed", 0) + 1.5 * counters.get("direct_extensions", 0)) if dom == "k_seed" else None,
                 "algorithmic_bytes_per_launch": int(dom_bytes),
                 "algorithmic_GBps_standalone": round(dom_bytes / (ms_alone * 1e-3) / 1e9, 1),
