@@ -427,6 +427,7 @@ def main():
                          "this many 2x101 pairs against the chr20-sized genome; 0 = skip (the default since round 4: --cli-big-pairs measures the same on the headline index, "
                          "and the run's time goes to the human-like leg instead)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (other entry point, device-resident)")
+    ap.add_argument("--repeats", type=int, default=-1, help="more runs of the same K steps after the timed region (value_repeats); default: 2, with --no-secondary 0")
     ap.add_argument("--human-like-budget", type=float, default=330.0,
                     help="the default workload on one GPU with the CPU legs on: after the measurement, the same timed region on the human-like genome (--genome-model human) as a "
                          "second child process, if the run has used fewer seconds than this so far (the leg costs ~110 s: genome, index, batches); 0 = never")
@@ -655,7 +656,7 @@ def main():
             kern[k] = kern.get(k, 0.0) + v
     kern = {k: v / max(runs, 1) for k, v in kern.items()}
     # the spread of the figure: two more runs of the same K steps (the line's `value` is the first, the contract's)
-    repeats = [elapsed] + [timed(args.steps * nb, args.input) for _ in range(0 if args.no_secondary else 2)]
+    repeats = [elapsed] + [timed(args.steps * nb, args.input) for _ in range(args.repeats if args.repeats >= 0 else (0 if args.no_secondary else 2))]
     counters = workers[0].gpu.counters()
     # batches a context had to run again since it was created, over all contexts: capacities that grew (expected while the first batches
     # size the buffers), scans that did not complete (dg_scan.h: should be 0)

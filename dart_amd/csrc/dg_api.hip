@@ -61,6 +61,10 @@ struct IndexShared {
     void *d_ktab = nullptr, *d_sa_dense = nullptr;
     std::string report, report_out;
     int device = 0;
+    // the re-seeding kernels' streams, shared by the contexts of this index (DG_S2_SHARED, make_ctx_objects)
+    hipStream_t s2[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n_s2 = -1;                            // -1 = not decided yet
+    std::atomic<int> n_ctx{0};
 };
 
 struct dg_ctx {
@@ -68,6 +72,7 @@ struct dg_ctx {
     IndexShared *shared_ix = nullptr; uint32_t ix_gen = 0;
     bool owns_index = true;       // false for dg_clone()d contexts: the index arrays belong to the parent
     hipStream_t stream = nullptr, stream2 = nullptr;
+    bool owns_stream2 = true;
     hipEvent_t ev_dl = nullptr, ev_dl_block = nullptr;      // this context's place in the device's copy stream (copy_stream below); _block: the host thread sleeps (DG_BLOCKING_SYNC)
     bool dl_on_copy_stream = false;
     int env_copy_stream = 1;                           // DG_COPY_STREAM: 0 = the downloads on the context's own stream, 1 = on the device's copy stream
@@ -534,6 +539,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->owns_index && c->shared_ix) for (hipStream_t &q : c->shared_ix->s2) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); q = nullptr; }   // (clones go before their parent)
     if (c->owns_index && c->shared_ix) {          // the aids thread may still be allocating or building: it ends by itself (a failed upload tells it so)
         IndexShared *sh = c->shared_ix;
         { std::lock_guard<std::mutex> lk(sh->mu); if (!sh->upload_done) { sh->upload_done = true; sh->upload_ok = false; } }
@@ -560,7 +566,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     if (c->ev_dl_block) (void)hipEventDestroy(c->ev_dl_block);
     if (c->ev_reseed0) (void)hipEventDestroy(c->ev_reseed0);
     if (c->ev_reseed1) (void)hipEventDestroy(c->ev_reseed1);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream2 && c->owns_stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->owns_shared_caps) delete c->shared_caps;
     delete c;
@@ -574,6 +580,10 @@ static hipError_t make_ctx_objects(dg_ctx *c)
     // DG_CU_PARTS=P (measurement switch, profiles/r04/y_*): context k's two streams only get the compute units of part k % P (DG_CU_LAYOUT 0: P contiguous
     // ranges of the mask's bits, 1: bit i belongs to part (i % 8) % P) -- fewer different kernels share a CU's instruction cache and LDS at a time
     static std::atomic<int> n_made{0};
+    if (getenv("DG_EXP_CTX_PAD_KB")) {         // measurement switch: context k's allocations start behind a pad of (k + 1) x this many KB (never freed: an experiment)
+        void *pad = nullptr; static std::atomic<int> n_pad{0};
+        (void)hipMalloc(&pad, (size_t)(n_pad.fetch_add(1) + 1) * (size_t)atoll(getenv("DG_EXP_CTX_PAD_KB")) * 1024);
+    }
     const int parts = getenv("DG_CU_PARTS") ? atoi(getenv("DG_CU_PARTS")) : 0, layout = getenv("DG_CU_LAYOUT") ? atoi(getenv("DG_CU_LAYOUT")) : 0;
     if (parts > 1) {
         int n_cu = 0; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
@@ -581,8 +591,25 @@ static hipError_t make_ctx_objects(dg_ctx *c)
         std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
         for (int i = 0; i < n_cu; i++) { const int pi = layout == 1 ? (i % 8) % parts : (int)((long long)i * parts / n_cu); if (pi == part) mask[(size_t)i / 32] |= 1u << (i % 32); }
         if ((e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data())) != hipSuccess || (e = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)mask.size(), mask.data())) != hipSuccess) return e;
-    } else
-    if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) return e;
+    } else {
+        // A device's contexts share a few streams for their re-seeding kernels (four launches per batch) instead of owning one each: the runtime maps streams
+        // onto GPU_MAX_HW_QUEUES hardware queues, least-used first with ties broken by the queues' addresses -- with twelve contexts x two streams on sixteen
+        // queues, which contexts' MAIN streams ended up on one queue (and then ran their kernels one after the other) differed from process to process:
+        // 826 to 985 M reads/s for the same command (profiles/r04/x_modes_*).  Twelve main streams + DG_S2_SHARED (3) shared ones + the caller's own stream
+        // fit the sixteen queues without sharing.  0 = a private stream per context (rounds 2-3).
+        IndexShared *sh = c->shared_ix;
+        if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return e;
+        if (sh) {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            if (sh->n_s2 < 0) { const int n = getenv("DG_S2_SHARED") ? atoi(getenv("DG_S2_SHARED")) : 3; sh->n_s2 = n < 0 ? 0 : (n > 8 ? 8 : n); }
+            if (sh->n_s2 > 0) {
+                const int k = sh->n_ctx.fetch_add(1) % sh->n_s2;
+                if (!sh->s2[k] && (e = hipStreamCreate(&sh->s2[k])) != hipSuccess) return e;
+                c->stream2 = sh->s2[k]; c->owns_stream2 = false;
+            }
+        }
+        if (!c->stream2 && (e = hipStreamCreate(&c->stream2)) != hipSuccess) return e;
+    }
     if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_dl, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_dl_block, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return e;
@@ -786,6 +813,17 @@ static dg_ctx *init_index(const IndexMeta &m, UpSrc bwt, uint64_t bwt_off, UpSrc
     if (e != hipSuccess || ndev == 0) return bail(DG_ERR_NO_DEVICE, "no HIP device (libdartgpu has no CPU fallback)", e);
     if (device < 0 || device >= ndev) return bail(DG_ERR_NO_DEVICE, "device ordinal out of range", hipSuccess);
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(DG_ERR_HIP, "hipSetDevice", e);
+    if (getenv("DG_EXP_PREALLOC_GB")) {        // measurement switch (where the allocations land: profiles/r04/x_modes_*): take and give back this much memory first
+        void *dummy = nullptr;
+        if (hipMalloc(&dummy, (size_t)atoll(getenv("DG_EXP_PREALLOC_GB")) << 30) == hipSuccess) { (void)hipMemset(dummy, 0, 1 << 20); (void)hipDeviceSynchronize(); (void)hipFree(dummy); }
+    }
+    if (getenv("DG_EXP_HOLD_GB")) { void *hold = nullptr; (void)hipMalloc(&hold, (size_t)atoll(getenv("DG_EXP_HOLD_GB")) << 30); }      // (kept: shifts what follows)
+    if (getenv("DG_EXP_CHURN_GB")) {           // this much memory in 4 GB blocks, every other one given back first, then the rest: a free list in pieces
+        std::vector<void *> blk((size_t)atoll(getenv("DG_EXP_CHURN_GB")) / 4, nullptr);
+        for (auto &b : blk) (void)hipMalloc(&b, (size_t)4 << 30);
+        for (size_t i = 0; i < blk.size(); i += 2) (void)hipFree(blk[i]);
+        for (size_t i = 1; i < blk.size(); i += 2) (void)hipFree(blk[i]);
+    }
     c = new dg_ctx();
     c->device = device;
     c->shared_caps = new dg_ctx::SharedCaps(); c->owns_shared_caps = true;
@@ -1468,7 +1506,7 @@ static int finish_run(dg_ctx *c, size_t used[3])
     for (int attempt = 0; attempt < 6; attempt++) {
         c->runs_of_last_batch++;
         HIPCHK(wait_stream(c));
-        HIPCHK(hipStreamSynchronize(c->stream2));
+        if (c->owns_stream2) HIPCHK(hipStreamSynchronize(c->stream2));      // (a shared one holds other contexts' kernels too; this context's are behind ev_reseed1, which its main stream waited for)
         if (c->enc_ready && c->h_tail->input_bad) { snprintf(c->err, 512, "packed batch: the N list holds a position outside the batch"); c->enqueued = false; return DG_ERR_ARG; }
         const DSizes &sz = c->h_tail->sizes;
         const int derr = c->h_tail->err;

@@ -246,6 +246,13 @@ __host__ __device__ inline bool d_small_nw_is_diagonal(uint64_t a8, uint64_t b8,
 struct ReadAscii {
     const unsigned char *p;
     __host__ __device__ __forceinline__ uint64_t get8(int i, int e) const { uint64_t v = 0; for (int t = 0; t < e; t++) v |= (uint64_t)p[i + t] << (8 * t); return v; }
+    // characters i .. i + e - 1 against RefSequence[g .. g + e): how many differ, and whether one of the read's is a '-' (tools.cpp:130-164 compares characters)
+    __host__ __device__ __forceinline__ int mismatches8(const DIndex &ix, int i, int e, int64_t g, bool &dash) const {
+        const uint64_t ref = d_ref8(ix, g), a8 = get8(i, e), keep = e == 8 ? ~0ull : (1ull << (8 * e)) - 1ull, lo7 = 0x7F7F7F7F7F7F7F7Full, hi1 = 0x8080808080808080ull;
+        const uint64_t x = (a8 ^ ref) & keep, y = (a8 ^ 0x2D2D2D2D2D2D2D2Dull) | ~keep;
+        dash = dash || ((~(((y & lo7) + lo7) | y)) & hi1) != 0ull;
+        return __builtin_popcountll((((x & lo7) + lo7) | x) & hi1);
+    }
 };
 struct ReadWords {
     const uint32_t *w; int W2;           // k_encode's format: W2 words of 2-bit codes (first base on top), then W2 words with 0b11 where the base is no A/C/G/T
@@ -260,6 +267,29 @@ struct ReadWords {
             v |= (uint64_t)(m ? 0x4Eu : ((0x54474341u >> (8u * c)) & 0xFFu)) << (8 * t);
         }
         return v;
+    }
+    // the same count in the 2-bit domain: a packed batch's reads are A/C/G/T/N by contract (never a '-'), RefSequence is A/C/G/T (pac), so characters differ
+    // exactly where the codes differ or the read's base is masked -- no character is ever built.  Windows that are not wholly inside one strand of the
+    // text (d_ref8's per-character path: 0 outside) take the character form.
+    __host__ __device__ __forceinline__ int mismatches8(const DIndex &ix, int i, int e, int64_t g, bool &dash) const {
+        const int64_t L = ix.l_pac;
+        uint32_t g16;                              // eight genome codes, base k at bits 15-2k .. 14-2k
+        if (g >= 0 && g + 8 <= L) g16 = (__builtin_bswap32(*(const uint32_a1 *)(ix.pac + (g >> 2))) << ((g & 3) << 1)) >> 16;
+        else if (g >= L && g + 8 <= 2 * L) {
+            const int64_t lo = 2 * L - 1 - g - 7;                                                                  // fwd[lo .. lo+7], Ref[g+k] = 3 - fwd[lo+7-k]
+            const uint32_t w = (__builtin_bswap32(*(const uint32_a1 *)(ix.pac + (lo >> 2))) << ((lo & 3) << 1)) >> 16;   // fwd[lo+q] at bits 15-2q .. 14-2q
+            uint32_t r = ((w & 0x3333u) << 2) | ((w >> 2) & 0x3333u); r = ((r & 0x0F0Fu) << 4) | ((r >> 4) & 0x0F0Fu); r = ((r & 0x00FFu) << 8) | (r >> 8);   // 2-bit groups reversed
+            g16 = ~r & 0xFFFFu;
+        } else {
+            const uint64_t ref = d_ref8(ix, g), a8 = get8(i, e), keep = e == 8 ? ~0ull : (1ull << (8 * e)) - 1ull, lo7 = 0x7F7F7F7F7F7F7F7Full, hi1 = 0x8080808080808080ull;
+            const uint64_t x = (a8 ^ ref) & keep;
+            return __builtin_popcountll((((x & lo7) + lo7) | x) & hi1);
+        }
+        const int w0 = i >> 4, sh = (i & 15) << 1;
+        const uint32_t chi = w[w0], clo = w0 + 1 < W2 ? w[w0 + 1] : 0u, mhi = w[W2 + w0], mlo = w0 + 1 < W2 ? w[W2 + w0 + 1] : 0xFFFFFFFFu;
+        const uint32_t c16 = (sh ? (chi << sh) | (clo >> (32 - sh)) : chi) >> 16, m16 = (sh ? (mhi << sh) | (mlo >> (32 - sh)) : mhi) >> 16;
+        const uint32_t x = c16 ^ g16, keep = (0xFFFF0000u >> (2 * e)) & 0xFFFFu;
+        return __builtin_popcount(((x | (x >> 1)) | m16) & 0x5555u & keep);
     }
 };
 
@@ -293,15 +323,7 @@ __host__ __device__ inline bool d_unit_reports(const DIndex &ix, const LocTab &l
             const int64_t gp = sk_gpos(prev) + sk_rlen(prev);
             int nm = 0;
             bool dash = false;
-            for (int q = 0; q < g; q += 8) {
-                const uint64_t ref = d_ref8(ix, gp + q);
-                const int e = g - q < 8 ? g - q : 8;
-                // e characters at once: bytes that differ from the genome's, and whether one of them is a '-' (tools.cpp:130-164 compares characters)
-                const uint64_t a8 = seq.get8(from + q, e), keep = e == 8 ? ~0ull : (1ull << (8 * e)) - 1ull, lo7 = 0x7F7F7F7F7F7F7F7Full, hi1 = 0x8080808080808080ull;
-                const uint64_t x = (a8 ^ ref) & keep, y = (a8 ^ 0x2D2D2D2D2D2D2D2Dull) | ~keep;
-                nm += __builtin_popcountll((((x & lo7) + lo7) | x) & hi1);
-                dash = dash || ((~(((y & lo7) + lo7) | y)) & hi1) != 0ull;
-            }
+            for (int q = 0; q < g; q += 8) nm += seq.mismatches8(ix, from + q, g - q < 8 ? g - q : 8, gp + q, dash);     // eight characters at once
             if (nm <= 2 && nm <= (int)(g * 0.2)) { aln += g - nm; mis += nm; }
             else if (g == 1 && !dash) { calls++; cells++; mis += 1; }
             else if (g <= SMALL_NW && !dash && d_small_nw_is_diagonal(seq.get8(from, g), d_ref8(ix, gp), g)) {
@@ -480,6 +502,16 @@ __host__ __device__ inline uint32_t d_unit_emit_read(bool first, const DRead &rd
 // ---------------------------------------------------------------------------------------------
 #include "dg_scan.h"
 
+// the pac word a gap comparison that starts behind seed k will read first (ReadWords::mismatches8 / d_ref8: the same address on either strand); 0 for windows
+// at the edges of the text, which take the per-character path
+__device__ __forceinline__ uint32_t d_pac_touch(const DIndex &ix, SKey k)
+{
+    const int64_t L = ix.l_pac, g = sk_gpos(k) + sk_rlen(k);
+    if (g >= 0 && g + 8 <= L) return *(const uint32_a1 *)(ix.pac + (g >> 2));
+    if (g >= L && g + 8 <= 2 * L) return *(const uint32_a1 *)(ix.pac + ((2 * L - 1 - g - 7) >> 2));
+    return 0u;
+}
+
 template <bool PACKED>      // the reads of the batch: their 2-bit + mask words (a packed batch: enc, W2) or their ASCII bytes (seq, seq_off)
 __global__ void __launch_bounds__(PU_THREADS)
 k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast, int write_all_sorted,
@@ -528,9 +560,12 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
 #endif
     int r1 = 0, n1 = 0, n2 = 0, len1 = 0, len2 = 0;
     uint32_t b1 = 0;
+    uint32_t pf = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0;
     bool heavy = false;
     if (valid) {
         r1 = paired ? 2 * u : u;
+        len1 = rlen[r1]; len2 = paired ? rlen[r1 + 1] : 0;        // (asked for here, beside the seed offsets: not one more round trip behind the seeds)
+        if (PACKED) { pf = enc[(size_t)r1 * 2 * W2 + (W2 >> 1)]; if (paired) pf2 = enc[(size_t)(r1 + 1) * 2 * W2 + (W2 >> 1)]; }     // touched early, see below
         b1 = seed_off[r1];
         const uint32_t e1 = seed_off[r1 + 1], e2 = paired ? seed_off[r1 + 2] : e1;
         n1 = (int)(e1 - b1); n2 = (int)(e2 - e1);
@@ -545,7 +580,14 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
                 if (i0 + 2 < nt) key[(i0 + 2) * PU_THREADS] = k2;
                 if (i0 + 3 < nt) key[(i0 + 3) * PU_THREADS] = k3;
             }
-            len1 = rlen[r1]; len2 = paired ? rlen[r1 + 1] : 0;
+#ifdef __HIP_DEVICE_COMPILE__
+            __asm__ volatile("" ::: "memory");   // (the seeds are in LDS: nothing below may use their registers, or its wait for them would be a wait for the touches too)
+#endif
+            // Touch now what the reports phase will read after sorting, clustering and the candidate rules: the unit's read words (above) and the text behind the
+            // first two seeds of each mate (where the gap to the next seed begins).  Those loads were the phase's dependent round trips to HBM, one per gap,
+            // one after the other; touched here they are on their way while the lane works in LDS.  The values only keep the loads alive (see the end).
+            if (n1 > 1) { pf3 = d_pac_touch(ix, key[0]); if (n1 > 2) pf4 = d_pac_touch(ix, key[1 * PU_THREADS]); }
+            if (n2 > 1) { pf5 = d_pac_touch(ix, key[n1 * PU_THREADS]); if (n2 > 2) pf6 = d_pac_touch(ix, key[(n1 + 1) * PU_THREADS]); }
             PP_STAMP(st.pp, st.pt, 0);       // ticket, seed offsets, seeds into LDS
             if (PACKED) {
                 const ReadWords a{enc + (size_t)r1 * 2 * W2, W2}, b{enc + (size_t)(r1 + (paired ? 1 : 0)) * 2 * W2, W2};
@@ -623,6 +665,7 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
         printf("kpair tile %u wave %d: total %llu | load %llu sort+cluster %llu rules %llu reports %llu settle %llu rest %llu blockscan %llu lookback %llu emit %llu\n", tile, (int)(threadIdx.x >> 6),
                __builtin_amdgcn_s_memtime() - pp_t0, st.pp[0], st.pp[1], st.pp[2], st.pp[3], st.pp[4], st.pp[5], st.pp[6], st.pp[7], st.pp[8]);
 #endif
+    if (n_units < 0 && (pf ^ pf2 ^ pf3 ^ pf4 ^ pf5 ^ pf6) == 0x5A17C3E1u) atomicMax(err, DG_E_SCAN);      // (never true: what keeps the touches above from being dropped)
     d_wave_add(ctr + CTR_CANDS, n_cands);
     d_wave_add(ctr + CTR_NW, n_nw);
     d_wave_add(ctr + CTR_NWCELLS, n_cells);
