@@ -510,12 +510,32 @@ int main(int argc, char *argv[])
     const int inflight_cfg = std::max(1, getenv("DART_INFLIGHT") ? atoi(getenv("DART_INFLIGHT")) : 2);
     FastqIndex pre;                         // the first library's read files are mapped and indexed while the HIP runtime starts, the genome index loads and dg_init_files runs
     bool fast_first = false;
+    // A library of .gz FASTQ files small enough to be inflated whole (libdeflate, ~3x zlib; DART_GZ_WHOLE_MAX_GB per file, default 8) goes through the
+    // parallel pipeline too -- if the inflated text is one the reference's gz reader and its plain reader see alike (FastqIndex::run); else, and for
+    // everything libdeflate cannot take, the streaming reader below.
+    const size_t gz_whole_max = (size_t)((getenv("DART_GZ_WHOLE_MAX_GB") ? atof(getenv("DART_GZ_WHOLE_MAX_GB")) : 8.0) * (double)(1ull << 30));
+    auto is_gz = [](const std::string &fn) { return fn.substr(fn.find_last_of('.') + 1) == "gz"; };
+    auto gz_whole_candidate = [&](size_t lib) -> bool {
+        if (o.bam || getenv("DART_STREAMING") || !lib_deflate().ok() || gz_whole_max == 0) return false;
+        const bool two = o.f1.size() == o.f2.size();
+        struct stat st;
+        const std::string *fns[2] = {&o.f1[lib], two ? &o.f2[lib] : nullptr};
+        for (const std::string *fn : fns) {
+            if (!fn) continue;
+            if (!is_gz(*fn) || !check_read_format(fn->c_str()) || stat(fn->c_str(), &st) != 0 || (size_t)st.st_size > gz_whole_max / 2) return false;
+        }
+        return true;
+    };
+    bool gz_first = false;
     {
         const std::string &fn0 = o.f1[0];
-        if (!o.bam && !getenv("DART_STREAMING") && fn0.substr(fn0.find_last_of('.') + 1) != "gz" && check_read_format(fn0.c_str())) {
+        const bool two = o.f1.size() == o.f2.size();
+        if (!o.bam && !getenv("DART_STREAMING") && !is_gz(fn0) && check_read_format(fn0.c_str())) {
             fast_first = true;
-            const bool two = o.f1.size() == o.f2.size();
-            if (!two || o.f2[0].substr(o.f2[0].find_last_of('.') + 1) != "gz") pre.start(fn0.c_str(), two ? o.f2[0].c_str() : nullptr, o.threads);
+            if (!two || !is_gz(o.f2[0])) pre.start(fn0.c_str(), two ? o.f2[0].c_str() : nullptr, o.threads);
+        } else if (gz_whole_candidate(0)) {
+            fast_first = gz_first = true;
+            pre.start(fn0.c_str(), two ? o.f2[0].c_str() : nullptr, o.threads, true, gz_whole_max);
         }
     }
     // every device of the node maps batches (reads shard, the index is replicated; the reference's -t threads over one shared index,
@@ -552,7 +572,7 @@ int main(int argc, char *argv[])
         if (L.sep && !L.fast_host) { L.pf1.start(&L.s1, false); L.pf2.start(&L.s2, true); }      // (separate mate files: paired, mate 2 reverse-complemented)
         return L.state = 0;
     };
-    if (!fast_first && o.index && file_exists(std::string(o.index) + ".ann")) open_lib(0);
+    if (!fast_first && o.index && file_exists(std::string(o.index) + ".ann")) open_lib(0);      // (a whole-file .gz library that turns out not to qualify opens its streams late: rare)
     HostIndex ix;
     if (!o.index || !file_exists(std::string(o.index) + ".ann") || !file_exists(std::string(o.index) + ".amb") || !file_exists(std::string(o.index) + ".pac")) {
         fprintf(stderr, "Error! Please specify a valid reference index!\n"); usage(argv[0], o); return 1;
@@ -617,6 +637,26 @@ int main(int argc, char *argv[])
     if (o.silent) fprintf(stdout, "Start read mapping...\n");
     bool pair_end = o.pair_end;
     for (size_t lib = 0; lib < o.f1.size(); lib++) {
+        {   // .gz FASTQ inflated whole: the parallel pipeline on the inflated text (library 0's files have been inflating since before the GPU was touched)
+            std::unique_ptr<FastqIndex> own_gz;
+            FastqIndex *gi = nullptr;
+            if (lib == 0 && gz_first) { pre.wait(); gi = &pre; }
+            else if (lib > 0 && gz_whole_candidate(lib)) { own_gz.reset(new FastqIndex()); own_gz->run(o.f1[lib].c_str(), o.f1.size() == o.f2.size() ? o.f2[lib].c_str() : nullptr, o.threads, true, gz_whole_max); gi = own_gz.get(); }
+            if (gi && gi->ok) {
+                const bool sep = o.f1.size() == o.f2.size();
+                if (sep) pair_end = true;
+                fflush(sam);
+                uint64_t off = (uint64_t)ftello(sam);
+                std::string ferr; FastStats fst;
+                const int frc = run_fast_library(o.f1[lib].c_str(), sep ? o.f2[lib].c_str() : nullptr, pair_end, o.threads, batch_reads, ctx, o.p, ix.names, o.unique, o.multi, o.silent,
+                                                 fileno(sam), &off, total, sjmap, t0, ferr, fst, pool, gi);
+                fseeko(sam, (off_t)off, SEEK_SET);
+                if (frc) { fprintf(stderr, "\nError! GPU mapping failed (%d): %s\n", frc, ferr.c_str()); return 1; }
+                if (getenv("DART_TIMING")) fprintf(stderr, "[dart timing] start-up %.3f s (%s), inflate (libdeflate, whole files) + index %.3f s, assemble %.3f s (of which page-locked allocation %.3f s), map (sum over workers) %.3f s, format %.3f s, write %.3f s\n", t_init1 - t_proc0, dg_init_report(roots[0]), fst.t_index, fst.t_asm, fst.t_alloc, fst.t_map, fst.t_fmt, fst.t_write);
+                gi->m1.close_now(); gi->m2.close_now();
+                continue;
+            }
+        }
         const int orc = open_lib(lib);              // (library 0 was opened before the index went to the GPU: its files are being inflated and parsed since)
         if (orc == 2) return 1;
         if (orc == 1) continue;

@@ -30,8 +30,23 @@ extern "C" const char *dg_last_error(const dg_ctx *) { return ""; }
 static unsigned long long rs = 88172645463325252ull;
 static unsigned long long rnd() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; }
 
-int main()
+// `host_text_checks gz FILE.gz PLAIN`: the whole-file .gz path (MappedFile::open_gz + FastqIndex::run(gz)): prints whether the library qualifies for the
+// parallel pipeline and, if so, whether the inflated bytes are PLAIN's and how many records were indexed
+static int gz_mode(const char *gz, const char *plain)
 {
+    if (!lib_deflate().ok()) { printf("libdeflate missing\n"); return 0; }
+    FastqIndex fi;
+    fi.run(gz, nullptr, 3, true, (size_t)1 << 30);
+    if (!fi.ok) { printf("qualifies=0\n"); return 0; }
+    MappedFile pf;
+    const bool same = pf.open(plain) && pf.n == fi.m1.n && (pf.n == 0 || memcmp(pf.p, fi.m1.p, pf.n) == 0);
+    printf("qualifies=1 same_bytes=%d records=%zu\n", (int)same, fi.r1.size());
+    return same ? 0 : 1;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc == 4 && strcmp(argv[1], "gz") == 0) return gz_mode(argv[2], argv[3]);
     long bad = 0, n_str = 0, n_files = 0, n_recs = 0;
     const char *al = "ACGTacgtNnRYxX-*@!";
     for (int it = 0; it < 100000; it++) {
