@@ -235,34 +235,42 @@ def test_gpu_records_as_torch_tensor_for_rccl(ctxs):
     assert np.array_equal(back, res.reads)
 
 
-def test_gpu_cloned_contexts_run_concurrently(workdir):
+def test_gpu_cloned_contexts_run_concurrently(workdir, monkeypatch):
     """dg_clone: contexts sharing one index, one host thread each, different batches in flight at once (bench.py's
-    pipeline); every context's records equal the oracle's"""
+    pipeline); every context's records equal the oracle's.  The contexts' re-seeding kernels (a sixth of these reads span an intron) run on streams the
+    contexts SHARE (DG_S2_SHARED, 3 by default; dg_api.hip make_ctx_objects): five contexts on three, on one, and on private streams (0)."""
     import threading
     g = synth.make_genome([1200000, 800000], seed=51, repeat_scale=40.0, n_introns=200)
     prefix = os.path.join(workdir, "clones")
     index_build.build_index_from_genome(g, prefix)
     ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
-    gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
-    ctx = [gpu, gpu.clone(), gpu.clone()]
-    batches = []
-    for j in range(3):
-        m1, m2 = synth.make_reads(g, 15000 + 3000 * j, rlen=101, seed=52 + j, spliced_frac=0.15, indel_frac=0.04, n_frac=0.01)
+    n_ctx = 5
+    batches, want = [], []
+    for j in range(n_ctx):
+        m1, m2 = synth.make_reads(g, 9000 + 2000 * j, rlen=101, seed=52 + j, spliced_frac=0.15, indel_frac=0.04, n_frac=0.01)
         batches.append(host.pack_reads(host.interleave_pairs(m1, m2)))
-    out, errs = [None] * 3, []
-    def work(j):
-        try:
-            for _ in range(3):                       # several rounds so that the batches really overlap
-                out[j] = ctx[j].map_batch(*batches[j])
-        except Exception as e:
-            errs.append(e)
-    th = [threading.Thread(target=work, args=(j,)) for j in range(3)]
-    for t in th: t.start()
-    for t in th: t.join()
-    assert not errs, errs
-    for j in range(3):
-        assert_same(out[j], orc.map_batch(orc.params(paired=1, max_mismatch=5), *batches[j], threads=16))
-    gpu.close(); orc.close()
+        want.append(orc.map_batch(orc.params(paired=1, max_mismatch=5), *batches[j], threads=16))
+    for shared in (None, "1", "0"):
+        if shared is None: monkeypatch.delenv("DG_S2_SHARED", raising=False)
+        else: monkeypatch.setenv("DG_S2_SHARED", shared)
+        gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5))
+        ctx = [gpu] + [gpu.clone() for _ in range(n_ctx - 1)]
+        out, errs = [None] * n_ctx, []
+        def work(j):
+            try:
+                for _ in range(3):                       # several rounds so that the batches really overlap
+                    out[j] = ctx[j].map_batch(*batches[j])
+            except Exception as e:
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(j,)) for j in range(n_ctx)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not errs, (shared, errs)
+        for j in range(n_ctx):
+            assert_same(out[j], want[j])
+        gpu.close()
+    monkeypatch.delenv("DG_S2_SHARED", raising=False)
+    orc.close()
 
 
 def test_gpu_reference_equivalent_counters(workdir):
