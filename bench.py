@@ -441,7 +441,7 @@ def main():
                          "and the run's time goes to the human-like leg instead)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (other entry point, device-resident)")
     ap.add_argument("--repeats", type=int, default=-1, help="more runs of the same K steps after the timed region (value_repeats); default: 2, with --no-secondary 0")
-    ap.add_argument("--human-like-budget", type=float, default=330.0,
+    ap.add_argument("--human-like-budget", type=float, default=200.0,
                     help="the default workload on one GPU with the CPU legs on: after the measurement, the same timed region on the human-like genome (--genome-model human) as a "
                          "second child process, if the run has used fewer seconds than this so far (the leg costs ~110 s: genome, index, batches); 0 = never")
     ap.add_argument("--as-child", action="store_true", help="(set by this file) the measurement itself, in a process of its own: see with_human_like_leg")
