@@ -9,12 +9,13 @@
 //   an integer tag is read like strtol reads it: "XS:i:7 XS:A:+" (the reference joins its strand tag with a blank, not a tab) gives
 //   XS:i:7 and nothing else, exactly as the reference's BAM loses the strand tag;
 //   a line htslib would refuse (quality and sequence of different lengths, an unknown reference name) is dropped, as there;
-//   BGZF    = blocks of at most 0xff00 input bytes, raw deflate at zlib's default level, 'BC' extra field, CRC32, ISIZE; the header has
+//   BGZF    = blocks of at most 0xff00 input bytes, raw deflate at zlib's default level (by the system's libdeflate when it is there: libdeflate_dl.h), 'BC' extra field, CRC32, ISIZE; the header has
 //             its own block(s); the 28-byte end-of-file block closes the file.  Blocks are compressed by `threads` workers, written in order.
 // htslib itself cannot be built here (its Makefile generates version.h / config.h), so the COMPRESSED bytes are not pinned against the
 // reference's; the decoded content is: tests/test_host_text.py decodes the BAM and compares it with the reference-generated golden SAM.
 #pragma once
 #include <zlib.h>
+#include "libdeflate_dl.h"
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
@@ -227,14 +228,25 @@ private:
     static bool compress_block(const uint8_t *src, size_t n, std::vector<uint8_t> &dst)
     {
         dst.resize(18 + compressBound((uLong)n) + 8);
-        z_stream zs; memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-        zs.next_in = (Bytef *)src; zs.avail_in = (uInt)n;
-        zs.next_out = dst.data() + 18; zs.avail_out = (uInt)(dst.size() - 18 - 8);
-        const int rc = deflate(&zs, Z_FINISH);
-        const size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) return false;
+        size_t clen = 0;
+        const LibDeflate &ld = lib_deflate();
+        if (ld.ok_deflate()) {                        // level 6 = zlib's default; one compressor per worker thread
+            struct Own { void *c = nullptr; const LibDeflate *l = nullptr; ~Own() { if (c) l->release_c(c); } };
+            static thread_local Own own;
+            if (!own.c) { own.c = ld.alloc_c(6); own.l = &ld; }
+            if (own.c) clen = ld.deflate(own.c, src, n, dst.data() + 18, dst.size() - 18 - 8);       // 0: did not fit (cannot happen at compressBound) -> zlib below
+        }
+        if (clen == 0) {
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+            zs.next_in = (Bytef *)src; zs.avail_in = (uInt)n;
+            zs.next_out = dst.data() + 18; zs.avail_out = (uInt)(dst.size() - 18 - 8);
+            const int rc = deflate(&zs, Z_FINISH);
+            clen = zs.total_out;
+            deflateEnd(&zs);
+            if (rc != Z_STREAM_END) return false;
+        }
+        if (18 + clen + 8 > 65536) return false;
         static const uint8_t hd[16] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0 };
         memcpy(dst.data(), hd, 16);
         const uint32_t bsize = (uint32_t)(18 + clen + 8 - 1);

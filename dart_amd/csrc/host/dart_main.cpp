@@ -516,7 +516,7 @@ int main(int argc, char *argv[])
     const size_t gz_whole_max = (size_t)((getenv("DART_GZ_WHOLE_MAX_GB") ? atof(getenv("DART_GZ_WHOLE_MAX_GB")) : 8.0) * (double)(1ull << 30));
     auto is_gz = [](const std::string &fn) { return fn.substr(fn.find_last_of('.') + 1) == "gz"; };
     auto gz_whole_candidate = [&](size_t lib) -> bool {
-        if (o.bam || getenv("DART_STREAMING") || !lib_deflate().ok() || gz_whole_max == 0) return false;
+        if (o.bam || getenv("DART_STREAMING") || getenv("DART_GZ_STREAM") || !lib_deflate().ok() || gz_whole_max == 0) return false;
         const bool two = o.f1.size() == o.f2.size();
         struct stat st;
         const std::string *fns[2] = {&o.f1[lib], two ? &o.f2[lib] : nullptr};

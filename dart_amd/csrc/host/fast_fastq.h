@@ -19,26 +19,10 @@
 #include <cerrno>
 #include <fcntl.h>
 #include <sys/mman.h>
-#include <dlfcn.h>
+#include "libdeflate_dl.h"
 #include <unistd.h>
 
-// libdeflate, when the system has it (it is no build dependency: loaded at run time, zlib's streaming reader is the fallback): a whole gzip file inflated in one
-// call, ~3x zlib's rate.  It has no streaming interface, so the output must fit a buffer: open_gz below.
-struct LibDeflate {
-    void *h = nullptr; void *(*alloc)() = nullptr; void (*release)(void *) = nullptr;
-    int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
-    LibDeflate() {
-        if (getenv("DART_GZ_STREAM")) return;                     // DART_GZ_STREAM=1: always the streaming reader
-        for (const char *nm : {"libdeflate.so.0", "libdeflate.so"}) if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
-        if (!h) return;
-        alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor"); release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
-        gunzip = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(h, "libdeflate_gzip_decompress_ex");
-        if (!alloc || !release || !gunzip) { alloc = nullptr; }
-    }
-    bool ok() const { return alloc != nullptr; }
-};
-static const LibDeflate &lib_deflate() { static LibDeflate l; return l; }
-
+// (libdeflate_dl.h: the system's libdeflate when it is there; it has no streaming interface, so a .gz file's output must fit a buffer: open_gz below)
 struct MappedFile {
     const char *p = nullptr; size_t n = 0; int fd = -1;
     size_t cap = 0;                                   // > 0: p is an anonymous mapping of cap bytes holding an inflated file
@@ -46,7 +30,7 @@ struct MappedFile {
     // max_out, not a clean gzip file): the caller takes the streaming reader, which has gzread's behaviour for whatever this is.
     bool open_gz(const char *fn, size_t max_out) {
         const LibDeflate &ld = lib_deflate();
-        if (!ld.ok()) return false;
+        if (!ld.ok() || getenv("DART_GZ_STREAM")) return false;          // DART_GZ_STREAM=1: always the streaming reader
         MappedFile z;
         if (!z.open(fn) || z.n < 18 || (unsigned char)z.p[0] != 0x1f || (unsigned char)z.p[1] != 0x8b) return false;
         uint32_t isize; memcpy(&isize, z.p + z.n - 4, 4);                       // the last member's size mod 2^32: the first guess

@@ -9,7 +9,7 @@ def test_host_text_kernels_and_fastq_index(workdir):
     src = os.path.join(common.ROOT, "tests", "native", "host_text_checks.cpp")
     exe = os.path.join(workdir, "host_text_checks")
     subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(common.ROOT, "include"), "-I", os.path.join(common.ROOT, "dart_amd", "csrc", "host"),
-                    "-o", exe, src], check=True)
+                    "-o", exe, src, "-ldl"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("bad=0"), out.stdout + out.stderr
 
@@ -67,7 +67,7 @@ def test_bam_writer_against_golden_sam(workdir):
     sequence differ in length is dropped, as sam_parse1 fails on it."""
     src = os.path.join(common.ROOT, "tests", "native", "bam_checks.cpp")
     exe = os.path.join(workdir, "bam_checks")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(common.ROOT, "dart_amd", "csrc", "host"), "-o", exe, src, "-lz"], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(common.ROOT, "dart_amd", "csrc", "host"), "-o", exe, src, "-lz", "-ldl"], check=True)
     bases = sorted(f[:-7] for f in os.listdir(common.GOLDEN) if f.endswith(".sam.gz"))
     assert len(bases) >= 5
     for k, base in enumerate(bases):
