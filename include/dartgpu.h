@@ -97,7 +97,8 @@ dg_ctx     *dg_init_files(const dg_index_files *, const dg_params *, int device,
 int         dg_index_wait(dg_ctx *);
 const char *dg_init_report(const dg_ctx *);
 void        dg_destroy(dg_ctx *);
-/* a second context on the same device sharing the parent's index (no copy): own streams and batch buffers, so two
+/* a second context on the same device sharing the parent's index (no copy): its own stream and batch buffers (the re-seeding kernels of a
+ * device's contexts run on a few shared streams: DG_S2_SHARED, INTEGRATION.md 5 -- keep contexts + 3 + the host's streams <= GPU_MAX_HW_QUEUES), so two
  * batches can be in flight at once, one host thread per context -- what the reference gets from running
  * ReadMapping in `-t` threads over one shared index (Mapping.cpp:760-790).  Destroy clones before the parent. */
 dg_ctx     *dg_clone(dg_ctx *parent, int *status);
