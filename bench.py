@@ -395,6 +395,13 @@ class Worker:
         return (12 * n + 16 * u[0] if self.last_records == "compact" else 36 * n + 40 * u[0]) + 4 * u[1] + 24 * u[2]
 
 
+T_PHASE = []          # (name, wall clock) marks of the run's phases: rank 0 prints what each took, and the line carries it (the driver gives a run 600 s)
+
+
+def phase(name):
+    T_PHASE.append((name, time.time()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -426,6 +433,8 @@ def main():
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="STRONG scaling (BASELINE configs[3]: 50 M pairs sharded over 8 GPUs): a step = this many pairs in all, sharded over the ranks in contiguous, "
                          "balanced pair ranges (dart_amd/dist.py); the reads are the same whatever the number of ranks.  Default 0 = weak scaling: --batches per rank")
+    ap.add_argument("--weak", action="store_true", help="N>1: weak scaling (every rank maps its own --batches per step) as `value`; the default for N>1 is BASELINE configs[3], "
+                                                       "one 50 M-pair job per step sharded over the ranks (strong scaling), with the weak rate beside it as `value_weak_scaling`")
     ap.add_argument("--verify-gather", action="store_true",
                     help="N>1, after the timed region: rank 0 expands what it gathered from every rank for one step and compares it, batch by batch, with its own "
                          "single-rank mapping of the same reads")
@@ -451,6 +460,9 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    T_PHASE.append(("start", time.time()))
+    if args.gpus > 1 and args.total_pairs == 0 and not args.weak:
+        args.total_pairs = 50000000              # BASELINE configs[3]: "Full GRCh38, 50 M paired-end 2x101 bp sharded across 8xMI355X" -- the N>1 line IS that job
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
     if (world == 1 and "RANK" not in os.environ and not args.as_child and args.human_like_budget > 0 and not args.no_cpu_baseline and not args.no_secondary and
@@ -495,6 +507,7 @@ def main():
         label, gnames, glens = genome_spec("chr20")
         label = "FALLBACK (GRCh38-sized index build failed) " + label
         prefix, g = prepare_index(args.cache, (gnames, glens), rank, barrier, args.introns, args.repeat_scale, args.genome_model)
+    phase("genome + index (rank 0 builds, the others wait)")
     # ---- the step's distinct batches, in page-locked host memory (before the library context is created: the index builder has just released
     #      > 100 GB of HBM, which the driver clears in the background; allocations that need those pages wait for it -- seconds of hipMalloc) ----
     lib = host._load_lib()
@@ -527,6 +540,7 @@ def main():
     if rank == 0:
         log("[bench] %d distinct batches of %d pairs generated in %.1f s" % (nb, args.pairs, time.time() - t))
 
+    phase("this rank's batches")
     ix = host.Index(prefix)
     params = host.default_params(paired=1, max_mismatch=args.mis, max_intron=args.max_intron)
     t = time.time()
@@ -604,7 +618,8 @@ def main():
 
     stagger_s = float(os.environ.get("DART_BENCH_STAGGER_MS", "1.0")) * 1e-3
 
-    def run_items(n_items, mode, ws=workers, first_item=0):
+    def run_items(n_items, mode, ws=workers, first_item=0, bl=None):
+        bl_ = batches if bl is None else bl
         done = [threading.Semaphore(0) for _ in ws]        # an item of this context has finished
         free = [threading.Semaphore(0) for _ in ws]        # its records have been gathered, the next item may start
         errs = []
@@ -616,7 +631,7 @@ def main():
                 if stagger_s > 0 and k:
                     time.sleep(k * stagger_s)
                 for i in range(k, n_items, len(ws)):
-                    ws[k].map(batches[(first_item + i) % nb], mode)
+                    ws[k].map(bl_[(first_item + i) % len(bl_)], mode)
                     done[k].release()
                     if do_gather:
                         free[k].acquire()
@@ -646,10 +661,10 @@ def main():
         if errs:
             raise errs[0]
 
-    def timed(n_items, mode, ws=workers):
+    def timed(n_items, mode, ws=workers, bl=None):
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_items(n_items, mode, ws)
+        run_items(n_items, mode, ws, 0, bl)
         barrier(); torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if dist is not None:
@@ -658,10 +673,13 @@ def main():
             el = float(tt.item())
         return el
 
+    phase("library start-up + first batch of every context")
     run_items(args.warmup * nb, args.input)
     for w in workers:
         w.kern = {}; w.n_runs = 0
+    phase("warm-up steps")
     elapsed = timed(args.steps * nb, args.input)
+    phase("timed region")
     runs = sum(w.n_runs for w in workers)
     kern = {}
     for w in workers:                                       # per-worker sums, merged after the threads have joined
@@ -687,7 +705,8 @@ def main():
     #      (registers as the hardware allocates them: next_free_vgpr rounded up to 8) and of its LDS that each kernel holds on average ----
     period_ms = elapsed / (args.steps * nb) * 1e3
     tick_ms = 1e-5
-    res = {"k_seed_qf": (136, 51200 / 4), "k_seed_heavy": (232, 0), "k_chain_heavy": (56, 39440), "k_pair": (128, 73896 / 4), "k_report": (256, 16128), "k_reseed": (48, 14720)}
+    # (registers as allocated = next_free_vgpr rounded up to 8, LDS per wave: profiles/probes/kres.py on this round's build)
+    res = {"k_seed_qf": (136, 51200 / 4), "k_seed_heavy": (232, 0), "k_chain_heavy": (136, 12952), "k_pair": (176, 77992 / 4), "k_report": (232, 16128), "k_reseed": (136, 15744)}
     n_cu_ = torch.cuda.get_device_properties(local).multi_processor_count
     occupancy = {"batch_period_ms": round(period_ms, 3), "kernels": {}}
     tot = [0.0, 0.0, 0.0]
@@ -708,6 +727,18 @@ def main():
         e_dl = timed(args.steps * nb, args.input)
         writer_dl[0] = False
         secondary["value_with_writer_download"] = round(reads_per_step * args.steps / e_dl / 1e6, 3)
+    if strong and world > 1 and not args.no_secondary:
+        # the weak-scaling rate beside the strong one: every rank maps ITS OWN whole batches of the job again (as many as the rank with the fewest has, at most
+        # --batches), the gathers as in the timed region; whole-job reads of that pass / its max-over-ranks time
+        own = [b_ for b_ in batches if b_.n == 2 * args.pairs][:max(1, args.batches)]
+        tt = torch.tensor([len(own)], dtype=torch.int64, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        nbw = int(tt.item())
+        if nbw > 0:
+            e_w = timed(args.steps * nbw, args.input, workers, own[:nbw])
+            secondary["value_weak_scaling"] = round(2 * args.pairs * nbw * world * args.steps / e_w / 1e6, 3)
+            secondary["weak_scaling_pass"] = "every rank maps %d whole batches of its share of the job per step (the rank with the fewest sets the number), %d steps, gathers as in the timed region" % (nbw, args.steps)
+    phase("secondary passes with the gather")
     gather_timed = do_gather
     do_gather = False                                      # (the secondary rates are per-GPU diagnostics of other entry points: no gather)
     if not args.no_secondary:
@@ -996,6 +1027,10 @@ def main():
     if cli:
         line["value_cli_end_to_end"] = cli["value"]
         line["cli_end_to_end"] = cli
+    phase("secondary rates, one batch in flight, CPU legs")
+    line["phases_s"] = {T_PHASE[i][0]: round(T_PHASE[i][1] - T_PHASE[i - 1][1], 1) for i in range(1, len(T_PHASE))}
+    line["phases_s"]["total"] = round(T_PHASE[-1][1] - T_PHASE[0][1], 1)
+    log("[bench] phases (s):", line["phases_s"])
     if gather_mode == "full":
         line["gather"] = {"mode": "full", "bytes_received_by_rank0_total": gather_bytes[0], "verified_against_single_rank_mapping": gather_verified}
     line.update(secondary)

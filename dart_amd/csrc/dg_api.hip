@@ -43,7 +43,7 @@ template <typename T> struct DBuf {
 #define N_TIMERS 20
 #define N_TOPS 128              // small device counters of a batch (bump tops, tickets, list sizes, class histogram), zeroed per run
 enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAVY_UNITS, TOP_SEED_NEXT, TOP_SEED_HEAVY,
-       TOP_WORK = 16, TOP_TICKET_PAIR = 17, TOP_TICKET_EMIT = 18, TOP_RESEED_COUNT = 19 /* 19..21 */, TOP_RESEED_TICKET = 22 /* 22..24 */, TOP_TICKET_SEED = 25,
+       TOP_WORK = 16, TOP_TICKET_PAIR = 17, TOP_TICKET_EMIT = 18, TOP_RESEED_COUNT = 19 /* 19..21: items per ring size; 22: diagonals per chunk */, TOP_RESEED_TICKET = 23 /* 23..25 */, TOP_TICKET_SEED = 26, TOP_RS_POOL = 27,
        TOP_ORDER_INFO = 28 /* 28..30 */, TOP_CLASS_HIST = 32 /* 32..63 */, TOP_CLASS_FILL = 64 /* 64..95 */ };        // (explicit values: every index names its own word)
 
 // The index of a device as its contexts see it: the root context owns it, dg_clone()d contexts point to it.  The look-up aids may still be
@@ -92,7 +92,7 @@ struct dg_ctx {
     // them without asking the device for a size first, the device reports what it needed (DSizes) and flags an overflow
     // (d_err >= DG_ABORT), in which case the host grows the buffer and runs the batch again
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, rep_off, tile_sums, tile_read, slow_units;
-    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<uint32_t> job_lists; DBuf<uint8_t> done; DBuf<uint32_t> perm, hist, heavy; DBuf<DHeavy> seed_heavy;
+    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<unsigned long long> job_items, job_pool; DBuf<RsChunkOut> job_outs; DBuf<uint32_t> job_pool_next; DBuf<unsigned long long> items; DBuf<uint32_t> hist, heavy; DBuf<DHeavy> seed_heavy;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c; DBuf<uint32_t> cig_c;     // compact records and their stored CIGAR ops (written by k_pair / k_emit_slow)
@@ -106,7 +106,8 @@ struct dg_ctx {
     struct SharedCaps { std::atomic<size_t> seeds{0}, rep{0}, work{0}, cig{0}; } *shared_caps = nullptr;
     bool owns_shared_caps = false;
     unsigned long long *d_ctr = nullptr; unsigned int *d_tops = nullptr; int *d_err = nullptr; DSizes *d_sizes = nullptr; unsigned int *d_input_bad = nullptr;
-    struct HostTail { DSizes sizes; int err; unsigned int input_bad; unsigned int tops[N_TOPS]; unsigned long long ctr[CTR_STRIDE]; } *h_tail = nullptr;   // page-locked; written by k_batch_end
+    struct HostTail { DSizes sizes; int err; unsigned int input_bad; unsigned int tops[N_TOPS]; unsigned long long ctr[CTR_STRIDE]; __host__ __device__ uint32_t *sizes_words() { return (uint32_t *)&sizes; } } *h_tail = nullptr;   // page-locked; written by k_batch_end
+    bool state_zeroed = false;   // the small device state (counters, tops, status, sizes) is zero: k_batch_end of the previous run left it so
     size_t used[3] = {0, 0, 0};
     bool enqueued = false;
     // timings
@@ -119,8 +120,9 @@ struct dg_ctx {
     int env_seed_waves = 4, env_bail_trips = 0 /* 0: 64 trips in k_seed_qf (a trip there is up to three dependent accesses), 128 in the other two */, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
     int env_seed_phases = 0, env_seed_wg_waves = 4, env_seed_partial = 32, env_seed_multi = 4;   // DG_SEED_PHASES=1: round 2's barrier-phased queue kernel (k_seed_q) instead of the free-running one (k_seed_qf)
     bool seed_qf_used = false;     // the last run's seeding kernel was k_seed_qf (its own-work counters are derived from its slot counts)
-    int env_scan_mask = 7, env_one_stream = 0, env_packed_pair = 1, env_drain_bail = 0;
+    int env_scan_mask = 7, env_one_stream = 1, env_packed_pair = 1, env_drain_bail = 0;
     int env_chain_bpc = 8, env_seedh_bpc = 8, env_reseed_pct = 100;      // persistent one-wave workgroups per CU of k_chain_heavy / k_seed_heavy; k_reseed's grids in per cent (sweeps: DG_CHAIN_BPC, DG_SEEDH_BPC, DG_RESEED_PCT)
+    int env_rs_chunk = RS_CHUNK_DIAGS, env_rs_inline = RS_ENT_INLINE, env_rs_pool = 0;      // test hooks (DG_RS_CHUNK, DG_RS_ENT_MAX, DG_RS_POOL_BLOCKS): diagonals per chunk of a shared re-seeding window, entries a chunk record holds inline, blocks of the entry pool
     int env_scan_budget = 0;      // DG_SCAN_POLL_BUDGET: poll budget of a look-back on the FIRST attempt of a batch (test hook: forces the DG_E_SCAN re-run path)
 };
 
@@ -132,8 +134,10 @@ static void read_env(dg_ctx *c)
     c->env_report_bpc = geti("DG_REPORT_BPC", 8); c->env_no_fast = geti("DG_NO_FAST_PAIR", 0);
     c->env_scan_budget = geti("DG_SCAN_POLL_BUDGET", 0); c->env_scan_mask = geti("DG_SCAN_POLL_SCANS", 7);
     c->env_seed_phases = geti("DG_SEED_PHASES", 0); c->env_seed_wg_waves = geti("DG_SEED_WG_WAVES", 4); c->env_seed_partial = geti("DG_SEED_PARTIAL_MIN", 32);
-    c->env_copy_stream = geti("DG_COPY_STREAM", 1); c->env_one_stream = geti("DG_ONE_STREAM", 0); c->env_packed_pair = geti("DG_PACKED_PAIR", 1); c->env_drain_bail = geti("DG_SEED_DRAIN_BAIL", 0);
+    c->env_copy_stream = geti("DG_COPY_STREAM", 1); c->env_one_stream = geti("DG_ONE_STREAM", 1); c->env_packed_pair = geti("DG_PACKED_PAIR", 1); c->env_drain_bail = geti("DG_SEED_DRAIN_BAIL", 0);
     c->env_chain_bpc = std::max(1, geti("DG_CHAIN_BPC", 8)); c->env_seedh_bpc = std::max(1, geti("DG_SEEDH_BPC", 8)); c->env_reseed_pct = std::max(10, geti("DG_RESEED_PCT", 100));
+    c->env_rs_chunk = geti("DG_RS_CHUNK", RS_CHUNK_DIAGS); c->env_rs_chunk = std::min(1 << 24, std::max(RS_SUPER, c->env_rs_chunk / RS_SUPER * RS_SUPER));      // (a multiple of the pac super-chunk)
+    c->env_rs_inline = std::min(RS_ENT_INLINE, std::max(0, geti("DG_RS_ENT_MAX", RS_ENT_INLINE))); c->env_rs_pool = std::max(0, geti("DG_RS_POOL_BLOCKS", 0));
     c->env_seed_multi = geti("DG_SEED_MULTI", 4); if (c->env_seed_multi < 0 || c->env_seed_multi > SQF_MULTI_MAX) c->env_seed_multi = SQF_MULTI_MAX;   // rows of an interval that are located and compared with the text at once (0: single rows only)
 }
 
@@ -218,9 +222,10 @@ k_seed_offsets(int n_reads, int paired, const uint32_t *__restrict__ nseeds, uin
 {
     __shared__ unsigned long long s_scan[20];
     __shared__ unsigned int s_tile;
-    if (*err >= DG_ABORT) return;          // raised before this launch (the seeding kernel's safety net): nseeds cannot be trusted.  DG_E_SEEDS is raised
-                                           // below by the workgroup with the LAST ticket, when every other workgroup is past this line
-    const unsigned int tile = d_tile_ticket(ts, &s_tile);
+    // a status raised before this launch (the seeding kernel's safety net): nseeds cannot be trusted.  DG_E_SEEDS is raised below by the workgroup with the LAST
+    // ticket, when every other workgroup is past this line; DG_E_SCAN may come from a look-back of this very launch: the decision is thread 0's (d_tile_ticket_unless)
+    const unsigned int tile = d_tile_ticket_unless(ts, &s_tile, threadIdx.x == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= DG_ABORT);
+    if (tile == SCAN_LEAVE) return;
     const uint32_t first = tile * (256u * SO_PER) + threadIdx.x * SO_PER;
     uint32_t v[SO_PER], sum = 0;
     if (first + SO_PER <= (uint32_t)n_reads) {
@@ -318,15 +323,14 @@ static hipError_t wait_stream(dg_ctx *c)
 // ------------------------------------------------------------------------------------------
 #ifdef DG_PROFILE_CLASSES          // diagnostic build only (profiles/probes/class_profile.sh): shader cycles per cost class
 __device__ unsigned long long g_class_cycles[COST_CLASSES + 1], g_class_chunks[COST_CLASSES + 1];
-__device__ const uint8_t *g_costkey;
 #endif
 template <int MINW>
 __global__ void __launch_bounds__(64, MINW)
 k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsigned char *__restrict__ seq,
          const uint32_t *__restrict__ seq_off, const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ seed_off,
-         const DJob *__restrict__ jobs, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand,
-         const uint32_t *__restrict__ rep_off, DSeed *__restrict__ work, const uint32_t *__restrict__ perm,
-         const uint32_t *__restrict__ n_jobreads_p, const uint32_t *__restrict__ heavy_end_p, const uint32_t *__restrict__ single_first_p, int job_part, dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
+         const DJob *__restrict__ jobs, DCand *__restrict__ cands,
+         const uint32_t *__restrict__ rep_off, DSeed *__restrict__ work, const unsigned long long *__restrict__ items,
+         const uint32_t *__restrict__ n_jobitems_p, const uint32_t *__restrict__ n_items_p, int job_part, dg_report_out *__restrict__ reports, uint32_t *cigpool, uint32_t cigcap,
          unsigned int *tops, unsigned char *ws, const WSLayout L, unsigned long long *ctr, int *err)
 {
     const unsigned long long t_wave0 = wall_clock64();
@@ -345,49 +349,34 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
     cx.ix = &ix; cx.pr = &pr; cx.L = &L;
     cx.ws = ws + (size_t)lane * L.stride;
     cx.n_nw = cx.nw_cells = cx.n_reseed = cx.reseed_w = 0;
-    // perm = [reads that wait for k_reseed | all other reads, heaviest class first]; this launch takes one part.
-    // The heavy head of the part (all job reads; classes 1-3 of the rest: many seeds AND a long segment pair) is handed
-    // out in groups of g < 64 reads, g ~ one group per wave: 64 such reads in ONE wave were the kernel's critical
-    // path (one chunk = 7 M cycles, as long as everything else together).
-    const unsigned int n_jobreads = *n_jobreads_p;
-    const unsigned int lo = job_part ? 0u : n_jobreads, hi = job_part ? n_jobreads : *single_first_p;   // (end of the list: reads that k_pair finished are not on it)
-    const unsigned int n_heavy = job_part ? hi - lo : *heavy_end_p - n_jobreads;
-    // few heavy reads (the usual case: some dozens per million): ONE read per wave, lane = candidate
-    const bool cpar = n_heavy <= 2u * gridDim.x;
-    unsigned int g = cpar ? 1 : 8;
-    while (!cpar && g < 64 && (unsigned long long)g * gridDim.x < n_heavy) g <<= 1;
-    const unsigned int hgroups = (n_heavy + g - 1) / g;
-    unsigned int *next = tops + (job_part ? 4 : 3);
+    // items = [candidates that wait for k_reseed | all other live candidates of the listed reads, heaviest class first] (k_order_items); this launch takes
+    // one part, 64 items per ticket: lane = candidate.  (Rounds 1-4: lane = read, and the reads with dozens of candidates a wave each.)
+    const unsigned int n_jobitems = *n_jobitems_p;
+    const unsigned int lo = job_part ? 0u : n_jobitems, hi = job_part == 1 ? n_jobitems : *n_items_p;       // job_part 2: the whole list (k_reseed has run)
+    unsigned int *next = tops + (job_part == 1 ? 4 : 3);
     while (true) {
         unsigned int ticket = 0;
         if ((threadIdx.x & 63) == 0) ticket = atomicAdd(next, 1u);
         ticket = (unsigned int)__shfl((int)ticket, 0, 64);
-        unsigned int base, cnt;
-        if (ticket < hgroups) { base = lo + ticket * g; cnt = n_heavy - ticket * g < g ? n_heavy - ticket * g : g; }
-        else { base = lo + n_heavy + (ticket - hgroups) * 64u; cnt = 64; }
+        const unsigned int base = lo + ticket * 64u;
         if (base >= hi) break;
-        const bool wave_read = cpar && ticket < hgroups;
-        const unsigned int idx = wave_read ? base : base + (threadIdx.x & 63);
-        const bool valid = wave_read || ((threadIdx.x & 63) < cnt && idx < hi);   // every lane enters d_gen_mapping_report (it has wave-wide steps)
-        const int r = valid ? (int)perm[idx] : 0;
+        const unsigned int idx = base + (threadIdx.x & 63);
+        const bool valid = idx < hi;                               // every lane enters d_gen_mapping_report (it has wave-wide steps)
+        const unsigned long long item = valid ? items[idx] : 0ull;
+        const int r = (int)(item >> 32);
+        const uint32_t ci = (uint32_t)item, rep_i = valid ? rep_off[r] + (ci - seed_off[r]) : 0u;
         DRead rd;
-        rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0;           // defined start state
+        rd.sub_score = 0; rd.mis_num = 0; rd.mapq = 0;
         cx.seq = seq + seq_off[r]; cx.rlen = rlen[r];
 #ifdef DG_PROFILE_CLASSES
         const long long t_begin = clock64();
-        cx.cls = g_costkey[perm[base]]; cx.t_last = t_begin;
+        cx.cls = (int)(cands[(uint32_t)items[base]].final_n & 31); cx.t_last = t_begin;
 #endif
-        d_gen_mapping_report(cx, valid, paired ? (r & 1) == 0 : true, rd, cands + seed_off[r], valid ? (int)ncand[r] : 0, jobs, work,
-                             reports + rep_off[r], rep_off[r], cigpool, tops + 0, cigcap, err, wave_read ? (int)(threadIdx.x & 63) : 0, wave_read ? 64 : 1);
+        d_gen_mapping_report(cx, valid, paired ? (r & 1) == 0 : true, rd, cands + ci, valid ? 1 : 0, jobs, work,
+                             reports + rep_i, rep_i, cigpool, tops + 0, cigcap, err, 0, 1, true);
 #ifdef DG_PROFILE_CLASSES
         if ((threadIdx.x & 63) == 0) { cls_acc[cx.cls] += (unsigned long long)(clock64() - t_begin); cls_acc[DG_NCLS + cx.cls] += 1ull; }
 #endif
-        if (valid && (!wave_read || (threadIdx.x & 63) == 0)) {
-            dg_read_out o;
-            o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = 0;
-            o.n_rep = rd.CanNum; o.best = rd.iBest; o.rep_off = (int32_t)rep_off[r]; o.sj_off = 0; o.n_sj = 0;
-            rout[r] = o;
-        }
     }
 #ifdef DG_PROFILE_CLASSES
     __syncthreads();
@@ -407,7 +396,7 @@ k_report(const DIndex ix, const DParams pr, int n_reads, int paired, const unsig
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_finalize(const DIndex ix, const DParams pr, int paired, const uint32_t *__restrict__ slow_units, const DSizes *__restrict__ sizes,
-           const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const DSeed *__restrict__ work,
+           const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ rep_off, const DSeed *__restrict__ work,
            dg_read_out *__restrict__ rout, dg_report_out *__restrict__ reports, dg_sj_out *sjpool, uint32_t sjcap, unsigned int *tops, int *err)
 {
     if (*err >= DG_ABORT) return;
@@ -420,10 +409,21 @@ k_finalize(const DIndex ix, const DParams pr, int paired, const uint32_t *__rest
         RepMem<dg_report_out> rp[2];
         for (int m = 0; m < nm; m++) {
             const int r = paired ? 2 * u + m : u;
-            o[m] = rout[r];
-            rd[m].score = o[m].score; rd[m].sub_score = o[m].sub_score; rd[m].mis_num = o[m].mis_num; rd[m].mapq = 0;
-            rd[m].CanNum = o[m].n_rep; rd[m].iBest = o[m].best;
-            rp[m].p = reports + o[m].rep_off;
+            const int nc = (int)ncand[r];
+            dg_report_out *rep = reports + rep_off[r];
+            // the running best / second best of GenMappingReport :1161-1172, in candidate order, over what k_report's lanes (one candidate each) left:
+            // aln_score, and the candidate's mismatch count parked in `flag`.  SURVEY F6: sub_score, mis_num, mapq start at 0
+            rd[m].score = 0; rd[m].sub_score = 0; rd[m].mis_num = 0; rd[m].mapq = 0; rd[m].iBest = 0; rd[m].CanNum = nc > 0 ? nc : 1;
+            for (int i = 0; i < nc; i++) {
+                const int aln = rep[i].aln_score, mis_num = rep[i].flag;
+                if (mis_num) rep[i].flag = 0;                       // (also where the reference zeroes aln late, :1157: the parked value must not stay)
+                if (aln <= 0) continue;                            // such an aln changes nothing: score and sub_score are 0 or stay
+                if (aln > rd[m].score) { rd[m].iBest = i; rd[m].mis_num = mis_num; rd[m].sub_score = rd[m].score; rd[m].score = aln; }
+                else if (aln == rd[m].score) rd[m].sub_score = rd[m].score;
+            }
+            o[m].score = rd[m].score; o[m].sub_score = rd[m].sub_score; o[m].mis_num = rd[m].mis_num; o[m].mapq = 0;
+            o[m].n_rep = rd[m].CanNum; o[m].best = rd[m].iBest; o[m].rep_off = (int32_t)rep_off[r]; o[m].sj_off = 0; o[m].n_sj = 0;
+            rp[m].p = rep;
         }
         if (paired) {
             d_settle_pair(pr, rd[0], rp[0], rd[1], rp[1]);
@@ -453,9 +453,10 @@ k_emit_slow(int paired, const uint32_t *__restrict__ slow_units, DSizes *sizes, 
 {
     __shared__ unsigned long long s_scan[20];
     __shared__ unsigned int s_tile;
-    const int e0 = *err;
-    if (e0 >= DG_ABORT && e0 != DG_E_CIGFINAL) return;            // (DG_E_CIGFINAL may have been raised by an earlier workgroup of this launch)
-    const unsigned int tile = d_tile_ticket(ts, &s_tile);
+    bool leave = false;                                           // (DG_E_CIGFINAL may have been raised by an earlier workgroup of this launch; thread 0 decides for the workgroup)
+    if (threadIdx.x == 0) { const int e0 = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); leave = e0 >= DG_ABORT && e0 != DG_E_CIGFINAL; }
+    const unsigned int tile = d_tile_ticket_unless(ts, &s_tile, leave);
+    if (tile == SCAN_LEAVE) return;
     const unsigned int n_items = sizes->n_slow_units * (paired ? 2u : 1u);
     if (tile > 0 && tile * 256u >= n_items) return;
     const unsigned int it = tile * 256u + threadIdx.x;
@@ -556,7 +557,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     if (c->h_tail) (void)hipHostFree(c->h_tail);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->packed_in.release(); c->nlist_in.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
-    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_lists.release(); c->done.release(); c->perm.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
+    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_items.release(); c->job_outs.release(); c->job_pool.release(); c->job_pool_next.release(); c->items.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release(); c->scan_state.release(); c->scan_trace.release(); c->reads_c.release(); c->reports_c.release(); c->cig_c.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -580,10 +581,12 @@ static hipError_t make_ctx_objects(dg_ctx *c)
     // DG_CU_PARTS=P (measurement switch, profiles/r04/y_*): context k's two streams only get the compute units of part k % P (DG_CU_LAYOUT 0: P contiguous
     // ranges of the mask's bits, 1: bit i belongs to part (i % 8) % P) -- fewer different kernels share a CU's instruction cache and LDS at a time
     static std::atomic<int> n_made{0};
-    if (getenv("DG_EXP_CTX_PAD_KB")) {         // measurement switch: context k's allocations start behind a pad of (k + 1) x this many KB (never freed: an experiment)
+#ifdef DG_EXPERIMENTS      /* measurement builds only (profiles/r04/x_modes_*): a stray environment variable must not take HBM away from a product run */
+    if (getenv("DG_EXP_CTX_PAD_KB")) {         // context k's allocations start behind a pad of (k + 1) x this many KB (never freed: an experiment)
         void *pad = nullptr; static std::atomic<int> n_pad{0};
         (void)hipMalloc(&pad, (size_t)(n_pad.fetch_add(1) + 1) * (size_t)atoll(getenv("DG_EXP_CTX_PAD_KB")) * 1024);
     }
+#endif
     const int parts = getenv("DG_CU_PARTS") ? atoi(getenv("DG_CU_PARTS")) : 0, layout = getenv("DG_CU_LAYOUT") ? atoi(getenv("DG_CU_LAYOUT")) : 0;
     if (parts > 1) {
         int n_cu = 0; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
@@ -599,7 +602,8 @@ static hipError_t make_ctx_objects(dg_ctx *c)
         // fit the sixteen queues without sharing.  0 = a private stream per context (rounds 2-3).
         IndexShared *sh = c->shared_ix;
         if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return e;
-        if (sh) {
+        const bool one_stream = !getenv("DG_ONE_STREAM") || atoi(getenv("DG_ONE_STREAM")) != 0;      // (the default since round 5: no second stream exists at all -- a stream that is never used still takes its place among the hardware queues)
+        if (sh && !one_stream) {
             std::lock_guard<std::mutex> lk(sh->mu);
             if (sh->n_s2 < 0) { const int n = getenv("DG_S2_SHARED") ? atoi(getenv("DG_S2_SHARED")) : 3; sh->n_s2 = n < 0 ? 0 : (n > 8 ? 8 : n); }
             if (sh->n_s2 > 0) {
@@ -608,7 +612,7 @@ static hipError_t make_ctx_objects(dg_ctx *c)
                 c->stream2 = sh->s2[k]; c->owns_stream2 = false;
             }
         }
-        if (!c->stream2 && (e = hipStreamCreate(&c->stream2)) != hipSuccess) return e;
+        if (!one_stream && !c->stream2 && (e = hipStreamCreate(&c->stream2)) != hipSuccess) return e;
     }
     if ((e = hipEventCreate(&c->ev_prep)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed0)) != hipSuccess || (e = hipEventCreate(&c->ev_reseed1)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess ||
@@ -813,6 +817,7 @@ static dg_ctx *init_index(const IndexMeta &m, UpSrc bwt, uint64_t bwt_off, UpSrc
     if (e != hipSuccess || ndev == 0) return bail(DG_ERR_NO_DEVICE, "no HIP device (libdartgpu has no CPU fallback)", e);
     if (device < 0 || device >= ndev) return bail(DG_ERR_NO_DEVICE, "device ordinal out of range", hipSuccess);
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(DG_ERR_HIP, "hipSetDevice", e);
+#ifdef DG_EXPERIMENTS      /* measurement builds only: where the allocations land (profiles/r04/x_modes_*) */
     if (getenv("DG_EXP_PREALLOC_GB")) {        // measurement switch (where the allocations land: profiles/r04/x_modes_*): take and give back this much memory first
         void *dummy = nullptr;
         if (hipMalloc(&dummy, (size_t)atoll(getenv("DG_EXP_PREALLOC_GB")) << 30) == hipSuccess) { (void)hipMemset(dummy, 0, 1 << 20); (void)hipDeviceSynchronize(); (void)hipFree(dummy); }
@@ -824,6 +829,7 @@ static dg_ctx *init_index(const IndexMeta &m, UpSrc bwt, uint64_t bwt_off, UpSrc
         for (size_t i = 0; i < blk.size(); i += 2) (void)hipFree(blk[i]);
         for (size_t i = 1; i < blk.size(); i += 2) (void)hipFree(blk[i]);
     }
+#endif
     c = new dg_ctx();
     c->device = device;
     c->shared_caps = new dg_ctx::SharedCaps(); c->owns_shared_caps = true;
@@ -1307,26 +1313,30 @@ static size_t scan_tiles_seed(int n_reads) { return (size_t)(n_reads + 256 * SO_
 static size_t scan_tiles_pair(int n_units) { return (size_t)(n_units + PU_THREADS - 1) / PU_THREADS + 1; }
 
 // the tail of a batch: sizes, status word, tops and the work counters (their 64 stripes summed -- or, for the two maxima, maximised -- here)
-// written straight into the context's page-locked host block by ONE launch (round 2: four device-to-host copies)
+// written straight into the context's page-locked host block by ONE launch (round 2: four device-to-host copies) -- and, since round 5, left ZEROED for
+// the next run of the context, which then needs no k_batch_begin in front (one launch per batch less; every thread clears what it has just read)
 __global__ void __launch_bounds__(256)
-k_batch_end(const DSizes *__restrict__ sizes, const int *__restrict__ err, const unsigned int *__restrict__ tops, const unsigned long long *__restrict__ ctr, dg_ctx::HostTail *out)
+k_batch_end(DSizes *__restrict__ sizes, int *__restrict__ err, unsigned int *__restrict__ tops, unsigned long long *__restrict__ ctr, dg_ctx::HostTail *out)
 {
     const int t = threadIdx.x;
-    if (t < (int)(sizeof(DSizes) / 4)) ((uint32_t *)&out->sizes)[t] = ((const uint32_t *)sizes)[t];
-    if (t < N_TOPS) out->tops[t] = tops[t];
-    if (t == 0) out->err = *err;
+    if (t < (int)(sizeof(DSizes) / 4)) { out->sizes_words()[t] = ((const uint32_t *)sizes)[t]; ((uint32_t *)sizes)[t] = 0u; }
+    if (t < N_TOPS) { out->tops[t] = tops[t]; tops[t] = 0u; }
+    if (t == 0) { out->err = *err; *err = 0; }
     if (t < CTR_STRIDE) {
         const bool is_max = t == CTR_MAXTRIPS || t == CTR_WTRIPS_MAX;
         unsigned long long v = 0;
-        for (int s_ = 0; s_ < CTR_STRIPES; s_++) { const unsigned long long x = ctr[s_ * CTR_STRIDE + t]; v = is_max ? (x > v ? x : v) : v + x; }
+        for (int s_ = 0; s_ < CTR_STRIPES; s_++) { const unsigned long long x = ctr[s_ * CTR_STRIDE + t]; ctr[s_ * CTR_STRIDE + t] = 0ull; v = is_max ? (x > v ? x : v) : v + x; }
         out->ctr[t] = v;
     }
 }
 
 static int zero_batch_state(dg_ctx *c, int n_reads, int n_units)
 {
-    k_batch_begin<<<1, 256, 0, c->stream>>>(c->d_ctr, c->d_tops, c->d_err, c->d_sizes);
-    HIPCHK(hipGetLastError());
+    if (!c->state_zeroed) {                     // (a context's first run, or the run after one whose enqueue failed half-way: k_batch_end of every complete run leaves the state zeroed)
+        k_batch_begin<<<1, 256, 0, c->stream>>>(c->d_ctr, c->d_tops, c->d_err, c->d_sizes);
+        HIPCHK(hipGetLastError());
+    }
+    c->state_zeroed = false;
     // the look-back state of the two single-pass scans is NOT zeroed per batch: its words carry the run's epoch (dg_scan.h).
     // Zeroed once, when (re)allocated: epoch 0 is never used.
     const size_t tiles2 = (size_t)(2 * n_units + 255) / 256 + 1;
@@ -1365,11 +1375,16 @@ static int enqueue_run(dg_ctx *c)
     if (c->cap_cig < 3 * c->cap_rep) c->cap_cig = 3 * c->cap_rep;
     if (c->cap_work < (size_t)n * 8 + 65536) c->cap_work = (size_t)n * 8 + 65536;
     const size_t cigcap = (size_t)n * 48 + c->cap_rep * (16 + CIG_SLOT) + 4096, sjcap = (size_t)n * 4 + 1024;
-    HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n)); HIPCHK(c->done.ensure((size_t)n + 16));      // done: class key per listed read
+    HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n));
     HIPCHK(c->heavy.ensure((size_t)n_units + 16)); HIPCHK(c->slow_units.ensure((size_t)n_units + 16));
-    HIPCHK(c->reports.ensure(c->cap_rep + 1)); HIPCHK(c->work.ensure(c->cap_work + 16)); HIPCHK(c->jobs.ensure(c->cap_seeds + 16)); HIPCHK(c->job_lists.ensure(3 * c->jobs.cap + 16));
+    HIPCHK(c->reports.ensure(c->cap_rep + 1)); HIPCHK(c->work.ensure(c->cap_work + 16)); HIPCHK(c->jobs.ensure(c->cap_seeds + 16));
+    // k_reseed's work list: (window, chunk) items per ring size, and one record per chunk of the windows that several waves share (dg_reseed.h)
+    const uint32_t rs_out_cap = (uint32_t)std::max<size_t>(16384, (size_t)n / 8), rs_list_cap = (uint32_t)std::min<size_t>(c->jobs.cap + rs_out_cap, 0xFFFFFFF0u);
+    HIPCHK(c->job_outs.ensure(rs_out_cap)); HIPCHK(c->job_items.ensure(3 * (size_t)rs_list_cap + 16));
+    const uint32_t rs_pool_cap = (uint32_t)std::max<size_t>(16384, (size_t)n / 32);           // blocks of 64 entries for the chunks that report more than their record holds
+    HIPCHK(c->job_pool.ensure((size_t)rs_pool_cap * 64)); HIPCHK(c->job_pool_next.ensure(rs_pool_cap));
     HIPCHK(c->cigpool.ensure(cigcap)); HIPCHK(c->cigfinal.ensure(c->cap_cig + 16)); HIPCHK(c->sjpool.ensure(sjcap)); HIPCHK(c->sjfinal.ensure(sjcap));
-    HIPCHK(c->perm.ensure((size_t)n + 16));
+    HIPCHK(c->items.ensure(c->cap_seeds + 16));                 // k_report's work list: one item per live candidate of the general path (candidates <= seeds)
     unsigned int *tops = c->d_tops;
 
     // units with more seeds than a lane of k_pair holds: a wave each, before k_pair (which needs their candidate counts)
@@ -1425,40 +1440,43 @@ static int enqueue_run(dg_ctx *c)
     HIPCHK(c->ws.ensure((size_t)blocks * 64 * L.stride));
     unsigned slow_grid = (unsigned)c->n_cu * 4u;
     if ((size_t)slow_grid * 256 > (size_t)n) slow_grid = nb;
-    k_prep<<<slow_grid, 256, 0, c->stream>>>(c->pr, paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work.p, tops + TOP_WORK,
-                                             (uint32_t)c->cap_work, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_err, c->rlen.p, c->done.p, tops + TOP_CLASS_HIST);
+    k_prep<dg_report_out><<<slow_grid, 256, 0, c->stream>>>(c->pr, paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work.p, tops + TOP_WORK,
+                                             (uint32_t)c->cap_work, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_err, c->rlen.p, c->rep_off.p, c->reports.p, tops + TOP_CLASS_HIST);
     HIPCHK(hipGetLastError());
     TICK("k_prep");
-    // k_reseed runs on a second stream, concurrently with the report of every read that has no re-seeding job; only the job reads wait for it
+    // Round 5: the re-seeding kernels run on the context's main stream, before the report kernel, which then takes ALL candidates in one launch.  Rounds 1-4
+    // gave a wave a whole window (up to 500 kb = ~1000 serial trips): the kernel was one long tail, so it ran on a second stream beside the report of the
+    // candidates without jobs -- whose persistent waves held 113 of a CU's 160 KB of LDS and left k_reseed three waves per CU (cfg5: 3.8 s of wave time in
+    // 5.4 ms).  With windows shared by several waves (dg_reseed.h) it is a balanced throughput kernel that wants the GPU for itself for a short time; a
+    // context owns ONE stream (the sixteen hardware queues of a process hold twelve contexts, the caller's stream and -- on a node -- RCCL's).
+    // DG_ONE_STREAM=0: the second stream as before (k_report in two launches: candidates without jobs beside k_reseed, the others behind it).
     HIPCHK(hipEventRecord(c->ev_prep, c->stream));
-    // DG_ONE_STREAM=1: the re-seeding kernels on the context's main stream (in order before the report kernel, no overlap with it) -- a context then
-    // owns ONE hardware queue instead of two: with a dozen contexts the runtime multiplexes 25 streams onto 16 queues, and two contexts that share
-    // a queue wait for each other's kernels
+    if (!c->stream2) c->env_one_stream = 1;                       // (the context was made without a second stream)
     const hipStream_t s2 = c->env_one_stream ? c->stream : c->stream2;
     if (!c->env_one_stream) HIPCHK(hipStreamWaitEvent(s2, c->ev_prep, 0));
     HIPCHK(hipEventRecord(c->ev_reseed0, s2));
     const uint32_t jobcap = (uint32_t)c->jobs.cap;
-    k_order_jobs<<<1, 1024, 0, s2>>>(c->jobs.p, tops + TOP_JOBS, jobcap, c->job_lists.p, tops + TOP_RESEED_COUNT, c->d_err);
-    // (one stream for the three ring sizes: side by side on streams of their own they finish sooner alone -- the wide ones have few jobs, but a
-    //  single 500 kb window keeps one wave busy for ~1 ms -- and cost the step 8 % with eight batches in flight: streams share 4 hardware queues)
-    k_reseed<1><<<c->n_cu * 10 * c->env_reseed_pct / 100, 64, 0, s2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p, tops + TOP_RESEED_COUNT, tops + TOP_RESEED_TICKET, c->d_ctr, c->d_err);
-    k_reseed<2><<<c->n_cu * 6 * c->env_reseed_pct / 100, 64, 0, s2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + jobcap, tops + TOP_RESEED_COUNT + 1, tops + TOP_RESEED_TICKET + 1, c->d_ctr, c->d_err);
-    k_reseed<4><<<c->n_cu * 4 * c->env_reseed_pct / 100, 64, 0, s2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_lists.p + 2 * (size_t)jobcap, tops + TOP_RESEED_COUNT + 2, tops + TOP_RESEED_TICKET + 2, c->d_ctr, c->d_err);
+    const RsPool rs_pool{c->job_pool.p, c->job_pool_next.p, tops + TOP_RS_POOL, c->env_rs_pool > 0 ? std::min<uint32_t>((uint32_t)c->env_rs_pool, rs_pool_cap) : rs_pool_cap};
+    const int rs_gap_max = c->max_rlen - 32, rs_need = rs_gap_max >= 8 ? (rs_gap_max - 8) / 64 + 1 : 1;        // (see below)
+    k_order_jobs<<<1, 1024, 0, s2>>>(c->jobs.p, tops + TOP_JOBS, jobcap, c->job_items.p, rs_list_cap, rs_out_cap, rs_need <= 1 ? 1 : (rs_need <= 2 ? 2 : 4), (uint32_t)c->env_rs_chunk, tops + TOP_RESEED_COUNT, c->d_err);
+    // One launch per ring size the batch can need: a read gap lies between two seeds of >= 16 bases (bwt_search.cpp:165), so it is at most rlen - 32 long and
+    // needs (gap - 16) / 64 + 1 bitmap words per diagonal -- one for reads of up to 103 bases (round 4 launched all three sizes for every batch), two up to 167.
+    // (one stream for the ring sizes: side by side on streams of their own they cost the step 8 % with eight batches in flight, profiles/r02)
+    k_reseed<1><<<c->n_cu * 10 * c->env_reseed_pct / 100, 64, 0, s2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_items.p, tops + TOP_RESEED_COUNT, tops + TOP_RESEED_COUNT + 3, tops + TOP_RESEED_TICKET, c->job_outs.p, rs_pool, c->env_rs_inline, c->d_ctr, c->d_err);
+    if (rs_need > 1) k_reseed<2><<<c->n_cu * 6 * c->env_reseed_pct / 100, 64, 0, s2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_items.p + rs_list_cap, tops + TOP_RESEED_COUNT + 1, tops + TOP_RESEED_COUNT + 3, tops + TOP_RESEED_TICKET + 1, c->job_outs.p, rs_pool, c->env_rs_inline, c->d_ctr, c->d_err);
+    if (rs_need > 2) k_reseed<4><<<c->n_cu * 4 * c->env_reseed_pct / 100, 64, 0, s2>>>(c->ix, c->seq.p, c->seq_off.p, c->jobs.p, c->job_items.p + 2 * (size_t)rs_list_cap, tops + TOP_RESEED_COUNT + 2, tops + TOP_RESEED_COUNT + 3, tops + TOP_RESEED_TICKET + 2, c->job_outs.p, rs_pool, c->env_rs_inline, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_reseed1, s2));
-    k_order_reads<<<slow_grid, 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->done.p, tops + TOP_CLASS_HIST, tops + TOP_CLASS_FILL, c->perm.p, tops + TOP_ORDER_INFO, c->d_err);
+    if (c->env_one_stream) TICK("k_reseed");
+    k_order_items<<<slow_grid, 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->cands.p, c->ncand.p, tops + TOP_CLASS_HIST, tops + TOP_CLASS_FILL, c->items.p, tops + TOP_ORDER_INFO, c->d_err);
     HIPCHK(hipGetLastError());
-    const uint32_t *n_jobreads_p = tops + TOP_ORDER_INFO;             // reads of class 0 (they wait for k_reseed)
-    const uint32_t *heavy_end_p = tops + TOP_ORDER_INFO + 1;          // end of the heavy classes 1-3
-    const uint32_t *single_first_p = tops + TOP_ORDER_INFO + 2;       // end of the list
+    const uint32_t *n_jobitems_p = tops + TOP_ORDER_INFO;             // items of class 0 (they wait for k_reseed)
+    const uint32_t *n_items_p = tops + TOP_ORDER_INFO + 1;            // end of the list
     TICK("order");
-    // one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves
-    const int blocks_main = blocks > c->n_cu * 4 ? blocks - c->n_cu : blocks;
-#ifdef DG_PROFILE_CLASSES
-    { const uint8_t *kp = c->done.p; HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_costkey), &kp, sizeof kp, 0, hipMemcpyHostToDevice, c->stream)); }
-#endif
+    // (two streams: one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves)
+    const int blocks_main = (!c->env_one_stream && blocks > c->n_cu * 4) ? blocks - c->n_cu : blocks;
     k_report<2><<<blocks_main, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
-                                               c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, heavy_end_p, single_first_p, 0, c->reads_out.p, c->reports.p, c->cigpool.p,
+                                               c->rep_off.p, c->work.p, c->items.p, n_jobitems_p, n_items_p, c->env_one_stream ? 2 : 0, c->reports.p, c->cigpool.p,
                                                (uint32_t)cigcap, tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
 #ifdef DG_PROFILE_CLASSES
@@ -1478,14 +1496,16 @@ static int enqueue_run(dg_ctx *c)
     }
 #endif
     TICK("k_report");
+    if (!c->env_one_stream) {
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_reseed1, 0));
-    // (the reads that waited for k_reseed: a handful on DNA, a third of a spliced batch -- the full persistent grid; waves without work leave at once)
+    // (the candidates that waited for k_reseed: a handful on DNA, a third of a spliced batch -- the full persistent grid; waves without work leave at once)
     k_report<2><<<blocks_main, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,
-                                               c->ncand.p, c->rep_off.p, c->work.p, c->perm.p, n_jobreads_p, heavy_end_p, single_first_p, 1, c->reads_out.p, c->reports.p, c->cigpool.p,
+                                               c->rep_off.p, c->work.p, c->items.p, n_jobitems_p, n_items_p, 1, c->reports.p, c->cigpool.p,
                                                (uint32_t)cigcap, tops, c->ws.p, L, c->d_ctr, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("k_report_jobs");
-    k_finalize<<<slow_grid, 256, 0, c->stream>>>(c->ix, c->pr, paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->cands.p, c->ncand.p, c->work.p,
+    }
+    k_finalize<<<slow_grid, 256, 0, c->stream>>>(c->ix, c->pr, paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->cands.p, c->ncand.p, c->rep_off.p, c->work.p,
                                                  c->reads_out.p, c->reports.p, c->sjpool.p, (uint32_t)sjcap, tops, c->d_err);
     k_emit_slow<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->reads_out.p, c->reports.p, c->cigpool.p, c->cigfinal.p,
                                                                     (uint32_t)c->cap_cig, c->sjpool.p, c->sjfinal.p, ts_emit, c->d_err, c->rlen.p, co);
@@ -1494,6 +1514,7 @@ static int enqueue_run(dg_ctx *c)
     // the tail: sizes, status, counters -> pinned host memory, one copy each
     k_batch_end<<<1, 256, 0, c->stream>>>(c->d_sizes, c->d_err, c->d_tops, c->d_ctr, c->h_tail);
     HIPCHK(hipGetLastError());
+    c->state_zeroed = true;
     TICK("tail");
     c->enqueued = true;
     return DG_OK;
@@ -1506,7 +1527,7 @@ static int finish_run(dg_ctx *c, size_t used[3])
     for (int attempt = 0; attempt < 6; attempt++) {
         c->runs_of_last_batch++;
         HIPCHK(wait_stream(c));
-        if (c->owns_stream2) HIPCHK(hipStreamSynchronize(c->stream2));      // (a shared one holds other contexts' kernels too; this context's are behind ev_reseed1, which its main stream waited for)
+        if (c->owns_stream2 && c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));      // (a shared one holds other contexts' kernels too; this context's are behind ev_reseed1, which its main stream waited for)
         if (c->enc_ready && c->h_tail->input_bad) { snprintf(c->err, 512, "packed batch: the N list holds a position outside the batch"); c->enqueued = false; return DG_ERR_ARG; }
         const DSizes &sz = c->h_tail->sizes;
         const int derr = c->h_tail->err;
@@ -1545,7 +1566,7 @@ static int finish_run(dg_ctx *c, size_t used[3])
     }
     c->enqueued = false;
     for (int i = 0; i < c->n_t; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]); c->tms[i] = ms; }
-    if (c->n_t < N_TIMERS) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_reseed0, c->ev_reseed1); c->tname[c->n_t] = "k_reseed(overlapped)"; c->tms[c->n_t] = ms; c->n_t++; }
+    if (!c->env_one_stream && c->n_t < N_TIMERS) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_reseed0, c->ev_reseed1); c->tname[c->n_t] = "k_reseed(overlapped)"; c->tms[c->n_t] = ms; c->n_t++; }
     static_assert(CTR_N <= CTR_STRIDE, "the work counters fill one stripe");
     for (int k = 0; k < CTR_N; k++) c->counters[k] = c->h_tail->ctr[k];
     if (c->seed_qf_used) {
@@ -1805,8 +1826,7 @@ extern "C" int dg_debug_random_blocks(dg_ctx *c, int iters, int dependent, int w
 // debugging aid (not in the public header): the re-seed job queue of the last run
 extern "C" int dg_debug_jobs(dg_ctx *c, void *out, int cap)
 {
-    unsigned int n = 0;
-    if (hipMemcpy(&n, c->d_tops + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    unsigned int n = c->h_tail ? c->h_tail->tops[TOP_JOBS] : 0u;       // (the device copy is zeroed by k_batch_end)
     if ((int)n > cap) n = (unsigned)cap;
     if (n && hipMemcpy(out, c->jobs.p, (size_t)n * sizeof(DJob), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)n;
@@ -1823,12 +1843,13 @@ extern "C" int dg_last_timings(dg_ctx *c, const char **names, float *ms, int cap
 extern "C" int dg_last_counters(dg_ctx *c, uint64_t *out, int cap)
 {
     if (!c) return 0;
-    int k = CTR_N < cap ? CTR_N : cap;
+    int k = CTR_R4_N < cap ? CTR_R4_N : cap;
     for (int i = 0; i < k; i++) out[i] = c->counters[i];
     // [36] units that took the general path, [37] units chained by a wave each, [38] times the batch was enqueued, [39] / [40] re-runs of this context so far: capacity grown / scan not completed (> 1: a buffer grew)
     const uint64_t extra[5] = { c->h_tail ? c->h_tail->sizes.n_slow_units : 0u, c->h_tail ? c->h_tail->tops[TOP_HEAVY_UNITS] : 0u, (uint64_t)c->runs_of_last_batch,
                                 c->reruns_capacity, c->reruns_scan };
     for (int i = 0; i < 5 && k < cap; i++) out[k++] = extra[i];
+    for (int i = CTR_R4_N; i < CTR_N && k < cap; i++) out[k++] = c->counters[i];        // [41] windows scanned again whole, [42] (window, chunk) items of k_reseed
     return k;
 }
 
@@ -1901,7 +1922,7 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
         if ((rc = enqueue_seeding(c, n, H, false, false))) return rc;
         // the production sorters, every read on its own (unpaired): k_chain_heavy for the long lists, k_pair (candidate stage
         // only, sorted seeds written back for every read) for the rest
-        HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n)); HIPCHK(c->done.ensure((size_t)n + 16));
+        HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n));
         HIPCHK(c->heavy.ensure((size_t)n + 16)); HIPCHK(c->slow_units.ensure((size_t)n + 16)); HIPCHK(c->reports.ensure(16)); HIPCHK(c->cigfinal.ensure(16));
         k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
         const TileScan ts = make_tile_scan(c, scan_tiles_seed(n), c->d_tops + TOP_TICKET_PAIR, 2);
@@ -1911,6 +1932,7 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
         HIPCHK(hipGetLastError());
         k_batch_end<<<1, 256, 0, c->stream>>>(c->d_sizes, c->d_err, c->d_tops, c->d_ctr, c->h_tail);
         HIPCHK(hipGetLastError());
+        c->state_zeroed = true;
         HIPCHK(hipStreamSynchronize(c->stream));
         total = c->h_tail->sizes.total_seeds;
         if (c->h_tail->err == DG_E_SEEDS && attempt < 3) { c->cap_seeds = (size_t)total + total / 4 + 1024; continue; }

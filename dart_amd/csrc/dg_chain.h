@@ -295,6 +295,23 @@ __device__ inline void d_bitonic_sort_keys(SKey *a, int n, int lane)   // n <= C
 #ifdef DG_PROFILE_CLASSES
 __device__ unsigned long long g_chain_max, g_chain_units, g_chain_cycles;
 #endif
+// what the candidate rules read and write of a DCand, staged in LDS (16 of its 48 bytes)
+struct __attribute__((aligned(8))) CandLite { int64_t PosDiff; int32_t Score, PairedIdx; };
+struct CandLiteView {
+    CandLite *c; int cnt;
+    __host__ __device__ int n() const { return cnt; }
+    __host__ __device__ int score(int i) const { return c[i].Score; }
+    __host__ __device__ void set_score(int i, int v) { c[i].Score = v; }
+    __host__ __device__ int64_t diag(int i) const { return c[i].PosDiff; }
+    __host__ __device__ int mate(int i) const { return c[i].PairedIdx; }
+    __host__ __device__ void set_mate(int i, int v) { c[i].PairedIdx = v; }
+};
+// LDS of one wave, 12.4 KB (round 4: 39 KB -- both mates' seeds, whole DCand records and the clustering scratch side by side; a wave of this kernel held a
+// quarter of a CU's LDS, 17 % of the GPU's LDS-time on a genome with human-like repeat content): the sort + clustering of one mate at a time needs
+// the seeds, the covered-bases prefix and the start masks; the pairing afterwards needs the two candidate lists and the picks -- the two phases share the bytes.
+#define CH_LDS_SORT (CH_MAXS * 8 + (CH_MAXS + 1) * 4 + 4 + (CH_MAXS / 64) * 8)
+#define CH_LDS_PAIR (2 * CH_MAXC * 16 + CH_MAXC * 2)
+#define CH_LDS_BYTES (CH_LDS_SORT > CH_LDS_PAIR ? CH_LDS_SORT : CH_LDS_PAIR)
 __global__ void __launch_bounds__(64)
 k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const uint16_t *__restrict__ rlen,
               const uint32_t *__restrict__ seed_off, SKey *__restrict__ seeds, DCand *__restrict__ cands,
@@ -302,13 +319,14 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
               unsigned long long *ctr, const int *__restrict__ abort_p)
 {
     const unsigned long long t_wave0 = wall_clock64();
-    __shared__ SKey ls[2][CH_MAXS];
-    __shared__ DCand lc[2][CH_MAXC];
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[CH_LDS_BYTES];
+    SKey *ls = (SKey *)s_mem;                                                       // phase 1: one mate's seeds ...
+    uint32_t *s_pref = (uint32_t *)(s_mem + CH_MAXS * 8);                            // ... the prefix of covered bases ...
+    unsigned long long *s_starts = (unsigned long long *)(s_mem + CH_MAXS * 8 + (CH_MAXS + 1) * 4 + 4);      // ... and the start masks
+    CandLite *lc0 = (CandLite *)s_mem, *lc1 = lc0 + CH_MAXC;                          // phase 2: the two candidate lists ...
+    int16_t *s_pick = (int16_t *)(s_mem + 2 * CH_MAXC * 16);                          // ... and every candidate's pick
     __shared__ int s_n[2], s_pairing;
-    __shared__ int16_t s_pick[CH_MAXC];
-    __shared__ uint32_t s_pref[CH_MAXS + 1];
-    __shared__ unsigned long long s_starts[CH_MAXS / 64];
-    // the ChrLocMap keys in LDS when they fit (32 chromosomes: 512 bytes, four waves still share a CU): the clustering asks "does this seed lie
+    // the ChrLocMap keys in LDS when they fit (32 chromosomes: 512 bytes): the clustering asks "does this seed lie
     // before the end of its neighbour's chromosome half" through a binary search, six dependent loads from memory otherwise (dg_common.h, LocTab)
     __shared__ int64_t s_lkey[CH_LOC_MAX];
     const bool tab_in_lds = 2 * ix.n_chr <= CH_LOC_MAX;
@@ -327,39 +345,33 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
 #endif
         const int r1 = paired ? 2 * u : u;
         uint32_t b[2] = {0, 0}, n[2] = {0, 0};
-        bool fits = true;
-        for (int m = 0; m < nm; m++) { b[m] = seed_off[r1 + m]; n[m] = seed_off[r1 + m + 1] - b[m]; fits = fits && n[m] <= CH_MAXS; }
+        for (int m = 0; m < nm; m++) { b[m] = seed_off[r1 + m]; n[m] = seed_off[r1 + m + 1] - b[m]; }
         __syncthreads();
-        if (fits) {
-            for (int m = 0; m < nm; m++) {
-                for (uint32_t i = lane; i < n[m]; i += 64) ls[m][i] = seeds[b[m] + i];
+        for (int m = 0; m < nm; m++) {                       // one mate at a time: sort, write back, cluster
+            if (n[m] <= CH_MAXS) {
+                for (uint32_t i = lane; i < n[m]; i += 64) ls[i] = seeds[b[m] + i];
                 __syncthreads();
-                d_bitonic_sort_keys(ls[m], (int)n[m], lane);
-                for (uint32_t i = lane; i < n[m]; i += 64) seeds[b[m] + i] = ls[m][i];
-            }
-            __syncthreads();
-        }
-        if (fits) {
-            for (int m = 0; m < nm; m++) {
-                const int made = d_gen_candidates_wave(lt, pr, rlen[r1 + m], ls[m], (int)n[m], b[m], cands + b[m], s_pref, s_starts, lane);
+                d_bitonic_sort_keys(ls, (int)n[m], lane);
+                for (uint32_t i = lane; i < n[m]; i += 64) seeds[b[m] + i] = ls[i];
+                __syncthreads();
+                const int made = d_gen_candidates_wave(lt, pr, rlen[r1 + m], ls, (int)n[m], b[m], cands + b[m], s_pref, s_starts, lane);
                 if (lane == 0) s_n[m] = made;
-            }
-        } else if (lane == 0) {
-            for (int m = 0; m < nm; m++) {
+            } else if (lane == 0) {                          // longer than the staging: the serial route through memory (same functions)
                 d_sort_keys(seeds + b[m], (int)n[m]);
                 s_n[m] = d_gen_candidates(ix, pr, rlen[r1 + m], seeds + b[m], (int)n[m], b[m], cands + b[m]);
             }
+            __syncthreads();
         }
-        __syncthreads();
         const int n1 = s_n[0], n2 = paired ? s_n[1] : 0;
         DCand *c1 = cands + b[0], *c2 = paired ? cands + b[1] : nullptr;
+        __syncthreads();                                       // (the candidates are in memory; the sort phase's LDS is free)
         if (paired) {
             const bool stage = n1 <= CH_MAXC && n2 <= CH_MAXC;
             if (stage) {
-                for (int i = lane; i < n1; i += 64) lc[0][i] = c1[i];
-                for (int i = lane; i < n2; i += 64) lc[1][i] = c2[i];
+                for (int i = lane; i < n1; i += 64) { const DCand &c = c1[i]; lc0[i] = CandLite{c.PosDiff, c.Score, c.PairedIdx}; }
+                for (int i = lane; i < n2; i += 64) { const DCand &c = c2[i]; lc1[i] = CandLite{c.PosDiff, c.Score, c.PairedIdx}; }
                 __syncthreads();
-                CandMem a1{lc[0], n1}, a2{lc[1], n2};
+                CandLiteView a1{lc0, n1}, a2{lc1, n2};
                 if (n1 * n2 > 1000) { if (lane == 0) { d_keep_top(a1); d_keep_top(a2); } __syncthreads(); }
                 if (lane == 0) s_pairing = 0;
                 __syncthreads();
@@ -397,8 +409,8 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
                     d_keep_top(a1); d_keep_top(a2);
                 }
                 __syncthreads();
-                for (int i = lane; i < n1; i += 64) c1[i] = lc[0][i];
-                for (int i = lane; i < n2; i += 64) c2[i] = lc[1][i];
+                for (int i = lane; i < n1; i += 64) { c1[i].Score = lc0[i].Score; c1[i].PairedIdx = lc0[i].PairedIdx; }
+                for (int i = lane; i < n2; i += 64) { c2[i].Score = lc1[i].Score; c2[i].PairedIdx = lc1[i].PairedIdx; }
             } else if (lane == 0) { CandMem a1{c1, n1}, a2{c2, n2}; d_candidate_rules(true, a1, a2); }
         } else if (lane == 0) { CandMem a1{c1, n1}; d_keep_top(a1); }
         __syncthreads();

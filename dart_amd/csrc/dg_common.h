@@ -51,9 +51,9 @@ struct __attribute__((aligned(8))) DCand {
     int32_t job_count;
 };
 
-// One ReseedingWithSpecificRegion call (AlignmentCandidates.cpp:596-624), queued by k_prep,
-// executed by one wave in k_reseed, consumed by k_report.
-struct __attribute__((aligned(8))) DJob {
+// One ReseedingWithSpecificRegion call (AlignmentCandidates.cpp:596-624), queued by k_prep, executed by k_reseed -- one wave when the
+// genome window has at most `chunk` diagonals, else one wave per chunk of diagonals (dg_reseed.h) --, consumed by k_report.
+struct __attribute__((aligned(16))) DJob {
     int64_t Lb;           // genome window [Lb, Lb+glen)
     int64_t gPos;         // result: seed genome position
     int32_t glen;
@@ -61,8 +61,12 @@ struct __attribute__((aligned(8))) DJob {
     uint32_t read;        // read index (for the sequence)
     int32_t found;        // result: 1 = seed accepted
     int32_t rPos, len;    // result
-    int32_t pad;
+    uint32_t n_chunks;    // k_order_jobs: waves that share this window (1: the whole window by one wave, nothing below is used)
+    uint32_t out_first;   // first of its n_chunks RsChunkOut records
+    uint32_t done;        // chunks finished so far (the wave that finishes the last one folds all of them)
+    uint32_t pad[2];
 };
+static_assert(sizeof(DJob) == 64, "DJob is four 16-byte words");
 
 // The index on the device.  bwt keeps the reference's Occ-interleaved layout (one 64-byte block
 // per 128 rows = 4 x u64 cumulative counts + 8 x u32 of 2-bit symbols, bwtindex.c:53-75) at a
@@ -110,7 +114,8 @@ enum { CTR_STEPS = 0, CTR_BLOCKS, CTR_LF, CTR_SA, CTR_SEEDS, CTR_CANDS, CTR_NW, 
        CTR_STEPS_ACT, CTR_BLOCKS_ACT, CTR_KTAB, CTR_LF_ACT, CTR_DIRECT, CTR_MAXTRIPS, CTR_WTRIPS_MAX, CTR_WTRIPS_SUM,
        CTR_RESEED_TRIPS, CTR_RESEED_TICKS,
        CTR_SQ_TRIPS, CTR_SQ_LANES = CTR_SQ_TRIPS + 5, CTR_SQ_PHASES = CTR_SQ_LANES + 5,
-       CTR_WT_SEEDQF, CTR_WT_SEEDH, CTR_WT_CHAIN, CTR_WT_PAIR, CTR_WT_REPORT, CTR_N };             // CTR_WT_*: time the kernel's waves were resident, summed over its waves, in wall-clock ticks (10 ns): which resource do a dozen batches in flight fill?   // k_seed_q: wave-trips and slots served per queue (begin, step, compare, locate, refill)   // *_ACT: steps/blocks this implementation really executed
+       CTR_WT_SEEDQF, CTR_WT_SEEDH, CTR_WT_CHAIN, CTR_WT_PAIR, CTR_WT_REPORT, CTR_R4_N /* dg_last_counters lists these, then its five host-side values, then the ones below */,
+       CTR_RESEED_WHOLE = CTR_R4_N /* windows shared by several waves that one wave had to scan again whole (the entry pool ran out) */, CTR_RESEED_ITEMS /* (window, chunk) items k_reseed served */, CTR_RESEED_POOLED /* chunks whose entries went through the pool */, CTR_N };             // CTR_WT_*: time the kernel's waves were resident, summed over its waves, in wall-clock ticks (10 ns): which resource do a dozen batches in flight fill?   // k_seed_q: wave-trips and slots served per queue (begin, step, compare, locate, refill)   // *_ACT: steps/blocks this implementation really executed
 
 __host__ __device__ __forceinline__ uint8_t d_nt4(unsigned char c)   // nst_nt4_table, BWT_Index/bntseq.c:40: ACGT/acgt -> 0..3, '-' -> 5, else 4
 {

@@ -539,13 +539,14 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
         for (int i = threadIdx.x; i < ix.n_chr; i += PU_THREADS) s_coff[i] = ix.chr_off[i];
     }                                                  // (d_tile_ticket's barrier below orders these stores before every use)
     const LocTab lt = tab_in_lds ? LocTab{s_lkey, s_lchr, s_coff, 2 * ix.n_chr} : d_loc_tab(ix);
-    { const int e0 = *err; if (e0 == DG_E_SEEDS || e0 == DG_E_SEEDQ || e0 == DG_E_SCAN) return; }
-                                                       // SEEDS / SEEDQ are raised before this launch (seeds that do not fit, the seeding kernel's safety net), SCAN by
-                                                       // k_seed_offsets before it or by a look-back inside it: seed_off / nseeds cannot be trusted, the host runs the batch
-                                                       // again.  Leaving BEFORE the ticket is safe: no tile exists that a successor could wait for, and pollers of a
-                                                       // DG_E_SCAN run give up by themselves.  Capacity errors raised INSIDE this launch never make a workgroup leave:
-                                                       // its successors wait for its totals
-    const unsigned int tile = d_tile_ticket(ts, &s_tile);
+    // SEEDS / SEEDQ are raised before this launch (seeds that do not fit, the seeding kernel's safety net), SCAN by k_seed_offsets before it or by a look-back
+    // inside it: seed_off / nseeds cannot be trusted, the host runs the batch again.  Leaving BEFORE the ticket is safe: no tile exists that a successor could wait
+    // for, and pollers of a DG_E_SCAN run give up by themselves.  The decision is thread 0's, the same for the whole workgroup (d_tile_ticket_unless).  Capacity
+    // errors raised INSIDE this launch never make a workgroup leave: its successors wait for its totals
+    bool leave = false;
+    if (threadIdx.x == 0) { const int e0 = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); leave = e0 == DG_E_SEEDS || e0 == DG_E_SEEDQ || e0 == DG_E_SCAN; }
+    const unsigned int tile = d_tile_ticket_unless(ts, &s_tile, leave);
+    if (tile == SCAN_LEAVE) return;
     const int u = (int)(tile * PU_THREADS + threadIdx.x);
     const bool valid = u < n_units;
     SKey *key = s_key + threadIdx.x;
@@ -633,7 +634,7 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
                 n_nw = st.n_nw; n_cells = st.n_cells;
             }
         } else {
-            slow_units[slow_at] = (uint32_t)u;
+            if (slow_at < (uint32_t)n_units) slow_units[slow_at] = (uint32_t)u;      // (a prefix from a look-back that gave up is garbage: the batch runs again, nothing may be written outside the list)
             if ((uint64_t)rep0 + mine.x > cap_rep) atomicMax(err, DG_E_REPORTS);       // its reports would not fit either
         }
         if (!heavy && (!st.fast || write_all_sorted)) {

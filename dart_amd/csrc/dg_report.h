@@ -1030,14 +1030,15 @@ struct DRead {
 // CALLED BY ALL 64 LANES OF THE WAVE TOGETHER (valid = false: a lane without a read): the candidate loop
 // runs to the wave's largest candidate count with per-lane guards, because in its middle the wave
 // aligns the lanes' LARGE segment pairs cooperatively, one after the other (d_nw_coop).
-// Two lane layouts: one read per lane (cstride = 1, cstart = 0: the lane walks its read's candidates in order), or ONE read
-// for the whole wave with lane = candidate (cstride = 64, cstart = lane; the few reads with dozens of candidates that
-// otherwise set the kernel's critical path).  In the second layout the running best/second-best state of
-// :1161-1172 is replayed in candidate order by lane 0 afterwards (rd is valid in lane 0 only).
+// Three lane layouts: one read per lane (cstride = 1, cstart = 0: the lane walks its read's candidates in order; k_pair's host-compiled
+// checks and the probes), ONE read for the whole wave with lane = candidate (cstride = 64, cstart = lane), or -- k_report since round 5 --
+// one CANDIDATE per lane, whichever read it belongs to (`cands` / `rep` point at that candidate, ncand = 1, park = true).  In the second
+// layout the running best/second-best state of :1161-1172 is replayed in candidate order by lane 0 afterwards (rd is valid in lane 0
+// only); in the third the candidate's mismatch count is parked in its report's flag and k_finalize replays the read's candidates.
 template <typename ReportT>
 __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first, DRead &rd, DCand *cands, int ncand, const DJob *jobs,
                                             DSeed *work, ReportT *rep, uint32_t rep_index0, uint32_t *cigpool, unsigned int *cigtop, uint32_t cigcap, int *err,
-                                            int cstart = 0, int cstride = 1)
+                                            int cstart = 0, int cstride = 1, bool park = false)
 {
     const DIndex &ix = *cx.ix;
     const int lane = threadIdx.x & 63;
@@ -1210,7 +1211,7 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                     else { for (int j = 0; j < m; j++) cigpool[off + j] = cig[j]; rp.cigar_off = off; rp.n_cigar = (uint32_t)m; }
                 }
                 rp.aln_score = aln;
-                if (cstride != 1) rp.flag = mis_num;               // parked for the replay below
+                if (cstride != 1 || park) rp.flag = mis_num;       // parked for the replay (below, or in k_finalize)
                 else if (aln > rd.score) { rd.iBest = i; rd.mis_num = mis_num; rd.sub_score = rd.score; rd.score = aln; }
                 else if (aln == rd.score) rd.sub_score = rd.score;
             }

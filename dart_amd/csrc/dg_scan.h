@@ -47,21 +47,30 @@ __device__ __forceinline__ void ts_publish(const TileScan &ts, unsigned int tile
     ts_store(p, ts_pack(tag, x)); ts_store(p + 1, ts_pack(tag, y)); ts_store(p + 2, ts_pack(tag, z)); ts_store(p + 3, ts_pack(tag, w));
 }
 
-// ticket of this workgroup (call once, by every thread; sh = one u32 of LDS)
-__device__ __forceinline__ unsigned int d_tile_ticket(const TileScan &ts, unsigned int *sh)
+// Ticket of this workgroup (call once, by every thread; sh = one u32 of LDS) -- unless thread 0 says the workgroup leaves: kernels leave a batch whose status
+// word says "this run is void" (dg_common.h, DG_ABORT).  That decision is thread 0's alone, made BEFORE it takes the ticket and handed to the workgroup through
+// LDS behind the ticket's barrier, so the waves of a workgroup can never disagree: a status raised INSIDE the launch by another tile's look-back (DG_E_SCAN)
+// reaches the waves of one workgroup at different times, and with every wave reading *err on its own (round 4) some left while the others went on with a tile
+// number or block sums nobody had written.  Returns 0xFFFFFFFF = leave: no ticket was taken, so no tile exists that a successor could wait for.
+#define SCAN_LEAVE 0xFFFFFFFFu
+__device__ __forceinline__ unsigned int d_tile_ticket_unless(const TileScan &ts, unsigned int *sh, bool leave_says_thread0)
 {
     if (threadIdx.x == 0) {
-        const unsigned int t = atomicAdd(ts.ticket, 1u);
-        *sh = t;
-        if (ts.trace) {
-            unsigned long long *p = ts.trace + (size_t)t * SCAN_TRACE_WORDS;
-            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_HW_ID, HW_REG_XCC_ID
-            p[0] = ((unsigned long long)ts.epoch << 32) | hw; p[1] = wall_clock64(); p[2] = 0ull; p[3] = (unsigned long long)(xcc & 0xFFu) << 56;
+        if (leave_says_thread0) *sh = SCAN_LEAVE;
+        else {
+            const unsigned int t = atomicAdd(ts.ticket, 1u);
+            *sh = t;
+            if (ts.trace) {
+                unsigned long long *p = ts.trace + (size_t)t * SCAN_TRACE_WORDS;
+                const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_HW_ID, HW_REG_XCC_ID
+                p[0] = ((unsigned long long)ts.epoch << 32) | hw; p[1] = wall_clock64(); p[2] = 0ull; p[3] = (unsigned long long)(xcc & 0xFFu) << 56;
+            }
         }
     }
     __syncthreads();
     return *sh;
 }
+__device__ __forceinline__ unsigned int d_tile_ticket(const TileScan &ts, unsigned int *sh) { return d_tile_ticket_unless(ts, sh, false); }
 
 // exclusive prefix of this tile's totals over all earlier tiles; every thread of the workgroup calls it with the tile's totals
 // (only thread 0's copy is published) and gets the same result.  sh = 4 u64 of LDS (behind d_block_exclusive's 16).  Workgroups must have >= 64 threads.

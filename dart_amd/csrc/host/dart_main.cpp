@@ -541,8 +541,8 @@ int main(int argc, char *argv[])
     // every device of the node maps batches (reads shard, the index is replicated; the reference's -t threads over one shared index,
     // Mapping.cpp:792-793); DART_GPUS=n restricts it to the first n
     int n_gpu = dg_device_count();
-    if (getenv("DART_GPUS")) n_gpu = std::min(std::max(1, atoi(getenv("DART_GPUS"))), std::max(1, n_gpu));
     if (n_gpu < 1) { fprintf(stderr, "Error! No HIP device (this build of dart has no CPU path)\n"); return 1; }
+    if (getenv("DART_GPUS")) n_gpu = std::min(std::max(1, atoi(getenv("DART_GPUS"))), n_gpu);      // (HIP_VISIBLE_DEVICES picks WHICH devices; a job of a few million reads is done before a second device has its index)
     SlotPool pool;                          // batch slots of the parallel FASTQ pipeline (page-locked in the background with DART_PINNED=1)
     if (fast_first) pool.start((size_t)n_gpu * inflight_cfg + 2, batch_reads, 160);
     // The read files of a library.  Plain FASTQ goes through the parallel host pipeline (fast_fastq.h); FASTA, .gz, -bo and DART_STREAMING=1 through the
@@ -590,9 +590,14 @@ int main(int argc, char *argv[])
         files.l_pac = ix.l_pac; files.n_chr = (int32_t)ix.names.size(); files.chr_off = ix.off.data(); files.chr_len = ix.len.data();
         {   // the size of the job, from the sizes of its input files: ~250 bytes per FASTQ read of 2x101 (a quarter of that gzipped; FASTA: half).
             // A coarse figure is all the library needs: it decides between lean and full look-up aids at some hundred million reads.
-            uint64_t bytes = 0; struct stat st;
-            for (auto &v : {&o.f1, &o.f2}) for (auto &fn : *v) if (stat(fn.c_str(), &st) == 0) bytes += (uint64_t)st.st_size * (fn.size() > 3 && fn.substr(fn.size() - 3) == ".gz" ? 4u : 1u);
-            files.expected_reads = std::max<uint64_t>(1, bytes / 250);
+            // An input whose size cannot be known (a FIFO, process substitution, /dev/stdin, a failed stat) makes the whole job "unknown" (0): the library then
+            // builds the full aids -- a very large piped job must not run its seeding stage at half speed for its whole length
+            uint64_t bytes = 0; struct stat st; bool known = true;
+            for (auto &v : {&o.f1, &o.f2}) for (auto &fn : *v) {
+                if (stat(fn.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) bytes += (uint64_t)st.st_size * (fn.size() > 3 && fn.substr(fn.size() - 3) == ".gz" ? 4u : 1u);
+                else known = false;
+            }
+            files.expected_reads = known ? std::max<uint64_t>(1, bytes / 250) : 0;
             if (getenv("DART_EXPECTED_READS")) files.expected_reads = (uint64_t)atoll(getenv("DART_EXPECTED_READS"));
         }
         o.p.paired = (o.pair_end || o.f1.size() == o.f2.size()) ? 1 : 0;

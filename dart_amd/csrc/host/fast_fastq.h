@@ -28,32 +28,62 @@ struct MappedFile {
     size_t cap = 0;                                   // > 0: p is an anonymous mapping of cap bytes holding an inflated file
     // A .gz file, inflated whole into memory (every member, as gzread concatenates them).  false = not possible here (no libdeflate, larger than
     // max_out, not a clean gzip file): the caller takes the streaming reader, which has gzread's behaviour for whatever this is.
+    // What this process may still take: MemAvailable, and what the cgroup (v2, then v1) leaves -- a container's limit is not in /proc/meminfo.  0 = unknown.
+    static size_t memory_left() {
+        size_t avail = 0;
+        if (FILE *f = fopen("/proc/meminfo", "r")) {
+            char line[256];
+            while (fgets(line, sizeof line, f)) { unsigned long long kb; if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = (size_t)kb << 10; break; } }
+            fclose(f);
+        }
+        if (!avail) { const long pg = sysconf(_SC_AVPHYS_PAGES), sz = sysconf(_SC_PAGESIZE); if (pg > 0 && sz > 0) avail = (size_t)pg * (size_t)sz; }
+        auto read_u64 = [](const char *path, unsigned long long &v) { FILE *f = fopen(path, "r"); if (!f) return false; const bool ok = fscanf(f, "%llu", &v) == 1; fclose(f); return ok; };
+        unsigned long long lim = 0, cur = 0;
+        if ((read_u64("/sys/fs/cgroup/memory.max", lim) && read_u64("/sys/fs/cgroup/memory.current", cur)) ||
+            (read_u64("/sys/fs/cgroup/memory/memory.limit_in_bytes", lim) && read_u64("/sys/fs/cgroup/memory/memory.usage_in_bytes", cur))) {
+            const size_t room = lim > cur ? (size_t)(lim - cur) : 0;
+            if (lim < (1ull << 60) && (!avail || room < avail)) avail = room;
+        }
+        return avail;
+    }
+    // A .gz file, inflated whole into memory (every member, as gzread concatenates them).  false = not possible here (no libdeflate, larger than
+    // max_out or than a third of the memory this process may still take -- both mates are inflated at once and the batch buffers come on top; the
+    // streaming reader runs such a job in constant memory --, not a clean gzip file): the caller takes the streaming reader, which has gzread's
+    // behaviour for whatever this is.  The mapping grows in place (mremap) and the inflate goes on with the member that did not fit: the last
+    // member's ISIZE is only a first guess (multi-member and bgzip files), and starting over doubled the work each time.
     bool open_gz(const char *fn, size_t max_out) {
         const LibDeflate &ld = lib_deflate();
         if (!ld.ok() || getenv("DART_GZ_STREAM")) return false;          // DART_GZ_STREAM=1: always the streaming reader
         MappedFile z;
         if (!z.open(fn) || z.n < 18 || (unsigned char)z.p[0] != 0x1f || (unsigned char)z.p[1] != 0x8b) return false;
+        { const size_t left = memory_left(); if (left && left / 3 < max_out) max_out = left / 3; }
         uint32_t isize; memcpy(&isize, z.p + z.n - 4, 4);                       // the last member's size mod 2^32: the first guess
         size_t want = std::max<size_t>((size_t)isize + 64, z.n * 4);
+        if (want > max_out) return false;
         void *d = ld.alloc();
         if (!d) return false;
-        bool done = false;
-        while (!done && want <= max_out) {
-            void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-            if (m == MAP_FAILED) break;
-            size_t in_at = 0, out_at = 0; int rc = 0;
-            while (in_at < z.n) {
-                if (z.n - in_at < 18 || (unsigned char)z.p[in_at] != 0x1f || (unsigned char)z.p[in_at + 1] != 0x8b) { rc = 1; break; }    // bytes behind the last member: gzread's business
-                size_t used = 0, made = 0;
-                rc = ld.gunzip(d, z.p + in_at, z.n - in_at, (char *)m + out_at, want - out_at, &used, &made);
-                if (rc) break;
-                in_at += used; out_at += made;
+        void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) { ld.release(d); return false; }
+        size_t in_at = 0, out_at = 0; int rc = 0;
+        while (in_at < z.n) {
+            if (z.n - in_at < 18 || (unsigned char)z.p[in_at] != 0x1f || (unsigned char)z.p[in_at + 1] != 0x8b) { rc = 1; break; }    // bytes behind the last member: gzread's business
+            size_t used = 0, made = 0;
+            rc = ld.gunzip(d, z.p + in_at, z.n - in_at, (char *)m + out_at, want - out_at, &used, &made);
+            if (rc == 3) {                                                      // LIBDEFLATE_INSUFFICIENT_SPACE: this member again, into a larger mapping (what the earlier members gave stays)
+                const size_t bigger = want * 2;
+                if (bigger > max_out) break;
+                void *m2 = mremap(m, want, bigger, MREMAP_MAYMOVE);
+                if (m2 == MAP_FAILED) break;
+                m = m2; want = bigger; rc = 0;
+                continue;
             }
-            if (rc == 0) { p = (const char *)m; n = out_at; cap = want; done = true; }
-            else { munmap(m, want); if (rc != 3) break; want *= 2; }                                        // 3 = LIBDEFLATE_INSUFFICIENT_SPACE
+            if (rc) break;
+            in_at += used; out_at += made;
         }
         ld.release(d);
-        return done;
+        if (rc != 0 || in_at < z.n) { munmap(m, want); return false; }
+        p = (const char *)m; n = out_at; cap = want;
+        return true;
     }
     bool open(const char *fn) {
         fd = ::open(fn, O_RDONLY);

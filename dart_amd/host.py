@@ -469,7 +469,8 @@ class DartGPU:
                 "steps_executed", "occ_blocks_executed", "ktab_lookups", "lf_steps_executed", "direct_extensions", "k_seed_max_trips_per_read", "k_seed_wave_trips_max", "k_seed_wave_trips_sum", "k_reseed_trips", "k_reseed_wave_ticks_100mhz",
                 "seedq_trips_begin", "seedq_trips_step", "seedq_trips_compare", "seedq_trips_locate", "seedq_trips_refill",
                 "seedq_slots_begin", "seedq_slots_step", "seedq_slots_compare", "seedq_slots_locate", "seedq_slots_refill", "seedq_phases",
-                "wave_ticks_k_seed_qf", "wave_ticks_k_seed_heavy", "wave_ticks_k_chain_heavy", "wave_ticks_k_pair", "wave_ticks_k_report", "general_path_units", "wave_chained_units", "batch_runs", "reruns_capacity_total", "reruns_scan_total"]
+                "wave_ticks_k_seed_qf", "wave_ticks_k_seed_heavy", "wave_ticks_k_chain_heavy", "wave_ticks_k_pair", "wave_ticks_k_report", "general_path_units", "wave_chained_units", "batch_runs", "reruns_capacity_total", "reruns_scan_total",
+                "k_reseed_windows_scanned_again_whole", "k_reseed_items", "k_reseed_chunks_through_pool"]
         return {keys[i]: int(out[i]) for i in range(min(n, len(keys)))}
 
     def probe_seeds(self, seq_off, rlen, flat):

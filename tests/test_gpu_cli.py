@@ -161,7 +161,7 @@ def test_bench_two_ranks_through_the_self_launcher(workdir):
     env = dict(os.environ, DART_BENCH_REHEARSE="1", DART_BENCH_CACHE=os.path.join(workdir, "bench2_cache"))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--genome", "3000000", "--pairs", "20000", "--batches", "3", "--steps", "2",
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--genome", "3000000", "--pairs", "20000", "--batches", "3", "--steps", "2", "--weak",
                         "--warmup", "1", "--inflight", "2", "--cpu-sample-pairs", "4000", "--verify-gather"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
@@ -184,9 +184,10 @@ def test_bench_two_ranks_strong_scaling_one_job_sharded(workdir):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--genome", "3000000", "--pairs", "20000", "--total-pairs", "70001", "--steps", "2",
-                        "--warmup", "1", "--inflight", "2", "--no-cpu-baseline", "--no-secondary", "--verify-gather"], env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--inflight", "2", "--no-cpu-baseline", "--verify-gather"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "70001 pairs" in line["config"]["parallelism"]
     assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 / (2 * 70001) - 1) < 1e-3  # value = the whole job's reads over the step time
     assert line["gather"]["verified_against_single_rank_mapping"] is True
+    assert line["value_weak_scaling"] > 0 and line["phases_s"]["total"] > 0          # the weak-scaling rate beside it (every rank's own whole batches), and where the run's time went

@@ -329,6 +329,41 @@ def test_gpu_spliced_2x151_batch_matches_oracle(workdir):
     gpu.close(); orc.close()
 
 
+def test_gpu_reseed_windows_shared_by_several_waves(workdir, monkeypatch):
+    """k_reseed splits a genome window of more than 32 768 diagonals into chunks that different waves scan; the wave that finishes the
+    last chunk replays the chunks' reported diagonals through the reference's scan (KmerAnalysis.cpp:146-163).  Introns of up to 500 kb
+    on a 6 Mbp genome, 2x151 and 2x101.  The default chunk size; 4096-diagonal chunks (the test hook: up to 120 chunks per window);
+    chunk records that hold 0 or 1 entries inline (every chunk with a hit then sends its entries through the pool of 64-entry blocks);
+    a pool of two blocks (exhausted at once: such windows are scanned again whole by their last wave) -- all must give the oracle's
+    records and its re-seeding counters."""
+    g = synth.make_genome([4000000, 2000000], seed=61, repeat_scale=30.0, n_introns=1500)
+    prefix = os.path.join(workdir, "rs_shared")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    gpu = host.DartGPU(ix)
+    for rlen, n_pairs in ((151, 40000), (101, 40000)):
+        m1, m2 = synth.make_reads(g, n_pairs, rlen=rlen, seed=62 + rlen, sub_rate=0.01, indel_frac=0.02, n_frac=0.002, spliced_frac=0.5)
+        so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+        want = orc.map_batch(orc.params(paired=1, max_mismatch=5, max_intron=500000), so, rl, flat, threads=16)
+        oc = dict(orc.counters)
+        seen = {}
+        for chunk, inline, pool in ((None, None, None), (4096, None, None), (4096, 0, None), (8192, 1, None), (4096, 0, 2), (65536, None, None)):
+            for k, v in (("DG_RS_CHUNK", chunk), ("DG_RS_ENT_MAX", inline), ("DG_RS_POOL_BLOCKS", pool)):
+                if v is None: monkeypatch.delenv(k, raising=False)
+                else: monkeypatch.setenv(k, str(v))
+            gpu.set_params(host.default_params(paired=1, max_mismatch=5, max_intron=500000))      # (reads the DG_* switches)
+            assert_same(gpu.map_batch(so, rl, flat), want)
+            c = gpu.counters()
+            assert c["reseed_calls"] == oc["n_reseed"] and c["reseed_window"] == oc["reseed_window"], (chunk, inline, pool)
+            seen[(chunk, inline, pool)] = (c["k_reseed_items"], c["k_reseed_windows_scanned_again_whole"], c["k_reseed_chunks_through_pool"], c["reseed_calls"])
+        dflt, small, pooled, starved = seen[(None, None, None)], seen[(4096, None, None)], seen[(4096, 0, None)], seen[(4096, 0, 2)]
+        assert dflt[0] > dflt[3] > 300, seen              # windows longer than a chunk occurred ...
+        assert small[0] > 3 * dflt[3], seen               # ... and the small chunks multiplied the items
+        assert dflt[1] == 0 and small[1] == 0 and pooled[2] > 100 and pooled[2] > small[2] and pooled[1] < starved[1], seen      # the pool carried what the records could not hold
+        assert starved[1] > 50, seen                      # and without a pool the last wave did the window again
+    gpu.close(); orc.close()
+
+
 def test_gpu_noisy_long_reads_wave_nw_paths(workdir):
     """Stress of the wave-wide alignment service and of the wave-per-read layout: a repeat-rich 3 Mbp genome, 2x250 reads with
     4 % substitutions and an indel in a third of them (segment pairs wider than 64 columns: one pair per wave; up to 64: eight
