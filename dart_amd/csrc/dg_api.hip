@@ -1052,7 +1052,7 @@ k_unpack(const uint32_t *__restrict__ words, uint32_t n_words, int W2, double in
     const int ww = (int)(t - r * (uint32_t)W2);
     const int len = rlen_in ? rlen_in[r] : rlen_all, left = len - 16 * ww;
     const uint32_t w = words[t];
-    // (no ASCII copy of the batch: the seeding stage and the fused pair kernel read the words; k_unpack_listed rebuilds the characters of the
+    // (no ASCII copy of the batch: the seeding stage and the fused pair kernel read the words; k_prep rebuilds the characters of the
     //  units that take the general path -- a twentieth of a DNA batch)
     const uint32_t past = left >= 16 ? 0u : (left <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu >> (2 * left));          // mask 0b11 past the end, as k_encode
     enc[(size_t)r * 2 * W2 + ww] = w & ~past;
@@ -1069,33 +1069,6 @@ k_unpack_n(const uint32_t *__restrict__ nlist, uint32_t n_n, int W2, uint32_t n_
     const uint32_t bit = 3u << (30 - 2 * (pos & 15u));
     atomicAnd(&enc[(size_t)r * 2 * W2 + (pos >> 4)], ~bit);
     atomicOr(&enc[(size_t)r * 2 * W2 + W2 + (pos >> 4)], bit);
-}
-
-// the ASCII bytes of the reads of the units on the general path's list (k_pair's slow_units), from the batch's 2-bit + mask words: A/C/G/T by code,
-// 'N' where the mask says so.  One thread = 16 bases of one read; grid-stride over (listed unit, mate, word).
-__global__ void __launch_bounds__(256)
-k_unpack_listed(const uint32_t *__restrict__ slow_units, const uint32_t *__restrict__ n_slow_p, int paired, int W2, const uint32_t *__restrict__ enc,
-                unsigned char *__restrict__ seq, const int *__restrict__ err)
-{
-    if (*err >= DG_ABORT) return;
-    const uint32_t per_unit = (uint32_t)(paired ? 2 : 1) * (uint32_t)W2;
-    const uint64_t total = (uint64_t)*n_slow_p * per_unit;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t k = (uint32_t)(t / per_unit), rem = (uint32_t)(t - (uint64_t)k * per_unit), mate = rem / (uint32_t)W2, ww = rem - mate * (uint32_t)W2;
-        const uint32_t r = (paired ? 2u * slow_units[k] : slow_units[k]) + mate;
-        const uint32_t w = enc[(size_t)r * 2 * W2 + ww], m = enc[(size_t)r * 2 * W2 + W2 + ww];
-        uint32_t out[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            // four codes (one byte of w, first base on top) -> one selector byte each (copies of the byte at shifts 0, 10, 20, 30 put the
-            // k-th pair at bit 8 k + 6), then "ACGT"[code] for all four with one byte permute; the mask's pairs the same way -> 'N'
-            const uint32_t a = (w >> (24 - 8 * q)) & 0xFFu, b = (m >> (24 - 8 * q)) & 0xFFu;
-            const uint32_t sel = ((a * 0x40100401u) >> 6) & 0x03030303u, nb = ((b * 0x40100401u) >> 6) & 0x03030303u;
-            const uint32_t isn = ((nb | (nb >> 1)) & 0x01010101u) * 0xFFu;
-            out[q] = (__builtin_amdgcn_perm(0u, 0x54474341u, sel) & ~isn) | (0x4E4E4E4Eu & isn);
-        }
-        *(uint4 *)(seq + (size_t)r * 16 * W2 + 16 * ww) = make_uint4(out[0], out[1], out[2], out[3]);       // (bases past the end: 'N', never read)
-    }
 }
 
 // DG_PACKED_PAIR=0 (a measurement switch): the ASCII copy of the WHOLE packed batch, as rounds 2-3 made it, for k_pair<false>
@@ -1422,10 +1395,6 @@ static int enqueue_run(dg_ctx *c)
             c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->enc.p, W2p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
             c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err, co);
     HIPCHK(hipGetLastError());
-    if (packed_pair) {
-        k_unpack_listed<<<(unsigned)c->n_cu * 8u, 256, 0, c->stream>>>(c->slow_units.p, &c->d_sizes->n_slow_units, paired, W2p, c->enc.p, c->seq.p, c->d_err);
-        HIPCHK(hipGetLastError());
-    }
     TICK("k_pair");
 
     // ---- the general path, on the units k_pair listed ----
@@ -1441,7 +1410,8 @@ static int enqueue_run(dg_ctx *c)
     unsigned slow_grid = (unsigned)c->n_cu * 4u;
     if ((size_t)slow_grid * 256 > (size_t)n) slow_grid = nb;
     k_prep<dg_report_out><<<slow_grid, 256, 0, c->stream>>>(c->pr, paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->work.p, tops + TOP_WORK,
-                                             (uint32_t)c->cap_work, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_err, c->rlen.p, c->rep_off.p, c->reports.p, tops + TOP_CLASS_HIST);
+                                             (uint32_t)c->cap_work, c->jobs.p, tops + TOP_JOBS, (uint32_t)c->jobs.cap, c->d_err, c->rlen.p, c->rep_off.p, c->reports.p, tops + TOP_CLASS_HIST,
+                                             packed_pair ? c->enc.p : nullptr, W2p, c->seq.p);      // (a packed batch: the listed reads get their ASCII copy here)
     HIPCHK(hipGetLastError());
     TICK("k_prep");
     // Round 5: the re-seeding kernels run on the context's main stream, before the report kernel, which then takes ALL candidates in one launch.  Rounds 1-4
@@ -1450,15 +1420,19 @@ static int enqueue_run(dg_ctx *c)
     // 5.4 ms).  With windows shared by several waves (dg_reseed.h) it is a balanced throughput kernel that wants the GPU for itself for a short time; a
     // context owns ONE stream (the sixteen hardware queues of a process hold twelve contexts, the caller's stream and -- on a node -- RCCL's).
     // DG_ONE_STREAM=0: the second stream as before (k_report in two launches: candidates without jobs beside k_reseed, the others behind it).
-    HIPCHK(hipEventRecord(c->ev_prep, c->stream));
     if (!c->stream2) c->env_one_stream = 1;                       // (the context was made without a second stream)
     const hipStream_t s2 = c->env_one_stream ? c->stream : c->stream2;
-    if (!c->env_one_stream) HIPCHK(hipStreamWaitEvent(s2, c->ev_prep, 0));
-    HIPCHK(hipEventRecord(c->ev_reseed0, s2));
     const uint32_t jobcap = (uint32_t)c->jobs.cap;
     const RsPool rs_pool{c->job_pool.p, c->job_pool_next.p, tops + TOP_RS_POOL, c->env_rs_pool > 0 ? std::min<uint32_t>((uint32_t)c->env_rs_pool, rs_pool_cap) : rs_pool_cap};
     const int rs_gap_max = c->max_rlen - 32, rs_need = rs_gap_max >= 8 ? (rs_gap_max - 8) / 64 + 1 : 1;        // (see below)
-    k_order_jobs<<<1, 1024, 0, s2>>>(c->jobs.p, tops + TOP_JOBS, jobcap, c->job_items.p, rs_list_cap, rs_out_cap, rs_need <= 1 ? 1 : (rs_need <= 2 ? 2 : 4), (uint32_t)c->env_rs_chunk, tops + TOP_RESEED_COUNT, c->d_err);
+    // k_order: k_report's work list (the candidates grouped by cost class) and, by its last workgroup, k_reseed's ((window, chunk) items per ring size)
+    const RsOrder rs_order{c->jobs.p, tops + TOP_JOBS, jobcap, c->job_items.p, rs_list_cap, rs_out_cap, rs_need <= 1 ? 1 : (rs_need <= 2 ? 2 : 4), (uint32_t)c->env_rs_chunk, tops + TOP_RESEED_COUNT};
+    k_order<<<slow_grid + 1, 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->cands.p, c->ncand.p, tops + TOP_CLASS_HIST, tops + TOP_CLASS_FILL, c->items.p, tops + TOP_ORDER_INFO, rs_order, c->d_err);
+    HIPCHK(hipGetLastError());
+    TICK("order");
+    HIPCHK(hipEventRecord(c->ev_prep, c->stream));
+    if (!c->env_one_stream) HIPCHK(hipStreamWaitEvent(s2, c->ev_prep, 0));
+    HIPCHK(hipEventRecord(c->ev_reseed0, s2));
     // One launch per ring size the batch can need: a read gap lies between two seeds of >= 16 bases (bwt_search.cpp:165), so it is at most rlen - 32 long and
     // needs (gap - 16) / 64 + 1 bitmap words per diagonal -- one for reads of up to 103 bases (round 4 launched all three sizes for every batch), two up to 167.
     // (one stream for the ring sizes: side by side on streams of their own they cost the step 8 % with eight batches in flight, profiles/r02)
@@ -1468,11 +1442,8 @@ static int enqueue_run(dg_ctx *c)
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_reseed1, s2));
     if (c->env_one_stream) TICK("k_reseed");
-    k_order_items<<<slow_grid, 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->cands.p, c->ncand.p, tops + TOP_CLASS_HIST, tops + TOP_CLASS_FILL, c->items.p, tops + TOP_ORDER_INFO, c->d_err);
-    HIPCHK(hipGetLastError());
     const uint32_t *n_jobitems_p = tops + TOP_ORDER_INFO;             // items of class 0 (they wait for k_reseed)
     const uint32_t *n_items_p = tops + TOP_ORDER_INFO + 1;            // end of the list
-    TICK("order");
     // (two streams: one wave slot per CU is left free so that k_reseed's waves are resident beside the persistent report waves)
     const int blocks_main = (!c->env_one_stream && blocks > c->n_cu * 4) ? blocks - c->n_cu : blocks;
     k_report<2><<<blocks_main, 64, 0, c->stream>>>(c->ix, c->pr, n, paired, c->seq.p, c->seq_off.p, c->rlen.p, c->seed_off.p, c->jobs.p, c->cands.p,

@@ -241,7 +241,7 @@ __host__ __device__ inline bool d_small_nw_is_diagonal(uint64_t a8, uint64_t b8,
 
 // A read as the fused kernel looks at it: the ASCII bytes of dg_map_batch (case, '-' and IUPAC letters matter to the reference: tools.cpp:40-104), or the
 // 2-bit + mask words of a packed batch (dg_map_batch_packed: A/C/G/T/N by contract, so the characters follow from the words and the ASCII copy of the
-// batch -- 202 MB per million pairs, written by k_unpack and read back here -- is only made for the units of the general path: k_unpack_listed).
+// batch -- 202 MB per million pairs, written by k_unpack and read back here -- is only made for the units of the general path: k_prep).
 // get8(i, e): the characters i .. i + e - 1 (e <= 8) as the bytes of a word, character i in the low byte -- the form d_ref8 gives the genome in
 struct ReadAscii {
     const unsigned char *p;

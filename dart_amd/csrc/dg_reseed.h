@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256)
 k_prep(const DParams pr, int paired, const uint32_t *__restrict__ slow_units, const DSizes *__restrict__ sizes, const uint32_t *__restrict__ seed_off,
        const SKey *__restrict__ seeds, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, DSeed *__restrict__ work, unsigned int *worktop, uint32_t workcap,
        DJob *__restrict__ jobs, unsigned int *jobtop, uint32_t jobcap, int *err, const uint16_t *__restrict__ rlen, const uint32_t *__restrict__ rep_off,
-       ReportT *__restrict__ reports, unsigned int *class_hist)
+       ReportT *__restrict__ reports, unsigned int *class_hist, const uint32_t *__restrict__ enc, int W2, unsigned char *__restrict__ seq)
 {
     __shared__ unsigned int s_hist[DG_COST_CLASSES];
     if (*err >= DG_ABORT) return;
@@ -74,6 +74,26 @@ k_prep(const DParams pr, int paired, const uint32_t *__restrict__ slow_units, co
         const int r = on ? (paired ? (int)(2u * slow_units[it >> 1] + (it & 1u)) : (int)slow_units[it]) : 0;
         DCand *cd = cands + seed_off[r];
         const int nc = on ? (int)ncand[r] : 0;
+        if (on && enc) {
+            // A packed batch has no ASCII copy (k_pair reads the 2-bit + mask words); the reads of the general path get theirs here: A/C/G/T by code, 'N' where
+            // the mask says so, 16 bases per store (round 4: a launch of its own, k_unpack_listed).  Four codes (one byte of w, first base on top) -> one
+            // selector byte each (copies of the byte at shifts 0, 10, 20, 30 put the k-th pair at bit 8 k + 6), then "ACGT"[code] for all four with one byte
+            // permute; the mask's pairs the same way -> 'N'
+            const uint32_t *wsrc = enc + (size_t)r * 2 * W2;
+            unsigned char *dst = seq + (size_t)r * 16 * W2;
+            for (int ww = 0; ww < W2; ww++) {
+                const uint32_t w = wsrc[ww], m = wsrc[W2 + ww];
+                uint32_t out[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t a = (w >> (24 - 8 * q)) & 0xFFu, b = (m >> (24 - 8 * q)) & 0xFFu;
+                    const uint32_t sel = ((a * 0x40100401u) >> 6) & 0x03030303u, nb = ((b * 0x40100401u) >> 6) & 0x03030303u;
+                    const uint32_t isn = ((nb | (nb >> 1)) & 0x01010101u) * 0xFFu;
+                    out[q] = (__builtin_amdgcn_perm(0u, 0x54474341u, sel) & ~isn) | (0x4E4E4E4Eu & isn);
+                }
+                *(uint4 *)(dst + 16 * ww) = make_uint4(out[0], out[1], out[2], out[3]);       // (bases past the end: 'N', never read)
+            }
+        }
         uint32_t need = 0;
         for (int i = 0; i < nc; i++) if (cd[i].Score != 0) need += d_work_need(cd[i].count);
         // the wave's regions in one atomic
@@ -137,48 +157,6 @@ k_prep(const DParams pr, int paired, const uint32_t *__restrict__ slow_units, co
     }
     __syncthreads();
     if (threadIdx.x < DG_COST_CLASSES && s_hist[threadIdx.x]) atomicAdd(class_hist + threadIdx.x, s_hist[threadIdx.x]);
-}
-
-// k_report's work list from the candidates' classes and the class histogram of k_prep: items = (read << 32 | index of the candidate in cands[]) grouped by
-// class, class 0 first (any order inside a class: the order decides who computes what when, never a result); info[0] = items of class 0 (they wait for
-// k_reseed), info[1] = all items.  One launch over the listed reads; a workgroup reserves its share of every class with one atomic per class.
-__global__ void __launch_bounds__(256)
-k_order_items(int paired, const uint32_t *__restrict__ slow_units, const DSizes *__restrict__ sizes, const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands,
-              const uint32_t *__restrict__ ncand, const unsigned int *__restrict__ class_hist, unsigned int *class_fill, unsigned long long *__restrict__ items, uint32_t *__restrict__ info,
-              const int *__restrict__ abort_p)
-{
-    __shared__ uint32_t s_start[DG_COST_CLASSES], s_cnt[DG_COST_CLASSES], s_base[DG_COST_CLASSES];
-    if (*abort_p >= DG_ABORT) return;
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x < 64) {                                        // exclusive scan of the 32 class totals by the first wave
-        uint32_t v = lane < DG_COST_CLASSES ? class_hist[lane] : 0u, incl = v;
-        for (int o = 1; o < DG_COST_CLASSES; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-        if (lane < DG_COST_CLASSES) { s_start[lane] = incl - v; s_cnt[lane] = 0; }
-        if (blockIdx.x == 0) {
-            if (lane == 1) info[0] = incl;                         // keys 0 and 1 = class 0
-            if (lane == DG_COST_CLASSES - 1) info[1] = incl;
-        }
-    }
-    __syncthreads();
-    const unsigned int n_items = sizes->n_slow_units * (paired ? 2u : 1u);
-    for (unsigned int base = blockIdx.x * blockDim.x; base < n_items; base += gridDim.x * blockDim.x) {      // uniform per workgroup
-        const unsigned int it = base + threadIdx.x;
-        const bool on = it < n_items;
-        const uint32_t r = on ? (paired ? 2u * slow_units[it >> 1] + (it & 1u) : slow_units[it]) : 0u;
-        const uint32_t c0 = seed_off[r];
-        const int nc = on ? (int)ncand[r] : 0;
-        for (int i = 0; i < nc; i++) if (cands[c0 + i].Score != 0) atomicAdd(&s_cnt[cands[c0 + i].final_n & (DG_COST_CLASSES - 1)], 1u);
-        __syncthreads();
-        if (threadIdx.x < DG_COST_CLASSES) { const uint32_t k = s_cnt[threadIdx.x]; s_base[threadIdx.x] = s_start[threadIdx.x] + (k ? atomicAdd(class_fill + threadIdx.x, k) : 0u); s_cnt[threadIdx.x] = 0; }
-        __syncthreads();
-        for (int i = 0; i < nc; i++) if (cands[c0 + i].Score != 0) {
-            const uint32_t cls = (uint32_t)cands[c0 + i].final_n & (DG_COST_CLASSES - 1);
-            items[s_base[cls] + atomicAdd(&s_cnt[cls], 1u)] = ((unsigned long long)r << 32) | (unsigned long long)(c0 + (uint32_t)i);
-        }
-        __syncthreads();
-        if (threadIdx.x < DG_COST_CLASSES) s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-    }
 }
 
 // 8-mer id (CreateKmerID, KmerAnalysis.cpp:25-32) of text positions t..t+7, t in [0, 2L)
@@ -344,13 +322,13 @@ __device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, uint32_t
 // info[0..2] = items per ring size, info[3] = C.  One workgroup.
 #define RS_CHUNK_DIAGS 32768
 __device__ __forceinline__ uint32_t d_rs_nchunks(int glen, uint32_t C) { return glen > 7 ? (uint32_t)(((int64_t)(glen - 7) + (int64_t)C - 1) / (int64_t)C) : 1u; }
-__global__ void __launch_bounds__(1024)
-k_order_jobs(DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, uint32_t jobcap, unsigned long long *__restrict__ lists, uint32_t list_cap, uint32_t out_cap,
-             int max_words /* widest ring the host launches */, uint32_t chunk0 /* diagonals per chunk to start from: RS_CHUNK_DIAGS (a test hook lowers it) */,
-             unsigned int *__restrict__ info, const int *__restrict__ abort_p)
+struct RsOrder { DJob *jobs; const unsigned int *jobtop; uint32_t jobcap; unsigned long long *lists; uint32_t list_cap, out_cap; int max_words /* widest ring the host launches */;
+                 uint32_t chunk0 /* diagonals per chunk to start from: RS_CHUNK_DIAGS (a test hook lowers it) */; unsigned int *info; };
+__device__ inline void d_order_jobs(const RsOrder &o)               // one workgroup (any size); round 4: a launch of its own, now the last workgroup of k_order
 {
+    DJob *__restrict__ jobs = o.jobs; unsigned long long *__restrict__ lists = o.lists; unsigned int *__restrict__ info = o.info;
+    const uint32_t jobcap = o.jobcap, list_cap = o.list_cap, out_cap = o.out_cap, chunk0 = o.chunk0; const int max_words = o.max_words; const unsigned int *jobtop = o.jobtop;
     __shared__ unsigned int s_need[8], s_items[3], s_out, s_C;
-    if (*abort_p >= DG_ABORT) return;
     const unsigned int njobs = *jobtop < jobcap ? *jobtop : jobcap;
     if (threadIdx.x < 8) s_need[threadIdx.x] = 0;
     if (threadIdx.x < 3) s_items[threadIdx.x] = 0;
@@ -389,6 +367,49 @@ k_order_jobs(DJob *__restrict__ jobs, const unsigned int *__restrict__ jobtop, u
     __syncthreads();
     if (threadIdx.x < 3) info[threadIdx.x] = s_items[threadIdx.x] < list_cap ? s_items[threadIdx.x] : list_cap;
     if (threadIdx.x == 3) info[3] = C;
+}
+
+// k_order: k_report's work list from the candidates' classes and the class histogram of k_prep (and, by its last workgroup, k_reseed's: d_order_jobs): items = (read << 32 | index of the candidate in cands[]) grouped by
+// class, class 0 first (any order inside a class: the order decides who computes what when, never a result); info[0] = items of class 0 (they wait for
+// k_reseed), info[1] = all items.  One launch over the listed reads; a workgroup reserves its share of every class with one atomic per class.
+__global__ void __launch_bounds__(256)
+k_order(int paired, const uint32_t *__restrict__ slow_units, const DSizes *__restrict__ sizes, const uint32_t *__restrict__ seed_off, const DCand *__restrict__ cands,
+        const uint32_t *__restrict__ ncand, const unsigned int *__restrict__ class_hist, unsigned int *class_fill, unsigned long long *__restrict__ items, uint32_t *__restrict__ info,
+        const RsOrder jobs_order, const int *__restrict__ abort_p)
+{
+    __shared__ uint32_t s_start[DG_COST_CLASSES], s_cnt[DG_COST_CLASSES], s_base[DG_COST_CLASSES];
+    if (*abort_p >= DG_ABORT) return;
+    if (blockIdx.x == gridDim.x - 1) { d_order_jobs(jobs_order); return; }      // the launch's last workgroup lays out k_reseed's work list (below), the others k_report's
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {                                        // exclusive scan of the 32 class totals by the first wave
+        uint32_t v = lane < DG_COST_CLASSES ? class_hist[lane] : 0u, incl = v;
+        for (int o = 1; o < DG_COST_CLASSES; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (lane < DG_COST_CLASSES) { s_start[lane] = incl - v; s_cnt[lane] = 0; }
+        if (blockIdx.x == 0) {
+            if (lane == 1) info[0] = incl;                         // keys 0 and 1 = class 0
+            if (lane == DG_COST_CLASSES - 1) info[1] = incl;
+        }
+    }
+    __syncthreads();
+    const unsigned int n_items = sizes->n_slow_units * (paired ? 2u : 1u);
+    for (unsigned int base = blockIdx.x * blockDim.x; base < n_items; base += (gridDim.x - 1) * blockDim.x) {      // uniform per workgroup
+        const unsigned int it = base + threadIdx.x;
+        const bool on = it < n_items;
+        const uint32_t r = on ? (paired ? 2u * slow_units[it >> 1] + (it & 1u) : slow_units[it]) : 0u;
+        const uint32_t c0 = seed_off[r];
+        const int nc = on ? (int)ncand[r] : 0;
+        for (int i = 0; i < nc; i++) if (cands[c0 + i].Score != 0) atomicAdd(&s_cnt[cands[c0 + i].final_n & (DG_COST_CLASSES - 1)], 1u);
+        __syncthreads();
+        if (threadIdx.x < DG_COST_CLASSES) { const uint32_t k = s_cnt[threadIdx.x]; s_base[threadIdx.x] = s_start[threadIdx.x] + (k ? atomicAdd(class_fill + threadIdx.x, k) : 0u); s_cnt[threadIdx.x] = 0; }
+        __syncthreads();
+        for (int i = 0; i < nc; i++) if (cands[c0 + i].Score != 0) {
+            const uint32_t cls = (uint32_t)cands[c0 + i].final_n & (DG_COST_CLASSES - 1);
+            items[s_base[cls] + atomicAdd(&s_cnt[cls], 1u)] = ((unsigned long long)r << 32) | (unsigned long long)(c0 + (uint32_t)i);
+        }
+        __syncthreads();
+        if (threadIdx.x < DG_COST_CLASSES) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+    }
 }
 
 #define RS_TAB      512          // open-addressing table: 8-mer id -> first entry of km[] with that id (at most 256 ids: half full)

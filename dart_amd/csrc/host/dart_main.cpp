@@ -543,6 +543,10 @@ int main(int argc, char *argv[])
     int n_gpu = dg_device_count();
     if (n_gpu < 1) { fprintf(stderr, "Error! No HIP device (this build of dart has no CPU path)\n"); return 1; }
     if (getenv("DART_GPUS")) n_gpu = std::min(std::max(1, atoi(getenv("DART_GPUS"))), n_gpu);      // (HIP_VISIBLE_DEVICES picks WHICH devices; a job of a few million reads is done before a second device has its index)
+    // DART_SAME_DEVICE_TIMES=k (a test hook for one-GPU boxes): k "devices" that are all device 0 -- each with its own index replica, root context and clones --, so
+    // that the multi-device pool (several roots, one ordered writer: Mapping.cpp:644-664) runs where only one GPU exists
+    const int same_device_times = getenv("DART_SAME_DEVICE_TIMES") ? std::max(1, std::min(8, atoi(getenv("DART_SAME_DEVICE_TIMES")))) : 0;
+    if (same_device_times) n_gpu = same_device_times;
     SlotPool pool;                          // batch slots of the parallel FASTQ pipeline (page-locked in the background with DART_PINNED=1)
     if (fast_first) pool.start((size_t)n_gpu * inflight_cfg + 2, batch_reads, 160);
     // The read files of a library.  Plain FASTQ goes through the parallel host pipeline (fast_fastq.h); FASTA, .gz, -bo and DART_STREAMING=1 through the
@@ -605,7 +609,7 @@ int main(int argc, char *argv[])
         roots.assign(n_gpu, nullptr);
         std::vector<int> st(n_gpu, 0); std::vector<std::string> msg(n_gpu);
         std::vector<std::thread> th;
-        for (int d = 0; d < n_gpu; d++) th.emplace_back([&, d]() { roots[d] = dg_init_files(&files, &o.p, d, init_flags, &st[d]); if (!roots[d]) msg[d] = dg_last_error(nullptr); });
+        for (int d = 0; d < n_gpu; d++) th.emplace_back([&, d]() { roots[d] = dg_init_files(&files, &o.p, same_device_times ? 0 : d, init_flags, &st[d]); if (!roots[d]) msg[d] = dg_last_error(nullptr); });
         for (auto &t : th) t.join();
         for (int d = 0; d < n_gpu; d++) if (!roots[d]) {
             if (st[d] == DG_ERR_ARG) fprintf(stderr, "\n\nError! Index files are corrupt!\n"); else fprintf(stderr, "\nError! GPU %d: %s\n", d, msg[d].c_str());

@@ -131,6 +131,25 @@ def test_dart_cli_three_contexts_in_flight_keep_input_order(host_path, workdir):
     assert open(os.path.join(d, "orc3.j")).read() == open(os.path.join(d, "gpu3.j")).read()
 
 
+@pytest.mark.parametrize("host_path", ["parallel", "streaming"])
+def test_dart_cli_two_devices_in_one_pool_keep_input_order(host_path, workdir):
+    """`dart` drives every device of the node from one pool of mapping threads (one root context + clones per device, one ordered writer:
+    Mapping.cpp:644-664,792-793).  A one-GPU box has one device, so that path never ran: DART_SAME_DEVICE_TIMES=2 opens
+    device 0 twice -- two index replicas, two roots, 2 x 2 contexts in flight, small batches finishing out of order -- and the SAM and the
+    junctions must still be the oracle command line's, byte for byte."""
+    oracle_py.build()
+    c, d = cli_inputs.make(workdir)
+    env = dict(os.environ, DART_BATCH="3000", DART_SAME_DEVICE_TIMES="2", DART_INFLIGHT="2")
+    if host_path == "streaming":
+        env["DART_STREAMING"] = "1"
+    flags = ["-f", "q1.fq", "q1.fq", "q1.fq", "-f2", "q2.fq", "q2.fq", "q2.fq", "-mis", "5"]
+    subprocess.run([DART, "-i", c["prefix"]] + flags + ["-o", "gpu2d.sam", "-j", "gpu2d.j", "-t", "4"], cwd=d, stdout=subprocess.DEVNULL, check=True, env=env)
+    subprocess.run([oracle_py.ORACLE_CLI, "-i", c["prefix"]] + flags + ["-o", "orc2d.sam", "-j", "orc2d.j"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    a, b_ = open(os.path.join(d, "orc2d.sam")).read(), open(os.path.join(d, "gpu2d.sam")).read()
+    assert a == b_, common.first_diff(b_, a)
+    assert open(os.path.join(d, "orc2d.j")).read() == open(os.path.join(d, "gpu2d.j")).read()
+
+
 def test_dart_cli_error_behaviour(workdir):
     r = subprocess.run([DART, "-intron", "5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"Error! Unknow parameter: -intron" in r.stderr
