@@ -155,14 +155,14 @@ def with_human_like_leg(args, argv):
     else:
         try:
             t = time.time()
-            h = subprocess.run([sys.executable, me, "--as-child", "--genome-model", "human", "--no-secondary", "--no-cpu-baseline", "--steps", str(args.steps), "--warmup", str(args.warmup),
+            h = subprocess.run([sys.executable, me, "--as-child", "--genome-model", "human", "--no-secondary", "--no-cpu-baseline", "--sustained-s", "12", "--steps", str(args.steps), "--warmup", str(args.warmup),
                                 "--pairs", str(args.pairs), "--batches", str(args.batches), "--inflight", str(args.inflight), "--mis", str(args.mis), "--cache", args.cache],
                                stdout=subprocess.PIPE, timeout=400)
             hl = json.loads(h.stdout.decode().strip().splitlines()[-1])
             line["value_human_like"] = hl["value"]
             line["human_like"] = {
                 "value": hl["value"], "unit": hl["unit"], "ms_per_step": hl["ms_per_step"], "steps": hl["steps"], "warmup": hl["warmup"], "workload": hl["config"]["workload"],
-                "kernels_ms": hl["kernels_ms"], "kernels_ms_one_batch_in_flight": hl["kernels_ms_one_batch_in_flight"],
+                "kernels_ms": hl["kernels_ms"], "kernels_ms_one_batch_in_flight": hl["kernels_ms_one_batch_in_flight"], "sustained": hl.get("sustained"),
                 "roofline": {k: hl["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_standalone", "frac_of_random_line_ceiling", "seeding_mixed_ceiling", "fingerprint", "stages")},
                 "counters_per_launch": {k: hl["counters_per_launch"].get(k) for k in ("steps", "steps_executed", "occ_blocks_executed", "seeds", "candidates", "nw_calls", "reseed_calls", "general_path_units", "wave_chained_units")},
                 "what": "`bench.py --genome-model human --no-secondary --no-cpu-baseline` with this run's steps / warm-up / batches, a second child process after the first one has left the GPU "
@@ -257,6 +257,35 @@ def run_cli(dart_exe, prefix, g, label, seed_pairs, args, cpu_pairs=0, gz_pairs=
                                                "extrapolation to %d pairs = index load + (the rest) x %d / %d" % (n_c, cores, total_pairs, total_pairs, n_c),
                                        "sam_and_junctions_identical_to_dart_on_these_pairs": bool(same)}
             res["speedup_vs_cpu_command_line_whole_job"] = round(whole / best[0], 1)
+            # The reference's OWN object code on this box's host CPU (oracle/_ref/ref_harness: the reference's translation units compiled where they lie, linked under
+            # our driver of its ReadMapping loop; the built binary travels with the repo, the sources do not): one thread -- the harness has no -t --, the first
+            # ref_pairs pairs of the same files, its mapping loop timed by itself (FASTQ parsing and SAM text included, as in the reference's ReadMapping; index load apart).
+            ref_exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+            n_r = min(n_c, int(os.environ.get("DART_BENCH_REF_PAIRS", "100000")))
+            if os.path.exists(ref_exe) and n_r > 0:
+                try:
+                    synth.write_fastq_fast(os.path.join(d, "r1.fq"), head[0][:n_r], 1); synth.write_fastq_fast(os.path.join(d, "r2.fq"), head[1][:n_r], 2)
+                    t0 = time.perf_counter()
+                    rr = subprocess.run([ref_exe, "map", "-i", prefix, "-f", "r1.fq", "-f2", "r2.fq", "-o", "ref.sam", "-j", "ref.j", "-mis", str(args.mis)], cwd=d,
+                                        stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+                    dtr = time.perf_counter() - t0
+                    mr = re.search(r"index load ([0-9.]+) s, mapping phase ([0-9.]+) s, (\d+) reads", rr.stderr.decode())
+                    if rr.returncode == 0 and mr:
+                        # its SAM against the port's on the same pairs (the head of cpu.sam: header + the records of the first n_r pairs are a prefix, reads are independent)
+                        ref_sam = open(os.path.join(d, "ref.sam"), "rb").read()
+                        same_ref = open(os.path.join(d, "cpu.sam"), "rb").read(len(ref_sam)) == ref_sam
+                        r_map = float(mr.group(2))
+                        res["cpu_reference_object_code"] = {"kind": "reference", "cores": 1, "pairs": n_r, "wall_s": round(dtr, 3), "index_load_s": float(mr.group(1)), "mapping_phase_s": r_map,
+                                                            "value": round(2 * n_r / r_map / 1e6, 5), "unit": "M reads/s (mapping phase, one thread)",
+                                                            "port_mapping_phase_per_thread": round(2 * n_c / map_s / cores / 1e6, 5),
+                                                            "sam_identical_to_the_port_on_these_pairs": bool(same_ref),
+                                                            "what": "oracle/_ref/ref_harness = the reference's own translation units (bwt_search, AlignmentCandidates, nw_alignment, tools, KmerAnalysis, Mapping, "
+                                                                    "GetData, bwt_index, BWT_Index/*) compiled in the builder's container and linked under a driver of ReadMapping's loop; first %d pairs of "
+                                                                    "the command-line run's files, -mis %d, one thread; value = reads / its mapping loop's wall (parsing and SAM text included)" % (n_r, args.mis)}
+                    else:
+                        log("[bench] reference harness: rc %d, %s" % (rr.returncode, rr.stderr.decode()[-300:]))
+                except Exception as e:
+                    log("[bench] reference harness leg failed:", repr(e))
         if gz_pairs > 0 and head is not None:
             import gzip
             n_z = min(gz_pairs, total_pairs)
@@ -395,6 +424,8 @@ class Worker:
         return (12 * n + 16 * u[0] if self.last_records == "compact" else 36 * n + 40 * u[0]) + 4 * u[1] + 24 * u[2]
 
 
+RATE_LOG = [] if os.environ.get("DART_BENCH_RATE_LOG") else None      # (items done, perf_counter) marks of the timed region: the rate over time of a long run
+RATE_EVERY = int(os.environ.get("DART_BENCH_RATE_EVERY", "1000"))
 T_PHASE = []          # (name, wall clock) marks of the run's phases: rank 0 prints what each took, and the line carries it (the driver gives a run 600 s)
 
 
@@ -403,12 +434,13 @@ def phase(name):
 
 
 def main():
+    global RATE_LOG, RATE_EVERY
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30, help="timed steps (one step = --batches distinct batches); 30 steps = about one second: filling and draining the\n                    pipeline of batches in flight costs a fixed ~20 ms, which a 6-step run (0.2 s) shows as -8 %%")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=1000000, help="pairs per batch")
-    ap.add_argument("--batches", type=int, default=10, help="distinct batches per step and GPU (10 x 1 M pairs = BASELINE configs[2])")
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("DART_BENCH_PAIRS", "1000000")), help="pairs per batch")
+    ap.add_argument("--batches", type=int, default=int(os.environ.get("DART_BENCH_BATCHES", "10")), help="distinct batches per step and GPU (10 x 1 M pairs = BASELINE configs[2])")
     ap.add_argument("--genome", default=os.environ.get("DART_BENCH_GENOME", "grch38"),
                     help="grch38 (default: 24 chromosomes with GRCh38 sizes, 3.09 Gbp) | chr20 | <bp> (one chromosome)")
     ap.add_argument("--genome-model", choices=["planted", "human"], default="planted",
@@ -450,7 +482,10 @@ def main():
                          "and the run's time goes to the human-like leg instead)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (other entry point, device-resident)")
     ap.add_argument("--repeats", type=int, default=-1, help="more runs of the same K steps after the timed region (value_repeats); default: 2, with --no-secondary 0")
-    ap.add_argument("--human-like-budget", type=float, default=200.0,
+    ap.add_argument("--sustained-s", type=float, default=-1.0,
+                    help="one GPU, secondary rates on: after the timed region, the same steps for about this many seconds (`value_sustained`, with the rate of each quarter "
+                         "of the run: a 0.4 s timed region says nothing about the rate a long job settles at); 0 = skip; default: 20 s, 0 with --no-secondary")
+    ap.add_argument("--human-like-budget", type=float, default=330.0,
                     help="the default workload on one GPU with the CPU legs on: after the measurement, the same timed region on the human-like genome (--genome-model human) as a "
                          "second child process, if the run has used fewer seconds than this so far (the leg costs ~110 s: genome, index, batches); 0 = never")
     ap.add_argument("--as-child", action="store_true", help="(set by this file) the measurement itself, in a process of its own: see with_human_like_leg")
@@ -618,11 +653,30 @@ def main():
 
     stagger_s = float(os.environ.get("DART_BENCH_STAGGER_MS", "1.0")) * 1e-3
 
-    def run_items(n_items, mode, ws=workers, first_item=0, bl=None):
+    def run_items(n_items, mode, ws=workers, first_item=0, bl=None, static=False):
+        """n_items work items over the contexts ws, each driven by its own host thread.  A context takes the NEXT item when it is free (the reference's threads
+        pull the next chunk under a lock, Mapping.cpp:598-603: GetNextChunk) -- rounds 1-4 dealt item i to context i mod n, and a long run then lasted as long as
+        its slowest context (the contexts of a process do not progress at one rate: profiles/r05/f_sustained_*); static=True keeps the deal (every context exactly
+        its share: the passes that must leave a batch in every context).  The main thread takes the items in order: gathers (N > 1) happen in item order."""
         bl_ = batches if bl is None else bl
-        done = [threading.Semaphore(0) for _ in ws]        # an item of this context has finished
+        owner = [-1] * n_items                              # which context mapped item i
+        cv = threading.Condition()
+        n_done = [0]                                        # items 0 .. n_done-1 are not all done; done_flag marks single items
+        done_flag = bytearray(n_items)
         free = [threading.Semaphore(0) for _ in ws]        # its records have been gathered, the next item may start
+        next_item = [0]
         errs = []
+
+        def take(k, mine):
+            if static:
+                i = k + mine * len(ws)
+                return i if i < n_items else -1
+            with cv:
+                i = next_item[0]
+                if i >= n_items:
+                    return -1
+                next_item[0] = i + 1
+                return i
 
         def work(k):
             try:
@@ -630,28 +684,40 @@ def main():
                 # the GPU would have nothing to do; context k hands its first batch over k x stagger later (a streaming host is in this state anyway)
                 if stagger_s > 0 and k:
                     time.sleep(k * stagger_s)
-                for i in range(k, n_items, len(ws)):
+                mine = 0
+                while not errs:
+                    i = take(k, mine)
+                    if i < 0:
+                        break
+                    mine += 1
                     ws[k].map(bl_[(first_item + i) % len(bl_)], mode)
-                    done[k].release()
+                    with cv:
+                        owner[i] = k; done_flag[i] = 1
+                        cv.notify_all()
                     if do_gather:
                         free[k].acquire()
             except Exception as e:                          # surface the failure instead of hanging the main thread
-                errs.append(e)
-                done[k].release()
+                with cv:
+                    errs.append(e)
+                    cv.notify_all()
         th = [threading.Thread(target=work, args=(k,)) for k in range(len(ws))]
         for t_ in th:
             t_.start()
         try:
             for i in range(n_items):
-                k = i % len(ws)
-                done[k].acquire()
+                with cv:
+                    while not done_flag[i] and not errs:
+                        cv.wait()
                 if errs:
                     break
+                if RATE_LOG is not None and (i + 1) % RATE_EVERY == 0:
+                    RATE_LOG.append((i + 1, time.perf_counter()))       # DART_BENCH_RATE_LOG: when the (i + 1)-th item of this call was back (profiles/probes/sustained.sh)
                 if do_gather:
-                    gather(ws[k], first_item + i)
-                    free[k].release()
+                    gather(ws[owner[i]], first_item + i)
+                    free[owner[i]].release()
         except BaseException as e:                          # (a failing gather must not leave the context threads waiting for their turn for ever)
-            errs.append(e)
+            with cv:
+                errs.append(e)
         finally:
             for k in range(len(ws)):
                 for _ in range(n_items):
@@ -678,8 +744,19 @@ def main():
     for w in workers:
         w.kern = {}; w.n_runs = 0
     phase("warm-up steps")
+    if RATE_LOG is not None:
+        del RATE_LOG[:]
     elapsed = timed(args.steps * nb, args.input)
     phase("timed region")
+    if RATE_LOG is not None and rank == 0:
+        t_wall0 = time.time() - (time.perf_counter() - RATE_LOG[0][1]) if RATE_LOG else 0
+        with open(os.environ["DART_BENCH_RATE_LOG"], "w") as f:
+            prev = None
+            for n_done, t_ in RATE_LOG:
+                if prev is not None:
+                    f.write("%.3f items %d rate_M_reads_per_s %.1f\n" % (t_wall0 + (t_ - RATE_LOG[0][1]), n_done, (n_done - prev[0]) * reads_per_step / nb / (t_ - prev[1]) / 1e6))
+                prev = (n_done, t_)
+        del RATE_LOG[:]
     runs = sum(w.n_runs for w in workers)
     kern = {}
     for w in workers:                                       # per-worker sums, merged after the threads have joined
@@ -688,6 +765,20 @@ def main():
     kern = {k: v / max(runs, 1) for k, v in kern.items()}
     # the spread of the figure: two more runs of the same K steps (the line's `value` is the first, the contract's)
     repeats = [elapsed] + [timed(args.steps * nb, args.input) for _ in range(args.repeats if args.repeats >= 0 else (0 if args.no_secondary else 2))]
+    sustained = None
+    if args.sustained_s < 0:
+        args.sustained_s = 0.0 if args.no_secondary else 20.0
+    if world == 1 and args.sustained_s > 0:
+        keep = (RATE_LOG, RATE_EVERY)
+        n_sus = max(args.steps, int(args.sustained_s / (elapsed / args.steps)))
+        RATE_LOG, RATE_EVERY = [], max(1, n_sus * nb // 8)
+        t_s0 = time.perf_counter()
+        e_s = timed(n_sus * nb, args.input)
+        marks = [(0, t_s0)] + RATE_LOG
+        RATE_LOG, RATE_EVERY = keep
+        sustained = {"value": round(reads_per_step * n_sus / e_s / 1e6, 2), "steps": n_sus, "seconds": round(e_s, 1),
+                     "rate_by_eighth_of_the_run": [round((marks[i][0] - marks[i - 1][0]) * reads_per_step / nb / (marks[i][1] - marks[i - 1][1]) / 1e6, 1) for i in range(1, len(marks))]}
+        phase("sustained pass")
     counters = workers[0].gpu.counters()
     # batches a context had to run again since it was created, over all contexts: capacities that grew (expected while the first batches
     # size the buffers), scans that did not complete (dg_scan.h: should be 0)
@@ -751,7 +842,7 @@ def main():
         secondary["value_%s_records" % other_rec] = round(reads_per_step / nb * items / timed(items, args.input) / 1e6, 3)
         for w in workers:
             w.records = args.records
-        run_items(len(workers), "resident")                # (every context holds the batch it mapped last)
+        run_items(len(workers), "resident", static=True)   # (every context holds the batch it mapped last)
         secondary["value_device_resident"] = round(reads_per_step / nb * items / timed(items, "resident") / 1e6, 3)
     # the same item with ONE batch in flight, for per-kernel durations without other batches' kernels sharing the GPU
     w0 = workers[0]; w0.kern = {}; w0.n_runs = 0
@@ -1021,6 +1112,13 @@ def main():
         "cpu_baseline": cpu,
         "accuracy": accuracy,
     }
+    if cli_big and cpu and "cpu_reference_object_code" in cli_big:
+        # the reference's own object code, timed on THIS box (one thread), beside the port: the ratio replaces the builder's-container figure
+        ro = cli_big["cpu_reference_object_code"]
+        cpu["reference_object_code_one_thread"] = ro
+        if ro["value"] > 0:
+            cpu["port_vs_reference_measured_here"] = round(ro["port_mapping_phase_per_thread"] / ro["value"], 3)
+            cpu["value_reference_equivalent_measured_here"] = round(cpu["value"] / cpu["port_vs_reference_measured_here"], 5)
     if cli_big:
         line["value_cli_end_to_end_grch38"] = cli_big["value"]
         line["cli_end_to_end_grch38"] = cli_big
@@ -1033,6 +1131,9 @@ def main():
     log("[bench] phases (s):", line["phases_s"])
     if gather_mode == "full":
         line["gather"] = {"mode": "full", "bytes_received_by_rank0_total": gather_bytes[0], "verified_against_single_rank_mapping": gather_verified}
+    if sustained:
+        line["value_sustained"] = sustained["value"]
+        line["sustained"] = sustained
     line.update(secondary)
     print(json.dumps(line), flush=True)
     if dist is not None:
