@@ -43,7 +43,7 @@ template <typename T> struct DBuf {
 #define N_TIMERS 20
 #define N_TOPS 128              // small device counters of a batch (bump tops, tickets, list sizes, class histogram), zeroed per run
 enum { TOP_CIG = 0, TOP_SJ, TOP_JOBS, TOP_REPORT_MAIN, TOP_REPORT_JOBS, TOP_HEAVY_UNITS, TOP_SEED_NEXT, TOP_SEED_HEAVY,
-       TOP_WORK = 16, TOP_TICKET_PAIR = 17, TOP_TICKET_EMIT = 18, TOP_RESEED_COUNT = 19 /* 19..21: items per ring size; 22: diagonals per chunk */, TOP_RESEED_TICKET = 23 /* 23..25 */, TOP_TICKET_SEED = 26, TOP_RS_POOL = 27,
+       TOP_WORK = 16, TOP_TICKET_PAIR = 17, TOP_TICKET_EMIT = 18, TOP_RESEED_COUNT = 19 /* 19..21: items per ring size; 22: diagonals per chunk */, TOP_RESEED_TICKET = 23 /* 23..25 */, TOP_TICKET_SEED = 26, TOP_RS_POOL = 27, TOP_RS_OUT = 31,
        TOP_ORDER_INFO = 28 /* 28..30 */, TOP_CLASS_HIST = 32 /* 32..63 */, TOP_CLASS_FILL = 64 /* 64..95 */ };        // (explicit values: every index names its own word)
 
 // The index of a device as its contexts see it: the root context owns it, dg_clone()d contexts point to it.  The look-up aids may still be
@@ -92,7 +92,7 @@ struct dg_ctx {
     // them without asking the device for a size first, the device reports what it needed (DSizes) and flags an overflow
     // (d_err >= DG_ABORT), in which case the host grows the buffer and runs the batch again
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, rep_off, tile_sums, tile_read, slow_units;
-    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<unsigned long long> job_items, job_pool; DBuf<RsChunkOut> job_outs; DBuf<uint32_t> job_pool_next; DBuf<unsigned long long> items; DBuf<uint32_t> hist, heavy; DBuf<DHeavy> seed_heavy;
+    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<unsigned long long> job_items, job_pool; DBuf<RsChunkOut> job_outs; DBuf<uint32_t> job_pool_next; DBuf<unsigned long long> items; DBuf<uint32_t> hist, heavy; DBuf<DHeavy> seed_heavy; DBuf<int32_t> seed_heavy_sfail;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c; DBuf<uint32_t> cig_c;     // compact records and their stored CIGAR ops (written by k_pair / k_emit_slow)
@@ -557,7 +557,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     if (c->h_tail) (void)hipHostFree(c->h_tail);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->packed_in.release(); c->nlist_in.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
-    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_items.release(); c->job_outs.release(); c->job_pool.release(); c->job_pool_next.release(); c->items.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release();
+    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_items.release(); c->job_outs.release(); c->job_pool.release(); c->job_pool_next.release(); c->items.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_heavy_sfail.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release(); c->scan_state.release(); c->scan_trace.release(); c->reads_c.release(); c->reports_c.release(); c->cig_c.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1226,7 +1226,10 @@ static hipError_t launch_seed(dg_ctx *c, int n, int H, hipEvent_t after_encode =
     } else
     if (W <= 78) k_seed<true><<<blocks, 64, ((size_t)2 * W * 64 + 64) * 4, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr);
     else k_seed<false><<<blocks, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, n, W, H, c->hits.p, c->nhits.p, c->nseeds.p, tops + TOP_SEED_NEXT, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr, bail_trips, both_thr);
-    k_seed_heavy<<<(unsigned)c->n_cu * (unsigned)c->env_seedh_bpc, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->d_ctr);
+    // the backward walk of every listed read, lane = read (dg_fm.h): from which start on all searches fail without being made
+    if ((e = c->seed_heavy_sfail.ensure((size_t)n + 16)) != hipSuccess) return e;
+    k_seed_heavy_walk<<<(unsigned)c->n_cu * 8u, 64, 0, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->seed_heavy_sfail.p, c->d_ctr);
+    k_seed_heavy<<<(unsigned)c->n_cu * (unsigned)c->env_seedh_bpc, 64, (size_t)W * 4 + 16, c->stream>>>(c->ix, c->pr, c->enc.p, c->rlen.p, W, H, c->hits.p, c->nhits.p, c->nseeds.p, c->seed_heavy.p, tops + TOP_SEED_HEAVY, c->seed_heavy_sfail.p, c->d_ctr);
     return hipGetLastError();
 }
 
@@ -1425,9 +1428,9 @@ static int enqueue_run(dg_ctx *c)
     const uint32_t jobcap = (uint32_t)c->jobs.cap;
     const RsPool rs_pool{c->job_pool.p, c->job_pool_next.p, tops + TOP_RS_POOL, c->env_rs_pool > 0 ? std::min<uint32_t>((uint32_t)c->env_rs_pool, rs_pool_cap) : rs_pool_cap};
     const int rs_gap_max = c->max_rlen - 32, rs_need = rs_gap_max >= 8 ? (rs_gap_max - 8) / 64 + 1 : 1;        // (see below)
-    // k_order: k_report's work list (the candidates grouped by cost class) and, by its last workgroup, k_reseed's ((window, chunk) items per ring size)
-    const RsOrder rs_order{c->jobs.p, tops + TOP_JOBS, jobcap, c->job_items.p, rs_list_cap, rs_out_cap, rs_need <= 1 ? 1 : (rs_need <= 2 ? 2 : 4), (uint32_t)c->env_rs_chunk, tops + TOP_RESEED_COUNT};
-    k_order<<<slow_grid + 1, 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->cands.p, c->ncand.p, tops + TOP_CLASS_HIST, tops + TOP_CLASS_FILL, c->items.p, tops + TOP_ORDER_INFO, rs_order, c->d_err);
+    // k_order: k_reseed's work list ((window, chunk) items per ring size) and k_report's (the candidates grouped by cost class)
+    const RsOrder rs_order{c->jobs.p, tops + TOP_JOBS, jobcap, c->job_items.p, rs_list_cap, rs_out_cap, rs_need <= 1 ? 1 : (rs_need <= 2 ? 2 : 4), (uint32_t)c->env_rs_chunk, tops + TOP_RESEED_COUNT, tops + TOP_RS_OUT};
+    k_order<<<slow_grid, 256, 0, c->stream>>>(paired, c->slow_units.p, c->d_sizes, c->seed_off.p, c->cands.p, c->ncand.p, tops + TOP_CLASS_HIST, tops + TOP_CLASS_FILL, c->items.p, tops + TOP_ORDER_INFO, rs_order, c->d_err);
     HIPCHK(hipGetLastError());
     TICK("order");
     HIPCHK(hipEventRecord(c->ev_prep, c->stream));

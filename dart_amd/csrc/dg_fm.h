@@ -678,6 +678,76 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_seed_heavy_walk: lane = one read of k_seed_heavy's list.
+// The tail of a read inside a high-copy repeat (satellites, microsatellites, young interspersed copies): the reference restarts its search at
+// every base (a failed search advances by one, AlignmentCandidates.cpp:209) and each of those searches runs to the end of the read --
+// O(rlen^2) Occ steps, two thirds of k_seed_heavy's work on a human-like genome.  A search from s that matches through to the read's end e
+// stops there with the interval of read[s, e) (bwt_search.cpp:152-171), and that interval only grows as s moves right.  So ONE backward
+// walk from e (prepending a base = extending the reverse complement on the right: the text holds both strands) finds the leftmost s_f
+// whose read[s_f, e) occurs more than max_dup times -- and at least 128 times, so that every step of those searches fetched two Occ
+// blocks, which keeps the reference-equivalent block count exact: every start in [s_f, e) fails (bwt_search.cpp:173) after e - s - 1 steps.
+// Round 4 made this walk inside k_seed_heavy, once per read by the whole wave: its values are wave-uniform, so the compiler turned it into ~80 scalar
+// instructions per step -- up to ~85 steps per read, 0.37 G instructions per 2 M reads of the human-like genome (a quarter of the batch's, 64 % of
+// them SALU) for one lane's worth of work.  Here 64 reads share an instruction.  sfail_out[hi] = s_f (the read's length: nothing fails for free).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_seed_heavy_walk(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int W,
+                  const DHeavy *__restrict__ heavy, const unsigned int *__restrict__ n_heavy_p, int32_t *__restrict__ sfail_out, unsigned long long *ctr)
+{
+    const int W2 = W >> 1;
+    const unsigned int n_heavy = *n_heavy_p;
+    SeedCtr c = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int K = ix.ktab ? ix.ktab_k : 0;
+    for (unsigned int hi = blockIdx.x * blockDim.x + threadIdx.x; hi < n_heavy; hi += gridDim.x * blockDim.x) {
+        const DHeavy hv = heavy[hi];
+        const int r = (int)hv.read, len = rlen[r], pos = hv.pos;
+        const uint32_t *ew = enc + (size_t)r * W;
+        auto rb = [&](int w) -> uint32_t { const uint32_t v = ew[w < W2 ? w : W2 - 1]; return w < W2 ? v : 0u; };
+        auto rm = [&](int w) -> uint32_t { const uint32_t v = ew[W2 + (w < W2 ? w : W2 - 1)]; return w < W2 ? v : 0xFFFFFFFFu; };
+        int sfail = len;
+        {
+            const uint64_t thr = (uint64_t)(pr.max_dup + 1 > 128 ? pr.max_dup + 1 : 128);
+            int q = len - 1;
+            if (q >= pos && d_at(rm, q) == 0) {
+                uint64_t x0 = 0, x1 = 0, x2 = 0;
+                bool have = false;
+                if (K && len - K >= pos) {
+                    const uint32_t sft = 32u - 2u * (uint32_t)K;
+                    if ((d_win16(rm, len - K) >> sft) == 0) {           // the read's last K bases, none of them N
+                        const uint4 e4 = *(const uint4_a4 *)(ix.ktab + (size_t)(d_win16(rb, len - K) >> sft) * 2);
+                        const uint64_t w0 = d_u64(e4.x, e4.y), w1 = d_u64(e4.z, e4.w);
+                        c.ktab++;
+                        if (!(w1 >> 63)) {                               // (an overflowing entry: start from the last base instead)
+                            have = true;
+                            if ((w1 >> 62) & 1ull) x2 = 1;               // a located (unique) K-mer
+                            else { x2 = (w1 >> 16) & 0x7FFFFFFFull; x0 = w0 & 0xFFFFFFFFFFull; x1 = (w0 >> 40) | ((w1 & 0xFFFFull) << 24); q = len - K; }
+                        }
+                    }
+                }
+                if (!have) { const int cc = (int)d_at(rb, q); x0 = d_L2(ix, cc) + 1; x1 = d_L2(ix, 3 - cc) + 1; x2 = d_L2(ix, cc + 1) - d_L2(ix, cc); }
+                if (x2 >= thr) {
+                    sfail = q;
+                    while (q > pos) {
+                        const int qq = q - 1;
+                        if (d_at(rm, qq)) break;
+                        uint64_t y0 = x1, y1 = x0, y2 = x2;              // the bi-interval of the reverse complement
+                        uint32_t nb;
+                        const bool ok = d_extend(ix, 3 - (int)d_at(rb, qq), y0, y1, y2, nb);
+                        c.steps_act++; c.blocks_act += nb;
+                        if (!ok || y2 < thr) break;
+                        x1 = y0; x0 = y1; x2 = y2; q = qq; sfail = q;
+                    }
+                }
+            }
+        }
+        sfail_out[hi] = sfail;
+    }
+    d_wave_add(ctr + CTR_STEPS_ACT, c.steps_act);
+    d_wave_add(ctr + CTR_BLOCKS_ACT, c.blocks_act);
+    d_wave_add(ctr + CTR_KTAB, c.ktab);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_seed_heavy: one wave = one read whose greedy walk is long (almost every start fails: an
 // unmappable or very noisy read).  BWT_Search(start) does not depend on earlier searches -- only
 // WHICH starts get searched does -- so the wave evaluates 64 consecutive starts at once, one per
@@ -688,7 +758,7 @@ k_seed(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, cons
 __global__ void __launch_bounds__(64)
 k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc, const uint16_t *__restrict__ rlen, int W, int H,
              DHit *__restrict__ hits, uint32_t *__restrict__ nhits, uint32_t *__restrict__ nseeds,
-             const DHeavy *__restrict__ heavy, const unsigned int *__restrict__ n_heavy_p, unsigned long long *ctr)
+             const DHeavy *__restrict__ heavy, const unsigned int *__restrict__ n_heavy_p, const int32_t *__restrict__ sfail_in, unsigned long long *ctr)
 {
     const unsigned long long t_wave0 = wall_clock64();
     extern __shared__ uint32_t sh[];                 // the read's words (k_encode format), shared by the wave
@@ -708,50 +778,7 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
         auto rm = [&](int w) -> uint32_t { const uint32_t v = sh[W2 + (w < W2 ? w : W2 - 1)]; return w < W2 ? v : 0xFFFFFFFFu; };
         int pos = hv.pos, nh = hv.nh;
         uint32_t ns = hv.ns;
-        // The tail of a read inside a high-copy repeat (satellites, microsatellites, young interspersed copies): the reference restarts its search at
-        // every base (a failed search advances by one, AlignmentCandidates.cpp:209) and each of those searches runs to the end of the read --
-        // O(rlen^2) Occ steps, two thirds of this kernel's work on a human-like genome.  A search from s that matches through to the read's end e
-        // stops there with the interval of read[s, e) (bwt_search.cpp:152-171), and that interval only grows as s moves right.  So ONE backward
-        // walk from e (prepending a base = extending the reverse complement on the right: the text holds both strands) finds the leftmost s_f
-        // whose read[s_f, e) occurs more than max_dup times -- and at least 128 times, so that every step of those searches fetched two Occ
-        // blocks, which keeps the reference-equivalent block count exact: every start in [s_f, e) fails (bwt_search.cpp:173) after e - s - 1 steps.
-        // (The whole wave computes the walk redundantly: the values are uniform, the loads broadcast.)
-        int sfail = len;
-        {
-            const uint64_t thr = (uint64_t)(pr.max_dup + 1 > 128 ? pr.max_dup + 1 : 128);
-            int q = len - 1;
-            if (q >= pos && d_at(rm, q) == 0) {
-                uint64_t x0 = 0, x1 = 0, x2 = 0;
-                bool have = false;
-                if (K && len - K >= pos) {
-                    const uint32_t sft = 32u - 2u * (uint32_t)K;
-                    if ((d_win16(rm, len - K) >> sft) == 0) {           // the read's last K bases, none of them N
-                        const uint4 e4 = *(const uint4_a4 *)(ix.ktab + (size_t)(d_win16(rb, len - K) >> sft) * 2);
-                        const uint64_t w0 = d_u64(e4.x, e4.y), w1 = d_u64(e4.z, e4.w);
-                        if (lane == 0) c.ktab++;
-                        if (!(w1 >> 63)) {                               // (an overflowing entry: start from the last base instead)
-                            have = true;
-                            if ((w1 >> 62) & 1ull) x2 = 1;               // a located (unique) K-mer
-                            else { x2 = (w1 >> 16) & 0x7FFFFFFFull; x0 = w0 & 0xFFFFFFFFFFull; x1 = (w0 >> 40) | ((w1 & 0xFFFFull) << 24); q = len - K; }
-                        }
-                    }
-                }
-                if (!have) { const int cc = (int)d_at(rb, q); x0 = d_L2(ix, cc) + 1; x1 = d_L2(ix, 3 - cc) + 1; x2 = d_L2(ix, cc + 1) - d_L2(ix, cc); }
-                if (x2 >= thr) {
-                    sfail = q;
-                    while (q > pos) {
-                        const int qq = q - 1;
-                        if (d_at(rm, qq)) break;
-                        uint64_t y0 = x1, y1 = x0, y2 = x2;              // the bi-interval of the reverse complement
-                        uint32_t nb;
-                        const bool ok = d_extend(ix, 3 - (int)d_at(rb, qq), y0, y1, y2, nb);
-                        if (lane == 0) { c.steps_act++; c.blocks_act += nb; }
-                        if (!ok || y2 < thr) break;
-                        x1 = y0; x0 = y1; x2 = y2; q = qq; sfail = q;
-                    }
-                }
-            }
-        }
+        const int sfail = sfail_in[hi];              // from where on every start fails without being searched (k_seed_heavy_walk, below the comment there)
         while (pos < end_pos) {                      // uniform
             if (pos >= sfail) {                      // every remaining start fails after len - s - 1 steps: the sum over s = pos .. end_pos - 1
                 if (lane == 0) {
@@ -782,30 +809,39 @@ k_seed_heavy(const DIndex ix, const DParams pr, const uint32_t *__restrict__ enc
                     if (acgt && direct && s.mode == 1 && s.x2 == 1) { s.mode = 3; s.lk = s.x0; s.lsteps = 0; }
                 }
             }
-            // replay the walk over the 64 results
-            int cur = pos;
-            const int lim = pos + 64 < end_pos ? pos + 64 : end_pos;
-            while (cur < lim) {                      // uniform
-                const int src = cur - pos;
-                const int is_acgt = __shfl((int)acgt, src, 64);
-                const int hl = __shfl(s.hit_len, src, 64);
-                if (lane == src && doomed) { c.steps += (unsigned long long)(len - st - 1); c.blocks += 2ull * (unsigned long long)(len - st - 1); }
-                if (lane == src && acgt) {           // this search is one the reference performs
-                    c.steps += s.ref_steps; c.blocks += s.ref_blocks;
-                    if (s.hit_len) {
-                        if (nh < H) {
-                            DHit h; h.rPos = (uint16_t)s.start; h.len = (uint16_t)s.hit_len;
-                            if (s.located) { h.x0 = (uint64_t)s.tpos; h.freq = 1u | 0x80000000u; c.lf_ref += s.lsteps + (uint32_t)(s.lk >> 40); }
-                            else { h.x0 = s.x0; h.freq = (uint32_t)s.x2; }
-                            hits[(size_t)r * H + nh] = h;
-                        }
-                    }
-                }
-                if (is_acgt && hl) {
-                    const uint32_t fr = (uint32_t)__shfl((int)(uint32_t)s.x2, src, 64);
-                    nh++; ns += fr; cur += hl;
-                } else cur++;
+            // Replay the reference's walk (hit: pos += len, else pos++; AlignmentCandidates.cpp:198-209) over the 64 results.  Only the starts with a hit
+            // change where the walk goes, so it jumps from hit to hit (round 5; rounds 1-4 stepped through the starts one by one with shuffles: ~40 scalar
+            // instructions x 64 per round, two thirds of this kernel's 0.37 G instructions on a genome with human-like repeats) and marks what it
+            // passed over; the visited lanes then add their own counters, the visited hits take their places by popcount.
+            const int nlim = (pos + 64 < end_pos ? pos + 64 : end_pos) - pos;          // starts of this round (1 .. 64)
+            const unsigned long long in_round = nlim >= 64 ? ~0ull : ((1ull << nlim) - 1ull);
+            const unsigned long long hitm = __ballot(acgt && s.hit_len > 0) & in_round;
+            unsigned long long vis = 0;
+            int cur = 0;                             // relative to pos
+            while (cur < nlim) {                     // uniform; one iteration per visited hit
+                const unsigned long long m = hitm >> cur;
+                if (!m) { vis |= in_round & ~((1ull << cur) - 1ull); cur = nlim; break; }
+                const int j = cur + (__ffsll((long long)m) - 1);
+                vis |= (j >= 63 ? ~0ull : ((1ull << (j + 1)) - 1ull)) & ~((1ull << cur) - 1ull);
+                cur = j + __shfl(s.hit_len, j, 64);
             }
+            const bool seen = (vis >> lane) & 1ull;
+            if (seen && doomed) { c.steps += (unsigned long long)(len - st - 1); c.blocks += 2ull * (unsigned long long)(len - st - 1); }
+            if (seen && acgt) { c.steps += s.ref_steps; c.blocks += s.ref_blocks; }      // a search the reference performs
+            const unsigned long long vh = vis & hitm;
+            if ((vh >> lane) & 1ull) {
+                const int at = nh + __popcll(vh & ((1ull << lane) - 1ull));
+                if (at < H) {
+                    DHit h; h.rPos = (uint16_t)s.start; h.len = (uint16_t)s.hit_len;
+                    if (s.located) { h.x0 = (uint64_t)s.tpos; h.freq = 1u | 0x80000000u; c.lf_ref += s.lsteps + (uint32_t)(s.lk >> 40); }
+                    else { h.x0 = s.x0; h.freq = (uint32_t)s.x2; }
+                    hits[(size_t)r * H + at] = h;
+                }
+            }
+            uint32_t fr = ((vh >> lane) & 1ull) ? (uint32_t)s.x2 : 0u;
+            for (int o = 32; o > 0; o >>= 1) fr += (uint32_t)__shfl_xor((int)fr, o, 64);
+            nh += __popcll(vh); ns += fr;
+            cur += pos;
             pos = cur;
         }
         if (lane == 0) { nhits[r] = (uint32_t)nh; nseeds[r] = ns; }

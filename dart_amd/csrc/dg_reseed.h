@@ -316,60 +316,39 @@ __device__ __forceinline__ void d_rs_finalize(unsigned long long *ring, uint32_t
 
 // Work list of the re-seeding kernel: per ring size (1, 2, 4 bitmap words per diagonal) the CHUNKS of that size's jobs.  A window of glen bases has the
 // diagonals [D0, glen - 8] (D0 = -(read-gap span) rounded down to a group of 64); chunk 0 takes [D0, C), chunk k >= 1 takes [k C, (k + 1) C): n_chunks =
-// ceil((glen - 7) / C), at least 1.  C (a multiple of the 4096-position pac super-chunk) starts at RS_CHUNK_DIAGS and doubles until the RsChunkOut records
-// of all windows with more than one chunk fit `out_cap`: no new capacity to overflow, a batch with absurdly many long windows just gets coarser chunks.
+// ceil((glen - 7) / C), at least 1, C = RS_CHUNK_DIAGS (a multiple of the 4096-position pac super-chunk).  A window whose RsChunkOut records do not fit the
+// buffer any more stays whole (one wave, as round 4 did for every window): no new capacity to overflow.
 // Round 4: one wave per window, longest first -- a 500 kb window was ~1000 trips of one wave, and the kernel's duration.  Items are (job << 32 | chunk).
-// info[0..2] = items per ring size, info[3] = C.  One workgroup.
+// info[0..2] = items per ring size (atomics), info[3] = C; out_top = RsChunkOut records handed out.  Every thread of k_order's grid takes jobs (a first version gave
+// the whole list to the launch's last workgroup: 0.5 ms alone for the 31 k jobs of a spliced batch, in front of k_reseed).
 #define RS_CHUNK_DIAGS 32768
 __device__ __forceinline__ uint32_t d_rs_nchunks(int glen, uint32_t C) { return glen > 7 ? (uint32_t)(((int64_t)(glen - 7) + (int64_t)C - 1) / (int64_t)C) : 1u; }
 struct RsOrder { DJob *jobs; const unsigned int *jobtop; uint32_t jobcap; unsigned long long *lists; uint32_t list_cap, out_cap; int max_words /* widest ring the host launches */;
-                 uint32_t chunk0 /* diagonals per chunk to start from: RS_CHUNK_DIAGS (a test hook lowers it) */; unsigned int *info; };
-__device__ inline void d_order_jobs(const RsOrder &o)               // one workgroup (any size); round 4: a launch of its own, now the last workgroup of k_order
+                 uint32_t chunk0 /* diagonals per chunk: RS_CHUNK_DIAGS (a test hook lowers it) */; unsigned int *info; unsigned int *out_top; };
+__device__ inline void d_order_jobs(const RsOrder &o)               // called by every thread of the grid
 {
-    DJob *__restrict__ jobs = o.jobs; unsigned long long *__restrict__ lists = o.lists; unsigned int *__restrict__ info = o.info;
-    const uint32_t jobcap = o.jobcap, list_cap = o.list_cap, out_cap = o.out_cap, chunk0 = o.chunk0; const int max_words = o.max_words; const unsigned int *jobtop = o.jobtop;
-    __shared__ unsigned int s_need[8], s_items[3], s_out, s_C;
-    const unsigned int njobs = *jobtop < jobcap ? *jobtop : jobcap;
-    if (threadIdx.x < 8) s_need[threadIdx.x] = 0;
-    if (threadIdx.x < 3) s_items[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_out = 0;
-    __syncthreads();
-    // RsChunkOut records needed with C = RS_CHUNK_DIAGS << i, i = 0..7
-    unsigned int need[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (unsigned int i = threadIdx.x; i < njobs; i += blockDim.x) {
-        if (jobs[i].found < 0) continue;                                        // too long for the LDS ring: serial path in k_report
-        { const int nw = jobs[i].rl >= 8 ? (jobs[i].rl - 8) / 64 + 1 : 1; if ((nw <= 1 ? 1 : (nw <= 2 ? 2 : 4)) > max_words) continue; }
-        const int glen = jobs[i].glen;
-#pragma unroll
-        for (int q = 0; q < 8; q++) { const uint32_t n = d_rs_nchunks(glen, chunk0 << q); if (n > 1) need[q] += n; }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; q++) if (need[q]) atomicAdd(&s_need[q], need[q]);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int q = 0;
-        while (q < 7 && s_need[q] > out_cap) q++;
-        s_C = s_need[q] > out_cap ? 0x7FFFF000u : chunk0 << q;                   // (still too many: every window whole, as round 4)
-    }
-    __syncthreads();
-    const uint32_t C = s_C;
-    for (unsigned int i = threadIdx.x; i < njobs; i += blockDim.x) {
+    DJob *__restrict__ jobs = o.jobs; unsigned long long *__restrict__ lists = o.lists;
+    const unsigned int njobs = *o.jobtop < o.jobcap ? *o.jobtop : o.jobcap;
+    const uint32_t C = o.chunk0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) o.info[3] = C;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < njobs; i += gridDim.x * blockDim.x) {
         DJob &j = jobs[i];
-        if (j.found < 0) continue;
+        if (j.found < 0) continue;                                        // too long for the LDS ring: serial path in k_report
         const int need_w = j.rl >= 8 ? (j.rl - 8) / 64 + 1 : 1;
         const int w = need_w <= 1 ? 0 : (need_w <= 2 ? 1 : 2);
-        if ((1 << w) > max_words) { j.found = -1; continue; }                    // (cannot happen: the host derives max_words from the longest read; the serial path in k_report would take it)
-        const uint32_t n = d_rs_nchunks(j.glen, C);
-        const unsigned int at = atomicAdd(&s_items[w], n);
-        j.n_chunks = n; j.done = 0; j.out_first = n > 1 ? atomicAdd(&s_out, n) : 0u;
-        for (uint32_t k = 0; k < n; k++) if (at + k < list_cap) lists[(size_t)w * list_cap + at + k] = ((unsigned long long)i << 32) | k;     // (list_cap = jobcap + out_cap: always enough)
+        if ((1 << w) > o.max_words) { j.found = -1; continue; }                // (cannot happen: the host derives max_words from the longest read; the serial path in k_report would take it)
+        uint32_t n = d_rs_nchunks(j.glen, C), first = 0;
+        if (n > 1) {
+            first = atomicAdd(o.out_top, n);
+            if ((uint64_t)first + n > o.out_cap) { n = 1; first = 0; }          // (the records are full: this window by one wave)
+        }
+        const unsigned int at = atomicAdd(o.info + w, n);
+        j.n_chunks = n; j.done = 0; j.out_first = first;
+        for (uint32_t k = 0; k < n; k++) if (at + k < o.list_cap) lists[(size_t)w * o.list_cap + at + k] = ((unsigned long long)i << 32) | k;     // (list_cap = jobcap + out_cap: always enough)
     }
-    __syncthreads();
-    if (threadIdx.x < 3) info[threadIdx.x] = s_items[threadIdx.x] < list_cap ? s_items[threadIdx.x] : list_cap;
-    if (threadIdx.x == 3) info[3] = C;
 }
 
-// k_order: k_report's work list from the candidates' classes and the class histogram of k_prep (and, by its last workgroup, k_reseed's: d_order_jobs): items = (read << 32 | index of the candidate in cands[]) grouped by
+// k_order: k_report's work list from the candidates' classes and the class histogram of k_prep (and k_reseed's: d_order_jobs): items = (read << 32 | index of the candidate in cands[]) grouped by
 // class, class 0 first (any order inside a class: the order decides who computes what when, never a result); info[0] = items of class 0 (they wait for
 // k_reseed), info[1] = all items.  One launch over the listed reads; a workgroup reserves its share of every class with one atomic per class.
 __global__ void __launch_bounds__(256)
@@ -379,7 +358,7 @@ k_order(int paired, const uint32_t *__restrict__ slow_units, const DSizes *__res
 {
     __shared__ uint32_t s_start[DG_COST_CLASSES], s_cnt[DG_COST_CLASSES], s_base[DG_COST_CLASSES];
     if (*abort_p >= DG_ABORT) return;
-    if (blockIdx.x == gridDim.x - 1) { d_order_jobs(jobs_order); return; }      // the launch's last workgroup lays out k_reseed's work list (below), the others k_report's
+    d_order_jobs(jobs_order);                                                   // k_reseed's work list: every thread takes re-seeding jobs (above); then k_report's
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < 64) {                                        // exclusive scan of the 32 class totals by the first wave
         uint32_t v = lane < DG_COST_CLASSES ? class_hist[lane] : 0u, incl = v;
@@ -392,7 +371,7 @@ k_order(int paired, const uint32_t *__restrict__ slow_units, const DSizes *__res
     }
     __syncthreads();
     const unsigned int n_items = sizes->n_slow_units * (paired ? 2u : 1u);
-    for (unsigned int base = blockIdx.x * blockDim.x; base < n_items; base += (gridDim.x - 1) * blockDim.x) {      // uniform per workgroup
+    for (unsigned int base = blockIdx.x * blockDim.x; base < n_items; base += gridDim.x * blockDim.x) {      // uniform per workgroup
         const unsigned int it = base + threadIdx.x;
         const bool on = it < n_items;
         const uint32_t r = on ? (paired ? 2u * slow_units[it >> 1] + (it & 1u) : slow_units[it]) : 0u;

@@ -364,6 +364,29 @@ def test_gpu_reseed_windows_shared_by_several_waves(workdir, monkeypatch):
     gpu.close(); orc.close()
 
 
+def test_gpu_second_stream_for_the_reseeding_kernels_still_gives_the_same_records(workdir, monkeypatch):
+    """DG_ONE_STREAM=0 (rounds 2-4's arrangement, kept as a switch): k_reseed on a second stream beside the report of the candidates without
+    re-seeding jobs, the others in a second k_report launch behind it.  Same records as the oracle's, and as the default's (one stream, k_reseed in
+    front of one k_report launch), on a batch where a third of the units have jobs."""
+    g = synth.make_genome([3000000, 1500000], seed=71, repeat_scale=30.0, n_introns=800)
+    prefix = os.path.join(workdir, "two_streams")
+    index_build.build_index_from_genome(g, prefix)
+    ix = host.Index(prefix); orc = oracle_py.Oracle(prefix)
+    m1, m2 = synth.make_reads(g, 30000, rlen=125, seed=72, sub_rate=0.01, indel_frac=0.03, n_frac=0.002, spliced_frac=0.4)
+    so, rl, flat = host.pack_reads(host.interleave_pairs(m1, m2))
+    want = orc.map_batch(orc.params(paired=1, max_mismatch=5, max_intron=200000), so, rl, flat, threads=16)
+    for one in ("0", "1"):
+        monkeypatch.setenv("DG_ONE_STREAM", one)
+        gpu = host.DartGPU(ix, host.default_params(paired=1, max_mismatch=5, max_intron=200000))       # (the switch is read when a context is created)
+        res = gpu.map_batch(so, rl, flat)
+        assert_same(res, want)
+        names = [n for n, _ in gpu.timings()]
+        assert ("k_report_jobs" in names) == (one == "0"), names
+        assert gpu.counters()["reseed_calls"] == orc.counters["n_reseed"] > 100
+        gpu.close()
+    orc.close()
+
+
 def test_gpu_noisy_long_reads_wave_nw_paths(workdir):
     """Stress of the wave-wide alignment service and of the wave-per-read layout: a repeat-rich 3 Mbp genome, 2x250 reads with
     4 % substitutions and an indel in a third of them (segment pairs wider than 64 columns: one pair per wave; up to 64: eight
