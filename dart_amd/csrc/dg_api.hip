@@ -92,7 +92,7 @@ struct dg_ctx {
     // them without asking the device for a size first, the device reports what it needed (DSizes) and flags an overflow
     // (d_err >= DG_ABORT), in which case the host grows the buffer and runs the batch again
     DBuf<DHit> hits; DBuf<uint32_t> nhits, nseeds, seed_off, ncand, rep_off, tile_sums, tile_read, slow_units;
-    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<unsigned long long> job_items, job_pool; DBuf<RsChunkOut> job_outs; DBuf<uint32_t> job_pool_next; DBuf<unsigned long long> items; DBuf<uint32_t> hist, heavy; DBuf<DHeavy> seed_heavy; DBuf<int32_t> seed_heavy_sfail;
+    DBuf<SKey> seeds; DBuf<DSeed> work; DBuf<DCand> cands; DBuf<DJob> jobs; DBuf<unsigned long long> job_items, job_pool; DBuf<RsChunkOut> job_outs; DBuf<uint32_t> job_pool_next; DBuf<unsigned long long> items; DBuf<uint32_t> hist, heavy; DBuf<DHeavy> seed_heavy; DBuf<int32_t> seed_heavy_sfail; DBuf<int16_t> chain_picks; DBuf<uint8_t> chain_todo;
     DBuf<dg_read_out> reads_out; DBuf<dg_report_out> reports; DBuf<uint32_t> cigpool, cigfinal;
     DBuf<dg_sj_out> sjpool, sjfinal;
     DBuf<dg_read_c> reads_c; DBuf<dg_report_c> reports_c; DBuf<uint32_t> cig_c;     // compact records and their stored CIGAR ops (written by k_pair / k_emit_slow)
@@ -115,6 +115,7 @@ struct dg_ctx {
     uint64_t counters[CTR_N];
     uint64_t reruns_capacity = 0, reruns_scan = 0;      // since dg_init / dg_clone
     bool want_compact = true, packed_valid = false;     // compact records: written by this run's kernels too / present for the batch that ran last
+    bool want_full = true, full_valid = false;          // the full record types of the units k_pair finishes: written by this run (dg_map_batch_compact does not want them) / present for the batch that ran last
     int n_cu = 256, runs_of_last_batch = 0, attempt_no = 0;
     // environment switches, read once per context (not per batch)
     int env_seed_waves = 4, env_bail_trips = 0 /* 0: 64 trips in k_seed_qf (a trip there is up to three dependent accesses), 128 in the other two */, env_both = 0, env_report_bpc = 8, env_no_fast = 0, env_seed_legacy = 0, env_seed_slots_lg = 0, env_seed_wgs = 0, env_blocking_sync = 0;
@@ -557,7 +558,7 @@ extern "C" void dg_destroy(dg_ctx *c)
     if (c->h_tail) (void)hipHostFree(c->h_tail);
     c->seq.release(); c->seq_off.release(); c->rlen.release(); c->enc.release(); c->packed_in.release(); c->nlist_in.release(); c->hits.release(); c->nhits.release(); c->nseeds.release();
     c->seed_off.release(); c->ncand.release(); c->rep_off.release(); c->tile_sums.release(); c->tile_read.release(); c->slow_units.release();
-    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_items.release(); c->job_outs.release(); c->job_pool.release(); c->job_pool_next.release(); c->items.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_heavy_sfail.release();
+    c->seeds.release(); c->work.release(); c->cands.release(); c->jobs.release(); c->job_items.release(); c->job_outs.release(); c->job_pool.release(); c->job_pool_next.release(); c->items.release(); c->hist.release(); c->heavy.release(); c->seed_heavy.release(); c->seed_heavy_sfail.release(); c->chain_picks.release(); c->chain_todo.release();
     c->reads_out.release(); c->reports.release(); c->cigpool.release(); c->cigfinal.release(); c->sjpool.release(); c->sjfinal.release();
     c->ws.release(); c->scan_state.release(); c->scan_trace.release(); c->reads_c.release(); c->reports_c.release(); c->cig_c.release();
     for (int i = 0; i <= N_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1364,8 +1365,11 @@ static int enqueue_run(dg_ctx *c)
     unsigned int *tops = c->d_tops;
 
     // units with more seeds than a lane of k_pair holds: a wave each, before k_pair (which needs their candidate counts)
+    HIPCHK(c->chain_picks.ensure(c->cap_seeds + 16)); HIPCHK(c->chain_todo.ensure((size_t)n_units + 16));
     k_chain_heavy<<<c->n_cu * c->env_chain_bpc, 64, 0, c->stream>>>(c->ix, c->pr, n_units, paired, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p,
-                                                     c->heavy.p, tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
+                                                     c->heavy.p, tops + TOP_HEAVY_UNITS, c->chain_picks.p, c->chain_todo.p, c->d_ctr, c->d_err);
+    // the sequential rest of the candidate rules of those units, lane = unit (dg_chain.h)
+    k_chain_rules<<<c->n_cu * 4, 64, 0, c->stream>>>(paired, c->seed_off.p, c->cands.p, c->ncand.p, c->heavy.p, tops + TOP_HEAVY_UNITS, c->chain_picks.p, c->chain_todo.p, c->d_err);
     HIPCHK(hipGetLastError());
 #ifdef DG_PROFILE_CLASSES
     {
@@ -1391,11 +1395,11 @@ static int enqueue_run(dg_ctx *c)
     const bool packed_pair = c->enc_ready && c->env_packed_pair;
     if (packed_pair)        // a packed batch: the characters follow from its words; only the general path's units get an ASCII copy (below)
         k_pair<true><<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
-            c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->enc.p, W2p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
+            c->ix, c->pr, n_units, paired, try_fast, (c->want_full || !c->want_compact) ? 0 : 2, c->seq.p, c->seq_off.p, c->enc.p, W2p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
             c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err, co);
     else
         k_pair<false><<<(unsigned)((n_units + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
-            c->ix, c->pr, n_units, paired, try_fast, 0, c->seq.p, c->seq_off.p, c->enc.p, W2p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
+            c->ix, c->pr, n_units, paired, try_fast, (c->want_full || !c->want_compact) ? 0 : 2, c->seq.p, c->seq_off.p, c->enc.p, W2p, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,
             c->slow_units.p, c->reads_out.p, c->reports.p, c->cigfinal.p, (uint32_t)c->cap_rep, (uint32_t)c->cap_cig, ts_pair, c->d_sizes, tops + TOP_CIG, c->d_ctr, c->d_err, co);
     HIPCHK(hipGetLastError());
     TICK("k_pair");
@@ -1555,7 +1559,7 @@ static int finish_run(dg_ctx *c, size_t used[3])
     const int derr = c->h_tail->err;
     if (derr) { snprintf(c->err, 512, "device pool exhausted (%s)", derr == DG_E_CIGAR ? "cigar" : (derr == DG_E_SJ ? "splice junction" : "reseed jobs")); return DG_ERR_INTERNAL; }
     c->used[0] = sz.total_rep; c->used[1] = sz.total_cig; c->used[2] = sz.total_sj;
-    c->packed_valid = c->want_compact;
+    c->packed_valid = c->want_compact; c->full_valid = c->want_full || !c->want_compact;
     if (used) { used[0] = c->used[0]; used[1] = c->used[1]; used[2] = c->used[2]; }
     return DG_OK;
 }
@@ -1568,7 +1572,7 @@ extern "C" int dg_batch_run(dg_ctx *c, size_t used[3])
     memset(c->counters, 0, sizeof c->counters);
     if (used) used[0] = used[1] = used[2] = 0;
     c->n_t = 0;
-    c->packed_valid = false;
+    c->packed_valid = false; c->full_valid = false;
     if (c->n_reads == 0) return DG_OK;
     c->attempt_no = 0;
     const int rc = enqueue_run(c);
@@ -1658,7 +1662,9 @@ extern "C" int dg_map_batch_compact(dg_ctx *c, int n_reads, const uint32_t *seq_
     int rc = words ? enqueue_upload_packed(c, n_reads, rlen_all, rlen, words_per_read, words, nlist, n_n) : enqueue_upload(c, n_reads, seq_off, rlen, seq);
     if (rc) return rc;
     const auto t1 = std::chrono::steady_clock::now();
-    rc = dg_batch_run(c, used);                             // (writes the compact records beside the full ones)
+    c->want_full = false;                                   // this caller takes the compact records: the units k_pair finishes get no full ones (dg_batch_download would map the batch again)
+    rc = dg_batch_run(c, used);
+    c->want_full = true;
     if (rc) return rc;
     const auto t2 = std::chrono::steady_clock::now();
     size_t n_ops = 0;
@@ -1675,10 +1681,24 @@ extern "C" int dg_map_batch_compact(dg_ctx *c, int n_reads, const uint32_t *seq_
     return rc;
 }
 
+// The full record types of the units k_pair finished are not written when the caller asked for the compact records only (dg_map_batch_compact): a caller that
+// wants them after all (the compact types could not hold a field: DG_ERR_RANGE) gets the batch mapped again, with them -- the uploaded batch is still in HBM.
+static int ensure_full_records(dg_ctx *c)
+{
+    if (c->full_valid || c->n_reads == 0) return DG_OK;
+    const bool keep = c->want_full;
+    c->want_full = true;
+    size_t used[3];
+    const int rc = dg_batch_run(c, used);
+    c->want_full = keep;
+    return rc;
+}
+
 extern "C" int dg_batch_download(dg_ctx *c, dg_read_out *ro, dg_report_out *po, uint32_t *cig, dg_sj_out *so, const size_t caps[3])
 {
     if (!c || !caps) return DG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    { const int rf = ensure_full_records(c); if (rf) return rf; }
     const int rc = enqueue_download(c, ro, po, cig, so, caps);
     if (rc) return rc;
     HIPCHK(wait_download(c));
@@ -1717,6 +1737,7 @@ extern "C" int dg_map_batch_packed(dg_ctx *c, int n_reads, int rlen_all, const u
 extern "C" int dg_batch_device_ptrs(dg_ctx *c, void *ptrs[4])
 {
     if (!c || !ptrs) return DG_ERR_ARG;
+    { const int rf = ensure_full_records(c); if (rf) return rf; }
     ptrs[0] = c->reads_out.p; ptrs[1] = c->reports.p; ptrs[2] = c->cigfinal.p; ptrs[3] = c->sjfinal.p;
     return DG_OK;
 }
@@ -1898,7 +1919,9 @@ extern "C" int dg_probe_seeds(dg_ctx *c, int n_reads, const uint32_t *seq_off, c
         // only, sorted seeds written back for every read) for the rest
         HIPCHK(c->ncand.ensure(n)); HIPCHK(c->rep_off.ensure((size_t)n + 1)); HIPCHK(c->reads_out.ensure(n));
         HIPCHK(c->heavy.ensure((size_t)n + 16)); HIPCHK(c->slow_units.ensure((size_t)n + 16)); HIPCHK(c->reports.ensure(16)); HIPCHK(c->cigfinal.ensure(16));
-        k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->d_ctr, c->d_err);
+        HIPCHK(c->chain_picks.ensure(c->cap_seeds + 16)); HIPCHK(c->chain_todo.ensure((size_t)n + 16));
+        k_chain_heavy<<<c->n_cu * 4, 64, 0, c->stream>>>(c->ix, c->pr, n, 0, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->chain_picks.p, c->chain_todo.p, c->d_ctr, c->d_err);
+        k_chain_rules<<<c->n_cu * 4, 64, 0, c->stream>>>(0, c->seed_off.p, c->cands.p, c->ncand.p, c->heavy.p, c->d_tops + TOP_HEAVY_UNITS, c->chain_picks.p, c->chain_todo.p, c->d_err);
         const TileScan ts = make_tile_scan(c, scan_tiles_seed(n), c->d_tops + TOP_TICKET_PAIR, 2);
         k_pair<false><<<(unsigned)((n + PU_THREADS - 1) / PU_THREADS), PU_THREADS, 0, c->stream>>>(
             c->ix, c->pr, n, 0, 0, 1, c->seq.p, c->seq_off.p, c->enc.p, 1, c->rlen.p, c->seed_off.p, c->seeds.p, c->cands.p, c->ncand.p, c->rep_off.p,

@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(64)
 k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const uint16_t *__restrict__ rlen,
               const uint32_t *__restrict__ seed_off, SKey *__restrict__ seeds, DCand *__restrict__ cands,
               uint32_t *__restrict__ ncand, const uint32_t *__restrict__ heavy_list, const unsigned int *__restrict__ n_heavy_p,
-              unsigned long long *ctr, const int *__restrict__ abort_p)
+              int16_t *__restrict__ picks, uint8_t *__restrict__ todo, unsigned long long *ctr, const int *__restrict__ abort_p)
 {
     const unsigned long long t_wave0 = wall_clock64();
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[CH_LDS_BYTES];
@@ -325,7 +325,7 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
     unsigned long long *s_starts = (unsigned long long *)(s_mem + CH_MAXS * 8 + (CH_MAXS + 1) * 4 + 4);      // ... and the start masks
     CandLite *lc0 = (CandLite *)s_mem, *lc1 = lc0 + CH_MAXC;                          // phase 2: the two candidate lists ...
     int16_t *s_pick = (int16_t *)(s_mem + 2 * CH_MAXC * 16);                          // ... and every candidate's pick
-    __shared__ int s_n[2], s_pairing;
+    __shared__ int s_n[2];
     // the ChrLocMap keys in LDS when they fit (32 chromosomes: 512 bytes): the clustering asks "does this seed lie
     // before the end of its neighbour's chromosome half" through a binary search, six dependent loads from memory otherwise (dg_common.h, LocTab)
     __shared__ int64_t s_lkey[CH_LOC_MAX];
@@ -373,8 +373,6 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
                 __syncthreads();
                 CandLiteView a1{lc0, n1}, a2{lc1, n2};
                 if (n1 * n2 > 1000) { if (lane == 0) { d_keep_top(a1); d_keep_top(a2); } __syncthreads(); }
-                if (lane == 0) s_pairing = 0;
-                __syncthreads();
                 // d_pair_mates in two steps: which partner a candidate would pick depends only on scores and PosDiffs, which the
                 // pairing does not change -- so all picks are made first, 64 candidates of mate 1 at a time (every lane scans mate 2's
                 // list: broadcast LDS reads), and lane 0 then replays the take / change-hands decisions in candidate order
@@ -392,27 +390,17 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
                     s_pick[i] = (int16_t)pick;
                 }
                 __syncthreads();
-                if (lane == 0) {
-                    for (int i = 0; i < n1; i++) {
-                        const int pick = s_pick[i];
-                        if (pick < 0) continue;
-                        const int holder = a2.mate(pick);
-                        if (holder < 0) s_pairing = 1;
-                        else if (a1.score(i) > a1.score(holder)) a1.set_mate(holder, -1);
-                        else continue;
-                        a1.set_mate(i, pick); a2.set_mate(pick, i);
-                    }
+                // The rest of the candidate rules is sequential in candidate order (who takes or loses a partner, RemoveUnMatedAlignmentCandidates, the
+                // top / runner fold of RemoveRedundantCandidates): one lane's work.  Rounds 2-4 let lane 0 of this wave do it -- ~1000 wave-instructions per
+                // unit, 40 % of this kernel's -- ; now the picks go to memory and k_chain_rules finishes 64 units per wave, lane = unit.
+                for (int i = lane; i < n1; i += 64) picks[b[0] + i] = s_pick[i];
+                if (n1 * n2 > 1000) {                         // (the scores the early redundancy filter zeroed)
+                    for (int i = lane; i < n1; i += 64) c1[i].Score = lc0[i].Score;
+                    for (int i = lane; i < n2; i += 64) c2[i].Score = lc1[i].Score;
                 }
-                __syncthreads();
-                if (lane == 0) {
-                    if (s_pairing) d_settle_mates(a1, a2);
-                    d_keep_top(a1); d_keep_top(a2);
-                }
-                __syncthreads();
-                for (int i = lane; i < n1; i += 64) { c1[i].Score = lc0[i].Score; c1[i].PairedIdx = lc0[i].PairedIdx; }
-                for (int i = lane; i < n2; i += 64) { c2[i].Score = lc1[i].Score; c2[i].PairedIdx = lc1[i].PairedIdx; }
-            } else if (lane == 0) { CandMem a1{c1, n1}, a2{c2, n2}; d_candidate_rules(true, a1, a2); }
-        } else if (lane == 0) { CandMem a1{c1, n1}; d_keep_top(a1); }
+                if (lane == 0) todo[hi] = 1;
+            } else if (lane == 0) { CandMem a1{c1, n1}, a2{c2, n2}; d_candidate_rules(true, a1, a2); todo[hi] = 0; }      // (lists longer than the staging: everything here, by one lane)
+        } else if (lane == 0) todo[hi] = 2;                          // single-end: the redundancy filter alone (k_chain_rules)
         __syncthreads();
         if (lane == 0) {
             ncand[r1] = (uint32_t)n1; nc_total += (unsigned long long)n1;
@@ -428,3 +416,39 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
     if (lane == 0 && nc_total) atomicAdd(d_ctr_stripe(ctr) + CTR_CANDS, nc_total);
     d_wave_resident(ctr, CTR_WT_CHAIN, t_wave0);
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_chain_rules: lane = one unit of k_chain_heavy's list -- the sequential part of the candidate stage (CheckPairedAlignmentCandidates' take / change-hands
+// decisions over the picks k_chain_heavy made, Mapping.cpp:403-450; RemoveUnMatedAlignmentCandidates :452-477; RemoveRedundantCandidates :371-401) on the
+// DCand records in memory.  One lane's work per unit either way; here 64 units share an instruction.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_chain_rules(int paired, const uint32_t *__restrict__ seed_off, DCand *__restrict__ cands, const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ heavy_list,
+              const unsigned int *__restrict__ n_heavy_p, const int16_t *__restrict__ picks, const uint8_t *__restrict__ todo, const int *__restrict__ abort_p)
+{
+    if (*abort_p >= DG_ABORT) return;
+    const unsigned int n_heavy = *n_heavy_p;
+    for (unsigned int hi = blockIdx.x * blockDim.x + threadIdx.x; hi < n_heavy; hi += gridDim.x * blockDim.x) {
+        const int what = todo[hi];
+        if (what == 0) continue;
+        const int u = (int)heavy_list[hi], r1 = paired ? 2 * u : u;
+        const uint32_t b0 = seed_off[r1];
+        CandMem a1{cands + b0, (int)ncand[r1]};
+        if (what == 2) { d_keep_top(a1); continue; }
+        const uint32_t b1 = seed_off[r1 + 1];
+        CandMem a2{cands + b1, (int)ncand[r1 + 1]};
+        bool pairing = false;
+        for (int i = 0; i < a1.cnt; i++) {
+            const int pick = picks[b0 + i];
+            if (pick < 0) continue;
+            const int holder = a2.mate(pick);
+            if (holder < 0) pairing = true;
+            else if (a1.score(i) > a1.score(holder)) a1.set_mate(holder, -1);
+            else continue;
+            a1.set_mate(i, pick); a2.set_mate(pick, i);
+        }
+        if (pairing) d_settle_mates(a1, a2);
+        d_keep_top(a1); d_keep_top(a2);
+    }
+}
+

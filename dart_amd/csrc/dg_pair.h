@@ -452,12 +452,14 @@ __host__ __device__ inline uint32_t d_unit_compact_ops(const DRead &rd, const Re
 template <int S>
 __host__ __device__ inline uint32_t d_unit_emit_read(bool first, const DRead &rd, const RepLds<S> &p, uint32_t rep_off, uint32_t cig_off,
                                                      dg_read_out *rout_r, dg_report_out *reports, uint32_t *cigar, const CompactOut &co = CompactOut{nullptr, nullptr, nullptr, nullptr},
-                                                     dg_read_c *rc_r = nullptr, uint32_t cigc_off = 0)
+                                                     dg_read_c *rc_r = nullptr, uint32_t cigc_off = 0, bool full = true)
 {
+    // full = false (round 5): the caller takes the compact records only (dg_map_batch_compact) -- the 36 + 40 bytes per read of the full types and their CIGAR ops
+    // are not written for the units this kernel finishes (the general path's reads always get theirs: k_finalize / k_emit_slow work on them)
     dg_read_out o;
     o.score = rd.score; o.sub_score = rd.sub_score; o.mis_num = rd.mis_num; o.mapq = rd.mapq; o.n_rep = rd.CanNum; o.best = rd.iBest;
     o.rep_off = (int32_t)rep_off; o.sj_off = 0; o.n_sj = 0;
-    *rout_r = o;
+    if (full) *rout_r = o;
     bool fits = true;
     if (co.reads) { dg_read_c oc; fits = d_compact_read(o, oc); *rc_r = oc; }
     uint32_t used = 0, used_c = 0;
@@ -475,16 +477,16 @@ __host__ __device__ inline uint32_t d_unit_emit_read(bool first, const DRead &rd
                 const bool rev = (rp.bdir != 0) != first;                    // bDir = mate 1 on the forward half / mate 2 on the reverse half (:83-116);
                                                                              // a candidate on the reverse half has its CIGAR reversed (:1179)
                 const uint32_t lead = rev ? tail : head, trail = rev ? head : tail;
-                uint32_t *c = cigar + cig_off + used;
-                uint32_t m = 0;
-                if (lead) c[m++] = CIG(lead, OP_S);
-                c[m++] = CIG(span, OP_M);
-                if (trail) c[m++] = CIG(trail, OP_S);
+                // the ops [S] M [S] in registers (no indexed local array), then to whichever op arrays are wanted
+                const uint32_t o_mid = CIG(span, OP_M), o_trail = CIG(trail, OP_S);
+                const uint32_t a0 = lead ? CIG(lead, OP_S) : o_mid, a1 = lead ? o_mid : o_trail, a2 = o_trail;
+                const uint32_t m = 1u + (lead ? 1u : 0u) + (trail ? 1u : 0u);
+                if (full) { uint32_t *c = cigar + cig_off + used; c[0] = a0; if (m > 1) c[1] = a1; if (m > 2) c[2] = a2; }
                 rp.n_cigar = m; used += m;
-                if (co.reads && m > 1) { for (uint32_t k = 0; k < m; k++) co.cigar[cigc_off + used_c + k] = c[k]; used_c += m; }   // ("<span>M" alone = the whole read: not stored)
+                if (co.reads && m > 1) { uint32_t *c = co.cigar + cigc_off + used_c; c[0] = a0; c[1] = a1; if (m > 2) c[2] = a2; used_c += m; }   // ("<span>M" alone = the whole read: not stored)
             }
         }
-        reports[rep_off + (uint32_t)i] = rp;
+        if (full) reports[rep_off + (uint32_t)i] = rp;
         if (co.reads) { dg_report_c q; fits = d_compact_report(rp, rp.n_cigar == 1u, false, q) && fits; co.reports[rep_off + (uint32_t)i] = q; }
     }
     if (co.reads && !fits) *co.bad = 1u;
@@ -514,7 +516,7 @@ __device__ __forceinline__ uint32_t d_pac_touch(const DIndex &ix, SKey k)
 
 template <bool PACKED>      // the reads of the batch: their 2-bit + mask words (a packed batch: enc, W2) or their ASCII bytes (seq, seq_off)
 __global__ void __launch_bounds__(PU_THREADS)
-k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast, int write_all_sorted,
+k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast, int write_all_sorted /* bit 0: the sorted seeds and candidates of EVERY unit to memory (dg_probe_seeds); bit 1: no full record types for the units finished here (the caller takes the compact ones) */,
        const unsigned char *__restrict__ seq, const uint32_t *__restrict__ seq_off, const uint32_t *__restrict__ enc, int W2, const uint16_t *__restrict__ rlen,
        const uint32_t *__restrict__ seed_off, SKey *__restrict__ seeds, DCand *__restrict__ cands, uint32_t *__restrict__ ncand,
        uint32_t *__restrict__ rep_off, uint32_t *__restrict__ slow_units,
@@ -629,15 +631,16 @@ k_pair(const DIndex ix, const DParams pr, int n_units, int paired, int try_fast,
                 if (paired) d_unit_emit_read<PU_THREADS>(false, st.rd[1], p2, rep0 + nrep1, (uint32_t)cig0 + d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar, co, co.reads ? co.reads + r1 : nullptr, cigc0), rout + r1 + 1, reports, cigar, co, co.reads ? co.reads + r1 + 1 : nullptr, cigc0 + cc1);
                 __asm__ volatile("" ::: "memory");
 #endif
-                const uint32_t c1 = d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar, co, co.reads ? co.reads + r1 : nullptr, cigc0);
-                if (paired) d_unit_emit_read<PU_THREADS>(false, st.rd[1], p2, rep0 + nrep1, (uint32_t)cig0 + c1, rout + r1 + 1, reports, cigar, co, co.reads ? co.reads + r1 + 1 : nullptr, cigc0 + cc1);
+                const bool full = !(write_all_sorted & 2) || !co.reads;
+                const uint32_t c1 = d_unit_emit_read<PU_THREADS>(true, st.rd[0], p1, rep0, (uint32_t)cig0, rout + r1, reports, cigar, co, co.reads ? co.reads + r1 : nullptr, cigc0, full);
+                if (paired) d_unit_emit_read<PU_THREADS>(false, st.rd[1], p2, rep0 + nrep1, (uint32_t)cig0 + c1, rout + r1 + 1, reports, cigar, co, co.reads ? co.reads + r1 + 1 : nullptr, cigc0 + cc1, full);
                 n_nw = st.n_nw; n_cells = st.n_cells;
             }
         } else {
             if (slow_at < (uint32_t)n_units) slow_units[slow_at] = (uint32_t)u;      // (a prefix from a look-back that gave up is garbage: the batch runs again, nothing may be written outside the list)
             if ((uint64_t)rep0 + mine.x > cap_rep) atomicMax(err, DG_E_REPORTS);       // its reports would not fit either
         }
-        if (!heavy && (!st.fast || write_all_sorted)) {
+        if (!heavy && (!st.fast || (write_all_sorted & 1))) {
             const int nt = n1 + n2;
             for (int i = 0; i < nt; i++) seeds[b1 + i] = key[i * PU_THREADS];
             auto put_cands = [&](int first_cw, int first_key, uint32_t seg, int count, int r) {     // (called with constants: st stays in registers)

@@ -596,6 +596,12 @@ def test_gpu_packed_reads_and_pinned_buffers(workdir):
     assert_same(res_c, want)
     assert 0 < gpu.last_compact_ops < len(want[2])      # plain "101M" reports travel without their CIGAR op
     assert_same(gpu.map_batch_compact(words, nlist, 101), want)      # dg_map_batch_compact: one call, records packed inside the run, arrays grown on DG_ERR_CAPACITY
+    # a compact-only call leaves the units k_pair finished without the full record types (round 5); a caller that asks for them after all (DG_ERR_RANGE's
+    # way out) gets the batch mapped again, with them, by dg_batch_download itself
+    f_reads = np.zeros(len(want[0]), host.READ_OUT); f_rep = np.zeros(len(want[1]) + 16, host.REPORT_OUT); f_cig = np.zeros(len(want[2]) + 16, np.uint32); f_sj = np.zeros(len(want[3]) + 16, host.SJ_OUT)
+    f_caps = (C.c_size_t * 3)(len(f_rep), len(f_cig), len(f_sj))
+    assert gpu.lib.dg_batch_download(gpu.ctx, f_reads.ctypes.data, f_rep.ctypes.data, f_cig.ctypes.data, f_sj.ctypes.data, f_caps) == 0, gpu.lib.dg_last_error(gpu.ctx)
+    assert_same(host.BatchResult(f_reads, f_rep[:len(want[1])], f_cig[:len(want[2])], f_sj[:len(want[3])]), want)
     # ragged: every read cut to its own length (the tail bases stay in the words, the lengths say where the read ends)
     rng = np.random.default_rng(5)
     lens = rng.integers(30, 102, size=len(arr)).astype(np.uint16)
