@@ -230,6 +230,33 @@ def run_cli(dart_exe, prefix, g, label, seed_pairs, args, cpu_pairs=0, gz_pairs=
         m_ = re.search(r"start-up ([0-9.]+) s", best[1] or "")
         if m_:
             res["startup_s"] = float(m_.group(1))
+        if getattr(args, "cli_full_parity", False):
+            # The SAM text and the junctions of the WHOLE job against the CPU command line (the oracle's, all host cores) on the same files (the default leg
+            # compares the first --cli-cpu-pairs only): ~100 s of CPU for 10 M pairs, so it is opt-in (--cli-full-parity); the two SAM files are compared by digest.
+            import hashlib
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_py
+            oracle_py.build()
+
+            def digest(path):
+                h = hashlib.sha256()
+                with open(path, "rb") as f:
+                    for blk in iter(lambda: f.read(1 << 24), b""):
+                        h.update(blk)
+                return h.hexdigest(), os.path.getsize(path)
+            t0 = time.perf_counter()
+            r = subprocess.run([oracle_py.ORACLE_CLI, "-i", prefix, "-f", "1.fq", "-f2", "2.fq", "-o", "cpu_full.sam", "-j", "cpu_full.j", "-t", str(cores), "-mis", str(args.mis)], cwd=d,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            dt_full = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError("the CPU command line (whole job) exited with %d: %s" % (r.returncode, r.stderr.decode()[-300:]))
+            a_, b_ = digest(os.path.join(d, "out.sam")), digest(os.path.join(d, "cpu_full.sam"))
+            ja, jb = digest(os.path.join(d, "out.sam.j")), digest(os.path.join(d, "cpu_full.j"))
+            res["whole_job_parity"] = {"pairs": total_pairs, "sam_identical": a_ == b_, "junctions_identical": ja == jb, "sam_bytes": a_[1], "sam_sha256": a_[0][:16],
+                                       "cpu_command_line_wall_s": round(dt_full, 1), "speedup_whole_job_measured": round(dt_full / best[0], 1),
+                                       "what": "oracle/dart_oracle -t %d on the same 1.fq / 2.fq, process start to exit; SHA-256 of the two SAM files and of the two junction files" % cores}
+            log("[bench] whole-job parity of the command line:", res["whole_job_parity"])
+            os.remove(os.path.join(d, "cpu_full.sam"))
         if cpu_pairs > 0 and head is not None:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_py
@@ -474,6 +501,8 @@ def main():
     ap.add_argument("--cli-big-pairs", type=int, default=10000000,
                     help="after the timed region: `dart` end to end on BASELINE configs[2] itself -- this many 2x101 pairs (the timed region's reads, as FASTQ files) against the "
                          "GRCh38-sized index, process start to exit; 0 = skip (skipped too when the workload is not the default one)")
+    ap.add_argument("--cli-full-parity", action="store_true", help="the command-line leg also maps the WHOLE job with the CPU command line (~100 s on 16 cores for 10 M pairs) and compares "
+                                                                   "the two SAM files and junction files by digest")
     ap.add_argument("--cli-cpu-pairs", type=int, default=400000, help="pairs of the same files the CPU command line (oracle/dart_oracle, all host cores) maps beside it, end to end")
     ap.add_argument("--cli-gz-pairs", type=int, default=2000000, help="pairs of the same files, gzipped, through `dart` (what users feed DART: GetData.cpp:181-247); 0 = skip")
     ap.add_argument("--cli-pairs", type=int, default=0,

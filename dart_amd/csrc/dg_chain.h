@@ -348,7 +348,22 @@ k_chain_heavy(const DIndex ix, const DParams pr, int n_units, int paired, const 
         for (int m = 0; m < nm; m++) { b[m] = seed_off[r1 + m]; n[m] = seed_off[r1 + m + 1] - b[m]; }
         __syncthreads();
         for (int m = 0; m < nm; m++) {                       // one mate at a time: sort, write back, cluster
-            if (n[m] <= CH_MAXS) {
+            if (n[m] <= 64) {
+                // at most one key per lane (most heavy units: 17 .. 64 seeds per mate): the bitonic network in registers, partners by lane shuffles -- a third of the
+                // instructions of the LDS form below (no index arithmetic, no LDS round trips, no barriers between the steps)
+                SKey key = (uint32_t)lane < n[m] ? seeds[b[m] + lane] : ~0ull;
+                int mm = 2; while ((uint32_t)mm < n[m]) mm <<= 1;
+                for (int k = 2; k <= mm; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        const SKey other = d_u64((uint32_t)__shfl_xor((int)(uint32_t)key, j, 64), (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), j, 64));
+                        const bool keep_small = ((lane & k) == 0) == ((lane & j) == 0);
+                        key = (other < key) == keep_small ? other : key;
+                    }
+                if ((uint32_t)lane < n[m]) { ls[lane] = key; seeds[b[m] + lane] = key; }
+                __syncthreads();
+                const int made = d_gen_candidates_wave(lt, pr, rlen[r1 + m], ls, (int)n[m], b[m], cands + b[m], s_pref, s_starts, lane);
+                if (lane == 0) s_n[m] = made;
+            } else if (n[m] <= CH_MAXS) {
                 for (uint32_t i = lane; i < n[m]; i += 64) ls[i] = seeds[b[m] + i];
                 __syncthreads();
                 d_bitonic_sort_keys(ls, (int)n[m], lane);

@@ -1,4 +1,4 @@
-# round 5, call p: k_chain_rules (the sequential candidate rules of the heavy units, lane = unit) -- parity file + the human-like GRCh38-sized test, bench lines, instruction counts
+# round 5, call p (again): k_chain_heavy sorts up to 64 seeds per mate in registers -- parity file + the human-like GRCh38-sized test, bench lines, instruction counts
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
