@@ -93,6 +93,7 @@ def pack_sequences(seqs):
 
 
 _lib = None
+_sort_s = [0.0, 0, 0]                                   # seconds inside the sorter, calls, pairs (for the phase log)
 
 
 def sort_pairs(key: torch.Tensor, key_bits: int):
@@ -114,7 +115,10 @@ def sort_pairs(key: torch.Tensor, key_bits: int):
     key = key.contiguous()
     tk, tv = torch.empty_like(key), torch.empty_like(vals)
     torch.cuda.current_stream(key.device).synchronize()          # (the sorter runs on the NULL stream)
+    import time as _time
+    t0 = _time.time()
     rc = _lib.dg_sort_pairs(key.device.index or 0, key.data_ptr(), vals.data_ptr(), tk.data_ptr(), tv.data_ptr(), m, int(key_bits))
+    _sort_s[0] += _time.time() - t0; _sort_s[1] += 1; _sort_s[2] += m
     if rc != 0:
         raise RuntimeError("dg_sort_pairs failed (%d)" % rc)
     return key, vals
@@ -283,7 +287,14 @@ def _pack_bwt_occ(bwt: torch.Tensor, n: int):
 def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=None) -> dict:
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
+    if log:                                                       # every log line carries the seconds since the build began
+        import time as _time
+        _t0, _log0 = _time.time(), log
+        def log(msg):
+            if device != "cpu": torch.cuda.synchronize()
+            _log0("  [%6.1f s; sorter %5.1f s, %d calls, %.2f G pairs]%s" % (_time.time() - _t0, _sort_s[0], _sort_s[1], _sort_s[2] / 1e9, msg))
     fwd, holes, n_ambs = pack_sequences(seqs)
+    if log: log("  sequences packed")
     L = int(len(fwd))
     # ---- .pac / .ann / .amb ----
     pad = np.zeros((-L) % 4, dtype=np.uint8)
@@ -306,9 +317,11 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=
         for o, ln, ch in holes:
             f.write("%d %d %s\n" % (o, ln, ch))
     # ---- text = forward + reverse complement ----
+    if log: log("  .pac/.ann/.amb written")
     text = np.concatenate([fwd, (3 - fwd)[::-1]])
     n = 2 * L
     tt = torch.from_numpy(text).to(device)
+    if log: log("  text on the device")
     import os as _os
     big = n >= (3 << 29) or _os.environ.get("DART_SA_BUCKETED") == "1"      # >= 1.6 G symbols: the lean sorter
     sa = suffix_array_bucketed(tt, log) if big else suffix_array(tt)
@@ -350,11 +363,13 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=
         f.write(L2[1:5].tobytes())
         f.write(body.tobytes())
         f.write(occ_last.tobytes())
+    if log: log("  .bwt written")
     with open(prefix + ".sa", "wb") as f:
         f.write(np.array([primary], dtype=np.uint64).tobytes())
         f.write(L2[1:5].tobytes())
         f.write(np.array([32, n], dtype=np.uint64).tobytes())
         f.write(sa_s[: (n + 32) // 32 - 1].tobytes())
+    if log: log("  .sa written")
     return {"l_pac": L, "seq_len": n, "primary": primary}
 
 
