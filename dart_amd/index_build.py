@@ -257,6 +257,235 @@ def suffix_array_bucketed(codes: torch.Tensor, log=None) -> torch.Tensor:
     return sa
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# The MI355X path: every per-symbol step is a HIP kernel of libdartindex.so (dart_amd/csrc/index/dg_index.hip, C ABI
+# include/dartindex.h) or the radix sorter of libdartgpu.so; torch allocates the device memory and does the per-bucket bookkeeping
+# (prefix sums over per-tile counts, the cumulative Occ counts over 48 M blocks).  No fallback: on a GPU box a missing library is an error.
+_ilib = None
+
+
+def _index_lib():
+    global _ilib
+    if _ilib is None:
+        import ctypes as C, os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdartindex.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libdartindex.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); the GPU index builder has no CPU fallback")
+        lib = C.CDLL(path)
+        vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+        lib.di_last_error.restype = C.c_char_p
+        lib.di_text_words.restype = C.c_size_t
+        lib.di_text_words.argtypes = [u64]
+        lib.di_pack_text.argtypes = [C.c_int, vp, u64, vp]
+        lib.di_bucket_hist.argtypes = [C.c_int, vp, u64, vp]
+        lib.di_bucket_keys.argtypes = [C.c_int, vp, u64, C.c_int, vp, vp, vp]
+        lib.di_doubling_keys.argtypes = [C.c_int, vp, vp, u64, vp, u32, u64, u64, C.c_int, vp, vp]
+        lib.di_regroup.argtypes = [C.c_int, vp, vp, vp, u32, u64, vp, vp, vp, vp, C.POINTER(u32)]
+        lib.di_bwt_blocks.argtypes = [C.c_int, vp, vp, u64, u64, vp, vp]
+        _ilib = lib
+    return _ilib
+
+
+def _di(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, (_index_lib().di_last_error() or b"").decode()))
+
+
+def _sort_kv(keys, vals, tk, tv, m, key_bits):
+    """dg_sort_pairs on the first m pairs of (keys, vals); tk / tv are scratch of at least m elements."""
+    import ctypes as C, time as _time
+    global _lib
+    if _lib is None:
+        from . import host
+        _lib = host._load_lib()
+        _lib.dg_sort_pairs.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    if m < 2:
+        return
+    torch.cuda.current_stream(keys.device).synchronize()
+    t0 = _time.time()
+    rc = _lib.dg_sort_pairs(keys.device.index or 0, keys.data_ptr(), vals.data_ptr(), tk.data_ptr(), tv.data_ptr(), m, int(key_bits))
+    _sort_s[0] += _time.time() - t0; _sort_s[1] += 1; _sort_s[2] += m
+    if rc != 0:
+        raise RuntimeError("dg_sort_pairs failed (%d)" % rc)
+
+
+DI_TILE = 4096
+
+
+class _HipOps:
+    """The device steps of suffix_array_hip, one method per C entry point of include/dartindex.h (tensors in, nothing copied).  The CPU
+    suite swaps in tests/index_emul.py's numpy restatement of the same contracts to check the scheme and this file's bookkeeping; the
+    kernels themselves are checked on the GPU (tests/test_gpu_index.py: the reference indexer's bytes)."""
+
+    def __init__(self, dev):
+        self.lib, self.dev, self.di = _index_lib(), dev, dev.index or 0
+
+    def sync(self):
+        torch.cuda.synchronize(self.dev)
+
+    def bucket_hist(self, T, n, table):
+        self.sync(); _di(self.lib.di_bucket_hist(self.di, T.data_ptr(), n, table.data_ptr()), "di_bucket_hist")
+
+    def bucket_keys(self, T, n, pair, base, keys, vals):
+        self.sync(); _di(self.lib.di_bucket_keys(self.di, T.data_ptr(), n, pair, base.data_ptr(), keys.data_ptr(), vals.data_ptr()), "di_bucket_keys")
+
+    def doubling_keys(self, sa, rank, lo, pos, m, k, N, r2_bits, keys, vals):
+        self.sync(); _di(self.lib.di_doubling_keys(self.di, sa.data_ptr(), rank.data_ptr(), lo, pos.data_ptr(), m, k, N, r2_bits, keys.data_ptr(), vals.data_ptr()), "di_doubling_keys")
+
+    def sort(self, keys, vals, tk, tv, m, key_bits):
+        _sort_kv(keys, vals, tk, tv, m, key_bits)
+
+    def regroup(self, keys, vals, pos, m, lo, rank, sa, new_pos, scratch) -> int:
+        import ctypes as C
+        n_tied = C.c_uint32(0)
+        self.sync()
+        _di(self.lib.di_regroup(self.di, keys.data_ptr(), vals.data_ptr(), pos.data_ptr() if pos is not None else None, m, lo, rank.data_ptr(), sa.data_ptr(),
+                                new_pos.data_ptr(), scratch.data_ptr(), C.byref(n_tied)), "di_regroup")
+        return int(n_tied.value)
+
+
+def suffix_array_hip(T: torch.Tensor, n: int, last_sym: int, log=None, ops=None):
+    """Suffix array AND inverse (sa, rank: int64 [n + 1]) of the packed text T (di_pack_text's layout) + '$': bucketed prefix doubling with
+    every per-suffix step on the device (the scheme is described at the top of dg_index.hip).  last_sym = the text's last symbol."""
+    dev = T.device
+    ops = ops or _HipOps(dev)
+    N = n + 1
+    assert n >= 64
+    tiles = (N + DI_TILE - 1) // DI_TILE
+    table = torch.empty(16 * tiles, dtype=torch.int32, device=dev)
+    ops.bucket_hist(T, n, table)
+    table = table.view(16, tiles)
+    counts = [int(x) for x in table.sum(dim=1, dtype=torch.int64).cpu()]
+    assert sum(counts) == n - 1
+    m_max = max(counts)
+    assert m_max < (1 << 31) - DI_TILE, "a two-symbol bucket holds >= 2^31 suffixes"
+    r2_bits = N.bit_length()                                      # a rank + 1 is at most N
+    assert r2_bits + m_max.bit_length() <= 64, "rank pair does not fit 64 bits"
+    sa = torch.empty(N, dtype=torch.int64, device=dev)
+    rank = torch.empty(N, dtype=torch.int64, device=dev)
+    keys = torch.empty(m_max, dtype=torch.int64, device=dev)
+    vals = torch.empty(m_max, dtype=torch.int64, device=dev)
+    tk, tv = torch.empty_like(keys), torch.empty_like(vals)
+    new_pos = torch.empty(m_max, dtype=torch.int32, device=dev)
+    scratch = torch.empty(2 * ((m_max + DI_TILE - 1) // DI_TILE) + 4, dtype=torch.int32, device=dev)
+    # rows: '$' first, then per first symbol c0: the suffix "c0 $" (if the text ends in c0), then the buckets c0 A, c0 C, c0 G, c0 T
+    sa[0] = n
+    rank[n] = 0
+    row = 1
+    lows = {}
+    for c0 in range(4):
+        if c0 == last_sym:
+            sa[row] = n - 1
+            rank[n - 1] = row
+            row += 1
+        for c1 in range(4):
+            lows[c0 * 4 + c1] = row
+            row += counts[c0 * 4 + c1]
+    assert row == N
+    pending = {}
+    for pair in range(16):                                        # round 0: the first 31 symbols
+        m, lo = counts[pair], lows[pair]
+        if m == 0:
+            continue
+        r = table[pair]
+        base = (torch.cumsum(r, 0) - r).to(torch.int32)
+        ops.bucket_keys(T, n, pair, base, keys, vals)
+        del base
+        ops.sort(keys, vals, tk, tv, m, 63)
+        t = ops.regroup(keys, vals, None, m, lo, rank, sa, new_pos, scratch)
+        if t:
+            pending[pair] = new_pos[:t].clone()
+        if log:
+            log("  bucket %s: %d suffixes, %d still tied after 31 symbols" % ("ACGT"[pair >> 2] + "ACGT"[pair & 3], m, t))
+    del table
+    k = 31
+    while pending:
+        for pair in sorted(pending):
+            pos, lo = pending[pair], lows[pair]
+            m = int(pos.numel())
+            ops.doubling_keys(sa, rank, lo, pos, m, k, N, r2_bits, keys, vals)
+            ops.sort(keys, vals, tk, tv, m, min(64, r2_bits + counts[pair].bit_length()))
+            t = ops.regroup(keys, vals, pos, m, lo, rank, sa, new_pos, scratch)
+            if t:
+                pending[pair] = new_pos[:t].clone()
+            else:
+                del pending[pair]
+        k *= 2
+        if log:
+            log("  after %d symbols: %d suffixes still tied" % (k, sum(int(v.numel()) for v in pending.values())))
+    return sa, rank
+
+
+def _build_files_hip(prefix: str, fwd: np.ndarray, device: str, log=None) -> dict:
+    """.pac, .bwt, .sa of the forward codes `fwd` (uint8 0..3) on the MI355X."""
+    lib = _index_lib()
+    dev = torch.device(device if ":" in device else device + ":0")
+    di = dev.index or 0
+    L = int(len(fwd))
+    n = 2 * L
+    f = torch.from_numpy(fwd).to(dev)
+    if log: log("  forward codes on the device")
+    # .pac: 4 symbols per byte, first symbol in the top bits (bntseq.c:192-201)
+    f4 = torch.zeros((L + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+    f4[:L] = f
+    f4 = f4.view(-1, 4)
+    pac = (f4[:, 0] << 6) | (f4[:, 1] << 4) | (f4[:, 2] << 2) | f4[:, 3]
+    pac_h = pac.cpu().numpy()
+    del f4, pac
+    with open(prefix + ".pac", "wb") as fh:
+        pac_h.tofile(fh)
+        if L % 4 == 0:
+            fh.write(b"\0")
+        fh.write(bytes([L % 4]))
+    del pac_h
+    if log: log("  .pac written")
+    T = torch.empty(int(lib.di_text_words(n)), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    _di(lib.di_pack_text(di, f.data_ptr(), L, T.data_ptr()), "di_pack_text")
+    last_sym = 3 - int(fwd[0])
+    del f
+    if log: log("  text packed (forward + reverse complement, 2 bits per symbol)")
+    sa, rank = suffix_array_hip(T, n, last_sym, log)
+    primary = int(rank[0])                                        # the row of suffix 0
+    del rank
+    if log: log("  suffix array done, primary = %d" % primary)
+    sa_s = sa[32::32].cpu().numpy().view(np.uint64)               # rows 32, 64, ... of the (n+1)-row matrix
+    if log: log("  SA sampled")
+    nblk = (n + 127) // 128
+    blocks = torch.zeros(nblk * 16, dtype=torch.int32, device=dev)
+    c4 = torch.empty(nblk, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    _di(lib.di_bwt_blocks(di, sa.data_ptr(), T.data_ptr(), n, primary, blocks.data_ptr(), c4.data_ptr()), "di_bwt_blocks")
+    del sa, T
+    if log: log("  BWT gathered (16 symbols per word, symbol counts per block)")
+    per = torch.stack([(c4 >> (8 * c)) & 255 for c in range(4)], dim=0).to(torch.int64)      # [4, blocks] symbols per block; one contiguous row per symbol
+    del c4
+    cum = torch.cumsum(per, 1)
+    blocks.view(torch.int64).view(nblk, 8)[:, :4] = (cum - per).t()                          # the counts in front of each block
+    occ_last = cum[:, -1].cpu().numpy().astype(np.uint64)
+    del per, cum
+    if log: log("  Occ counts in the blocks")
+    flat = blocks.cpu().numpy().view(np.uint32)
+    del blocks
+    if log: log("  blocks on the host")
+    L2 = np.concatenate([[0], np.cumsum(occ_last)]).astype(np.uint64)          # the BWT is a permutation of the text: its totals are the symbol counts
+    nwords = (n + 15) // 16
+    body = flat[: (nblk - 1) * 16 + 8 + (nwords - (nblk - 1) * 8)]
+    with open(prefix + ".bwt", "wb") as fh:
+        fh.write(np.array([primary], dtype=np.uint64).tobytes())
+        fh.write(L2[1:5].tobytes())
+        body.tofile(fh)
+        fh.write(occ_last.tobytes())
+    if log: log("  .bwt written")
+    with open(prefix + ".sa", "wb") as fh:
+        fh.write(np.array([primary], dtype=np.uint64).tobytes())
+        fh.write(L2[1:5].tobytes())
+        fh.write(np.array([32, n], dtype=np.uint64).tobytes())
+        sa_s[: (n + 32) // 32 - 1].tofile(fh)
+    if log: log("  .sa written")
+    return {"l_pac": L, "seq_len": n, "primary": primary}
+
+
 def _pack_bwt_occ(bwt: torch.Tensor, n: int):
     """bwt: uint8 [n] on any device -> (blocks uint32 [nblk,16] numpy, occ_last uint64 [4]) in the .bwt layout, in chunks."""
     dev = bwt.device
@@ -284,7 +513,10 @@ def _pack_bwt_occ(bwt: torch.Tensor, n: int):
     return blocks, run.cpu().numpy().astype(np.uint64)
 
 
-def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=None) -> dict:
+def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=None, codes=None) -> dict:
+    """seqs: the sequences as bytes (FASTA text), or -- with codes = their concatenated 0..3 codes, no ambiguous base -- just their lengths.
+    device "cuda": the HIP builder (DART_SA_TORCH=plain|bucketed selects the older torch-orchestrated sorters, kept as cross-checks);
+    "cpu": torch on the host, for the small genomes of the CPU suite."""
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
     if log:                                                       # every log line carries the seconds since the build began
@@ -293,10 +525,32 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=
         def log(msg):
             if device != "cpu": torch.cuda.synchronize()
             _log0("  [%6.1f s; sorter %5.1f s, %d calls, %.2f G pairs]%s" % (_time.time() - _t0, _sort_s[0], _sort_s[1], _sort_s[2] / 1e9, msg))
-    fwd, holes, n_ambs = pack_sequences(seqs)
+    import os as _os
+    if codes is None:
+        fwd, holes, n_ambs = pack_sequences(seqs)
+        lengths = [len(s) for s in seqs]
+    else:
+        fwd, holes, n_ambs, lengths = np.ascontiguousarray(codes, dtype=np.uint8), [], [0] * len(seqs), [int(x) for x in seqs]
+        assert sum(lengths) == len(fwd)
     if log: log("  sequences packed")
     L = int(len(fwd))
-    # ---- .pac / .ann / .amb ----
+    # ---- .ann / .amb ----
+    with open(prefix + ".ann", "w") as f:
+        f.write("%d %d %u\n" % (L, len(seqs), 11))
+        off = 0
+        for name, anno, ln, na in zip(names, annos, lengths, n_ambs):
+            f.write("0 %s %s\n" % (name, anno if anno else "(null)"))
+            f.write("%d %d %d\n" % (off, ln, na))
+            off += ln
+    with open(prefix + ".amb", "w") as f:
+        f.write("%d %d %u\n" % (L, len(seqs), len(holes)))
+        for o, ln, ch in holes:
+            f.write("%d %d %s\n" % (o, ln, ch))
+    # ---- text = forward + reverse complement ----
+    torch_sorter = _os.environ.get("DART_SA_TORCH", "")
+    if str(device).startswith("cuda") and not torch_sorter and 2 * L >= 64:
+        return _build_files_hip(prefix, fwd, str(device), log)
+    # ---- .pac ----
     pad = np.zeros((-L) % 4, dtype=np.uint8)
     f4 = np.concatenate([fwd, pad]).reshape(-1, 4)
     pac = ((f4[:, 0] << 6) | (f4[:, 1] << 4) | (f4[:, 2] << 2) | f4[:, 3]).astype(np.uint8)
@@ -305,25 +559,12 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=
         if L % 4 == 0:
             f.write(b"\0")
         f.write(bytes([L % 4]))
-    with open(prefix + ".ann", "w") as f:
-        f.write("%d %d %u\n" % (L, len(seqs), 11))
-        off = 0
-        for name, anno, s, na in zip(names, annos, seqs, n_ambs):
-            f.write("0 %s %s\n" % (name, anno if anno else "(null)"))
-            f.write("%d %d %d\n" % (off, len(s), na))
-            off += len(s)
-    with open(prefix + ".amb", "w") as f:
-        f.write("%d %d %u\n" % (L, len(seqs), len(holes)))
-        for o, ln, ch in holes:
-            f.write("%d %d %s\n" % (o, ln, ch))
-    # ---- text = forward + reverse complement ----
     if log: log("  .pac/.ann/.amb written")
     text = np.concatenate([fwd, (3 - fwd)[::-1]])
     n = 2 * L
     tt = torch.from_numpy(text).to(device)
     if log: log("  text on the device")
-    import os as _os
-    big = n >= (3 << 29) or _os.environ.get("DART_SA_BUCKETED") == "1"      # >= 1.6 G symbols: the lean sorter
+    big = torch_sorter == "bucketed" or n >= (3 << 29) or _os.environ.get("DART_SA_BUCKETED") == "1"      # >= 1.6 G symbols: the lean sorter
     sa = suffix_array_bucketed(tt, log) if big else suffix_array(tt)
     if log: log("  suffix array done")
     primary = int(torch.argmin(sa))                           # the row of suffix 0 (nonzero() is limited to < 2^31 elements)
@@ -380,6 +621,4 @@ def build_index_from_fasta(fasta: str, prefix: str, device: str | None = None) -
 
 def build_index_from_genome(g, prefix: str, device: str | None = None, log=None) -> dict:
     """g: dart_amd.synth.Genome (no FASTA round trip)."""
-    asc = g.ascii()
-    seqs = [asc[o:o + l].tobytes() for o, l in zip(g.offsets, g.lengths)]
-    return build_index(prefix, g.names, [""] * len(seqs), seqs, device, log)
+    return build_index(prefix, g.names, [""] * len(g.names), [int(x) for x in g.lengths], device, log, codes=g.codes)
