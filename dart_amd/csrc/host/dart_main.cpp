@@ -6,7 +6,8 @@
 //   FASTA/FASTQ(.gz) readers, chunking, mate-2 reverse complement   GetData.cpp:44-247
 //   SAM header/records, statistics, junctions.tab   Mapping.cpp:208-369,567-577,683-716,741-751,806-822
 // Everything between "chunk read" and "records formatted" (Mapping.cpp:598-639) is dg_map_batch.
-// -bo: BAM through bam_writer.h (the reference hands its SAM lines to htslib).  Out of scope and refused with a message: `index`, `update`.
+// -bo: BAM through bam_writer.h (the reference hands its SAM lines to htslib).  `dart index ref.fa prefix`: index_cmd.h over libdartindex.so.
+// Out of scope and refused with a message: `update`.
 //
 // Batches are much larger than the reference's 4000-read chunks (a GPU launch needs >= 10^5 reads);
 // output order is input order, which equals the reference at -t 1.  -t keeps its
@@ -33,6 +34,7 @@
 
 #include "fast_fastq.h"
 #include "bam_writer.h"
+#include "index_cmd.h"
 
 static const char *VersionStr = "1.4.6";
 
@@ -460,8 +462,13 @@ int main(int argc, char *argv[])
     Options o;
     dg_params_default(&o.p);
     if (argc == 1 || strcmp(argv[1], "-h") == 0) { usage(argv[0], o); return 0; }
-    if (strcmp(argv[1], "update") == 0 || strcmp(argv[1], "index") == 0) {
-        fprintf(stderr, "dart (MI355X): the '%s' sub-command is outside this build's scope; build the index with bwt_index / bwa index\n", argv[1]);
+    if (strcmp(argv[1], "update") == 0) {          // main.cpp:120-124 runs git and make: not something a library drop-in does
+        fprintf(stderr, "dart (MI355X): the 'update' sub-command is outside this build's scope\n");
+        return 0;
+    }
+    if (strcmp(argv[1], "index") == 0) {           // main.cpp:125-132
+        if (argc == 4) return index_cmd::run(argv[0], argv[2], argv[3]);
+        fprintf(stderr, "usage: %s index ref.fa prefix\n", argv[0]);
         return 0;
     }
     for (int i = 1; i < argc; i++) {   // main.cpp:136-205

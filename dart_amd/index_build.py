@@ -282,6 +282,8 @@ def _index_lib():
         lib.di_doubling_keys.argtypes = [C.c_int, vp, vp, u64, vp, u32, u64, u64, C.c_int, vp, vp]
         lib.di_regroup.argtypes = [C.c_int, vp, vp, vp, u32, u64, vp, vp, vp, vp, C.POINTER(u32)]
         lib.di_bwt_blocks.argtypes = [C.c_int, vp, vp, u64, u64, vp, vp]
+        lib.DI_LOG = C.CFUNCTYPE(None, C.c_char_p, vp)
+        lib.di_build_files.argtypes = [C.c_int, vp, u64, C.c_char_p, lib.DI_LOG, vp, C.POINTER(u64)]
         _ilib = lib
     return _ilib
 
@@ -417,12 +419,22 @@ def suffix_array_hip(T: torch.Tensor, n: int, last_sym: int, log=None, ops=None)
 
 
 def _build_files_hip(prefix: str, fwd: np.ndarray, device: str, log=None) -> dict:
-    """.pac, .bwt, .sa of the forward codes `fwd` (uint8 0..3) on the MI355X."""
+    """.pac, .bwt, .sa of the forward codes `fwd` (uint8 0..3) on the MI355X: di_build_files, the library's own driver (the one `dart index`
+    uses).  DART_INDEX_DRIVER=python runs the same kernels from this file instead (suffix_array_hip below): a cross-check of the two drivers,
+    and the form whose bookkeeping the CPU suite can follow (tests/test_index_scheme.py)."""
+    import ctypes as C, os as _os
     lib = _index_lib()
     dev = torch.device(device if ":" in device else device + ":0")
     di = dev.index or 0
     L = int(len(fwd))
     n = 2 * L
+    if _os.environ.get("DART_INDEX_DRIVER", "") != "python":
+        fwd = np.ascontiguousarray(fwd, dtype=np.uint8)
+        cb = lib.DI_LOG((lambda line, arg: log(line.decode())) if log else (lambda line, arg: None))
+        primary = C.c_uint64(0)
+        torch.cuda.synchronize(dev)
+        _di(lib.di_build_files(di, fwd.ctypes.data, L, prefix.encode(), cb, None, C.byref(primary)), "di_build_files")
+        return {"l_pac": L, "seq_len": n, "primary": int(primary.value)}
     f = torch.from_numpy(fwd).to(dev)
     if log: log("  forward codes on the device")
     # .pac: 4 symbols per byte, first symbol in the top bits (bntseq.c:192-201)

@@ -61,6 +61,14 @@ int di_regroup(int device, const uint64_t *keys, const int64_t *vals, const uint
  * counts into the running totals of blocks[16 * b + 0 .. + 7]. */
 int di_bwt_blocks(int device, const int64_t *sa, const uint64_t *T, uint64_t n, uint64_t primary, uint32_t *blocks, uint32_t *counts);
 
+/* The whole build (bwtindex.c:77-148 from the packed forward strand on): writes PREFIX.pac (bntseq.c:192-201), PREFIX.bwt
+ * (bwtindex.c:53-75) and PREFIX.sa (bwt.c:101-123,185-196) for the l_pac codes 0..3 at `fwd` -- HOST memory, ambiguous bases already
+ * replaced (bntseq.c:144,173-174); PREFIX.ann / .amb are the caller's (they are text about names and holes).  log, if given, gets a
+ * line per phase.  -3 = a file could not be written.  HBM: about 17 x n bytes at the peak (n = 2 x l_pac).
+ * `dart index ref.fa prefix` (main.cpp:125-127) and dart_amd/index_build.py both end here. */
+typedef void (*di_log_fn)(const char *line, void *arg);
+int di_build_files(int device, const uint8_t *fwd, uint64_t l_pac, const char *prefix, di_log_fn log, void *log_arg, uint64_t *primary_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,3 +127,26 @@ def assert_same(res, ores):
     a, b = cigars_of(rep, cig), cigars_of(res.reports, res.cigar)
     assert np.array_equal(a, b), "CIGAR ops differ, first at flattened op %s" % (np.nonzero(a != b)[0][:5] if len(a) == len(b) else "(length)")
     assert np.array_equal(sj, res.sj)
+
+
+def write_holes_fasta(path: str) -> None:
+    """The FASTA of tests/golden/index_holes.json (made by tests/golden/make_index_holes.py with the reference's bwt_index): three records with
+    header comments, lower-case bases, runs of N / n and other ambiguity codes (adjacent runs of different characters, a run at the start and at
+    the end of a record, a run that ends one record while the next starts with the same character), lines of different widths, an empty line,
+    '\\r\\n' line ends in one record -- what bntseq.c:104-156 turns into holes and random bases."""
+    rng = np.random.default_rng(4242)
+    def bases(k):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+    rec1 = "NNNNN" + bases(700) + "NNNNNNNNNNRRRRNNN" + bases(1200).lower() + "n" + bases(333) + "YKM" + bases(2000) + "NNNN"
+    rec2 = "NN" + bases(5000) + "N" * 130 + bases(4100) + "acgtnnnnACGT" + bases(77)
+    rec3 = bases(1500) + "-" + bases(20) + "XX" + bases(901)
+    with open(path, "w", newline="") as f:
+        f.write(">chrA first record, with a comment\n")
+        for o in range(0, len(rec1), 60):
+            f.write(rec1[o:o + 60] + "\n")
+        f.write("\n>chrB\tsecond\n")
+        for o in range(0, len(rec2), 71):
+            f.write(rec2[o:o + 71] + "\r\n")
+        f.write(">chrC\n")
+        for o in range(0, len(rec3), 50):
+            f.write(rec3[o:o + 50] + "\n")

@@ -24,6 +24,54 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libdartgpu.so does not export %s" % s
 
 
+def test_index_library_exports_every_declared_symbol():
+    """libdartindex.so (the offline indexer's device side) against include/dartindex.h"""
+    import __graft_entry__ as ge
+    from dart_amd import index_build
+    ge.build()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(common.ROOT, "include", "dartindex.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(di_[a-z_0-9]+)\s*\(", text)))
+    assert len(syms) >= 9 and "di_build_files" in syms
+    lib = index_build._index_lib()
+    for s in syms:
+        assert hasattr(lib, s), "libdartindex.so does not export %s" % s
+    assert lib.di_text_words(64) == 4
+
+
+def test_dart_index_host_half_and_loud_failure_without_a_device(workdir):
+    """`dart index ref.fa prefix` (main.cpp:125-127): its host half -- FASTA records, holes, the lrand48 stream -- writes the reference indexer's
+    .ann / .amb for the FASTA with ambiguous bases (tests/golden/index_holes.json); without a device the build then fails with a message and a
+    non-zero exit, and writes no .bwt (no CPU fallback).  The five files on a GPU: tests/test_gpu_cli.py."""
+    import json, subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    gold = json.load(open(os.path.join(common.GOLDEN, "index_holes.json")))
+    fa = os.path.join(workdir, "holes_cli.fa")
+    common.write_holes_fasta(fa)
+    assert common.sha(fa) == gold["fasta_sha256"]
+    prefix = os.path.join(workdir, "holes_cli")
+    r = subprocess.run([os.path.join(common.ROOT, "dart_amd", "dart"), "index", fa, prefix], capture_output=True, text=True)
+    assert r.returncode != 0 and "di_build_files failed" in r.stderr
+    assert not os.path.exists(prefix + ".bwt")
+    assert open(prefix + ".ann").read() == gold["ann"] and open(prefix + ".amb").read() == gold["amb"]
+    r = subprocess.run([os.path.join(common.ROOT, "dart_amd", "dart"), "index", fa], capture_output=True, text=True)
+    assert "usage:" in r.stderr and "index ref.fa prefix" in r.stderr
+
+
+def test_index_builder_fasta_path_matches_reference_indexer(workdir):
+    """dart_amd/index_build.py from a FASTA with ambiguous bases (CPU path): the five files are the reference bwt_index's bytes"""
+    import json
+    from dart_amd import index_build
+    gold = json.load(open(os.path.join(common.GOLDEN, "index_holes.json")))
+    fa = os.path.join(workdir, "holes_py.fa")
+    common.write_holes_fasta(fa)
+    prefix = os.path.join(workdir, "holes_py")
+    index_build.build_index_from_fasta(fa, prefix, device="cpu")
+    for ext, want in gold["index_sha256"].items():
+        assert common.sha(prefix + "." + ext) == want, ext
+
+
 def test_no_device_is_a_loud_failure(workdir):
     import torch
     if torch.cuda.is_available():

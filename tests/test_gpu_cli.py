@@ -150,6 +150,59 @@ def test_dart_cli_two_devices_in_one_pool_keep_input_order(host_path, workdir):
     assert open(os.path.join(d, "orc2d.j")).read() == open(os.path.join(d, "gpu2d.j")).read()
 
 
+def test_dart_index_writes_the_reference_indexers_files(workdir):
+    """`dart index ref.fa prefix` (main.cpp:125-127 -> bwa_idx_build): FASTA with ambiguous bases, holes and header comments (.gz too) -> the five
+    files are the bytes the REFERENCE's bwt_index wrote (tests/golden/index_holes.json); then the golden genomes written as FASTA -> the digests
+    of tests/golden/manifest.json; and `dart -i` maps with an index `dart index` built."""
+    import gzip, json
+    gold = json.load(open(os.path.join(common.GOLDEN, "index_holes.json")))
+    fa = os.path.join(workdir, "holes_gpu.fa")
+    common.write_holes_fasta(fa)
+    with open(fa, "rb") as f, gzip.open(fa + ".gz", "wb") as g:
+        g.write(f.read())
+    for src, tag in ((fa, "plain"), (fa + ".gz", "gz")):
+        prefix = os.path.join(workdir, "holes_gpu_" + tag)
+        r = subprocess.run([DART, "index", src, prefix], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout
+        for ext, want in gold["index_sha256"].items():
+            assert common.sha(prefix + "." + ext) == want, (tag, ext, r.stdout)
+    for name in sorted(common.MANIFEST["cases"]):
+        c = common.build_case(name, workdir)
+        fa = os.path.join(workdir, "cli_index_%s.fa" % name)
+        c["genome"].write_fasta(fa)
+        prefix = os.path.join(workdir, "cli_index_" + name)
+        subprocess.run([DART, "index", fa, prefix], check=True, stdout=subprocess.DEVNULL)
+        for ext, want in common.MANIFEST["manifest"][name]["index_sha256"].items():
+            assert common.sha(prefix + "." + ext) == want, (name, ext)
+    # the last one, used: same SAM as with the test's own index
+    d = os.path.join(workdir, "cli_index_map"); os.makedirs(d, exist_ok=True)
+    synth.write_fastq(os.path.join(d, "1.fq"), c["m1"], 1)
+    files = ["-f", "1.fq"]
+    if c["spec"]["paired"]:
+        synth.write_fastq(os.path.join(d, "2.fq"), c["m2"], 2); files += ["-f2", "2.fq"]
+    run = c["runs"][0]
+    subprocess.run([DART, "-i", prefix] + files + ["-o", "o.sam", "-j", "o.j"] + run["flags"], cwd=d, stdout=subprocess.DEVNULL, check=True)
+    assert open(os.path.join(d, "o.sam")).read() == common.golden_sam(run["base"])
+
+
+def test_gpu_index_builder_fasta_path_matches_reference_indexer(workdir):
+    """dart_amd/index_build.py from the FASTA with ambiguous bases, on the GPU (both drivers of the kernels)"""
+    import json
+    from dart_amd import index_build
+    gold = json.load(open(os.path.join(common.GOLDEN, "index_holes.json")))
+    fa = os.path.join(workdir, "holes_gpu_py.fa")
+    common.write_holes_fasta(fa)
+    for driver in ("", "python"):
+        os.environ["DART_INDEX_DRIVER"] = driver
+        try:
+            prefix = os.path.join(workdir, "holes_gpu_py_" + (driver or "native"))
+            index_build.build_index_from_fasta(fa, prefix, device="cuda")
+        finally:
+            del os.environ["DART_INDEX_DRIVER"]
+        for ext, want in gold["index_sha256"].items():
+            assert common.sha(prefix + "." + ext) == want, (driver, ext)
+
+
 def test_dart_cli_error_behaviour(workdir):
     r = subprocess.run([DART, "-intron", "5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"Error! Unknow parameter: -intron" in r.stderr

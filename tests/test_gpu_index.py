@@ -12,15 +12,19 @@ CASES = sorted(common.MANIFEST["cases"])
 
 
 def _select(sorter, monkeypatch):
-    """hip = the builder's kernels (libdartindex.so, the default on a GPU); plain / bucketed = the torch-orchestrated sorters kept as cross-checks"""
+    """hip = the library's own build (di_build_files: kernels and their driver in libdartindex.so, the default on a GPU and what `dart index` runs);
+    hip-python = the same kernels driven from index_build.py; plain / bucketed = the torch-orchestrated sorters kept as cross-checks"""
     monkeypatch.delenv("DART_SA_BUCKETED", raising=False)
-    if sorter == "hip":
+    monkeypatch.delenv("DART_INDEX_DRIVER", raising=False)
+    if sorter.startswith("hip"):
         monkeypatch.delenv("DART_SA_TORCH", raising=False)
+        if sorter == "hip-python":
+            monkeypatch.setenv("DART_INDEX_DRIVER", "python")
     else:
         monkeypatch.setenv("DART_SA_TORCH", sorter)
 
 
-@pytest.mark.parametrize("sorter", ["hip", "plain", "bucketed"])
+@pytest.mark.parametrize("sorter", ["hip", "hip-python", "plain", "bucketed"])
 @pytest.mark.parametrize("name", CASES)
 def test_gpu_index_builder_matches_reference_indexer(name, sorter, workdir, monkeypatch):
     import torch
@@ -34,7 +38,7 @@ def test_gpu_index_builder_matches_reference_indexer(name, sorter, workdir, monk
         assert common.sha(prefix + "." + ext) == want, "GPU-built .%s differs from the reference bwt_index output (%s sorter)" % (ext, sorter)
 
 
-@pytest.mark.parametrize("sorter", ["hip", "plain", "bucketed"])
+@pytest.mark.parametrize("sorter", ["hip", "hip-python", "plain", "bucketed"])
 @pytest.mark.parametrize("name", sorted(common.MANIFEST["big_index"]))
 def test_gpu_index_builder_matches_reference_indexer_at_chr20_size(name, sorter, workdir, monkeypatch):
     """the same at the bench's size class: a 64 444 167 bp chromosome (129 M-symbol text, 2^27 sampled rows ...), the planted-repeat genome of
