@@ -96,6 +96,9 @@ def genome_spec(arg):
     return "%s synthetic genome (%d bp" % ("chr20-sized" if n == CHR20_LEN else "single-chromosome", n), ["chr20"], [n]
 
 
+PREP_S = {}                                       # rank 0: seconds spent making the synthetic genome and building its index in this run
+
+
 def prepare_index(cache_dir, genome, rank, barrier, n_introns=0, repeat_scale=1.0, model="planted"):
     """genome: a length in bp (one chromosome) or (names, lengths).  Rank 0 generates and indexes it once per box."""
     import numpy as np
@@ -112,10 +115,12 @@ def prepare_index(cache_dir, genome, rank, barrier, n_introns=0, repeat_scale=1.
         g = synth.make_genome(lengths, seed=20, repeat_scale=repeat_scale, n_introns=n_introns, names=names, model=model)
         np.save(prefix + ".codes.npy", g.codes)
         np.save(prefix + ".introns.npy", g.introns)
+        PREP_S["genome_generated_s"] = round(time.time() - t, 1)
         log("[bench] genome %d bp generated in %.1f s" % (total, time.time() - t))
         t = time.time()
         index_build.build_index_from_genome(g, prefix, log=log)
         torch.cuda.empty_cache()
+        PREP_S["index_build_s"] = round(time.time() - t, 1)      # di_build_files (libdartindex.so): the five files of this genome, written
         log("[bench] index built in %.1f s" % (time.time() - t))
         open(done, "w").write("ok")
     barrier()
@@ -1158,6 +1163,8 @@ def main():
     phase("secondary rates, one batch in flight, CPU legs")
     line["phases_s"] = {T_PHASE[i][0]: round(T_PHASE[i][1] - T_PHASE[i - 1][1], 1) for i in range(1, len(T_PHASE))}
     line["phases_s"]["total"] = round(T_PHASE[-1][1] - T_PHASE[0][1], 1)
+    if PREP_S:
+        line["phases_s"]["of the first phase"] = dict(PREP_S)
     log("[bench] phases (s):", line["phases_s"])
     if gather_mode == "full":
         line["gather"] = {"mode": "full", "bytes_received_by_rank0_total": gather_bytes[0], "verified_against_single_rank_mapping": gather_verified}
