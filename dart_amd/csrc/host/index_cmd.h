@@ -8,11 +8,13 @@
 #pragma once
 #include "dartindex.h"
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <ctime>
 #include <string>
 #include <vector>
@@ -64,6 +66,12 @@ static int run(const char *self, const char *fa, const char *prefix)
     fprintf(stdout, "[dart index] Pack FASTA... "); fflush(stdout);
     std::vector<Ann> anns; std::vector<Amb> ambs; std::vector<uint8_t> fwd;
     srand48(11);                                          // bntseq.c:173-174: a fixed seed
+    uint8_t tab[256];
+    for (int i = 0; i < 256; i++) tab[i] = (uint8_t)nt4((unsigned char)i);
+    {
+        struct stat sb;
+        if (stat(fa, &sb) == 0 && S_ISREG(sb.st_mode)) fwd.reserve((size_t)sb.st_size + (size_t)sb.st_size / 8);      // plain FASTA: about its size; .gz grows as it goes
+    }
     LineReader in(fp);
     std::string line;
     bool in_record = false;
@@ -89,17 +97,23 @@ static int run(const char *self, const char *fa, const char *prefix)
             continue;
         }
         Ann &a = anns.back();
-        for (unsigned char ch : line) {
-            int c = nt4(ch);
-            if (c >= 4) {
-                if (lasts == (int)ch) ambs.back().len++;  // the run of one ambiguous character goes on
-                else { ambs.push_back(Amb{(long long)fwd.size(), 1, (char)ch}); a.n_ambs++; }
-                c = (int)(lrand48() & 3);
+        const size_t base = fwd.size(), n = line.size();
+        if (fwd.capacity() < base + n) fwd.reserve(std::max(base + n, fwd.capacity() + fwd.capacity() / 2 + (size_t)(1 << 20)));
+        fwd.resize(base + n);
+        uint8_t *dst = fwd.data() + base, bad = 0;
+        for (size_t i = 0; i < n; i++) { const uint8_t c = tab[(unsigned char)line[i]]; dst[i] = c; bad |= c; }
+        if (bad & 4) {                                    // the line holds ambiguous characters: holes and random bases, in sequence order
+            for (size_t i = 0; i < n; i++) {
+                const unsigned char ch = (unsigned char)line[i];
+                if (dst[i] >= 4) {
+                    if (lasts == (int)ch) ambs.back().len++;  // the run of one ambiguous character goes on
+                    else { ambs.push_back(Amb{(long long)(base + i), 1, (char)ch}); a.n_ambs++; }
+                    dst[i] = (uint8_t)(lrand48() & 3);
+                }
+                lasts = (int)ch;
             }
-            lasts = (int)ch;
-            fwd.push_back((uint8_t)c);
-        }
-        a.len += (long long)line.size();
+        } else lasts = (int)(unsigned char)line[n - 1];
+        a.len += (long long)n;
     }
     gzclose(fp);
     const long long L = (long long)fwd.size();

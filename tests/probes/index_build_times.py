@@ -17,13 +17,30 @@ prefix = os.path.join(d, "g")
 t = time.time()
 info = index_build.build_index_from_genome(g, prefix, log=lambda m: print(m, flush=True))
 print("index built in %.1f s: %s" % (time.time() - t, info), flush=True)
-for ext in (".pac", ".ann", ".amb", ".bwt", ".sa"):
-    h = hashlib.sha256()
-    with open(prefix + ext, "rb") as f:
-        while True:
-            b = f.read(1 << 24)
-            if not b: break
-            h.update(b)
-    print("%s %d bytes sha256 %s" % (ext, os.path.getsize(prefix + ext), h.hexdigest()), flush=True)
-    os.unlink(prefix + ext)
+def digests(prefix):
+    out = {}
+    for ext in (".pac", ".ann", ".amb", ".bwt", ".sa"):
+        h = hashlib.sha256()
+        with open(prefix + ext, "rb") as f:
+            while True:
+                b = f.read(1 << 24)
+                if not b: break
+                h.update(b)
+        out[ext] = h.hexdigest()
+        print("%s %d bytes sha256 %s" % (ext, os.path.getsize(prefix + ext), out[ext]), flush=True)
+        os.unlink(prefix + ext)
+    return out
+
+want = digests(prefix)
+if os.environ.get("DART_INDEX_CLI") == "1":          # the same genome as FASTA through `dart index ref.fa prefix`, process start to exit
+    import subprocess
+    fa = os.path.join(d, "g.fa")
+    t = time.time(); g.write_fasta(fa); print("FASTA written in %.1f s (%d bytes)" % (time.time() - t, os.path.getsize(fa)), flush=True)
+    t = time.time()
+    r = subprocess.run([os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "dart_amd", "dart"), "index", fa, os.path.join(d, "cli")], capture_output=True, text=True)
+    print(r.stdout + r.stderr, flush=True)
+    print("dart index: rc %d, %.1f s from process start to exit" % (r.returncode, time.time() - t), flush=True)
+    os.unlink(fa)
+    got = digests(os.path.join(d, "cli"))
+    print("dart index files identical to the library call's:", got == want, flush=True)
 os.rmdir(d)
