@@ -1,6 +1,6 @@
 """Measurement probe: builds the GRCh38-sized index once on the GPU and prints the builder's phase log (seconds since the
 build began and seconds inside dg_sort_pairs at every line) plus the digests of the four files, so that two builder versions can
-be compared for time AND bytes.  usage: python tests/probes/index_build_times.py [total_bp] [model]"""
+be compared for time AND bytes.  usage: python tests/probes/index_build_times.py [total_bp] [model]   (64444167 = the chr20-sized genome of the golden digests; DART_INDEX_CLI=1 adds the `dart index` leg)"""
 import hashlib, os, sys, tempfile, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench
@@ -8,7 +8,7 @@ from dart_amd import index_build, synth
 
 total = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 model = sys.argv[2] if len(sys.argv) > 2 else "planted"
-names, lengths = (bench.GRCH38_NAMES, bench.GRCH38) if total == 0 else (["chrA", "chrB"], [total - total // 3, total // 3])
+names, lengths = (bench.GRCH38_NAMES, bench.GRCH38) if total == 0 else (["chr20"], [total]) if total == 64444167 else (["chrA", "chrB"], [total - total // 3, total // 3])
 t = time.time()
 g = synth.make_genome(lengths, seed=20, names=names, model=model)
 print("genome %d bp (%s) generated in %.1f s" % (sum(lengths), model, time.time() - t), flush=True)
