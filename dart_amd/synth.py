@@ -231,6 +231,16 @@ def make_genome(lengths, seed=20, repeat_scale=1.0, n_introns=0, names=None, mod
     return Genome(names, lengths, codes, introns)
 
 
+class _AsciiOf:
+    """asc[key] == _ACGT[codes][key] for slices and index arrays, translated on the way out."""
+
+    def __init__(self, codes):
+        self.codes = codes
+
+    def __getitem__(self, key):
+        return _ACGT[self.codes[key]]
+
+
 def make_reads(g: Genome, n_pairs: int, rlen: int = 101, seed: int = 7, sub_rate: float = 0.01,
                indel_frac: float = 0.02, spliced_frac: float = 0.0, n_frac: float = 0.002,
                paired: bool = True, frag_mean: float = 350.0, frag_sd: float = 40.0, return_truth: bool = False):
@@ -239,7 +249,7 @@ def make_reads(g: Genome, n_pairs: int, rlen: int = 101, seed: int = 7, sub_rate
     return_truth: also a dict with, per pair, the chromosome index, the 1-based leftmost forward-strand position of each
     mate's footprint, and `plain` = the pair is a plain fragment (no planted indel / splice: its truth is exact)."""
     rng = np.random.default_rng(seed)
-    asc = g.ascii()
+    asc = _AsciiOf(g.codes)                           # (the characters of what is read, not a 3 GB ASCII copy of the genome per call)
     total = g.total
     ends = np.cumsum(g.lengths)
     flen = np.clip(np.rint(rng.normal(frag_mean, frag_sd, n_pairs)).astype(np.int64), rlen + 5, None)
