@@ -536,7 +536,10 @@ def build_index(prefix: str, names, annos, seqs, device: str | None = None, log=
         _t0, _log0 = _time.time(), log
         def log(msg):
             if device != "cpu": torch.cuda.synchronize()
-            _log0("  [%6.1f s; sorter %5.1f s, %d calls, %.2f G pairs]%s" % (_time.time() - _t0, _sort_s[0], _sort_s[1], _sort_s[2] / 1e9, msg))
+            if msg.lstrip().startswith("["):                     # di_build_files' own lines carry their clock already
+                _log0(msg)
+            else:
+                _log0("  [%6.1f s; sorter %5.1f s, %d calls, %.2f G pairs]%s" % (_time.time() - _t0, _sort_s[0], _sort_s[1], _sort_s[2] / 1e9, msg))
     import os as _os
     if codes is None:
         fwd, holes, n_ambs = pack_sequences(seqs)
