@@ -323,7 +323,7 @@ static hipError_t wait_stream(dg_ctx *c)
 // AlignmentCandidates.cpp:1079-1207); results go to the read's dg_read_out / dg_report_out slots
 // ------------------------------------------------------------------------------------------
 #ifdef DG_PROFILE_CLASSES          // diagnostic build only (profiles/probes/class_profile.sh): shader cycles per cost class
-__device__ unsigned long long g_class_cycles[COST_CLASSES + 1], g_class_chunks[COST_CLASSES + 1];
+__device__ unsigned long long g_class_cycles[DG_COST_CLASSES + 1], g_class_chunks[DG_COST_CLASSES + 1];
 #endif
 template <int MINW>
 __global__ void __launch_bounds__(64, MINW)
@@ -1459,14 +1459,14 @@ static int enqueue_run(dg_ctx *c)
     HIPCHK(hipGetLastError());
 #ifdef DG_PROFILE_CLASSES
     {
-        unsigned long long cyc[COST_CLASSES + 1], cnt[COST_CLASSES + 1], z[COST_CLASSES + 1] = {0};
+        unsigned long long cyc[DG_COST_CLASSES + 1], cnt[DG_COST_CLASSES + 1], z[DG_COST_CLASSES + 1] = {0};
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_class_cycles), sizeof cyc)); HIPCHK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_class_chunks), sizeof cnt));
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_class_cycles), z, sizeof z)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_class_chunks), z, sizeof z));
-        unsigned long long tot = 0; for (int k = 0; k <= COST_CLASSES; k++) tot += cyc[k];
+        unsigned long long tot = 0; for (int k = 0; k <= DG_COST_CLASSES; k++) tot += cyc[k];
         unsigned long long ph[DG_NCLS][DG_NPHASE], zp[DG_NCLS][DG_NPHASE] = {{0}};
         HIPCHK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof ph)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zp, sizeof zp));
-        for (int k = 0; k < COST_CLASSES; k++) if (cnt[k]) {
+        for (int k = 0; k < DG_COST_CLASSES; k++) if (cnt[k]) {
             fprintf(stderr, "[class %2d] chunks %7llu  cycles/chunk %8llu  share %5.1f %%  phases/chunk:", k, cnt[k], cyc[k] / cnt[k], 100.0 * cyc[k] / (tot ? tot : 1));
             for (int q = 0; q < DG_NPHASE; q++) fprintf(stderr, " %llu", ph[k][q] / cnt[k]);
             fprintf(stderr, "\n");

@@ -323,7 +323,56 @@ __host__ __device__ inline bool d_check_seq_fragment(const DIndex &ix, int64_t L
     return true;
 }
 
+// RefSequence[g0 .. g0 + n) as 2-bit codes (A C G T = 0 1 2 3), n <= 28, first base in the top bits -- when the bases, and the eight pac bytes the fetch
+// reads, lie inside one strand half; *ok says so.  One 8-byte fetch instead of n dependent d_refchar loads.
+__host__ __device__ __forceinline__ uint64_t d_ref_codes(const DIndex &ix, int64_t g0, int n, bool *ok)
+{
+    typedef uint64_t __attribute__((aligned(1))) uint64_a1;
+    const int64_t L = ix.l_pac;
+    if (g0 >= 0 && g0 + 32 <= L) {
+        *ok = true;
+        return __builtin_bswap64(*(const uint64_a1 *)(ix.pac + (g0 >> 2))) << ((g0 & 3) << 1);
+    }
+    if (g0 >= L + 32 - n && g0 + n <= 2 * L) {            // RefSequence[g0 + j] = complement of forward base f0 - j
+        const int64_t lo = 2 * L - 1 - g0 - (n - 1);      // the window's last base is forward base lo: 0 <= lo, lo + 32 <= L
+        const uint64_t x = __builtin_bswap64(*(const uint64_a1 *)(ix.pac + (lo >> 2))) << ((lo & 3) << 1);       // forward base lo + k at bits 63-2k, 62-2k
+        uint64_t y = __builtin_bitreverse64(x);                                                                  // ... at bits 2k, 2k+1 (swapped inside the pair)
+        y = ((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull);
+        *ok = true;
+        return ~(y << (64 - 2 * n));                      // window base j = complement of forward base lo + (n-1-j), now at bits 63-2j, 62-2j
+    }
+    *ok = false;
+    return 0;
+}
+__host__ __device__ __forceinline__ uint64_t d_codes_field(uint64_t w, int first, int count) { return (w << (2 * first)) >> (64 - 2 * count); }      // count >= 1
+
+__host__ __device__ inline int d_identify_sj_chars(const DIndex &ix, int type, const DSeed &l, const DSeed &r);
 __host__ __device__ inline int d_identify_sj(const DIndex &ix, int type, const DSeed &l, const DSeed &r)   // :732-756
+{
+    // every base the search can look at is within 9 of the two boundaries: 20 bases from Lg - 9 on (donor pair at Lg + shift, the bases a shift moves across)
+    // and 20 from Rg - 11 on (acceptor pair at Rg - 2 + shift, the same bases on that side), fetched once; the loop then runs in registers
+    const int64_t Lg = l.gPos + l.gLen, Rg = r.gPos;
+    bool okl, okr;
+    const uint64_t WL = d_ref_codes(ix, Lg - 9, 20, &okl), WR = d_ref_codes(ix, Rg - 11, 20, &okr);
+    if (!(okl && okr)) return d_identify_sj_chars(ix, type, l, r);              // a window at a strand boundary or at the ends of the text
+    // SpliceJunctionArr = { "GT/AG", "CT/AC", "GC/AG", "CT/GC" } as codes
+    const uint64_t donor = type == 0 ? 0xBu : (type == 2 ? 0x9u : 0x7u), acceptor = type == 0 ? 0x2u : (type == 1 ? 0x1u : (type == 2 ? 0x2u : 0x9u));
+    int i = l.rLen < r.rLen ? l.rLen : r.rLen;
+    int j = l.gLen < r.gLen ? l.gLen : r.gLen;
+    if (i < j) j = i;
+    if (j > 9) j = 9;
+    j <<= 1;
+    int shift = 0;
+    for (i = 0; i <= j; i++) {
+        shift = d_shift_arr(i);
+        if (shift > 0 && d_codes_field(WL, 9, shift) != d_codes_field(WR, 11, shift)) continue;                 // CheckSeqFragment :702-730
+        if (shift < 0 && d_codes_field(WL, 9 + shift, -shift) != d_codes_field(WR, 11 + shift, -shift)) continue;
+        if (d_codes_field(WL, 9 + shift, 2) == donor && d_codes_field(WR, 9 + shift, 2) == acceptor) break;
+    }
+    return i > j ? 10 : shift;
+}
+
+__host__ __device__ inline int d_identify_sj_chars(const DIndex &ix, int type, const DSeed &l, const DSeed &r)   // the same through single characters
 {
     // SpliceJunctionArr = { "GT/AG", "CT/AC", "GC/AG", "CT/GC" }
     const char d0 = type == 0 ? 'G' : (type == 2 ? 'G' : 'C');
@@ -756,11 +805,16 @@ __device__ inline void d_nw_coop(const DIndex &ix, const unsigned char *a, int m
 // d_nw_coop: the per-phase profile (profiles/r01/i_k_report_class_profile.txt) had the one-pair-at-a-time
 // loop at 60 % of the large-pair class.  Same output as d_nw_coop: traceback bits, column-major, in the
 // owner lane's scratch.  All 64 lanes call it; the arguments are the GROUP's pair (has = false: none).
+// NWG_LANES = 16 (four pairs at a time, up to 128 columns; a DPP row is 16 lanes, so the same row shift serves): the 65 .. 128-column pairs of 2x151 reads -- the
+// gap between two exons' seeds, a long pair next to an indel -- went through d_nw_coop one after the other before (profiles/r05/al_k_report_by_class_and_phase.txt:
+// the class of candidates that waited for re-seeding spent 3.8 M cycles per 64 of them there).
 // ---------------------------------------------------------------------------------------------
-#define NWG_LANES 8
 #define NWG_MAXN  64
+#define NWG_MAXN16 128
+template <int NWG_LANES>
 __device__ inline void d_nw_group(const DIndex &ix, bool has, const unsigned char *a, int m, int64_t gPos, int n, unsigned char *ows, const WSLayout &L, int lane)
 {
+    static_assert(NWG_LANES == 8 || NWG_LANES == 16, "a group is half a DPP row or a whole one");
     const int k = lane & (NWG_LANES - 1);
     const int c = has ? (n + NWG_LANES - 1) / NWG_LANES : 0;
     const int j_first = k * c + 1;
@@ -826,7 +880,7 @@ __device__ inline void d_nw_group(const DIndex &ix, bool has, const unsigned cha
 }
 
 // Wave-wide nw_alignment service: every lane may ask for one alignment (has; read characters a[0..m), genome
-// gPos..gPos+n); requests of <= 64 columns run eight at a time (d_nw_group), wider ones one after the other
+// gPos..gPos+n); requests of <= 64 columns run eight at a time, those of <= 128 four at a time (d_nw_group<8>, <16>), wider ones one after the other
 // (d_nw_coop).  Traceback bits land in each requesting lane's own scratch.  Called by all 64 lanes.
 __device__ inline void d_nw_wave(LaneCtx &cx, bool has, const unsigned char *a, int m, int64_t gPos, int n, int lane, bool all_wide = false)
 {
@@ -836,7 +890,7 @@ __device__ inline void d_nw_wave(LaneCtx &cx, bool has, const unsigned char *a, 
     unsigned long long todo = __ballot(has && n <= NWG_MAXN && !all_wide);      // all_wide (dg_probe_nw_mode 3 only): every pair takes the whole-wave form
     while (todo) {
         int own = -1;
-        for (int q = 0; q < 64 / NWG_LANES; q++) {           // group q takes the q-th requester
+        for (int q = 0; q < 64 / 8; q++) {                   // group q takes the q-th requester
             const int b = todo ? __ffsll((long long)todo) - 1 : -1;
             if (q == (lane >> 3)) own = b;
             todo &= todo - 1;                                // (0 stays 0)
@@ -846,9 +900,24 @@ __device__ inline void d_nw_wave(LaneCtx &cx, bool has, const unsigned char *a, 
         const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), src, 64) << 32) | (uint32_t)__shfl((int)wp, src, 64);
         const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)gPos >> 32), src, 64) << 32) | (uint32_t)__shfl((int)gPos, src, 64);
         const int m_o = __shfl(m, src, 64), n_o = __shfl(n, src, 64);
-        d_nw_group(ix, own >= 0, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
+        d_nw_group<8>(ix, own >= 0, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
     }
-    todo = __ballot(has && (n > NWG_MAXN || all_wide));
+    todo = __ballot(has && n > NWG_MAXN && n <= NWG_MAXN16 && !all_wide);         // 65 .. 128 columns: four at a time, sixteen lanes each
+    while (todo) {
+        int own = -1;
+        for (int q = 0; q < 64 / 16; q++) {
+            const int b = todo ? __ffsll((long long)todo) - 1 : -1;
+            if (q == (lane >> 4)) own = b;
+            todo &= todo - 1;
+        }
+        const int src = own < 0 ? 0 : own;
+        const unsigned long long a_o = ((unsigned long long)(uint32_t)__shfl((int)(ap >> 32), src, 64) << 32) | (uint32_t)__shfl((int)ap, src, 64);
+        const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(wp >> 32), src, 64) << 32) | (uint32_t)__shfl((int)wp, src, 64);
+        const unsigned long long g_o = ((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)gPos >> 32), src, 64) << 32) | (uint32_t)__shfl((int)gPos, src, 64);
+        const int m_o = __shfl(m, src, 64), n_o = __shfl(n, src, 64);
+        d_nw_group<16>(ix, own >= 0, (const unsigned char *)a_o, m_o, (int64_t)g_o, n_o, (unsigned char *)w_o, *cx.L, lane);
+    }
+    todo = __ballot(has && (n > NWG_MAXN16 || all_wide));
     while (todo) {
         const int owner = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
