@@ -227,9 +227,7 @@ __host__ __device__ inline bool d_small_nw_is_diagonal(uint64_t a8, uint64_t b8,
             const int r = x > y ? x : y;
             x = tp[q] - 1; y = sp[q] - 3;
             const int t = x > y ? x : y;
-            const int d = d_tr2(diag + (ca == cb[q] ? 3 : -3));
-            const int rr = d_tr2(r), tt = d_tr2(t);
-            const int sv = d > rr ? (d > tt ? d : tt) : (rr > tt ? rr : tt);
+            const int sv = d_tr2(d_max3(diag + (ca == cb[q] ? 3 : -3), r, t));
             leaves = leaves || (q == i - 1 && (sv == r || sv == t));
             diag = sp[q];
             sp[q] = sv; tp[q] = t;

@@ -51,6 +51,9 @@ __device__ __forceinline__ uint32_t *ws_cig(LaneCtx &cx) { return (uint32_t *)(c
 __device__ __forceinline__ char *ws_str(LaneCtx &cx, int i) { return (char *)(cx.ws + cx.L->str_off + (uint32_t)i * cx.L->str_cap); }
 
 __host__ __device__ __forceinline__ int d_tr2(int v2) { return (int)(((unsigned)v2 + ((unsigned)v2 >> 31)) & ~1u); }   // 2*trunc(v2/2)
+// nw_alignment.cpp:40-47 takes the maximum of three operands that were each truncated to short first.  Truncation toward zero is monotone (a <= b => trunc(a) <= trunc(b)),
+// so max(tr(d), tr(r), tr(t)) == tr(max(d, r, t)): one truncation per cell instead of three (tests/native/host_checks.hip checks the identity over a range of triples).
+__host__ __device__ __forceinline__ int d_max3(int a, int b, int c) { const int m = a > b ? a : b; return m > c ? m : c; }
 
 // ---------------------------------------------------------------------------------------------
 // nw_alignment (nw_alignment.cpp:18-82) restated on integers x2: s is built from
@@ -100,9 +103,7 @@ __host__ __device__ inline int d_nw(LaneCtx &cx, const char *a, int m, const cha
                 const int r = x > y ? x : y;
                 x = tp[q] - 1; y = sp[q] - 3;
                 const int t = x > y ? x : y;
-                const int d = d_tr2(diag + (ca == cb[q] ? 3 : -3));
-                const int rr = d_tr2(r), tt = d_tr2(t);
-                const int sv = d > rr ? (d > tt ? d : tt) : (rr > tt ? rr : tt);
+                const int sv = d_tr2(d_max3(diag + (ca == cb[q] ? 3 : -3), r, t));      // = max of the three truncated operands: the truncation is monotone
                 acc |= ((sv == r ? 1u : 0u) | (sv == t ? 2u : 0u)) << (2 * q);
                 diag = sp[q];
                 sp[q] = sv; tp[q] = t;
@@ -563,13 +564,13 @@ __device__ inline bool d_local_quality(const char *a1, const char *a2, int len) 
 // ---------------------------------------------------------------------------------------------
 // the gapped alignment as a column list, 4 bits per column, column 0 = the LAST column (traceback order)
 struct ColList { uint64_t w0, w1, w2; int K; };
-__device__ __forceinline__ uint32_t d_colcode(const ColList &c, int p)          // p counts from the first column
+__host__ __device__ __forceinline__ uint32_t d_colcode(const ColList &c, int p)          // p counts from the first column
 {
     const int k = c.K - 1 - p;
     const uint64_t w = k < 16 ? c.w0 : (k < 32 ? c.w1 : c.w2);
     return (uint32_t)(w >> ((k & 15) << 2)) & 7u;
 }
-__device__ __forceinline__ uint32_t d_byte3(uint64_t a0, uint64_t a1, uint64_t a2, int i)   // byte i of 24
+__host__ __device__ __forceinline__ uint32_t d_byte3(uint64_t a0, uint64_t a1, uint64_t a2, int i)   // byte i of 24
 {
     const uint64_t w = i < 8 ? a0 : (i < 16 ? a1 : a2);
     return (uint32_t)(w >> ((i & 7) << 3)) & 0xFFu;
@@ -644,7 +645,7 @@ __device__ inline int d_pair_classify(LaneCtx &cx, const DSeed &sp, int mode, Pa
     return PC_NW;
 }
 
-__device__ inline void d_pair_nw(LaneCtx &cx, int m, int n, const PairStr &ps, ColList &cl)
+__host__ __device__ inline void d_pair_nw(LaneCtx &cx, int m, int n, const PairStr &ps, ColList &cl)
 {
     cx.n_nw++; cx.nw_cells += (unsigned long long)m * (unsigned long long)n;
     uint16_t *bits = (uint16_t *)cx.lds;                     // bits[(i-1) * 3 + strip]
@@ -676,9 +677,7 @@ __device__ inline void d_pair_nw(LaneCtx &cx, int m, int n, const PairStr &ps, C
                 const int r = x > y ? x : y;
                 x = tp_[q] - 1; y = sp_[q] - 3;
                 const int t = x > y ? x : y;
-                const int d = d_tr2(diag + (ca == cb[q] ? 3 : -3));
-                const int rr = d_tr2(r), tt = d_tr2(t);
-                const int sv = d > rr ? (d > tt ? d : tt) : (rr > tt ? rr : tt);
+                const int sv = d_tr2(d_max3(diag + (ca == cb[q] ? 3 : -3), r, t));      // = max of the three truncated operands: the truncation is monotone
                 acc |= ((sv == r ? 1u : 0u) | (sv == t ? 2u : 0u)) << (2 * q);
                 diag = sp_[q];
                 sp_[q] = sv; tp_[q] = t;
@@ -782,9 +781,7 @@ __device__ inline void d_nw_coop(const DIndex &ix, const unsigned char *a, int m
                 const int r = x > y ? x : y;
                 x = up_t - 1; y = up_s - 3;
                 const int tt = x > y ? x : y;
-                const int d = d_tr2(diag + (ca == cb ? 3 : -3));
-                const int rr = d_tr2(r), t2 = d_tr2(tt);
-                const int sv = d > rr ? (d > t2 ? d : t2) : (rr > t2 ? rr : t2);
+                const int sv = d_tr2(d_max3(diag + (ca == cb ? 3 : -3), r, tt));
                 acc |= ((sv == r ? 1u : 0u) | (sv == tt ? 2u : 0u)) << (((i - 1) & 15) << 1);
                 if (((i - 1) & 15) == 15 || i == m) { tb[(size_t)(j - 1) * RW + ((i - 1) >> 4)] = acc; acc = 0; }
                 prev_s = cur_s; cur_s = sv; cur_r = r; up_s = sv; up_t = tt;
@@ -859,9 +856,7 @@ __device__ inline void d_nw_group(const DIndex &ix, bool has, const unsigned cha
                     const int r = x > y ? x : y;
                     x = up_t[q] - 1; y = up_s[q] - 3;
                     const int tt = x > y ? x : y;
-                    const int d = d_tr2(diag + (ca == ((cbp >> (4 * q)) & 15u) ? 3 : -3));
-                    const int rr = d_tr2(r), t2 = d_tr2(tt);
-                    const int sv = d > rr ? (d > t2 ? d : t2) : (rr > t2 ? rr : t2);
+                    const int sv = d_tr2(d_max3(diag + (ca == ((cbp >> (4 * q)) & 15u) ? 3 : -3), r, tt));
                     acc[q] |= ((sv == r ? 1u : 0u) | (sv == tt ? 2u : 0u)) << sh;
                     diag = up_s[q];
                     new_prev = diag;                               // after the last valid column: s[i-1][last]
@@ -953,11 +948,111 @@ __device__ inline int d_tb_traceback(LaneCtx &cx, const char *a, int m, const ch
     return k;
 }
 
-// SeedExtension :577-594 for the wave's lanes together (live = this lane has a candidate to extend).  The two
-// nw_alignment calls of every FillGapsBetweenAdjacentSeeds (d_fill_gaps above, the one-lane form) are served by
-// d_nw_wave; the lane then reads its traceback, exactly the strings d_nw would have produced.  On spliced reads
-// these rGaps x rGaps alignments, one lane at a time, were most of k_report (and on plain reads the tail of
-// the job reads: one lane, 1.9 M cycles).
+// FillGapsBetweenAdjacentSeeds (called by SeedExtension :577-594) on the gapped strings of its two nw_alignment calls, in three steps the two forms below share
+// with the host-side check (tests/native/gap_checks.hip).  Right: the read gap against the genome behind the left seed; the read bases its alignment leaves
+// without a genome base at the end meet the genome that follows the window.  Rv[p] = identical columns among those of the gap's first p read bases.
+__host__ __device__ inline void d_gap_right_strings(const DIndex &ix, const char *f1, char *f2, int len, int64_t g_after, int *Rv)
+{
+    int q = len - 1;
+    while (q >= 0 && f2[q] == '-') q--;
+    int64_t gp = g_after;
+    for (q += 1; q < len; q++, gp++) f2[q] = d_refchar(ix, gp);
+    int p = 0, sc = 0;
+    for (q = 0; q < len; q++) { if (f1[q] == f2[q]) sc++; if (f1[q] != '-') p++; Rv[p] = sc; }
+}
+// Left: the read gap against the genome in front of the right seed, read from its end.  Lv[q] = identical columns among those of the gap's read bases q + 1 .. rGaps.
+__host__ __device__ inline void d_gap_left_strings(const DIndex &ix, const char *f3, char *f4, int len3, int64_t g_first, int rGaps, int *Lv)
+{
+    int q = 0;
+    while (q < len3 && f4[q] == '-') q++;
+    int64_t gp = g_first;
+    for (q -= 1; q >= 0; q--, gp--) f4[q] = d_refchar(ix, gp);
+    int p = 0, sc = 0;
+    for (q = len3 - 1; q >= 0; q--) { if (f3[q] == f4[q]) sc++; if (f3[q] != '-') p++; Lv[rGaps - p] = sc; }
+}
+// The split point with the most identical columns on both sides, and how much genome either side then covers
+__host__ __device__ inline void d_gap_split_strings(const DParams &pr, const int *Rv, const int *Lv, int rGaps, const char *f1, const char *f2, const char *f3, const char *f4, int len3,
+                                                    int &bp, int &right_ext, int &left_ext)
+{
+    int max_score = 0, p, q;
+    bp = 0;
+    for (q = 0; q <= rGaps; q++) { const int v = Rv[q] + Lv[q]; if (v > max_score) { max_score = v; bp = q; } }
+    right_ext = left_ext = 0;
+    if (!(max_score < (int)(rGaps * 0.8) || (rGaps - max_score) > pr.max_mismatch)) {
+        for (p = bp, q = 0; p > 0; q++) { if (f1[q] != '-') p--; if (f2[q] != '-') right_ext++; }
+        for (p = rGaps - bp, q = len3 - 1; p > 0; q--) { if (f3[q] != '-') p--; if (f4[q] != '-') left_ext++; }
+    }
+}
+
+// The same three steps for a read gap of at most PM_MAX bases WITHOUT the strings: both alignments by the lane itself (d_pair_nw: registers and the lane's LDS slice,
+// result = a column list in three registers), Rv / Lv as two bit masks over the gap's read positions (Rv[q] = the set bits below q, Lv[q] = those from q up), the
+// genome bases beyond the window fetched where a column needs one.  At a splice junction the two exact seeds around the intron end where the read stops matching
+// the intron, so the gap between them is a few bases: through d_nw_wave every such gap cost a wave-wide alignment pass, a traceback through bits in the lane's
+// global scratch (one dependent load per step) and five passes over strings in that scratch (profiles/r05/ao_*: 0.42 M cycles per 64 spliced candidates).
+// The caller keeps read gaps that hold a literal '-' on the string path (there the character decides what a column is).
+__host__ __device__ inline void d_gap_small(LaneCtx &cx, const unsigned char *rdp, int rGaps, int64_t g_right /* first base behind the left seed */, int64_t g_left /* first base of the window in front of the right seed */,
+                                            int &bp, int &right_ext, int &left_ext)
+{
+    const DIndex &ix = *cx.ix;
+    auto keep = [](int len, int w) -> uint64_t { const int r = len - 8 * w; return r >= 8 ? ~0ull : (r <= 0 ? 0ull : ((1ull << (8 * r)) - 1ull)); };
+    auto code_k = [](const ColList &c, int k) -> uint32_t { const uint64_t w = k < 16 ? c.w0 : (k < 32 ? c.w1 : c.w2); return (uint32_t)(w >> ((k & 15) << 2)) & 7u; };   // k counts from the LAST column
+    PairStr ps;
+    const uint2 r0 = *(const uint2_a1 *)rdp, r1 = *(const uint2_a1 *)(rdp + 8), r2 = *(const uint2_a1 *)(rdp + 16);
+    ps.A0 = d_u64(r0.x, r0.y) & keep(rGaps, 0); ps.A1 = d_u64(r1.x, r1.y) & keep(rGaps, 1); ps.A2 = d_u64(r2.x, r2.y) & keep(rGaps, 2);
+    auto genome = [&](int64_t g0) {
+        ps.B0 = d_ref8(ix, g0) & keep(rGaps, 0);
+        ps.B1 = rGaps > 8 ? d_ref8(ix, g0 + 8) & keep(rGaps, 1) : 0ull;
+        ps.B2 = rGaps > 16 ? d_ref8(ix, g0 + 16) & keep(rGaps, 2) : 0ull;
+    };
+    // ---- right ----
+    ColList c1;
+    genome(g_right);
+    d_pair_nw(cx, rGaps, rGaps, ps, c1);
+    int T = 0;                                                        // columns at the end without a genome base
+    while (T < c1.K && (code_k(c1, T) & 3u) == 2u) T++;
+    uint32_t RM = 0;
+    for (int k = c1.K - 1, ri = 0; k >= 0; k--) {                     // first column first
+        const uint32_t cd = code_k(c1, k), ty = cd & 3u;
+        if (ty == 1u) continue;
+        bool same = (cd & 4u) != 0u;                                  // (set on columns with both bases only)
+        if (ty == 2u && k < T) same = (unsigned char)d_byte3(ps.A0, ps.A1, ps.A2, ri) == (unsigned char)d_refchar(ix, g_right + rGaps + (T - 1 - k));
+        if (same) RM |= 1u << ri;
+        ri++;
+    }
+    // ---- left ----
+    ColList c3;
+    genome(g_left);
+    d_pair_nw(cx, rGaps, rGaps, ps, c3);
+    int H = 0;                                                        // columns at the start without a genome base
+    while (H < c3.K && (code_k(c3, c3.K - 1 - H) & 3u) == 2u) H++;
+    uint32_t LM = 0;
+    for (int k = 0, ri = rGaps - 1; k < c3.K; k++) {                  // last column first
+        const uint32_t cd = code_k(c3, k), ty = cd & 3u;
+        if (ty == 1u) continue;
+        bool same = (cd & 4u) != 0u;
+        const int pcol = c3.K - 1 - k;                                // the column's number from the start
+        if (ty == 2u && pcol < H) same = (unsigned char)d_byte3(ps.A0, ps.A1, ps.A2, ri) == (unsigned char)d_refchar(ix, g_left - (H - 1 - pcol));
+        if (same) LM |= 1u << ri;
+        ri--;
+    }
+    // ---- the split ----
+    int max_score = 0;
+    bp = 0;
+    for (int q = 0; q <= rGaps; q++) {
+        const int v = __builtin_popcount(RM & ((1u << q) - 1u)) + __builtin_popcount(LM >> q);       // (q <= 24: the shifts are defined)
+        if (v > max_score) { max_score = v; bp = q; }
+    }
+    right_ext = left_ext = 0;
+    if (!(max_score < (int)(rGaps * 0.8) || (rGaps - max_score) > cx.pr->max_mismatch)) {
+        for (int p = bp, k = c1.K - 1; p > 0; k--) { const uint32_t ty = code_k(c1, k) & 3u; if (ty != 1u) p--; if (ty != 2u || k < T) right_ext++; }
+        for (int p = rGaps - bp, k = 0; p > 0; k++) { const uint32_t ty = code_k(c3, k) & 3u; if (ty != 1u) p--; if (ty != 2u || c3.K - 1 - k < H) left_ext++; }
+    }
+}
+
+// SeedExtension :577-594 for the wave's lanes together (live = this lane has a candidate to extend).  The two nw_alignment calls of a
+// FillGapsBetweenAdjacentSeeds whose read gap is longer than PM_MAX bases are served by d_nw_wave; the lane then reads its traceback, exactly the
+// strings d_nw would have produced.  (On spliced reads these rGaps x rGaps alignments, one lane at a time, were most of k_report, and on plain reads
+// the tail of the job reads: one lane, 1.9 M cycles.)  Shorter gaps -- most of them: see d_gap_small -- never leave the lane.
 __device__ inline int d_seed_extension_wave(LaneCtx &cx, bool live, DSeed *s, int n, int lane)
 {
     const DIndex &ix = *cx.ix;
@@ -973,38 +1068,37 @@ __device__ inline int d_seed_extension_wave(LaneCtx &cx, bool live, DSeed *s, in
         DSeed Ls = s[has ? i - 1 : 0], Rs = s[has ? i : 0];
         int rGaps = has ? Rs.rPos - (Ls.rPos + Ls.rLen) : 0;
         const unsigned char *rdp = cx.seq + Ls.rPos + Ls.rLen;
+        bool small = has && rGaps <= PM_MAX;
+        if (small) {                                                  // a literal '-' in the read gap: the string path
+            const uint64_t k = 0x2D2D2D2D2D2D2D2Dull, o = 0x0101010101010101ull, h = 0x8080808080808080ull;
+            for (int w = 0; w < rGaps; w += 8) {
+                const uint2 rw = *(const uint2_a1 *)(rdp + w);
+                const int r = rGaps - w;
+                const uint64_t z = d_u64(rw.x, rw.y) ^ k, m = r >= 8 ? ~0ull : ((1ull << (8 * r)) - 1ull);
+                if ((z - o) & ~z & h & m) small = false;
+            }
+        }
+        const bool wide = has && !small;
         char *g = ws_str(cx, 0), *f1 = ws_str(cx, 1), *f2 = ws_str(cx, 2), *f3 = ws_str(cx, 3), *f4 = ws_str(cx, 4);
         int *Rv = (int *)ws_cig(cx), *Lv = Rv + rGaps + 1;      // the CIGAR scratch is idle at this stage
+        int bp = 0, right_ext = 0, left_ext = 0;
+        if (small) d_gap_small(cx, rdp, rGaps, Ls.gPos + Ls.gLen, Rs.gPos - rGaps, bp, right_ext, left_ext);
         int len = 0;
-        d_nw_wave(cx, has, rdp, rGaps, Ls.gPos + Ls.gLen, rGaps, lane);
-        if (has) {
+        d_nw_wave(cx, wide, rdp, rGaps, Ls.gPos + Ls.gLen, rGaps, lane);
+        if (wide) {
             for (int q = 0; q <= rGaps; q++) Rv[q] = Lv[q] = 0;
             d_ref_fill(ix, Ls.gPos + Ls.gLen, rGaps, g);
             len = d_tb_traceback(cx, (const char *)rdp, rGaps, g, rGaps, f1, f2);
-            int q = len - 1;
-            while (q >= 0 && f2[q] == '-') q--;
-            int64_t gp = Ls.gPos + Ls.gLen + rGaps;
-            for (q += 1; q < len; q++, gp++) f2[q] = d_refchar(ix, gp);
-            int p = 0, sc = 0;
-            for (q = 0; q < len; q++) { if (f1[q] == f2[q]) sc++; if (f1[q] != '-') p++; Rv[p] = sc; }
+            d_gap_right_strings(ix, f1, f2, len, Ls.gPos + Ls.gLen + rGaps, Rv);
         }
-        d_nw_wave(cx, has, rdp, rGaps, Rs.gPos - rGaps, rGaps, lane);
-        if (has) {
+        d_nw_wave(cx, wide, rdp, rGaps, Rs.gPos - rGaps, rGaps, lane);
+        if (wide) {
             d_ref_fill(ix, Rs.gPos - rGaps, rGaps, g);
             const int len3 = d_tb_traceback(cx, (const char *)rdp, rGaps, g, rGaps, f3, f4);
-            int q = 0;
-            while (q < len3 && f4[q] == '-') q++;
-            int64_t gp = Rs.gPos - rGaps;
-            for (q -= 1; q >= 0; q--, gp--) f4[q] = d_refchar(ix, gp);
-            int p = 0, sc = 0;
-            for (q = len3 - 1; q >= 0; q--) { if (f3[q] == f4[q]) sc++; if (f3[q] != '-') p++; Lv[rGaps - p] = sc; }
-            int max_score = 0, bp = 0;
-            for (q = 0; q <= rGaps; q++) { const int v = Rv[q] + Lv[q]; if (v > max_score) { max_score = v; bp = q; } }
-            int right_ext = 0, left_ext = 0;
-            if (!(max_score < (int)(rGaps * 0.8) || (rGaps - max_score) > cx.pr->max_mismatch)) {
-                for (p = bp, q = 0; p > 0; q++) { if (f1[q] != '-') p--; if (f2[q] != '-') right_ext++; }
-                for (p = rGaps - bp, q = len3 - 1; p > 0; q--) { if (f3[q] != '-') p--; if (f4[q] != '-') left_ext++; }
-            }
+            d_gap_left_strings(ix, f3, f4, len3, Rs.gPos - rGaps, rGaps, Lv);
+            d_gap_split_strings(*cx.pr, Rv, Lv, rGaps, f1, f2, f3, f4, len3, bp, right_ext, left_ext);
+        }
+        if (has) {
             if (bp > 0) {
                 DSeed x; x.flags = 0; x.rPos = Ls.rPos + Ls.rLen; x.gPos = Ls.gPos + Ls.gLen; x.rLen = bp; x.gLen = right_ext;
                 s[n++] = x;

@@ -476,10 +476,11 @@ __device__ __forceinline__ unsigned int d_rs_scan(const DIndex &ix, RsLds<WORDS>
         const int n_valid = glen - 7 - p0;                          // positions p0 + j with j < n_valid have their 8 bases inside the window
         uint32_t pass = 0;
 #pragma unroll
-        for (int j = 0; j < RS_PPL; j++) {
+        for (int j = 0; j < RS_PPL; j++) {                          // position j's filter bit enters at the top and moves down: one v_alignbit instead of and / shift / or
             const uint32_t fw = (y >> (16 - 2 * j)) & ((1u << RS_FLT_BITS) - 1u);
-            pass |= ((S.flt[fw >> 5] >> (fw & 31)) & 1u) << j;
+            pass = __builtin_amdgcn_alignbit(S.flt[fw >> 5] >> (fw & 31), pass, 1);
         }
+        pass >>= 32 - RS_PPL;
         pass &= n_valid >= RS_PPL ? (1u << RS_PPL) - 1u : (n_valid > 0 ? (1u << n_valid) - 1u : 0u);
         while (pass) {
             const int j = __ffs((int)pass) - 1;

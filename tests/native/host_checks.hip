@@ -18,6 +18,22 @@ int main()
     for (int c = 0; c < 256; c++) if (d_nt4((unsigned char)c) != ref_nt4((unsigned char)c)) { printf("d_nt4(%d)\n", c); bad++; }
     // d_tr2: the x2 restatement of a float truncated to short (nw_alignment.cpp): 2*trunc(v/2) for v = 2*value
     for (int v = -70000; v <= 70000; v++) { const int want = 2 * (v / 2); if (d_tr2(v) != want) { if (bad < 5) printf("d_tr2(%d) = %d want %d\n", v, d_tr2(v), want); bad++; } }
+    // one truncation per nw_alignment cell: the maximum of three truncated operands is the truncated maximum (d_tr2 is monotone); the sentinel of an
+    // impossible gap (-131072 and a little below) among the operands
+    {
+        const int vals[] = {-131080, -131073, -131072, -131071, -40, -7, -6, -5, -4, -3, -2, -1, 0, 1, 2, 3, 4, 5, 6, 7, 33, 300, 301};
+        const int nv = (int)(sizeof vals / sizeof vals[0]);
+        for (int a = 0; a < nv; a++) for (int b = 0; b < nv; b++) for (int c = 0; c < nv; c++) {
+            const int ta = d_tr2(vals[a]), tb = d_tr2(vals[b]), tc = d_tr2(vals[c]);
+            const int want = ta > tb ? (ta > tc ? ta : tc) : (tb > tc ? tb : tc);
+            if (d_tr2(d_max3(vals[a], vals[b], vals[c])) != want) { if (bad < 5) printf("d_tr2(max3(%d,%d,%d))\n", vals[a], vals[b], vals[c]); bad++; }
+        }
+        for (int a = -600; a <= 600; a += 1) for (int b = -600; b <= 600; b += 7) for (int c = -131075; c <= -131069; c++) {
+            const int ta = d_tr2(a), tb = d_tr2(b), tc = d_tr2(c);
+            const int want = ta > tb ? (ta > tc ? ta : tc) : (tb > tc ? tb : tc);
+            if (d_tr2(d_max3(a, b, c)) != want || d_tr2(d_max3(c, a, b)) != want) bad++;
+        }
+    }
     // d_enc4 against one base at a time
     uint64_t s = 88172645463325252ull;
     const char *al = "ACGTacgtNn-\0\xC1\x21XB";

@@ -130,3 +130,20 @@ def test_pair_kernel_unit_code_on_host_against_oracle(workdir):
         packed += int(f[f.index("words") + 1].rstrip(";"))
     # (packed: units whose reads hold A/C/G/T/N only were run a second time from 2-bit + mask words -- what k_pair does for a packed batch -- and gave the same state)
     assert total > 20000 and fast > 0.5 * total and multi > 200 and packed > 0.5 * total, (total, fast, multi, packed)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_gap_filling_without_strings_equals_the_string_form(workdir):
+    """dg_report.h's two forms of FillGapsBetweenAdjacentSeeds (called by SeedExtension, AlignmentCandidates.cpp:577-594): d_gap_small -- read gaps of at most 24 bases, both
+    alignments by the lane itself, the split search on bit masks -- against the gapped-string form on 400 000 random read gaps (both strands, the strand boundary, the ends of
+    the text, junctions inside the gap, indels, lower case, N); every split point 0 .. 24 must have occurred, and so must read bases beyond either window."""
+    src = os.path.join(common.ROOT, "tests", "native", "gap_checks.hip")
+    exe = os.path.join(workdir, "gap_checks")
+    subprocess.run(["hipcc", "-O2", "--offload-arch=gfx950", "-std=c++17", "-w", "-o", exe, src], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("bad=0"), r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("gap filling:")][0]
+    counts = [int(x) for x in line.split("split points:")[1].split()]
+    assert len(counts) == 25 and all(c > 0 for c in counts), counts
+    beyond = line.split("with read bases beyond")[0].split(",")[-1].split()
+    assert int(beyond[0]) > 1000 and int(beyond[2]) > 1000, line
