@@ -47,8 +47,8 @@ struct LaneCtx {
 #define OP_S 4u
 #define CIG(len, op) ((((uint32_t)(len)) << 4) | (op))
 
-__device__ __forceinline__ uint32_t *ws_cig(LaneCtx &cx) { return (uint32_t *)(cx.ws + cx.L->cig_off); }
-__device__ __forceinline__ char *ws_str(LaneCtx &cx, int i) { return (char *)(cx.ws + cx.L->str_off + (uint32_t)i * cx.L->str_cap); }
+__host__ __device__ __forceinline__ uint32_t *ws_cig(LaneCtx &cx) { return (uint32_t *)(cx.ws + cx.L->cig_off); }
+__host__ __device__ __forceinline__ char *ws_str(LaneCtx &cx, int i) { return (char *)(cx.ws + cx.L->str_off + (uint32_t)i * cx.L->str_cap); }
 
 __host__ __device__ __forceinline__ int d_tr2(int v2) { return (int)(((unsigned)v2 + ((unsigned)v2 >> 31)) & ~1u); }   // 2*trunc(v2/2)
 // nw_alignment.cpp:40-47 takes the maximum of three operands that were each truncated to short first.  Truncation toward zero is monotone (a <= b => trunc(a) <= trunc(b)),
@@ -526,7 +526,7 @@ __device__ inline bool d_check_coordinate_validity(const DIndex &ix, const DSeed
 // ---------------------------------------------------------------------------------------------
 // segment pair -> CIGAR elements (tools.cpp:40-104,130-300)
 // ---------------------------------------------------------------------------------------------
-__device__ inline int d_add_cigar(const char *s1, const char *s2, int len, uint32_t *cig, int &nc)   // AddNewCigarElements :49-104
+__host__ __device__ inline int d_add_cigar(const char *s1, const char *s2, int len, uint32_t *cig, int &nc)   // AddNewCigarElements :49-104
 {
     uint32_t state = 99;
     int c = 0, score = 0;
@@ -542,7 +542,7 @@ __device__ inline int d_add_cigar(const char *s1, const char *s2, int len, uint3
     return score;
 }
 
-__device__ inline bool d_local_quality(const char *a1, const char *a2, int len)   // CheckLocalAlignmentQuality :166-201
+__host__ __device__ inline bool d_local_quality(const char *a1, const char *a2, int len)   // CheckLocalAlignmentQuality :166-201
 {
     int n = 0, mis = 0, type = -1, st = 0;
     for (int i = 0; i < len; i++) {
@@ -925,7 +925,7 @@ __device__ inline void d_nw_wave(LaneCtx &cx, bool has, const unsigned char *a, 
 }
 
 // traceback (nw_alignment.cpp:61-74) from the column-major bits of d_nw_coop into the two gapped strings
-__device__ inline int d_tb_traceback(LaneCtx &cx, const char *a, int m, const char *b, int n, char *oa, char *ob)
+__host__ __device__ inline int d_tb_traceback(LaneCtx &cx, const char *a, int m, const char *b, int n, char *oa, char *ob)
 {
     const uint32_t *tb = (const uint32_t *)(cx.ws + cx.L->nwbits_off);
     const int RW = (m + 15) >> 4;
@@ -946,6 +946,105 @@ __device__ inline int d_tb_traceback(LaneCtx &cx, const char *a, int m, const ch
         c = ob[p]; ob[p] = ob[q]; ob[q] = c;
     }
     return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same traceback WITHOUT the strings.  d_tb_traceback pays a dependent load from the lane's global scratch per step (the bits are column-major and the
+// path changes column almost every step), then the passes over the two gapped strings -- reversal, CheckLocalAlignmentQuality, AddNewCigarElements, or
+// FillGapsBetweenAdjacentSeeds' five -- pay one per character again, because every iteration branches on what it loaded: for a 100-column alignment ~0.25 M
+// cycles of one lane waiting (profiles/r05/as_*: "assemble" 0.6 M cycles per 64 candidates with a large pair on the spliced shape).  TbWalk keeps a window
+// of the bits in the lane's LDS slice -- the words of TBW_COLS columns at the walk's block of 16 rows, fetched together: one memory latency per window
+// instead of one per step -- and the two sequences as 8-character words in registers (one fetch per 8 steps each); what the callers want from the
+// alignment (CIGAR runs, identical columns per read position, genome bases covered) is accumulated while walking.
+// ---------------------------------------------------------------------------------------------
+#define TBW_COLS 24
+struct TbWalk {
+    const uint32_t *tb; int RW;          // bits of cell (i, j): tb[(j - 1) * RW + ((i - 1) >> 4)] >> (((i - 1) & 15) << 1)
+    uint32_t *win;                       // win[k] = the word of column jtop - k at row block rb (0 for columns < 1)
+    int rb, jtop;
+    const unsigned char *a; int64_t gpos; const DIndex *ix;
+    uint64_t a8, g8; int ab, gb;         // characters 8 ab .. 8 ab + 7 of the read segment / of the genome segment (-1: none yet)
+};
+__host__ __device__ inline void tbw_init(TbWalk &w, LaneCtx &cx, const unsigned char *a, int m, int64_t gpos)
+{
+    w.tb = (const uint32_t *)(cx.ws + cx.L->nwbits_off); w.RW = (m + 15) >> 4; w.win = cx.lds; w.rb = -1; w.jtop = 0;
+    w.a = a; w.gpos = gpos; w.ix = cx.ix; w.ab = w.gb = -1; w.a8 = w.g8 = 0;
+}
+__host__ __device__ inline uint32_t tbw_flag(TbWalk &w, int i, int j)        // i, j >= 1
+{
+    const int rb = (i - 1) >> 4;
+    if (rb != w.rb || w.jtop - j >= TBW_COLS || j > w.jtop) {
+        w.rb = rb; w.jtop = j;
+#pragma unroll 8
+        for (int k = 0; k < TBW_COLS; k++) { const int c = j - k; w.win[k] = c >= 1 ? w.tb[(size_t)(c - 1) * w.RW + rb] : 0u; }
+    }
+    return (w.win[w.jtop - j] >> (((i - 1) & 15) << 1)) & 3u;
+}
+__host__ __device__ inline unsigned char tbw_read_char(TbWalk &w, int i)     // a[i - 1]
+{
+    const int b = (i - 1) >> 3;
+    if (b != w.ab) { w.ab = b; const uint2 v = *(const uint2_a1 *)(w.a + 8 * b); w.a8 = d_u64(v.x, v.y); }
+    return (unsigned char)(w.a8 >> (((i - 1) & 7) << 3));
+}
+__host__ __device__ inline unsigned char tbw_genome_char(TbWalk &w, int j)   // RefSequence[gpos + j - 1]
+{
+    const int b = (j - 1) >> 3;
+    if (b != w.gb) { w.gb = b; w.g8 = d_ref8(*w.ix, w.gpos + 8 * b); }
+    return (unsigned char)(w.g8 >> (((j - 1) & 7) << 3));
+}
+// a literal '-' among the m read characters at a: there the character, not the traceback, decides what AddNewCigarElements makes of a column (string path)
+__host__ __device__ inline bool d_has_dash(const unsigned char *a, int m)
+{
+    const uint64_t k = 0x2D2D2D2D2D2D2D2Dull, o = 0x0101010101010101ull, h = 0x8080808080808080ull;
+    uint64_t any = 0;
+    for (int w = 0; w < m; w += 8) {
+        const uint2 rw = *(const uint2_a1 *)(a + w);
+        const int r = m - w;
+        const uint64_t z = d_u64(rw.x, rw.y) ^ k;
+        any |= (z - o) & ~z & h & (r >= 8 ? ~0ull : ((1ull << (8 * r)) - 1ull));
+    }
+    return any != 0;
+}
+
+// ProcessNormal/Head/TailSequencePair (tools.cpp:130-164,203-300) for a pair whose nw_alignment bits lie in the lane's scratch (d_nw_wave), the caller having
+// established that the pair reaches nw_alignment (d_big_needs_nw) and holds no literal '-' in the read: the CIGAR runs, the identical columns and what
+// CheckLocalAlignmentQuality counts come from ONE walk; the runs land behind cig[nc] last one first and are turned round there.
+__host__ __device__ inline int d_process_pair_tb(LaneCtx &cx, DSeed &sp, int mode, uint32_t *cig, int &nc)
+{
+    const int m = sp.rLen, n = sp.gLen;
+    cx.n_nw++; cx.nw_cells += (unsigned long long)m * (unsigned long long)n;
+    TbWalk w; tbw_init(w, cx, cx.seq + sp.rPos, m, sp.gPos);
+    uint32_t *run = cig + nc;
+    int R = 0, i = m, j = n, score = 0, nn = 0, cnt = 0;
+    uint32_t state = 99;
+    while (i > 0 || j > 0) {
+        const uint32_t fl = i == 0 ? 1u : (j == 0 ? 2u : tbw_flag(w, i, j));
+        uint32_t st;
+        if (fl & 1u) { st = OP_D; j--; }
+        else if (fl & 2u) { st = OP_I; i--; }
+        else { st = OP_M; nn++; if (tbw_read_char(w, i) == tbw_genome_char(w, j)) score++; i--; j--; }
+        if (st == state) cnt++;
+        else { if (cnt > 0) run[R++] = CIG(cnt, state); cnt = 1; state = st; }
+    }
+    if (cnt > 0) run[R++] = CIG(cnt, state);
+    for (int p = 0, q = R - 1; p < q; p++, q--) { const uint32_t t = run[p]; run[p] = run[q]; run[q] = t; }     // first run first
+    if (mode == 2) { nc += R; return score; }
+    const int mis = nn - score;
+    if (R >= 4 || (mis >= 3 && mis >= (int)(nn * 0.3))) { cig[nc++] = CIG(sp.rLen, OP_S); return 0; }           // CheckLocalAlignmentQuality :166-201 (its st = the runs)
+    if (mode == 0) {
+        int k = 0, wr = 0;
+        if (k < R && (run[k] & 15u) == OP_D) { const int p = (int)(run[k] >> 4); sp.gPos += p; sp.gLen -= p; k++; }
+        if (k < R && (run[k] & 15u) == OP_I) { const int p = (int)(run[k] >> 4); sp.rPos += p; sp.rLen -= p; run[wr++] = CIG(p, OP_S); k++; }
+        for (; k < R; k++) run[wr++] = run[k];                 // (wr <= k: nothing is overwritten before it is read)
+        nc += wr;
+        return score;
+    }
+    int e = R, c = 0;
+    if (e > 0 && (run[e - 1] & 15u) == OP_D) { sp.gLen -= (int)(run[e - 1] >> 4); e--; }
+    if (e > 0 && (run[e - 1] & 15u) == OP_I) { c = (int)(run[e - 1] >> 4); sp.rLen -= c; e--; }
+    if (c > 0) run[e++] = CIG(c, OP_S);
+    nc += e;
+    return score;
 }
 
 // FillGapsBetweenAdjacentSeeds (called by SeedExtension :577-594) on the gapped strings of its two nw_alignment calls, in three steps the two forms below share
@@ -981,6 +1080,66 @@ __host__ __device__ inline void d_gap_split_strings(const DParams &pr, const int
     if (!(max_score < (int)(rGaps * 0.8) || (rGaps - max_score) > pr.max_mismatch)) {
         for (p = bp, q = 0; p > 0; q++) { if (f1[q] != '-') p--; if (f2[q] != '-') right_ext++; }
         for (p = rGaps - bp, q = len3 - 1; p > 0; q--) { if (f3[q] != '-') p--; if (f4[q] != '-') left_ext++; }
+    }
+}
+
+// The three steps on the traceback bits of a wide read gap (TbWalk) instead of the strings.  RJ[p], p = 0 .. m: low half = Rv[p], high half = the genome bases
+// -- those beyond the window included -- that the columns up to the one of read base p cover (what the right_ext loop counts for bp = p); LJ[q]: low half =
+// Lv[q], high half = the genome bases covered from the column of read base q + 1 to the end (the left_ext loop for bp = q).
+__host__ __device__ inline void d_gap_right_tb(LaneCtx &cx, const unsigned char *rdp, int m, int64_t g_right, uint32_t *RJ)
+{
+    cx.n_nw++; cx.nw_cells += (unsigned long long)m * (unsigned long long)m;
+    TbWalk w; tbw_init(w, cx, rdp, m, g_right);
+    int i = m, j = m, T = 0;
+    while (i > 0) {                                              // the read bases the alignment leaves without a genome base at the end ...
+        const uint32_t fl = j == 0 ? 2u : tbw_flag(w, i, j);
+        if ((fl & 1u) || !(fl & 2u)) break;
+        i--; T++;
+    }
+    for (int u = 0; u < T; u++)                                  // ... meet the genome that follows the window
+        RJ[m - T + 1 + u] = (rdp[m - T + u] == (unsigned char)d_refchar(*cx.ix, g_right + m + u) ? 1u : 0u) | ((uint32_t)(m + u + 1) << 16);
+    while (i > 0 || j > 0) {
+        const uint32_t fl = i == 0 ? 1u : (j == 0 ? 2u : tbw_flag(w, i, j));
+        if (fl & 1u) j--;
+        else if (fl & 2u) { RJ[i] = (uint32_t)j << 16; i--; }
+        else { RJ[i] = (tbw_read_char(w, i) == tbw_genome_char(w, j) ? 1u : 0u) | ((uint32_t)j << 16); i--; j--; }
+    }
+    RJ[0] = 0;
+    uint32_t acc = 0;
+    for (int p = 1; p <= m; p++) { const uint32_t v = RJ[p]; acc += v & 1u; RJ[p] = (v & 0xFFFF0000u) | acc; }
+}
+__host__ __device__ inline void d_gap_left_tb(LaneCtx &cx, const unsigned char *rdp, int m, int64_t g_left, uint32_t *LJ)
+{
+    cx.n_nw++; cx.nw_cells += (unsigned long long)m * (unsigned long long)m;
+    TbWalk w; tbw_init(w, cx, rdp, m, g_left);
+    int i = m, j = m, H = -1;
+    uint32_t sc = 0;
+    LJ[m] = 0;
+    while (i > 0 || j > 0) {
+        const uint32_t fl = i == 0 ? 1u : (j == 0 ? 2u : tbw_flag(w, i, j));
+        if (fl & 1u) { j--; continue; }
+        uint32_t same, cov;
+        if (fl & 2u) {
+            if (j == 0) {                                        // the read bases without a genome base at the start meet the genome from the window's first base backwards
+                if (H < 0) H = i;
+                same = rdp[i - 1] == (unsigned char)d_refchar(*cx.ix, g_left - (H - i)) ? 1u : 0u; cov = (uint32_t)(m + H - i + 1);
+            } else { same = 0u; cov = (uint32_t)(m - j); }
+            sc += same; LJ[i - 1] = sc | (cov << 16); i--;
+        } else {
+            same = tbw_read_char(w, i) == tbw_genome_char(w, j) ? 1u : 0u; cov = (uint32_t)(m - j + 1);
+            sc += same; LJ[i - 1] = sc | (cov << 16); i--; j--;
+        }
+    }
+}
+__host__ __device__ inline void d_gap_split_tb(const DParams &pr, const uint32_t *RJ, const uint32_t *LJ, int rGaps, int &bp, int &right_ext, int &left_ext)
+{
+    int max_score = 0;
+    bp = 0;
+    for (int q = 0; q <= rGaps; q++) { const int v = (int)(RJ[q] & 0xFFFFu) + (int)(LJ[q] & 0xFFFFu); if (v > max_score) { max_score = v; bp = q; } }
+    right_ext = left_ext = 0;
+    if (!(max_score < (int)(rGaps * 0.8) || (rGaps - max_score) > pr.max_mismatch)) {
+        if (bp > 0) right_ext = (int)(RJ[bp] >> 16);
+        if (rGaps - bp > 0) left_ext = (int)(LJ[bp] >> 16);
     }
 }
 
@@ -1079,24 +1238,28 @@ __device__ inline int d_seed_extension_wave(LaneCtx &cx, bool live, DSeed *s, in
             }
         }
         const bool wide = has && !small;
+        const bool strings = wide && (!cx.lds || d_has_dash(rdp, rGaps));      // a literal '-' in a wide read gap (or a caller without the LDS slice): the gapped strings
         char *g = ws_str(cx, 0), *f1 = ws_str(cx, 1), *f2 = ws_str(cx, 2), *f3 = ws_str(cx, 3), *f4 = ws_str(cx, 4);
         int *Rv = (int *)ws_cig(cx), *Lv = Rv + rGaps + 1;      // the CIGAR scratch is idle at this stage
         int bp = 0, right_ext = 0, left_ext = 0;
         if (small) d_gap_small(cx, rdp, rGaps, Ls.gPos + Ls.gLen, Rs.gPos - rGaps, bp, right_ext, left_ext);
         int len = 0;
         d_nw_wave(cx, wide, rdp, rGaps, Ls.gPos + Ls.gLen, rGaps, lane);
-        if (wide) {
+        if (strings) {
             for (int q = 0; q <= rGaps; q++) Rv[q] = Lv[q] = 0;
             d_ref_fill(ix, Ls.gPos + Ls.gLen, rGaps, g);
             len = d_tb_traceback(cx, (const char *)rdp, rGaps, g, rGaps, f1, f2);
             d_gap_right_strings(ix, f1, f2, len, Ls.gPos + Ls.gLen + rGaps, Rv);
-        }
+        } else if (wide) d_gap_right_tb(cx, rdp, rGaps, Ls.gPos + Ls.gLen, (uint32_t *)Rv);
         d_nw_wave(cx, wide, rdp, rGaps, Rs.gPos - rGaps, rGaps, lane);
-        if (wide) {
+        if (strings) {
             d_ref_fill(ix, Rs.gPos - rGaps, rGaps, g);
             const int len3 = d_tb_traceback(cx, (const char *)rdp, rGaps, g, rGaps, f3, f4);
             d_gap_left_strings(ix, f3, f4, len3, Rs.gPos - rGaps, rGaps, Lv);
             d_gap_split_strings(*cx.pr, Rv, Lv, rGaps, f1, f2, f3, f4, len3, bp, right_ext, left_ext);
+        } else if (wide) {
+            d_gap_left_tb(cx, rdp, rGaps, Rs.gPos - rGaps, (uint32_t *)Lv);
+            d_gap_split_tb(*cx.pr, (const uint32_t *)Rv, (const uint32_t *)Lv, rGaps, bp, right_ext, left_ext);
         }
         if (has) {
             if (bp > 0) {
@@ -1115,7 +1278,7 @@ __device__ inline int d_seed_extension_wave(LaneCtx &cx, bool live, DSeed *s, in
 }
 
 // does the string path reach nw_alignment for this pair (tools.cpp:130-164,203-300 up to the call)?
-__device__ inline bool d_big_needs_nw(LaneCtx &cx, const DSeed &sp, int mode)
+__host__ __device__ inline bool d_big_needs_nw(LaneCtx &cx, const DSeed &sp, int mode)
 {
     if (mode == 2 && (sp.gPos - sp.rPos == -1 || sp.rLen == 0 || sp.gLen == 0)) return false;
     if (sp.rLen != sp.gLen) return true;
@@ -1130,7 +1293,7 @@ __device__ inline bool d_big_needs_nw(LaneCtx &cx, const DSeed &sp, int mode)
 }
 
 // mode 0 = head (ProcessHeadSequencePair :203-249), 1 = tail (:251-300), 2 = normal (:130-164)
-__device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t *cig, int &nc, bool have_tb = false)
+__host__ __device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t *cig, int &nc, bool have_tb = false)
 {
     const DIndex &ix = *cx.ix;
     if (mode == 2) {
@@ -1142,6 +1305,7 @@ __device__ inline int d_process_pair(LaneCtx &cx, DSeed &sp, int mode, uint32_t 
         }
     }
     const char *rd = (const char *)cx.seq + sp.rPos;
+    if (have_tb && cx.lds && !d_has_dash(cx.seq + sp.rPos, sp.rLen)) return d_process_pair_tb(cx, sp, mode, cig, nc);     // (d_big_needs_nw was true: neither early-out below applies)
     char *g = ws_str(cx, 0);
     d_ref_fill(ix, sp.gPos, sp.gLen, g);
     if (sp.rLen == sp.gLen) {

@@ -147,3 +147,23 @@ def test_gap_filling_without_strings_equals_the_string_form(workdir):
     assert len(counts) == 25 and all(c > 0 for c in counts), counts
     beyond = line.split("with read bases beyond")[0].split(",")[-1].split()
     assert int(beyond[0]) > 1000 and int(beyond[2]) > 1000, line
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_traceback_consumers_on_the_bits_equal_the_string_forms(workdir):
+    """dg_report.h's consumers of a wave-wide nw_alignment that walk its traceback bits (TbWalk) -- d_process_pair_tb (tools.cpp:130-164,203-300: CIGAR runs, score,
+    CheckLocalAlignmentQuality, head / tail trimming) and d_gap_right_tb / d_gap_left_tb / d_gap_split_tb (FillGapsBetweenAdjacentSeeds on read gaps wider than 24 bases)
+    -- against the gapped-string forms on the same bits: 60 000 segment pairs in the three modes and 30 000 wide gaps; bits from the cell recurrence, from a random
+    source and from laid-out three-run paths, so that every trimming case and accepted splits occur in numbers."""
+    src = os.path.join(common.ROOT, "tests", "native", "tb_checks.hip")
+    exe = os.path.join(workdir, "tb_checks")
+    subprocess.run(["hipcc", "-O2", "--offload-arch=gfx950", "-std=c++17", "-w", "-o", exe, src], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("bad=0"), r.stdout + r.stderr
+    import re
+    pairs = [l for l in r.stdout.splitlines() if l.startswith("pairs:")][0]
+    gaps = [l for l in r.stdout.splitlines() if l.startswith("wide gaps:")][0]
+    n = [int(x) for x in re.findall(r"\d+", pairs)]
+    assert n[0] > 50000 and min(n[1:4]) > 15000 and n[5] > 10000 and n[6] > 2000 and n[7] > 2000, pairs      # compared, per mode, quality failures, head / tail trims
+    g = [int(x) for x in re.findall(r"\d+", gaps)]
+    assert g[0] == 30000 and g[1] > 3000 and g[2] > 2000 and g[3] > 2000, gaps
