@@ -1390,6 +1390,7 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
         rp.aln_score = 0; rp.sj_type = -1; rp.flag = 0; rp.paired_idx = -1; rp.chr = -1; rp.bdir = 0; rp.pos = 0;
         rp.cigar_off = 0; rp.n_cigar = 0;
         int final_n = 0, num = 0, nq = 0, bigj = -1, npl = 0;
+        bool lane_nw_before = false;
         uint32_t nwj = 0;                                 // seed indices (8 bits each) of the first PM_MAXQ small alignments
         uint64_t pcl = 0;                                 // outcome of d_pair_classify for the first 12 pairs, 5 bits each (class | mismatches << 3)
         DSeed *s = work;
@@ -1436,13 +1437,17 @@ __device__ inline void d_gen_mapping_report(LaneCtx &cx, bool valid, bool first,
                         const DSeed &sd = s[j];
                         if ((sd.rLen == 0 && sd.gLen == 0) || (sd.flags & SEED_SIMPLE) || j > 254) continue;
                         const int mode = j == 0 ? 0 : (j == num - 1 ? 1 : 2);
-                        if (sd.rLen > PM_MAX || sd.gLen > PM_MAX) {              // large: the first one is aligned by the whole wave
-                            if (bigj < 0 && sd.gLen <= 64 * 64 && d_big_needs_nw(cx, sd, mode)) bigj = j;
+                        if (sd.rLen > PM_MAX || sd.gLen > PM_MAX) {              // large: the first one is aligned by the whole wave ...
+                            if (bigj < 0 && d_big_needs_nw(cx, sd, mode)) { if (sd.gLen <= 64 * 64 && !lane_nw_before) bigj = j; else lane_nw_before = true; }
                             npl++;                                               // (slot stays PC_GENERIC)
                             continue;
                         }
                         PairStr ps; int nm = 0;
                         const int pc = d_pair_classify(cx, sd, mode, ps, nm);
+                        // ... unless a pair in front of it runs the one-lane d_nw in part 2 (a pair with a literal '-' in the read, or one whose genome side is too long for the
+                        // wave): d_nw keeps its traceback bits where the wave leaves the large pair's, and part 2 takes the pairs in order -- the large pair's traceback would
+                        // read the other alignment's bits (found by test_gpu_literal_dashes_in_read_gaps_and_segment_pairs; such a large pair goes the one-lane way too)
+                        if (pc == PC_GENERIC) lane_nw_before = true;
                         if (npl < 12) pcl |= (uint64_t)(pc | ((pc == PC_EQUAL ? nm : 0) << 3)) << (5 * npl);
                         npl++;
                         if (nq < PM_MAXQ && pc == PC_NW) {

@@ -124,6 +124,41 @@ def test_gpu_seed_queue_configurations(ctxs, monkeypatch):
     gpu.set_params(host.default_params())
 
 
+def test_gpu_literal_dashes_in_read_gaps_and_segment_pairs(ctxs):
+    """A literal '-' in a read changes what the reference's string code makes of an alignment column (AddNewCigarElements, tools.cpp:49-104, and FillGapsBetweenAdjacentSeeds
+    look at the characters), so the forms that never build the strings -- d_gap_small, d_gap_right_tb / d_gap_left_tb, d_process_pair_tb -- hand such gaps and pairs to the string
+    forms (d_has_dash).  Spliced and indel reads of 101 and 250 bases with dashes, lower case and N planted at random places, next to the junctions, and inside stretches of
+    noise between two seeds (wide gaps, large pairs): every record against the oracle."""
+    c, ix, gpu, orc = ctxs["pe101_spliced"]
+    rng = np.random.default_rng(77)
+    seqs = []
+    for rlen, n_pairs, seed in ((101, 6000, 501), (250, 2500, 502)):
+        m1, m2 = synth.make_reads(c["genome"], n_pairs, rlen=rlen, seed=seed, spliced_frac=0.6, indel_frac=0.3, n_frac=0.0)
+        for i in range(n_pairs):
+            for m in (m1, m2):
+                s = bytearray(m[i].tobytes())
+                k = i % 8
+                if k < 3:                                        # one to three characters anywhere: some land in the few bases between two exons' seeds
+                    for q in rng.integers(0, rlen, size=k + 1): s[int(q)] = ord("-")
+                elif k == 3:                                     # a stretch of noise with a dash in it: a wide gap or a large pair, depending on what lies around it
+                    a = int(rng.integers(20, rlen - 70)); w = int(rng.integers(26, 60))
+                    s[a:a + w] = bytes(rng.choice(list(b"ACGT"), w).astype(np.uint8)); s[a + w // 2] = ord("-")
+                elif k == 4:                                     # the same without the dash: the forms on the bits
+                    a = int(rng.integers(20, rlen - 70)); w = int(rng.integers(26, 60))
+                    s[a:a + w] = bytes(rng.choice(list(b"ACGT"), w).astype(np.uint8))
+                elif k == 5:                                     # lower case and N instead: characters that differ from the genome's without being a gap
+                    for q in rng.integers(0, rlen, size=4): s[int(q)] = s[int(q)] | 0x20
+                    s[int(rng.integers(0, rlen))] = ord("N")
+                seqs.append(bytes(s))
+    so, rl, flat = host.pack_reads(seqs)
+    for mis in (5, 12):
+        gpu.set_params(host.default_params(paired=1, max_mismatch=mis))
+        assert_same(gpu.map_batch(so, rl, flat), orc.map_batch(orc.params(paired=1, max_mismatch=mis), so, rl, flat))
+    ctr = gpu.counters()
+    assert ctr["nw_calls"] > 1000
+    gpu.set_params(host.default_params())
+
+
 def test_gpu_edge_cases(ctxs):
     """empty batch, ragged lengths, reads shorter than a seed, all-N reads, lower case, odd paired batch"""
     c, ix, gpu, orc = ctxs["pe101_spliced"]
