@@ -1,4 +1,4 @@
-"""Probe: the five reads of dash_debug.py that differ, alone, with their dashes as they are / as N / as a wrong base / as the right genome base is unknown -> as 'A'."""
+"""Probe (GPU box): the five reads with a literal '-' that led to the fix of DESIGN 6, round 5 item 18 (a one-lane d_nw in front of a candidate's large pair overwrote its traceback bits), alone, single-end, with their dashes as they are / as N / as a base / as a lower-case base: library against oracle, CIGAR and score.
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
