@@ -150,3 +150,36 @@ def write_holes_fasta(path: str) -> None:
         f.write(">chrC\n")
         for o in range(0, len(rec3), 50):
             f.write(rec3[o:o + 50] + "\n")
+
+
+def odd_character_reads(genome, n101: int = 1400, n250: int = 500):
+    """Reads for tests/golden/odd_characters.* (made by tests/golden/make_odd_characters.py with the reference's object code): spliced and indel reads of 101 and 250
+    bases over `genome` (the pe101_spliced case's) with a literal '-' (a gap to AddNewCigarElements, tools.cpp:49-104), lower case, N and IUPAC letters at random
+    places, next to junctions and inside stretches of noise between two seeds.  Single-end: every mate is a read of its own."""
+    rng = np.random.default_rng(7711)
+    seqs = []
+    for rlen, n_pairs, seed in ((101, n101, 7701), (250, n250, 7702)):
+        m1, m2 = synth.make_reads(genome, n_pairs, rlen=rlen, seed=seed, spliced_frac=0.6, indel_frac=0.3, n_frac=0.0)
+        for i in range(n_pairs):
+            for m in (m1, m2):
+                s = bytearray(m[i].tobytes())
+                k = i % 8
+                if k < 3:
+                    for q in rng.integers(0, rlen, size=k + 1): s[int(q)] = ord("-")
+                elif k == 3:
+                    a = int(rng.integers(20, rlen - 70)); w = int(rng.integers(26, 60))
+                    s[a:a + w] = bytes(rng.choice(list(b"ACGT"), w).astype(np.uint8)); s[a + w // 2] = ord("-")
+                elif k == 4:
+                    a = int(rng.integers(20, rlen - 70)); w = int(rng.integers(26, 60))
+                    s[a:a + w] = bytes(rng.choice(list(b"ACGT"), w).astype(np.uint8))
+                elif k == 5:
+                    for q in rng.integers(0, rlen, size=4): s[int(q)] = s[int(q)] | 0x20
+                    s[int(rng.integers(0, rlen))] = ord("N"); s[int(rng.integers(0, rlen))] = ord("R")
+                seqs.append(bytes(s))
+    return seqs
+
+
+def write_se_fastq(path: str, seqs) -> None:
+    with open(path, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, s.decode(), "I" * len(s)))

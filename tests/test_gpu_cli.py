@@ -28,6 +28,24 @@ def test_dart_cli_reproduces_golden_sam(workdir):
             assert common.stats_block(r.stdout) == common.golden_stats(run["base"]), (run["base"], r.stdout[-600:])
 
 
+def test_dart_cli_reads_with_odd_characters_reproduce_the_reference_sam(workdir):
+    """Single-end reads with a literal '-', lower case, N and IUPAC letters, -mis 12, through both host pipelines: the SAM and the junctions the reference's object code wrote
+    for them (tests/golden/odd_characters.*; half of the reads hold a dash -- what the string forms of dg_report.h are kept for)."""
+    import gzip, json, hashlib
+    c = common.build_case("pe101_spliced", workdir)
+    meta = json.load(open(os.path.join(common.GOLDEN, "odd_characters.json")))
+    seqs = common.odd_character_reads(c["genome"])
+    assert hashlib.sha256(b"\n".join(seqs)).hexdigest() == meta["reads_sha256"], "the read generator drifted from the golden inputs"
+    d = os.path.join(workdir, "odd_characters_gpu"); os.makedirs(d, exist_ok=True)
+    common.write_se_fastq(os.path.join(d, "odd.fq"), seqs)
+    want = gzip.open(os.path.join(common.GOLDEN, "odd_characters.mis12.sam.gz"), "rt").read()
+    for env in (dict(os.environ, DART_BATCH="1000"), dict(os.environ, DART_BATCH="1000", DART_STREAMING="1")):
+        subprocess.run([DART, "-i", c["prefix"], "-f", "odd.fq", "-mis", "12", "-o", "o.sam", "-j", "o.j", "-t", "4"], cwd=d, stdout=subprocess.DEVNULL, check=True, env=env)
+        got = open(os.path.join(d, "o.sam")).read()
+        assert got == want, common.first_diff(got, want)
+        assert open(os.path.join(d, "o.j")).read() == open(os.path.join(common.GOLDEN, "odd_characters.mis12.junctions.tab")).read()
+
+
 def test_dart_cli_bam_output(workdir):
     """`-bo`: the BAM that `dart` writes (host/bam_writer.h; the reference: htslib's sam_parse1 + sam_write1 per SAM line), decoded by
     the specification-based reader of the tests and compared with the reference-generated golden SAM; several batches, so the BGZF

@@ -139,3 +139,22 @@ def test_bucketed_suffix_sorter_gives_the_same_index(workdir, monkeypatch):
     index_build.build_index_from_genome(g, b, device="cpu")
     for ext in ("bwt", "sa", "pac", "ann", "amb"):
         assert open(a + "." + ext, "rb").read() == open(b + "." + ext, "rb").read(), ext
+
+
+def test_oracle_cli_matches_reference_on_reads_with_odd_characters(workdir):
+    """Single-end reads with a literal '-' (a gap to AddNewCigarElements, tools.cpp:49-104), lower case, N and IUPAC letters, -mis 12: the oracle's command line against the SAM
+    and junctions the reference's object code wrote for the same reads (tests/golden/odd_characters.*, made by tests/golden/make_odd_characters.py).  Half of the reads
+    hold a dash; such reads are what the library's string forms exist for."""
+    import json, hashlib, subprocess
+    oracle_py.build()
+    c = common.build_case("pe101_spliced", workdir)
+    meta = json.load(open(os.path.join(common.GOLDEN, "odd_characters.json")))
+    seqs = common.odd_character_reads(c["genome"])
+    assert len(seqs) == meta["reads"] and hashlib.sha256(b"\n".join(seqs)).hexdigest() == meta["reads_sha256"], "the read generator drifted from the golden inputs"
+    d = os.path.join(workdir, "odd_characters"); os.makedirs(d, exist_ok=True)
+    common.write_se_fastq(os.path.join(d, "odd.fq"), seqs)
+    subprocess.run([oracle_py.ORACLE_CLI, "-i", c["prefix"], "-f", "odd.fq", "-mis", "12", "-o", "orc.sam", "-j", "orc.j", "-t", "4"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    want = gzip.open(os.path.join(common.GOLDEN, "odd_characters.mis12.sam.gz"), "rt").read()
+    got = open(os.path.join(d, "orc.sam")).read()
+    assert got == want, common.first_diff(got, want)
+    assert open(os.path.join(d, "orc.j")).read() == open(os.path.join(common.GOLDEN, "odd_characters.mis12.junctions.tab")).read()
