@@ -89,6 +89,13 @@ def test_bam_writer_against_golden_sam(workdir):
         assert hdr == want_hdr
         assert ["@SQ\tSN:%s\tLN:%d" % r for r in refs] == [l for l in want_hdr.splitlines() if l.startswith("@SQ")]
         want = [re.sub(r" XS:A:[+-]$", "", l) for l in text.splitlines() if not l.startswith("@")]
+        # BAM holds a base as one of sixteen codes (htslib's seq_nt16_table, as sam_parse1 applies it): case is lost, everything but "=ACMGRSVTWYHKDBN" -- a '-' too -- reads back as N
+        def as_bam_stores_it(line):
+            f = line.split("\t")
+            if len(f) > 9 and f[9] != "*":
+                f[9] = "".join(ch if ch in "=ACMGRSVTWYHKDBN" else "N" for ch in f[9].upper())
+            return "\t".join(f)
+        want = [as_bam_stores_it(l) for l in want]
         if k == 0:
             assert "refused=1" in out.stdout
             del want[0]
