@@ -36,3 +36,21 @@ def test_oracle_matches_reference_on_fresh_fuzz(workdir):
     synth.write_fastq(os.path.join(d, "a.fq"), m1, 1); synth.write_fastq(os.path.join(d, "b.fq"), m2, 2)
     for flags in ([], ["-mis", "5"], ["-mis", "4", "-unique", "-max_dup", "500"]):
         run_both(d, os.path.join(d, "g"), ["-f", "a.fq", "-f2", "b.fq"] + flags)
+
+
+def test_oracle_matches_reference_on_reads_with_odd_characters(workdir):
+    """fresh genome, paired and single-end reads with a literal '-' (a gap to AddNewCigarElements), lower case, N and IUPAC letters planted at 1 % of the positions,
+    -mis 12 and 30: the reads that reach the reference's string code in ways the ACGTN fixtures do not"""
+    import numpy as np
+    oracle_py.build()
+    d = os.path.join(workdir, "fuzz_odd"); os.makedirs(d, exist_ok=True)
+    g = synth.make_genome([500000, 250000], seed=191, repeat_scale=40.0, n_introns=300)
+    g.write_fasta(os.path.join(d, "g.fa"))
+    subprocess.run([oracle_py.REF_INDEXER, "g.fa", "g"], cwd=d, stdout=subprocess.DEVNULL, check=True)
+    rng = np.random.default_rng(192)
+    m1, m2 = synth.make_reads(g, 5000, rlen=125, seed=193, spliced_frac=0.4, sub_rate=0.01, indel_frac=0.2, n_frac=0.0)
+    def odd(m):
+        return np.where(rng.random(m.shape) < 0.01, rng.choice(np.frombuffer(b"---acgtRYn", np.uint8), size=m.shape), m).astype(np.uint8)
+    synth.write_fastq(os.path.join(d, "a.fq"), odd(m1), 1); synth.write_fastq(os.path.join(d, "b.fq"), odd(m2), 2)
+    for flags in (["-f", "a.fq", "-f2", "b.fq", "-mis", "12"], ["-f", "a.fq", "-mis", "30"], ["-f", "a.fq", "b.fq", "-mis", "12", "-m"]):
+        run_both(d, os.path.join(d, "g"), flags)
